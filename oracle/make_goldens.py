@@ -1,0 +1,177 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+Runs only where /root/reference exists.  It stub-imports
+``/root/reference/vault/models/vault/model.py`` (SURVEY Appendix A recipe: the package
+``__init__`` pulls torchvision/ekphrasis/emoji which are absent here), builds the
+reference ``VaultForTMSC`` on HuggingFace ``ViltModel`` + ``RobertaModel``/``BertModel``
+from configs, overwrites every parameter with ``vault_amd.spec.fill_param`` values,
+applies the D1 fix (transformers 5.15 ignores ``position_embedding_type``; the reference
+under its pinned transformers 4.48 skips ViLT's text position embeddings when an LM is
+present), runs forward + backward on ``vault_amd.spec.synthetic_batch`` inputs and stores
+inputs-independent expected outputs.  Nothing from the reference is copied: the files
+hold numbers only (logits, pooled output, hidden-state slices, loss, gradient norms).
+
+Usage:  python oracle/make_goldens.py            (writes tests/golden/*.npz)
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from vault_amd.spec import LMSpec, VaultSpec, ViltSpec, build_state, param_entries, synthetic_batch  # noqa: E402
+
+REF = "/root/reference"
+
+
+def import_reference():
+    for n in ["ekphrasis", "ekphrasis.classes", "ekphrasis.classes.tokenizer",
+              "ekphrasis.classes.preprocessor", "emoji"]:
+        sys.modules[n] = types.ModuleType(n)
+    sys.modules["ekphrasis.classes.tokenizer"].SocialTokenizer = object
+    sys.modules["ekphrasis.classes.preprocessor"].TextPreProcessor = object
+    sys.modules["emoji"].demojize = lambda x, **k: x
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        return m
+
+    pkg = types.ModuleType("vault")
+    pkg.__path__ = [f"{REF}/vault"]
+    sys.modules["vault"] = pkg
+    load("vault.utils", f"{REF}/vault/utils.py")
+    return load("vault_model_ref", f"{REF}/vault/models/vault/model.py")
+
+
+def hf_configs(spec: VaultSpec):
+    from transformers import BertConfig, RobertaConfig, ViltConfig
+    v = spec.vilt
+    vc = ViltConfig(vocab_size=v.vocab_size, hidden_size=v.hidden_size, num_hidden_layers=v.num_hidden_layers,
+                    num_attention_heads=v.num_attention_heads, intermediate_size=v.intermediate_size,
+                    image_size=v.image_size, patch_size=v.patch_size, num_channels=v.num_channels,
+                    max_position_embeddings=v.max_position_embeddings, type_vocab_size=v.type_vocab_size,
+                    modality_type_vocab_size=v.modality_type_vocab_size, layer_norm_eps=v.layer_norm_eps)
+    lm = spec.lm
+    kw = dict(vocab_size=lm.vocab_size, max_position_embeddings=lm.max_position_embeddings,
+              type_vocab_size=lm.type_vocab_size, hidden_size=lm.hidden_size,
+              num_hidden_layers=lm.num_hidden_layers, num_attention_heads=lm.num_attention_heads,
+              intermediate_size=lm.intermediate_size, layer_norm_eps=lm.layer_norm_eps,
+              pad_token_id=lm.pad_token_id)
+    if lm.kind == "roberta":
+        lc = RobertaConfig(bos_token_id=0, eos_token_id=2, **kw)
+    else:
+        lc = BertConfig(**kw)
+    return vc, lc
+
+
+def build_reference_model(ref, spec: VaultSpec, seed: int = 0):
+    vc, lc = hf_configs(spec)
+    model = ref.VaultForTMSC(vc, n_classes=spec.n_classes, vilt_dropout_prob=0.1, bert_config=lc).eval()
+    state = build_state(spec, seed)
+    sd = model.state_dict()
+    ours = {n for n, _, _ in param_entries(spec)}
+    theirs = {k for k in sd.keys()}
+    missing = theirs - ours
+    extra = ours - theirs
+    assert not extra, f"names not in reference state_dict: {sorted(extra)[:5]}"
+    # the reference may carry non-parameter buffers (position_ids ...) - those stay
+    for k in missing:
+        assert "position_ids" in k or "token_type_ids" in k, f"unexpected reference key {k}"
+    with torch.no_grad():
+        for k, v in state.items():
+            assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
+            sd[k].copy_(torch.from_numpy(v))
+        if not spec.use_vilt_position_embeddings:
+            # D1: transformers-4.48 semantics of ``position_embedding_type = "NOT_absolute"``
+            model.embeddings.text_embeddings.position_embeddings.weight.zero_()
+    return model, state
+
+
+def run_reference(model, spec, batch_np):
+    kw = dict(input_ids=torch.from_numpy(batch_np["input_ids"]),
+              attention_mask=torch.from_numpy(batch_np["attention_mask"]),
+              pixel_values=torch.from_numpy(batch_np["pixel_values"]),
+              pixel_mask=torch.from_numpy(batch_np["pixel_mask"]))
+    if "token_type_ids" in batch_np:
+        kw["token_type_ids"] = torch.from_numpy(batch_np["token_type_ids"])
+    torch.manual_seed(0)
+    model.zero_grad(set_to_none=True)
+    # VaultForTMSC.forward returns logits only; grab the encoder output through the mixin
+    enc = super(type(model), model).forward(**kw)
+    logits = model.classifier(enc.pooler_output).squeeze(-1)
+    loss = torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(batch_np["labels"]))
+    loss.backward()
+    T = batch_np["input_ids"].shape[1]
+    out = {
+        "logits": logits.detach().numpy(),
+        "pooler_output": enc.pooler_output.detach().numpy(),
+        "hidden_text_cls": enc.last_hidden_state[:, : T + 1].detach().numpy(),
+        # patch tokens come back in a random order (D3): store an order-free summary
+        "hidden_patch_sorted_norms": np.sort(
+            enc.last_hidden_state[:, T + 1:].detach().norm(dim=-1).numpy(), axis=1),
+        "loss": np.float32(loss.item()),
+    }
+    names, norms = [], []
+    small = {}
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        if k == "embeddings.text_embeddings.position_embeddings.weight" and not spec.use_vilt_position_embeddings:
+            # D1: under the reference's pinned transformers 4.48 this table is skipped (no grad);
+            # the 5.15 emulation adds a zeroed table, which still receives a gradient
+            continue
+        names.append(k)
+        norms.append(float(p.grad.double().norm()))
+        if k in ("classifier.1.weight", "classifier.1.bias", "layernorm.weight", "layernorm.bias",
+                 "embeddings.cls_token", "embeddings.token_type_embeddings.weight",
+                 "bert.embeddings.LayerNorm.weight", "encoder.layer.0.attention.attention.query.bias",
+                 "bert.encoder.layer.0.attention.self.key.bias",
+                 "bert.embeddings.position_embeddings.weight"):
+            small["grad::" + k] = p.grad.detach().numpy().copy()
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array(norms, np.float64)
+    out.update(small)
+    return out
+
+
+CASES = {
+    # name: (spec factory, batch, data seed)
+    "tiny_roberta": (lambda: VaultSpec.tiny(3, "roberta"), 3, 11),
+    "tiny_bert": (lambda: VaultSpec.tiny(3, "bert"), 3, 12),
+    "full_bertweet_b2": (lambda: VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3), 2, 13),
+}
+
+
+def main():
+    ref = import_reference()
+    outdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    only = sys.argv[1:]
+    for name, (mk, B, dseed) in CASES.items():
+        if only and name not in only:
+            continue
+        spec = mk()
+        model, _ = build_reference_model(ref, spec, seed=0)
+        batch = synthetic_batch(spec, B, seed=dseed, n_classes=spec.n_classes)
+        # make sure one caption is short so padding/masking is exercised
+        out = run_reference(model, spec, batch)
+        out["meta_batch"] = np.int64(B)
+        out["meta_data_seed"] = np.int64(dseed)
+        path = os.path.join(outdir, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(name, "loss", out["loss"], "logits", out["logits"].ravel()[:6], "->", path,
+              f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,231 @@
+"""CPU oracle for the stacked BERT -> ViLT hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this file; the product (``vault_amd``) never does and fails loudly without its
+HIP library.
+
+What it is: a plain fp32 ``torch`` restatement (functional; no ``transformers``, no
+reference code) of the arithmetic the reference reaches through HuggingFace:
+
+  * LM embeddings   HF:models/roberta/modeling_roberta.py:75-155 / models/bert/modeling_bert.py:69-107
+  * LM layer        HF:models/roberta/modeling_roberta.py:158-250,329-463 (post-LN, erf-GELU)
+  * ViLT text embed HF:models/vilt/modeling_vilt.py:237-269 (with ``inputs_embeds``)
+  * patch embed     HF:models/vilt/modeling_vilt.py:290-300 (Conv2d k=s=patch)
+  * visual_embed    HF:models/vilt/modeling_vilt.py:92-178 for full pixel masks, static patch
+                    order (the reference shuffles valid patches with ``torch.multinomial``;
+                    attention is permutation-equivariant so pooler/logits are unchanged,
+                    SURVEY §8c D3)
+  * modality add    HF:models/vilt/modeling_vilt.py:204-219
+  * ViLT layer      HF:models/vilt/modeling_vilt.py:303-451 (pre-LN, additive finfo.min mask)
+  * tail            HF:models/vilt/modeling_vilt.py:636-663 (final LN, pooler)
+  * glue            ref: vault/models/vault/model.py:151-218 (LM output -> inputs_embeds),
+                    model.py:547-570 (Dropout -> Linear head), D1: ViLT text position
+                    embeddings are skipped unless ``use_vilt_position_embeddings``
+                    (model.py:78-79,113-116 under transformers 4.48)
+  * loss            ref: vault/tmsc_utils/trainer.py:241-242 (mean CrossEntropy)
+  * optimizer       transformers==4.48 ``AdamW`` as called at trainer.py:244-254
+                    (``correct_bias=False``), schedule trainer.py:274-278
+
+Pinning: the reference ships no tests or golden vectors for this path, so the
+oracle is pinned against outputs of the reference itself, run in the build container via
+``oracle/make_goldens.py`` and committed under ``tests/golden/`` (see
+tests/test_oracle_golden.py).  The optimizer has no importable reference under
+transformers 5.15 (``transformers.optimization.AdamW`` was removed) and is pinned by
+formula against a float64 restatement: that part is "parity unpinned" by the reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _t(x):
+    return x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+
+
+def to_torch_state(state: Dict[str, np.ndarray], requires_grad: bool = False) -> Dict[str, torch.Tensor]:
+    out = {}
+    for k, v in state.items():
+        t = _t(v).clone().float()
+        t.requires_grad_(requires_grad)
+        out[k] = t
+    return out
+
+
+def _ln(x, w, b, eps):
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def _mha(x, mask_add, P, pre, heads, att_name):
+    """softmax(QK^T/sqrt(d) + mask) V ; returns context [B,S,H] (before output dense)."""
+    B, S, H = x.shape
+    d = H // heads
+    q = F.linear(x, P[f"{pre}.{att_name}.query.weight"], P[f"{pre}.{att_name}.query.bias"])
+    k = F.linear(x, P[f"{pre}.{att_name}.key.weight"], P[f"{pre}.{att_name}.key.bias"])
+    v = F.linear(x, P[f"{pre}.{att_name}.value.weight"], P[f"{pre}.{att_name}.value.bias"])
+    q = q.view(B, S, heads, d).transpose(1, 2)
+    k = k.view(B, S, heads, d).transpose(1, 2)
+    v = v.view(B, S, heads, d).transpose(1, 2)
+    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d)
+    s = s + mask_add
+    p = torch.softmax(s, dim=-1)
+    c = torch.matmul(p, v)
+    return c.permute(0, 2, 1, 3).reshape(B, S, H)
+
+
+def lm_position_ids(input_ids: torch.Tensor, lm) -> torch.Tensor:
+    if lm.kind == "roberta":
+        m = input_ids.ne(lm.pad_token_id).int()
+        return (torch.cumsum(m, dim=1).type_as(m) * m).long() + lm.pad_token_id
+    return torch.arange(input_ids.shape[1]).unsqueeze(0).expand_as(input_ids)
+
+
+def lm_forward(P, spec, input_ids, attention_mask, token_type_ids=None, taps: Optional[dict] = None):
+    lm = spec.lm
+    pos = lm_position_ids(input_ids, lm)
+    if token_type_ids is None or lm.type_vocab_size < 2:
+        token_type_ids = torch.zeros_like(input_ids)   # ref: model.py:174-180
+    x = (P["bert.embeddings.word_embeddings.weight"][input_ids]
+         + P["bert.embeddings.token_type_embeddings.weight"][token_type_ids]
+         + P["bert.embeddings.position_embeddings.weight"][pos])
+    x = _ln(x, P["bert.embeddings.LayerNorm.weight"], P["bert.embeddings.LayerNorm.bias"], lm.layer_norm_eps)
+    if taps is not None:
+        taps["lm_embed"] = x
+    mask_add = (1.0 - attention_mask[:, None, None, :].float()) * torch.finfo(torch.float32).min
+    for i in range(lm.num_hidden_layers):
+        pre = f"bert.encoder.layer.{i}"
+        c = _mha(x, mask_add, P, pre, lm.num_attention_heads, "attention.self")
+        a = F.linear(c, P[f"{pre}.attention.output.dense.weight"], P[f"{pre}.attention.output.dense.bias"])
+        x = _ln(a + x, P[f"{pre}.attention.output.LayerNorm.weight"], P[f"{pre}.attention.output.LayerNorm.bias"],
+                lm.layer_norm_eps)
+        h = F.gelu(F.linear(x, P[f"{pre}.intermediate.dense.weight"], P[f"{pre}.intermediate.dense.bias"]))
+        o = F.linear(h, P[f"{pre}.output.dense.weight"], P[f"{pre}.output.dense.bias"])
+        x = _ln(o + x, P[f"{pre}.output.LayerNorm.weight"], P[f"{pre}.output.LayerNorm.bias"], lm.layer_norm_eps)
+        if taps is not None:
+            taps[f"lm_layer{i}"] = x
+    return x
+
+
+def vilt_embed(P, spec, text_in, attention_mask, token_type_ids, pixel_values, taps=None):
+    """text_in: LM output [B,T,H] (inputs_embeds) or int64 ids [B,T] when no LM is used."""
+    v = spec.vilt
+    B = pixel_values.shape[0]
+    T = attention_mask.shape[1]
+    if token_type_ids is None:
+        token_type_ids = torch.zeros((B, T), dtype=torch.long)
+    if text_in.dtype in (torch.int64, torch.int32):
+        e = P["embeddings.text_embeddings.word_embeddings.weight"][text_in]
+        use_pos = True
+    else:
+        e = text_in
+        use_pos = spec.use_vilt_position_embeddings or spec.lm is None
+    e = e + P["embeddings.text_embeddings.token_type_embeddings.weight"][token_type_ids]
+    if use_pos:
+        e = e + P["embeddings.text_embeddings.position_embeddings.weight"][:T].unsqueeze(0)
+    e = _ln(e, P["embeddings.text_embeddings.LayerNorm.weight"], P["embeddings.text_embeddings.LayerNorm.bias"],
+            v.layer_norm_eps)
+    mt = P["embeddings.token_type_embeddings.weight"]
+    text = e + mt[0]
+    pe = F.conv2d(pixel_values, P["embeddings.patch_embeddings.projection.weight"],
+                  P["embeddings.patch_embeddings.projection.bias"], stride=v.patch_size)
+    pe = pe.flatten(2).transpose(1, 2)                      # [B, g*g, H], row-major patch order
+    pos = P["embeddings.position_embeddings"]               # [1, 1+g*g, H]
+    img = torch.cat([P["embeddings.cls_token"].expand(B, -1, -1), pe], dim=1) + pos
+    img = img + mt[1]
+    x = torch.cat([text, img], dim=1)
+    if taps is not None:
+        taps["vilt_embed"] = x
+    mask = torch.cat([attention_mask, torch.ones((B, img.shape[1]), dtype=attention_mask.dtype)], dim=1)
+    return x, mask
+
+
+def vilt_encoder(P, spec, x, mask, taps=None):
+    v = spec.vilt
+    mask_add = (1.0 - mask[:, None, None, :].float()) * torch.finfo(torch.float32).min
+    for i in range(v.num_hidden_layers):
+        pre = f"encoder.layer.{i}"
+        n1 = _ln(x, P[f"{pre}.layernorm_before.weight"], P[f"{pre}.layernorm_before.bias"], v.layer_norm_eps)
+        c = _mha(n1, mask_add, P, pre, v.num_attention_heads, "attention.attention")
+        a = F.linear(c, P[f"{pre}.attention.output.dense.weight"], P[f"{pre}.attention.output.dense.bias"])
+        x = a + x
+        n2 = _ln(x, P[f"{pre}.layernorm_after.weight"], P[f"{pre}.layernorm_after.bias"], v.layer_norm_eps)
+        h = F.gelu(F.linear(n2, P[f"{pre}.intermediate.dense.weight"], P[f"{pre}.intermediate.dense.bias"]))
+        x = F.linear(h, P[f"{pre}.output.dense.weight"], P[f"{pre}.output.dense.bias"]) + x
+        if taps is not None:
+            taps[f"vilt_layer{i}"] = x
+    return x
+
+
+def vault_forward(P, spec, batch: Dict[str, torch.Tensor], taps: Optional[dict] = None,
+                  classifier_keep_mask: Optional[torch.Tensor] = None, classifier_p: float = 0.0):
+    """Returns dict(last_hidden_state, pooler_output[, logits]).  Eval-mode arithmetic
+    (all dropouts off) unless ``classifier_keep_mask`` is given (train-mode head dropout
+    with an explicit mask so a GPU run with the same mask can be compared)."""
+    ids = batch["input_ids"]
+    am = batch["attention_mask"]
+    tt = batch.get("token_type_ids")
+    pix = batch["pixel_values"]
+    if spec.lm is not None:
+        text_in = lm_forward(P, spec, ids, am, tt, taps)
+    else:
+        text_in = ids
+    x, mask = vilt_embed(P, spec, text_in, am, tt, pix, taps)
+    x = vilt_encoder(P, spec, x, mask, taps)
+    x = _ln(x, P["layernorm.weight"], P["layernorm.bias"], spec.vilt.layer_norm_eps)
+    out = {"last_hidden_state": x}
+    if spec.add_pooling_layer:
+        pooled = torch.tanh(F.linear(x[:, 0], P["pooler.dense.weight"], P["pooler.dense.bias"]))
+        out["pooler_output"] = pooled
+        if spec.n_classes > 0:
+            z = pooled
+            if classifier_keep_mask is not None:
+                z = z * classifier_keep_mask / (1.0 - classifier_p)
+            out["logits"] = F.linear(z, P["classifier.1.weight"], P["classifier.1.bias"]).squeeze(-1)
+    return out
+
+
+def vault_loss(P, spec, batch, **kw):
+    out = vault_forward(P, spec, batch, **kw)
+    loss = F.cross_entropy(out["logits"], batch["labels"])
+    return loss, out
+
+
+def torch_batch(batch: Dict[str, np.ndarray]) -> Dict[str, torch.Tensor]:
+    return {k: _t(v) for k, v in batch.items()}
+
+
+# --------------------------------------------------------------------------------------
+# optimizer / schedule (formula restatement, float64 capable)
+# --------------------------------------------------------------------------------------
+def hf_adamw_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+                  correct_bias=False):
+    """One transformers-4.48 ``AdamW.step`` on arrays (in place on p, m, v; returns them).
+
+    exp_avg.mul_(b1).add_(g, alpha=1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, value=1-b2)
+    denom = exp_avg_sq.sqrt().add_(eps); step_size = lr [* sqrt(1-b2^t)/(1-b1^t)]
+    p.addcdiv_(exp_avg, denom, value=-step_size); then p.add_(p, alpha=-lr*wd) if wd > 0.
+    """
+    m *= beta1
+    m += (1.0 - beta1) * g
+    v *= beta2
+    v += (1.0 - beta2) * g * g
+    denom = np.sqrt(v) + eps if isinstance(v, np.ndarray) else v.sqrt() + eps
+    step_size = lr
+    if correct_bias:
+        step_size = lr * math.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)
+    p -= step_size * (m / denom)
+    if weight_decay > 0.0:
+        p -= lr * weight_decay * p
+    return p, m, v
+
+
+def linear_schedule_lr(base_lr: float, step: int, warmup_steps: int, total_steps: int) -> float:
+    """``get_linear_schedule_with_warmup`` multiplier x base lr; ``step`` = number of
+    scheduler.step() calls so far (the lr used by optimizer step number ``step``, 0-based)."""
+    if step < warmup_steps:
+        return base_lr * float(step) / float(max(1, warmup_steps))
+    return base_lr * max(0.0, float(total_steps - step) / float(max(1, total_steps - warmup_steps)))

@@ -1,0 +1,95 @@
+// Shared device helpers for the VAuLT hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+#define GLB_PTR(T, p) ((const __attribute__((address_space(1))) T*)(p))
+
+// 16-byte async global -> LDS copy (global_load_lds_dwordx4).  `lds_dst` must be wave-uniform:
+// lane l lands at lds_dst + 16*l; the global address is per lane.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds(GLB_PTR(void, gsrc), LDS_PTR(void, lds_dst), 16, 0, 0);
+}
+
+// Transposed LDS read: per 16-lane group a 4-row x 16-col block of 16-bit elements, lane 4q+p gives
+// the address of row q / cols 4p..4p+3, lane i receives column i (rows 0..3).
+__device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds_addr));
+}
+
+__device__ __forceinline__ bf16x8 cat_tr(s16x4 lo, s16x4 hi) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ float bf16_to_f32(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f32_to_bf16(float x) { return (bf16)x; }
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  bf16x2 v = {(bf16)lo, (bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float2 unpack_bf16x2(uint32_t u) {
+  bf16x2 v = __builtin_bit_cast(bf16x2, u);
+  return make_float2((float)v[0], (float)v[1]);
+}
+
+// erf(x) by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): enough for values that are rounded to bf16
+// afterwards, at ~1/3 the VALU cost of the libm erff.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  p = p * t;
+  const float e = __expf(-ax * ax);
+  const float r = 1.0f - p * e;
+  return copysignf(r, x);
+}
+// exact-erf GELU (HF "gelu" == torch.nn.functional.gelu, HF:activations.py:70-89)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// counter-based keep/drop decision for dropout: a 32-bit mix of (seed, stream, element index).
+// The same function regenerates the mask in backward, so no mask tensor is stored.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool dropout_keep(uint32_t seed, uint32_t stream, uint32_t idx, uint32_t thresh) {
+  // keep iff hash >= thresh, thresh = p * 2^32
+  const uint32_t h = mix32(idx * 0x9E3779B9U + mix32(seed ^ (stream * 0x85EBCA6BU)));
+  return h >= thresh;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+#define VAULT_OK 0
+#define VAULT_EINVAL 22

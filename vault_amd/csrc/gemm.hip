@@ -1,0 +1,359 @@
+// bf16 MFMA GEMM for gfx950 with fused epilogues: the work-horse of the BERT->ViLT hot path.
+//
+//   C[M,N] (+)= A . B        fp32 accumulate, v_mfma_f32_16x16x32_bf16
+//
+// Operand storage modes (so forward, dgrad and wgrad all run without transposed copies):
+//   A_MODE 0: A stored [M][K] (K contiguous)   -> fragments by ds_read_b128
+//   A_MODE 1: A stored [K][M] (M contiguous)   -> fragments by ds_read_b64_tr_b16
+//   B_MODE 0: B stored [N][K] (K contiguous; an HF Linear weight [out,in])
+//   B_MODE 1: B stored [K][N] (N contiguous)
+//     forward  Y = X W^T        : A0 (X [M,K])      B0 (W [N,K])
+//     dgrad    dX = dY W        : A0 (dY [M,Nout])  B1 (W [Nout,Kin] = [K][N])
+//     wgrad    dW = dY^T X      : A1 (dY [Mtok,Nout] = [K][M])  B1 (X [Mtok,Kin] = [K][N])
+//
+// Structure: BMxBNx64 tiles, global->LDS by 16-byte global_load_lds (double buffered, one
+// barrier per K tile), XOR-swizzled LDS images (swizzle applied on the per-lane SOURCE address
+// and on the read address; the LDS destination of a global_load_lds is lane-linear),
+// XCD-aware block->tile mapping, LDS-staged epilogue so that every global store/load of the
+// epilogue is a full 128-byte row segment.
+//
+// Replaces (reference, via HuggingFace/ATen): every nn.Linear of
+// HF:models/vilt/modeling_vilt.py:303-414 and HF:models/roberta/modeling_roberta.py:222-398, the
+// Conv2d patch projection (modeling_vilt.py:290-300) and their autograd backward.
+#include "common.h"
+#include "gemm.h"
+
+namespace {
+
+constexpr int BK = 64;
+
+template <int EPI> struct EpiTraits;
+
+template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, int EPI>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM / 16;
+  constexpr int TN = BN / WN / 16;
+  constexpr int A_BYTES = BM * BK * 2;
+  constexpr int B_BYTES = BN * BK * 2;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int NIA = A_BYTES / 1024 / NW;  // global_load_lds wave-instructions per wave per tile
+  constexpr int NIB = B_BYTES / 1024 / NW;
+  static_assert(NIA >= 1 && NIB >= 1, "tile too small for the wave count");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave / WN) * (BM / WM);
+  const int wn0 = (wave % WN) * (BN / WN);
+
+  // ---- block -> tile (XCD-aware: blocks with equal id%8 share an L2; give each XCD a
+  //      contiguous run of tiles so the A row panel and the whole of B stay L2-resident)
+  const int tiles_n = p.N / BN;
+  int tile_m, tile_n;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    tile_m = wg / tiles_n;
+    tile_n = wg - tile_m * tiles_n;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- split-K range
+  const int nk_total = p.K / BK;
+  const int per = (nk_total + p.splits - 1) / p.splits;
+  const int kt0 = blockIdx.z * per;
+  const int kt1 = min(nk_total, kt0 + per);
+  const int nk = kt1 - kt0;
+
+  // ---- per-lane staging sources
+  const bf16* a_src[NIA];
+  const bf16* b_src[NIB];
+  if constexpr (A_MODE == 0) {
+    const int r8 = lane >> 3, pos = lane & 7;
+    const int c = pos ^ (((r8 >> 1) & 3) << 1);
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const int row = 8 * (wave * NIA + i) + r8;
+      a_src[i] = p.A + (size_t)(m0 + row) * p.lda + (size_t)kt0 * BK + c * 8;
+    }
+  } else {
+    constexpr int CPR = BM / 8;          // 16-byte chunks per k-row
+    constexpr int RPI = 64 / CPR;        // k-rows per wave-instruction
+    const int kin = lane / CPR, pos16 = lane % CPR;
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const int krow = (wave * NIA + i) * RPI + kin;
+      const int h = (krow & 3) | (((krow >> 3) & 1) << 2);
+      const int col = (((pos16 >> 1) ^ h) << 4) + ((pos16 & 1) << 3);
+      a_src[i] = p.A + (size_t)(kt0 * BK + krow) * p.lda + m0 + col;
+    }
+  }
+  if constexpr (B_MODE == 0) {
+    const int r8 = lane >> 3, pos = lane & 7;
+    const int c = pos ^ (((r8 >> 1) & 3) << 1);
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int row = 8 * (wave * NIB + i) + r8;
+      b_src[i] = p.B + (size_t)(n0 + row) * p.ldb + (size_t)kt0 * BK + c * 8;
+    }
+  } else {
+    constexpr int CPR = BN / 8;
+    constexpr int RPI = 64 / CPR;
+    const int kin = lane / CPR, pos16 = lane % CPR;
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int krow = (wave * NIB + i) * RPI + kin;
+      const int h = (krow & 3) | (((krow >> 3) & 1) << 2);
+      const int col = (((pos16 >> 1) ^ h) << 4) + ((pos16 & 1) << 3);
+      b_src[i] = p.B + (size_t)(kt0 * BK + krow) * p.ldb + n0 + col;
+    }
+  }
+  const size_t a_step = (A_MODE == 0) ? (size_t)BK : (size_t)BK * p.lda;
+  const size_t b_step = (B_MODE == 0) ? (size_t)BK : (size_t)BK * p.ldb;
+
+  auto stage = [&](int buf, int t) {
+    char* sa = smem + buf * STAGE + wave * NIA * 1024;
+    char* sb = smem + buf * STAGE + A_BYTES + wave * NIB * 1024;
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) glds16(a_src[i] + (size_t)t * a_step, sa + i * 1024);
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) glds16(b_src[i] + (size_t)t * b_step, sb + i * 1024);
+  };
+
+  // ---- per-lane fragment read offsets (bytes inside the A / B image of a stage)
+  const int g = lane >> 4, l15 = lane & 15;
+  int a_off[2], b_off[2];  // [k-step] for mode 0 ; [half] for mode 1
+  if constexpr (A_MODE == 0) {
+    const int fx = ((l15 >> 1) & 3) << 1;
+    a_off[0] = (wm0 + l15) * 128 + ((g ^ fx) << 4);
+    a_off[1] = (wm0 + l15) * 128 + (((4 + g) ^ fx) << 4);
+  } else {
+    const int q = l15 >> 2, pp = l15 & 3, h = q | ((g & 1) << 2);
+    // address of (krow = 8g + q [+4], col block cb): krow*BM*2 + ((cb ^ h) * 32) + pp*8 ; cb added later
+    a_off[0] = (8 * g + q) * (BM * 2) + pp * 8;
+    a_off[1] = h;  // swizzle key
+  }
+  if constexpr (B_MODE == 0) {
+    const int fx = ((l15 >> 1) & 3) << 1;
+    b_off[0] = (wn0 + l15) * 128 + ((g ^ fx) << 4);
+    b_off[1] = (wn0 + l15) * 128 + (((4 + g) ^ fx) << 4);
+  } else {
+    const int q = l15 >> 2, pp = l15 & 3, h = q | ((g & 1) << 2);
+    b_off[0] = (8 * g + q) * (BN * 2) + pp * 8;
+    b_off[1] = h;
+  }
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) stage(0, 0);
+  for (int t = 0; t < nk; ++t) {
+    __syncthreads();  // tile t has landed (vmcnt(0) precedes the barrier) and buffer (t+1)&1 is free
+    if (t + 1 < nk) stage((t + 1) & 1, t + 1);
+    const char* As = smem + (t & 1) * STAGE;
+    const char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (A_MODE == 0) {
+          af[i] = *LDS_PTR(const bf16x8, As + a_off[s] + i * 16 * 128);
+        } else {
+          const int cb = (wm0 >> 4) + i;
+          const char* base = As + a_off[0] + s * 32 * (BM * 2) + ((cb ^ a_off[1]) << 5);
+          af[i] = cat_tr(lds_read_tr16(base), lds_read_tr16(base + 4 * (BM * 2)));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (B_MODE == 0) {
+          bfr[j] = *LDS_PTR(const bf16x8, Bs + b_off[s] + j * 16 * 128);
+        } else {
+          const int cb = (wn0 >> 4) + j;
+          const char* base = Bs + b_off[0] + s * 32 * (BN * 2) + ((cb ^ b_off[1]) << 5);
+          bfr[j] = cat_tr(lds_read_tr16(base), lds_read_tr16(base + 4 * (BN * 2)));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: accumulators -> per-wave LDS scratch -> row segments of SEG floats per lane
+  __syncthreads();
+  constexpr int SEG = TN * 4;                 // floats per lane per row
+  constexpr int LDS_LD = TN * 16 + 4;         // padded scratch row (floats)
+  float* sc = reinterpret_cast<float*>(smem) + wave * (16 * LDS_LD);
+  const int rr = lane >> 2, cs = (lane & 3) * SEG;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc[(4 * g + r) * LDS_LD + j * 16 + l15] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
+    float v[SEG];
+#pragma unroll
+    for (int c = 0; c < SEG; c += 4) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(&sc[rr * LDS_LD + cs + c]);
+      v[c] = t4[0]; v[c + 1] = t4[1]; v[c + 2] = t4[2]; v[c + 3] = t4[3];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int m = m0 + wm0 + i * 16 + rr;
+    const int n = n0 + wn0 + cs;
+    if (m >= p.m_valid) continue;
+    size_t orow = (size_t)m;
+    if constexpr (EPI == EPI_F32_PATCH) {
+      const int grp = m / p.rpg, pi = m - grp * p.rpg;
+      orow = (size_t)grp * p.gstride + p.goff + pi;
+#pragma unroll
+      for (int c = 0; c < SEG; c += 4) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.addtab + (size_t)pi * p.N + n + c);
+        v[c] += t4[0]; v[c + 1] += t4[1]; v[c + 2] += t4[2]; v[c + 3] += t4[3];
+      }
+    } else if constexpr (EPI != EPI_F32_ATOMIC) {
+      if (p.bias != nullptr) {
+#pragma unroll
+        for (int c = 0; c < SEG; c += 4) {
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.bias + n + c);
+          v[c] += t4[0]; v[c + 1] += t4[1]; v[c + 2] += t4[2]; v[c + 3] += t4[3];
+        }
+      }
+    }
+    const size_t o = orow * p.ldo + n;
+    if constexpr (EPI == EPI_F32_ATOMIC) {
+      float* out = reinterpret_cast<float*>(p.out) + o;
+      if (p.splits == 1 && p.accumulate == 0) {
+#pragma unroll
+        for (int c = 0; c < SEG; c += 4)
+          *reinterpret_cast<f32x4*>(out + c) = f32x4{v[c], v[c + 1], v[c + 2], v[c + 3]};
+      } else {
+#pragma unroll
+        for (int c = 0; c < SEG; ++c) atomicAdd(out + c, v[c]);
+      }
+    } else if constexpr (EPI == EPI_F32_RES || EPI == EPI_F32_PATCH) {
+      float* out = reinterpret_cast<float*>(p.out) + o;
+      if constexpr (EPI == EPI_F32_RES) {
+        if (p.drop_thresh != 0u) {
+          const float sc_keep = p.drop_scale;
+#pragma unroll
+          for (int c = 0; c < SEG; ++c)
+            v[c] = dropout_keep(p.drop_seed, p.drop_stream, (uint32_t)(o + c), p.drop_thresh) ? v[c] * sc_keep : 0.f;
+        }
+        if (p.res != nullptr) {
+#pragma unroll
+          for (int c = 0; c < SEG; c += 4) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.res + o + c);
+            v[c] += t4[0]; v[c + 1] += t4[1]; v[c + 2] += t4[2]; v[c + 3] += t4[3];
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < SEG; c += 4)
+        *reinterpret_cast<f32x4*>(out + c) = f32x4{v[c], v[c + 1], v[c + 2], v[c + 3]};
+    } else {
+      // bf16 outputs
+      if constexpr (EPI == EPI_BF16_GELU) {
+        if (p.out2 != nullptr) {
+          bf16* o2 = reinterpret_cast<bf16*>(p.out2) + o;
+#pragma unroll
+          for (int c = 0; c < SEG; c += 8) {
+            u32x4 w = {pack_bf16x2(v[c], v[c + 1]), pack_bf16x2(v[c + 2], v[c + 3]),
+                       pack_bf16x2(v[c + 4], v[c + 5]), pack_bf16x2(v[c + 6], v[c + 7])};
+            *reinterpret_cast<u32x4*>(o2 + c) = w;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < SEG; ++c) v[c] = gelu_f(v[c]);
+      } else if constexpr (EPI == EPI_BF16_DGELU) {
+        const bf16* ax = p.aux + o;
+#pragma unroll
+        for (int c = 0; c < SEG; c += 8) {
+          const bf16x8 u = *reinterpret_cast<const bf16x8*>(ax + c);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[c + e] *= dgelu_f((float)u[e]);
+        }
+      } else if constexpr (EPI == EPI_BF16_DROPMASK) {
+        // dgrad through a dropout that sits behind this Linear's *output* in forward:
+        // handled by the caller masking dY; nothing to do here.
+      }
+      bf16* out = reinterpret_cast<bf16*>(p.out) + o;
+#pragma unroll
+      for (int c = 0; c < SEG; c += 8) {
+        u32x4 w = {pack_bf16x2(v[c], v[c + 1]), pack_bf16x2(v[c + 2], v[c + 3]),
+                   pack_bf16x2(v[c + 4], v[c + 5]), pack_bf16x2(v[c + 6], v[c + 7])};
+        *reinterpret_cast<u32x4*>(out + c) = w;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, int EPI>
+int launch_cfg(const GemmParams& p, hipStream_t st) {
+  if (p.M % BM || p.N % BN || p.K % BK) return VAULT_EINVAL;
+  constexpr int STAGE = (BM + BN) * BK * 2;
+  constexpr int LDS = 2 * STAGE;
+  auto kern = gemm_kernel<BM, BN, WM, WN, A_MODE, B_MODE, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  dim3 grid((p.M / BM) * (p.N / BN), 1, p.splits);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), LDS, st, p);
+  return (int)hipGetLastError();
+}
+
+template <int A_MODE, int B_MODE, int EPI>
+int launch_modes(const GemmParams& p, int cfg, hipStream_t st) {
+  switch (cfg) {
+    case 0: return launch_cfg<128, 128, 2, 2, A_MODE, B_MODE, EPI>(p, st);
+    case 1: return launch_cfg<256, 128, 4, 2, A_MODE, B_MODE, EPI>(p, st);
+    case 2: return launch_cfg<256, 256, 2, 4, A_MODE, B_MODE, EPI>(p, st);
+    default: return VAULT_EINVAL;
+  }
+}
+
+}  // namespace
+
+int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, int cfg, hipStream_t st) {
+  GemmParams p = p_in;
+  if (p.splits < 1) p.splits = 1;
+  if (p.A == nullptr || p.B == nullptr || p.out == nullptr) return VAULT_EINVAL;
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return VAULT_EINVAL;
+  if ((p.lda & 7) || (p.ldb & 7) || (p.ldo & 7)) return VAULT_EINVAL;
+  if (cfg < 0) {
+    // default tile choice: 256x128 for big forward/dgrad shapes, 128x128 otherwise
+    cfg = (p.M % 256 == 0 && p.N % 128 == 0 && epi != EPI_F32_ATOMIC) ? 1 : 0;
+  }
+  const int key = a_mode * 2 + b_mode;
+#define VAULT_DISPATCH(AM, BMD)                                                             \
+  switch (epi) {                                                                            \
+    case EPI_BF16: return launch_modes<AM, BMD, EPI_BF16>(p, cfg, st);                      \
+    case EPI_BF16_GELU: return launch_modes<AM, BMD, EPI_BF16_GELU>(p, cfg, st);            \
+    case EPI_BF16_DGELU: return launch_modes<AM, BMD, EPI_BF16_DGELU>(p, cfg, st);          \
+    case EPI_F32_RES: return launch_modes<AM, BMD, EPI_F32_RES>(p, cfg, st);                \
+    case EPI_F32_PATCH: return launch_modes<AM, BMD, EPI_F32_PATCH>(p, cfg, st);            \
+    case EPI_F32_ATOMIC: return launch_modes<AM, BMD, EPI_F32_ATOMIC>(p, cfg, st);          \
+    default: return VAULT_EINVAL;                                                           \
+  }
+  switch (key) {
+    case 0: VAULT_DISPATCH(0, 0)
+    case 1: VAULT_DISPATCH(0, 1)
+    case 3: VAULT_DISPATCH(1, 1)
+    default: return VAULT_EINVAL;
+  }
+#undef VAULT_DISPATCH
+}
