@@ -1,0 +1,141 @@
+"""GPU parity of the bf16 MFMA GEMM (through the C ABI) against a plain fp32 torch matmul of the
+same bf16-rounded operands.  Tolerance: fp32 accumulation order only -> 2e-3 * scale absolute for
+f32 outputs, plus one bf16 rounding (2^-8 relative) for bf16 outputs."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+from vault_amd import lib as L
+
+pytestmark = pytest.mark.gpu
+
+EPI_BF16, EPI_GELU, EPI_DGELU, EPI_RES, EPI_PATCH, EPI_ATOMIC = range(6)
+
+
+def _gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, cfg=-1, m_valid=0, splits=1, bias=None,
+          res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, accumulate=0):
+    lib = L.load()
+    a = L.GemmArgs()
+    a.A, a.B, a.out = A.data_ptr(), B.data_ptr(), out.data_ptr()
+    a.out2 = out2.data_ptr() if out2 is not None else None
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.res = res.data_ptr() if res is not None else None
+    a.aux = aux.data_ptr() if aux is not None else None
+    a.addtab = addtab.data_ptr() if addtab is not None else None
+    a.M, a.N, a.K, a.lda, a.ldb, a.ldo, a.m_valid = M, N, K, lda, ldb, ldo, m_valid
+    a.a_mode, a.b_mode, a.epi, a.cfg, a.splits, a.accumulate = a_mode, b_mode, epi, cfg, splits, accumulate
+    a.rpg, a.gstride, a.goff = rpg, gstride, goff
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(lib.vault_gemm(C.byref(a), C.c_void_p(st)), "vault_gemm")
+
+
+def _rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(512, 768, 768), (256, 2304, 768), (768, 768, 3072)])
+def test_forward_nt_bias(cfg, shape):
+    M, N, K = shape
+    A = _rand(M, K, seed=1).bfloat16()
+    W = _rand(N, K, scale=0.05, seed=2).bfloat16()
+    bias = _rand(N, seed=3)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    m_valid = M - 37
+    _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_BF16, cfg=cfg, bias=bias, m_valid=m_valid)
+    ref = A.float() @ W.float().t() + bias
+    torch.cuda.synchronize()
+    err = (out[:m_valid].float() - ref[:m_valid]).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= scale * 2 ** -7, (err, scale)
+    assert out[m_valid:].abs().max().item() == 0.0  # masked rows untouched
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+def test_forward_gelu_and_residual(cfg):
+    M, N, K = 512, 1024, 256
+    A = _rand(M, K, seed=4).bfloat16()
+    W = _rand(N, K, scale=0.1, seed=5).bfloat16()
+    bias = _rand(N, seed=6)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    pre = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_GELU, cfg=cfg, bias=bias, out2=pre)
+    z = A.float() @ W.float().t() + bias
+    ref = torch.nn.functional.gelu(z)
+    torch.cuda.synchronize()
+    assert (pre.float() - z).abs().max().item() <= z.abs().max().item() * 2 ** -7
+    assert (out.float() - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7
+    # f32 residual epilogue
+    res = _rand(M, N, seed=7)
+    o32 = torch.zeros(M, N, device="cuda")
+    _gemm(A, W, o32, M, N, K, K, K, N, 0, 0, EPI_RES, cfg=cfg, bias=bias, res=res)
+    torch.cuda.synchronize()
+    assert (o32 - (z + res)).abs().max().item() <= 2e-4 * z.abs().max().item()
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+def test_dgrad_nn_and_dgelu(cfg):
+    # dX[M,Kin] = dY[M,Nout] . W[Nout,Kin]  (A mode 0, B mode 1)
+    M, Nout, Kin = 512, 768, 1024
+    dY = _rand(M, Nout, seed=8).bfloat16()
+    W = _rand(Nout, Kin, scale=0.05, seed=9).bfloat16()
+    dX = torch.zeros(M, Kin, dtype=torch.bfloat16, device="cuda")
+    _gemm(dY, W, dX, M, Kin, Nout, Nout, Kin, Kin, 0, 1, EPI_BF16, cfg=cfg)
+    ref = dY.float() @ W.float()
+    torch.cuda.synchronize()
+    assert (dX.float() - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7
+    u = _rand(M, Kin, seed=10).bfloat16()
+    _gemm(dY, W, dX, M, Kin, Nout, Nout, Kin, Kin, 0, 1, EPI_DGELU, cfg=cfg, aux=u)
+    uf = u.float()
+    dg = 0.5 * (1 + torch.erf(uf / math.sqrt(2))) + uf * torch.exp(-0.5 * uf * uf) / math.sqrt(2 * math.pi)
+    ref2 = ref * dg
+    torch.cuda.synchronize()
+    assert (dX.float() - ref2).abs().max().item() <= ref2.abs().max().item() * 2 ** -7
+
+
+@pytest.mark.parametrize("cfg", [0, 2])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_wgrad_tn_splitk(cfg, splits):
+    # dW[Nout,Kin] = dY[Mtok,Nout]^T . X[Mtok,Kin]  (A mode 1, B mode 1), contraction over tokens
+    Mtok, Nout, Kin = 1024, 768, 512
+    dY = _rand(Mtok, Nout, seed=11).bfloat16()
+    X = _rand(Mtok, Kin, seed=12).bfloat16()
+    dY[1000:] = 0  # pad rows of a token buffer are zero
+    dW = torch.zeros(Nout, Kin, device="cuda")
+    _gemm(dY, X, dW, Nout, Kin, Mtok, Nout, Kin, Kin, 1, 1, EPI_ATOMIC, cfg=cfg, splits=splits)
+    ref = dY.float().t() @ X.float()
+    torch.cuda.synchronize()
+    assert (dW - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-3
+    # accumulate on top
+    _gemm(dY, X, dW, Nout, Kin, Mtok, Nout, Kin, Kin, 1, 1, EPI_ATOMIC, cfg=cfg, splits=splits, accumulate=1)
+    torch.cuda.synchronize()
+    assert (dW - 2 * ref).abs().max().item() <= 4e-4 * ref.abs().max().item() + 2e-3
+
+
+def test_patch_epilogue_rowmap():
+    # rows of group b (rpg patches) land at b*gstride + goff + p, plus a per-patch additive table
+    B_, rpg, N, K = 4, 144, 256, 192
+    M = 640  # 576 valid rows padded to a tile multiple
+    A = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+    A[: B_ * rpg] = _rand(B_ * rpg, K, seed=13).bfloat16()
+    W = _rand(N, K, scale=0.1, seed=14).bfloat16()
+    tab = _rand(rpg, N, seed=15)
+    S = 185
+    out = torch.zeros(B_ * S, N, device="cuda")
+    _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_PATCH, cfg=0, m_valid=B_ * rpg, addtab=tab, rpg=rpg,
+          gstride=S, goff=41)
+    ref = (A[: B_ * rpg].float() @ W.float().t()).view(B_, rpg, N) + tab
+    torch.cuda.synchronize()
+    got = out.view(B_, S, N)[:, 41:41 + rpg]
+    assert (got - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-4
+    assert out.view(B_, S, N)[:, :41].abs().max().item() == 0.0
+
+
+def test_einval_on_bad_shapes():
+    A = torch.zeros(128, 64, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(128, 128, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError):
+        _gemm(A, A, out, 100, 128, 64, 64, 64, 128, 0, 0, EPI_BF16)

@@ -1,0 +1,24 @@
+// C-ABI wrapper of the GEMM (see include/vault_hip.h).
+#include "common.h"
+#include "gemm.h"
+#include "../../include/vault_hip.h"
+
+extern "C" int vault_gemm(const vault_gemm_args* a, void* stream) {
+  if (a == nullptr) return VAULT_EINVAL;
+  GemmParams p{};
+  p.A = reinterpret_cast<const __bf16*>(a->A);
+  p.B = reinterpret_cast<const __bf16*>(a->B);
+  p.M = a->M; p.N = a->N; p.K = a->K;
+  p.lda = a->lda; p.ldb = a->ldb; p.ldo = a->ldo;
+  p.m_valid = a->m_valid > 0 ? a->m_valid : a->M;
+  p.splits = a->splits; p.accumulate = a->accumulate;
+  p.out = a->out; p.out2 = a->out2;
+  p.bias = a->bias; p.res = a->res;
+  p.aux = reinterpret_cast<const __bf16*>(a->aux);
+  p.addtab = a->addtab; p.rpg = a->rpg; p.gstride = a->gstride; p.goff = a->goff;
+  p.drop_thresh = a->drop_thresh; p.drop_seed = a->drop_seed; p.drop_stream = a->drop_stream;
+  p.drop_scale = a->drop_scale;
+  return vault_gemm_launch(p, a->a_mode, a->b_mode, a->epi, a->cfg, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int vault_abi_version(void) { return 1; }

@@ -1,0 +1,38 @@
+// Internal (C++) interface of the bf16 MFMA GEMM.  The public C-ABI wrapper is vault_gemm in
+// include/vault_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum GemmEpi {
+  EPI_BF16 = 0,        // out_bf16 = acc (+ bias)
+  EPI_BF16_GELU = 1,   // out2_bf16 = acc + bias (optional, pre-activation) ; out_bf16 = gelu(acc + bias)
+  EPI_BF16_DGELU = 2,  // out_bf16 = acc * gelu'(aux_bf16)
+  EPI_F32_RES = 3,     // out_f32 = dropout(acc + bias) + res_f32
+  EPI_F32_PATCH = 4,   // out_f32[rowmap(m)] = acc + addtab[m % rpg]   (patch embedding into the fused sequence)
+  EPI_F32_ATOMIC = 5,  // out_f32 += acc   (wgrad; split-K partials by float atomics)
+  EPI_BF16_DROPMASK = 6,
+};
+
+struct GemmParams {
+  const __bf16* A;
+  const __bf16* B;
+  int M, N, K;      // output M x N, contraction K; M % BM == N % BN == K % 64 == 0 (buffers padded)
+  int lda, ldb;     // leading dimensions in elements (see A_MODE / B_MODE in gemm.hip)
+  int m_valid;      // rows >= m_valid are never stored
+  int splits;       // split-K factor (grid.z)
+  int accumulate;   // EPI_F32_ATOMIC: 1 = add into out even when splits == 1
+  void* out;
+  int ldo;
+  void* out2;
+  const float* bias;
+  const float* res;
+  const __bf16* aux;
+  const float* addtab;
+  int rpg, gstride, goff;
+  // inverted dropout on (acc + bias) for EPI_F32_RES; thresh == 0 disables it
+  uint32_t drop_thresh, drop_seed, drop_stream;
+  float drop_scale;
+};
+
+int vault_gemm_launch(const GemmParams& p, int a_mode, int b_mode, int epi, int cfg, hipStream_t st);

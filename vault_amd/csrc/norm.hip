@@ -1,0 +1,247 @@
+// LayerNorm forward/backward and column-sum (bias gradient) kernels, fp32 statistics.
+// One wave per row, 16-byte accesses; H must be a multiple of 256 (64 lanes x float4).
+//
+// Replaces nn.LayerNorm at HF:models/vilt/modeling_vilt.py:431-447,637 (pre-LN, eps 1e-12) and
+// HF:models/roberta/modeling_roberta.py:339,397 (post-LN, eps 1e-5) and their backward.
+#include "common.h"
+#include "../../include/vault_hip.h"
+
+namespace {
+
+struct RowMap {  // logical row r -> physical row (r / rpg) * gstride + goff + r % rpg ; rpg == 0: identity
+  int rpg, gstride, goff;
+  __device__ __forceinline__ size_t operator()(int r) const {
+    if (rpg == 0) return (size_t)r;
+    const int gq = r / rpg;
+    return (size_t)gq * gstride + goff + (r - gq * rpg);
+  }
+};
+
+template <int VPT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, RowMap xmap,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, int rows, int H,
+                                                     bf16* __restrict__ y_bf16, float* __restrict__ y_f32, RowMap ymap,
+                                                     const float* __restrict__ post_add,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     uint32_t drop_thresh, uint32_t drop_seed, uint32_t drop_stream,
+                                                     float drop_scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + xmap(row) * H;
+  f32x4 v[VPT];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    v[j] = *reinterpret_cast<const f32x4*>(xr + (lane + 64 * j) * 4);
+    s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+  }
+  const float mu = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[j][e] - mu;
+      q += d * d;
+    }
+  const float var = wave_sum(q) / (float)H;
+  const float rs = 1.0f / sqrtf(var + eps);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+  const size_t orow = ymap(row);
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int c = (lane + 64 * j) * 4;
+    const f32x4 gw = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 bw = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mu) * rs * gw[e] + bw[e];
+    if (drop_thresh != 0u) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        o[e] = dropout_keep(drop_seed, drop_stream, (uint32_t)(orow * H + c + e), drop_thresh) ? o[e] * drop_scale : 0.f;
+    }
+    if (post_add) {
+      const f32x4 pa = *reinterpret_cast<const f32x4*>(post_add + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += pa[e];
+    }
+    if (y_f32) *reinterpret_cast<f32x4*>(y_f32 + orow * H + c) = o;
+    if (y_bf16) {
+      uint2 w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+      *reinterpret_cast<uint2*>(y_bf16 + orow * H + c) = w;
+    }
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ; dy = dy_bf16 + dy_f32 (either may be
+// null).  Outputs dx_f32 = dx + dres (optional) and a bf16 copy (optionally dropout-masked for the
+// branch that sits behind a dropout in forward).  dgamma / dbeta: per-block partials + float atomics.
+template <int VPT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy_bf16, const float* __restrict__ dy_f32,
+                                                     RowMap dymap, const float* __restrict__ x, RowMap xmap,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, int rows, int H,
+                                                     const float* __restrict__ dres, float* __restrict__ dx_f32,
+                                                     bf16* __restrict__ dx_bf16, RowMap dxmap, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int rows_per_block,
+                                                     uint32_t drop_thresh, uint32_t drop_seed, uint32_t drop_stream,
+                                                     float drop_scale) {
+  __shared__ float red[4][VPT * 256 * 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 gw[VPT], ag[VPT], ab[VPT];
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    gw[j] = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * j) * 4);
+    ag[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ab[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  for (int row = r0 + wave; row < r1; row += 4) {
+    const size_t xr = xmap(row) * H, dr = dymap(row) * H;
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[VPT], gy[VPT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + xr + c);
+      f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (dy_f32) d = *reinterpret_cast<const f32x4*>(dy_f32 + dr + c);
+      if (dy_bf16) {
+        const uint2 w = *reinterpret_cast<const uint2*>(dy_bf16 + dr + c);
+        const float2 a = unpack_bf16x2(w.x), b = unpack_bf16x2(w.y);
+        d[0] += a.x; d[1] += a.y; d[2] += b.x; d[3] += b.y;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[j][e] = (xv[e] - mu) * rs;
+        gy[j][e] = d[e] * gw[j][e];
+        s1 += gy[j][e];
+        s2 += gy[j][e] * xh[j][e];
+        ag[j][e] += d[e] * xh[j][e];
+        ab[j][e] += d[e];
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+    const size_t orow = dxmap(row) * H;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = rs * (gy[j][e] - s1 - xh[j][e] * s2);
+      if (dres) {
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(dres + orow + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += rv[e];
+      }
+      if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + orow + c) = o;
+      if (dx_bf16) {
+        if (drop_thresh != 0u) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            o[e] = dropout_keep(drop_seed, drop_stream, (uint32_t)(orow + c + e), drop_thresh) ? o[e] * drop_scale : 0.f;
+        }
+        uint2 w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        *reinterpret_cast<uint2*>(dx_bf16 + orow + c) = w;
+      }
+    }
+  }
+  if (dgamma == nullptr) return;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[wave][((lane + 64 * j) * 4 + e) * 2] = ag[j][e];
+      red[wave][((lane + 64 * j) * 4 + e) * 2 + 1] = ab[j][e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) {
+    const float sg = red[0][c * 2] + red[1][c * 2] + red[2][c * 2] + red[3][c * 2];
+    const float sb = red[0][c * 2 + 1] + red[1][c * 2 + 1] + red[2][c * 2 + 1] + red[3][c * 2 + 1];
+    atomicAdd(dgamma + c, sg);
+    atomicAdd(dbeta + c, sb);
+  }
+}
+
+// out[n] += sum over rows < rows of in[row][n]  (bias gradients); N % 256 == 0
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ in, int ld, int rows, int rows_per_block,
+                                                     float* __restrict__ out) {
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 256 + lane * 4;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int r = r0 + wave; r < r1; r += 4) {
+    const uint2 w = *reinterpret_cast<const uint2*>(in + (size_t)r * ld + c0);
+    const float2 x = unpack_bf16x2(w.x), y = unpack_bf16x2(w.y);
+    a0 += x.x; a1 += x.y; a2 += y.x; a3 += y.y;
+  }
+  red[wave][lane * 4] = a0; red[wave][lane * 4 + 1] = a1; red[wave][lane * 4 + 2] = a2; red[wave][lane * 4 + 3] = a3;
+  __syncthreads();
+  const int c = threadIdx.x;
+  atomicAdd(out + blockIdx.x * 256 + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+}
+
+}  // namespace
+
+extern "C" int vault_layernorm_fwd(const vault_ln_fwd_args* a, void* stream) {
+  if (!a || a->H % 256 || a->H > 1024 || a->rows <= 0) return VAULT_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const RowMap xm{a->x_rpg, a->x_gstride, a->x_goff}, ym{a->y_rpg, a->y_gstride, a->y_goff};
+  dim3 grid((a->rows + 3) / 4), block(256);
+#define LN_FWD(V)                                                                                          \
+  hipLaunchKernelGGL(ln_fwd_kernel<V>, grid, block, 0, st, a->x, xm, a->gamma, a->beta, a->eps, a->rows,   \
+                     a->H, reinterpret_cast<bf16*>(a->y_bf16), a->y_f32, ym, a->post_add, a->mean, a->rstd, \
+                     a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale)
+  switch (a->H / 256) {
+    case 1: LN_FWD(1); break;
+    case 2: LN_FWD(2); break;
+    case 3: LN_FWD(3); break;
+    case 4: LN_FWD(4); break;
+  }
+#undef LN_FWD
+  return (int)hipGetLastError();
+}
+
+extern "C" int vault_layernorm_bwd(const vault_ln_bwd_args* a, void* stream) {
+  if (!a || a->H % 256 || a->H > 1024 || a->rows <= 0) return VAULT_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const RowMap dym{a->dy_rpg, a->dy_gstride, a->dy_goff}, xm{a->x_rpg, a->x_gstride, a->x_goff},
+      dxm{a->dx_rpg, a->dx_gstride, a->dx_goff};
+  int rpb = (a->rows + 1023) / 1024;  // <= 1024 blocks
+  rpb = ((rpb + 3) / 4) * 4;
+  dim3 grid((a->rows + rpb - 1) / rpb), block(256);
+#define LN_BWD(V)                                                                                              \
+  hipLaunchKernelGGL(ln_bwd_kernel<V>, grid, block, 0, st, reinterpret_cast<const bf16*>(a->dy_bf16), a->dy_f32, \
+                     dym, a->x, xm, a->mean, a->rstd, a->gamma, a->rows, a->H, a->dres, a->dx_f32,               \
+                     reinterpret_cast<bf16*>(a->dx_bf16), dxm, a->dgamma, a->dbeta, rpb, a->drop_thresh,          \
+                     a->drop_seed, a->drop_stream, a->drop_scale)
+  switch (a->H / 256) {
+    case 1: LN_BWD(1); break;
+    case 2: LN_BWD(2); break;
+    case 3: LN_BWD(3); break;
+    case 4: LN_BWD(4); break;
+  }
+#undef LN_BWD
+  return (int)hipGetLastError();
+}
+
+extern "C" int vault_colsum(const void* in_bf16, int ld, int rows, int N, float* out, void* stream) {
+  if (!in_bf16 || !out || N % 256 || rows <= 0) return VAULT_EINVAL;
+  int rpb = (rows + 127) / 128;
+  rpb = ((rpb + 3) / 4) * 4;
+  dim3 grid(N / 256, (rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const bf16*>(in_bf16), ld, rows, rpb, out);
+  return (int)hipGetLastError();
+}
