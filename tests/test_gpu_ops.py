@@ -1,0 +1,155 @@
+"""GPU parity of the LayerNorm / column-sum / attention kernels (through the C ABI) against plain
+fp32 torch references of the same ops on the same (bf16-rounded) inputs."""
+import math
+
+import pytest
+import torch
+
+from vault_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+@pytest.mark.parametrize("H", [256, 768])
+@pytest.mark.parametrize("eps", [1e-12, 1e-5])
+def test_layernorm_fwd_bwd(H, eps):
+    rows = 333
+    x = _rand(rows, H, seed=1) * 2 + 0.3
+    gam = 1 + 0.1 * _rand(H, seed=2)
+    bet = 0.1 * _rand(H, seed=3)
+    post = _rand(H, seed=4)
+    y16 = torch.zeros(rows, H, dtype=torch.bfloat16, device="cuda")
+    y32 = torch.zeros(rows, H, device="cuda")
+    mean = torch.zeros(rows, device="cuda"); rstd = torch.zeros(rows, device="cuda")
+    ops.layernorm_fwd(x, gam, bet, eps, rows, H, y_bf16=y16, y_f32=y32, mean=mean, rstd=rstd, post_add=post)
+    xr = x.clone().requires_grad_(True)
+    gr = gam.clone().requires_grad_(True)
+    br = bet.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (H,), gr, br, eps) + post
+    torch.cuda.synchronize()
+    assert (y32 - ref).abs().max().item() < 1e-4
+    assert (y16.float() - ref).abs().max().item() < ref.abs().max().item() * 2 ** -8
+    # backward: dy = bf16 part + f32 part, plus residual gradient
+    dy16 = _rand(rows, H, seed=5).bfloat16()
+    dy32 = _rand(rows, H, seed=6)
+    dres = _rand(rows, H, seed=7)
+    dx32 = torch.zeros(rows, H, device="cuda"); dx16 = torch.zeros(rows, H, dtype=torch.bfloat16, device="cuda")
+    dg = torch.zeros(H, device="cuda"); db = torch.zeros(H, device="cuda")
+    ops.layernorm_bwd(x, mean, rstd, gam, rows, H, dy_bf16=dy16, dy_f32=dy32, dres=dres, dx_f32=dx32, dx_bf16=dx16,
+                      dgamma=dg, dbeta=db)
+    ref.backward(dy16.float() + dy32)
+    torch.cuda.synchronize()
+    tol = 5e-5 * max(1.0, xr.grad.abs().max().item())
+    assert (dx32 - (xr.grad + dres)).abs().max().item() < tol
+    assert (dx16.float() - dx32).abs().max().item() <= dx32.abs().max().item() * 2 ** -8
+    assert (dg - gr.grad).abs().max().item() < 2e-4 * gr.grad.abs().max().item() + 1e-4
+    assert (db - br.grad).abs().max().item() < 2e-4 * br.grad.abs().max().item() + 1e-4
+
+
+def test_layernorm_rowmaps():
+    # read rows b*S + t (t < T) of a fused sequence, write compact
+    B, S, T, H = 3, 185, 40, 256
+    xfull = _rand(B * S, H, seed=8)
+    gam = torch.ones(H, device="cuda"); bet = torch.zeros(H, device="cuda")
+    y = torch.zeros(B * T, H, device="cuda")
+    ops.layernorm_fwd(xfull, gam, bet, 1e-12, B * T, H, y_f32=y, xmap=(T, S, 0))
+    ref = torch.nn.functional.layer_norm(xfull.view(B, S, H)[:, :T].reshape(B * T, H), (H,))
+    torch.cuda.synchronize()
+    assert (y - ref).abs().max().item() < 1e-4
+    y2 = torch.zeros(B * S, H, device="cuda")
+    ops.layernorm_fwd(ref, gam, bet, 1e-12, B * T, H, y_f32=y2, ymap=(T, S, 0))
+    torch.cuda.synchronize()
+    assert y2.view(B, S, H)[:, T:].abs().max().item() == 0.0
+    assert (y2.view(B, S, H)[:, :T].reshape(B * T, H) - torch.nn.functional.layer_norm(ref, (H,))).abs().max().item() < 1e-4
+
+
+def test_colsum():
+    rows, N = 1000, 768
+    x = _rand(1024, N, seed=9).bfloat16()
+    out = torch.ones(N, device="cuda")
+    ops.colsum(x, N, rows, N, out)
+    torch.cuda.synchronize()
+    ref = 1 + x[:rows].float().sum(0)
+    assert (out - ref).abs().max().item() < 1e-3
+
+
+def _attn_ref(qkv, keymask, B, S, H, heads):
+    q, k, v = qkv.float().view(B, S, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) / 8.0
+    s = s + (1.0 - keymask)[:, None, None, :] * torch.finfo(torch.float32).min
+    p = torch.softmax(s, dim=-1)
+    o = p @ v
+    return o.permute(0, 2, 1, 3).reshape(B * S, H), s
+
+
+@pytest.mark.parametrize("S,heads", [(185, 12), (40, 12), (185, 4), (33, 2)])
+def test_attention_fwd_bwd(S, heads):
+    B, H = 3, heads * 64
+    M = B * S
+    qkv = (_rand(M, 3 * H, seed=10) * 1.5).bfloat16()
+    keymask = torch.ones(B, S, device="cuda")
+    keymask[1, 5:17] = 0
+    keymask[2, S - 9:] = 0
+    ctx = torch.zeros(M, H, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, heads, S, device="cuda")
+    ops.attention_fwd(qkv, keymask, ctx, lse, B, S, H, heads)
+    qr = qkv.float().clone().requires_grad_(True)
+    ref, s = _attn_ref(qr, keymask, B, S, H, heads)
+    torch.cuda.synchronize()
+    assert (ctx.float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
+    lse_ref = torch.logsumexp(s, dim=-1)
+    assert (lse - lse_ref).abs().max().item() < 1e-3
+    # backward
+    dctx = _rand(M, H, seed=11).bfloat16()
+    dqkv = torch.zeros(M, 3 * H, dtype=torch.bfloat16, device="cuda")
+    ops.attention_bwd(qkv, keymask, ctx, lse, dctx, dqkv, B, S, H, heads)
+    ref.backward(dctx.float())
+    torch.cuda.synchronize()
+    g = qr.grad
+    err = (dqkv.float() - g).abs().max().item()
+    assert err < 3e-2 * g.abs().max().item(), (err, g.abs().max().item())
+    # relative Frobenius error is the tighter, bf16-sized bound
+    rel = ((dqkv.float() - g).norm() / g.norm()).item()
+    assert rel < 1e-2, rel
+
+
+def test_attention_dropout_consistency():
+    """Dropout on the probabilities: forward and backward regenerate the same mask (finite-difference
+    free check: d<ctx, dctx>/dV equals P_drop^T dctx, so dV from bwd must match a V-gradient computed by
+    running fwd with one-hot perturbations -> instead use linearity in V: ctx(V1+V2) = ctx(V1)+ctx(V2))."""
+    B, S, heads = 2, 40, 2
+    H = heads * 64
+    M = B * S
+    qkv = _rand(M, 3 * H, seed=12).bfloat16()
+    keymask = torch.ones(B, S, device="cuda")
+    drop = ops.Drop(0.1, seed=7, stream=3)
+    ctx = torch.zeros(M, H, dtype=torch.bfloat16, device="cuda"); lse = torch.zeros(B, heads, S, device="cuda")
+    ops.attention_fwd(qkv, keymask, ctx, lse, B, S, H, heads, drop=drop)
+    ctx2 = torch.zeros_like(ctx)
+    ops.attention_fwd(qkv, keymask, ctx2, lse, B, S, H, heads, drop=drop)
+    torch.cuda.synchronize()
+    assert torch.equal(ctx, ctx2)  # deterministic mask
+    ctx0 = torch.zeros_like(ctx)
+    ops.attention_fwd(qkv, keymask, ctx0, lse, B, S, H, heads)
+    torch.cuda.synchronize()
+    assert not torch.equal(ctx, ctx0)
+    # E[dropout(P)] = P: means agree loosely
+    assert abs(ctx.float().mean().item() - ctx0.float().mean().item()) < 0.02
+    # backward consistency: dV = P_drop^T dO  <=>  <dV, V'> = <dO, ctx(V')> for any V' (ctx is linear in V)
+    dctx = _rand(M, H, seed=13).bfloat16()
+    dqkv = torch.zeros(M, 3 * H, dtype=torch.bfloat16, device="cuda")
+    ops.attention_bwd(qkv, keymask, ctx, lse, dctx, dqkv, B, S, H, heads, drop=drop)
+    qkv2 = qkv.clone()
+    vprime = _rand(M, H, seed=14).bfloat16()
+    qkv2[:, 2 * H:] = vprime
+    ctxp = torch.zeros_like(ctx)
+    ops.attention_fwd(qkv2, keymask, ctxp, lse.clone(), B, S, H, heads, drop=drop)
+    torch.cuda.synchronize()
+    lhs = (dqkv[:, 2 * H:].float() * vprime.float()).sum().item()
+    rhs = (dctx.float() * ctxp.float()).sum().item()
+    assert abs(lhs - rhs) < 2e-2 * max(1.0, abs(rhs)), (lhs, rhs)

@@ -1,0 +1,57 @@
+"""Micro-benchmark of the GEMM shapes of one ViLT layer at batch B (development tool)."""
+import ctypes as C
+import sys
+import torch
+sys.path.insert(0, ".")
+from tests.test_gpu_gemm import _gemm, EPI_BF16, EPI_GELU, EPI_DGELU, EPI_RES, EPI_ATOMIC
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+M = ((B * 185 + 255) // 256) * 256
+H, FF = 768, 3072
+
+
+def timeit(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def rb(*s):
+    return torch.randn(*s, device="cuda").bfloat16()
+
+
+X = rb(M, H); Xf = rb(M, FF)
+Wqkv = rb(3 * H, H) * 0.05; Wo = rb(H, H) * 0.05; W1 = rb(FF, H) * 0.05; W2 = rb(H, FF) * 0.05
+bias_q = torch.randn(3 * H, device="cuda"); bias_h = torch.randn(H, device="cuda"); bias_f = torch.randn(FF, device="cuda")
+o_qkv = torch.empty(M, 3 * H, dtype=torch.bfloat16, device="cuda")
+o_h32 = torch.empty(M, H, device="cuda"); res = torch.randn(M, H, device="cuda")
+o_f = torch.empty(M, FF, dtype=torch.bfloat16, device="cuda"); o_f2 = torch.empty(M, FF, dtype=torch.bfloat16, device="cuda")
+o_h = torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
+dW = torch.zeros(FF, H, device="cuda")
+
+cases = []
+for cfg in (0, 1, 2):
+    cases += [
+        (f"fwd qkv   cfg{cfg}", 2 * M * 3 * H * H, lambda cfg=cfg: _gemm(X, Wqkv, o_qkv, M, 3 * H, H, H, H, 3 * H, 0, 0, EPI_BF16, cfg=cfg, bias=bias_q)),
+        (f"fwd proj  cfg{cfg}", 2 * M * H * H, lambda cfg=cfg: _gemm(X, Wo, o_h32, M, H, H, H, H, H, 0, 0, EPI_RES, cfg=cfg, bias=bias_h, res=res)),
+        (f"fwd ffn1  cfg{cfg}", 2 * M * FF * H, lambda cfg=cfg: _gemm(X, W1, o_f, M, FF, H, H, H, FF, 0, 0, EPI_GELU, cfg=cfg, bias=bias_f, out2=o_f2)),
+        (f"fwd ffn2  cfg{cfg}", 2 * M * FF * H, lambda cfg=cfg: _gemm(Xf, W2, o_h32, M, H, FF, FF, FF, H, 0, 0, EPI_RES, cfg=cfg, bias=bias_h, res=res)),
+        (f"dgrad ffn2 cfg{cfg}", 2 * M * FF * H, lambda cfg=cfg: _gemm(X, W2, o_f, M, FF, H, H, FF, FF, 0, 1, EPI_DGELU, cfg=cfg, aux=o_f2)),
+        (f"dgrad ffn1 cfg{cfg}", 2 * M * FF * H, lambda cfg=cfg: _gemm(Xf, W1, o_h, M, H, FF, FF, H, H, 0, 1, EPI_BF16, cfg=cfg)),
+    ]
+for cfg in (0, 1, 2):
+    for splits in (4, 8, 16):
+        cases.append((f"wgrad ffn1 cfg{cfg} s{splits}", 2 * M * FF * H,
+                      lambda cfg=cfg, splits=splits: _gemm(Xf, X, dW, FF, H, M, FF, H, H, 1, 1, EPI_ATOMIC, cfg=cfg, splits=splits, accumulate=1)))
+        cases.append((f"wgrad proj cfg{cfg} s{splits*4}", 2 * M * H * H,
+                      lambda cfg=cfg, splits=splits: _gemm(X, X, dW, H, H, M, H, H, H, 1, 1, EPI_ATOMIC, cfg=cfg, splits=splits * 4, accumulate=1)))
+for name, flops, fn in cases:
+    t = timeit(fn)
+    print(f"{name:28s} {t*1e6:9.1f} us  {flops/t/1e12:8.1f} TF/s")

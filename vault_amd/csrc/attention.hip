@@ -1,0 +1,372 @@
+// Multi-head self-attention forward/backward for short sequences (S <= 32*NKT keys: the fused
+// [text | patch] sequence S = 185 -> NKT = 6, the text-only LM sequence S = 40 -> NKT = 2), d = 64.
+//
+// One workgroup per (batch, head).  The whole K and V of the head live in LDS (XOR-swizzled 128-byte
+// rows); scores are computed transposed (S^T = K Q^T) so that the softmax'd tile is, register for
+// register, the A operand of the following P.V MFMA - probabilities never leave registers.  V (and
+// in backward K, Q, dO) are consumed k-strided through ds_read_b64_tr_b16 from their row-major images.
+//
+// Replaces ViltSelfAttention.forward (HF:models/vilt/modeling_vilt.py:322-351: eager softmax with
+// an additive finfo.min key mask) and RobertaSelfAttention (HF:models/roberta/modeling_roberta.py:158-250)
+// plus their autograd backward.  Masked keys get probability exactly 0 (the reference adds
+// finfo.min, which underflows to the same 0 as long as one key is valid - always true: CLS/<s>).
+#include "common.h"
+#include "../../include/vault_hip.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int swz_row(int row) { return (row >> 1) & 3; }  // 32-byte block XOR key
+
+// stage a [rows<=S][64] bf16 matrix (row stride ld elements) into a swizzled [SK][128 B] LDS image
+template <int SK>
+__device__ __forceinline__ void stage_rows(char* dst, const bf16* src, int ld, int S, int tid) {
+  for (int c = tid; c < SK * 8; c += 256) {
+    const int row = c >> 3, pos = c & 7;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < S) v = *reinterpret_cast<const u32x4*>(src + (size_t)row * ld + pos * 8);
+    *reinterpret_cast<u32x4*>(dst + row * 128 + ((pos ^ (swz_row(row) << 1)) << 4)) = v;
+  }
+}
+
+// row-read fragment (A or B operand, k = d): rows tile*16 + l15, d = 32s + 8g .. +7
+__device__ __forceinline__ bf16x8 frag_rows(const char* img, int tile, int s, int g, int l15) {
+  const int fx = swz_row(l15) << 1;
+  return *LDS_PTR(const bf16x8, img + (tile * 16 + l15) * 128 + (((4 * s + g) ^ fx) << 4));
+}
+
+// transposed fragment (B operand, k = row index permuted as kappa(g,j) = 32T + 16(j>>2) + 4g + (j&3),
+// col = d = dt*16 + l15) from a row-major [rows][64] image
+__device__ __forceinline__ bf16x8 frag_tr(const char* img, int T, int dt, int g, int l15) {
+  const int qq = l15 >> 2, pp = l15 & 3;
+  const int row = 32 * T + 4 * g + qq;
+  const int x = (2 * (g & 1) + (qq >> 1)) & 3;  // == swz_row(row) and == swz_row(row + 16)
+  const char* a = img + row * 128 + ((dt ^ x) << 5) + pp * 8;
+  return cat_tr(lds_read_tr16(a), lds_read_tr16(a + 16 * 128));
+}
+
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4& lo, const f32x4& hi) {
+  bf16x8 f;
+  f[0] = (bf16)lo[0]; f[1] = (bf16)lo[1]; f[2] = (bf16)lo[2]; f[3] = (bf16)lo[3];
+  f[4] = (bf16)hi[0]; f[5] = (bf16)hi[1]; f[6] = (bf16)hi[2]; f[7] = (bf16)hi[3];
+  return f;
+}
+
+struct AttnDrop {
+  uint32_t thresh, seed, stream;
+  float scale;
+};
+
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
+                                                       bf16* __restrict__ ctx, float* __restrict__ lse, int S, int H,
+                                                       int heads, float scale, AttnDrop dr) {
+  constexpr int SK = NKT * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + SK * 128;
+  float* mb = reinterpret_cast<float*>(smem + 2 * SK * 128);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const size_t row0 = (size_t)b * S;
+  const int ld = 3 * H;
+  const bf16* qbase = qkv + row0 * ld + h * 64;
+  stage_rows<SK>(Ks, qbase + H, ld, S, tid);
+  stage_rows<SK>(Vs, qbase + 2 * H, ld, S, tid);
+  for (int k = tid; k < SK; k += 256)
+    mb[k] = (k < S && (keymask == nullptr || keymask[(size_t)b * S + k] != 0.f)) ? 0.f : -INFINITY;
+  __syncthreads();
+  const float sl2 = scale * LOG2E;
+  const int nqt = (S + 15) >> 4;
+  const uint32_t bh = (uint32_t)(b * heads + h);
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int qrow = min(qt * 16 + l15, S - 1);
+    bf16x8 qf[2];
+    qf[0] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * ld + 8 * g);
+    qf[1] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * ld + 32 + 8 * g);
+    f32x4 sc[2 * NKT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2 * NKT; ++kt) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, kt, 0, g, l15), qf[0], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, kt, 1, g, l15), qf[1], a, 0, 0, 0);
+      const f32x4 m4 = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a[r] += m4[r];
+        mx = fmaxf(mx, a[r]);
+      }
+      sc[kt] = a;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2 * NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = __builtin_amdgcn_exp2f((sc[kt][r] - mx) * sl2);
+        sc[kt][r] = pv;
+        sum += pv;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    const int q_l = qt * 16 + l15;
+    if (g == 0 && q_l < S) lse[(size_t)bh * S + q_l] = mx * scale + __logf(sum);
+#pragma unroll
+    for (int kt = 0; kt < 2 * NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pv = sc[kt][r] * inv;
+        if (dr.thresh != 0u) {
+          const uint32_t idx = (bh * (uint32_t)S + (uint32_t)q_l) * (uint32_t)S + (uint32_t)(kt * 16 + 4 * g + r);
+          pv = dropout_keep(dr.seed, dr.stream, idx, dr.thresh) ? pv * dr.scale : 0.f;
+        }
+        sc[kt][r] = pv;
+      }
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < NKT; ++T) {
+      const bf16x8 pf = pack_frag(sc[2 * T], sc[2 * T + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr(Vs, T, dt, g, l15), o[dt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = qt * 16 + 4 * g + r;
+      if (q < S) {
+        bf16* dst = ctx + (row0 + q) * H + h * 64 + l15;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dst[dt * 16] = (bf16)o[dt][r];
+      }
+    }
+  }
+}
+
+// Backward.  Phase A (wave = query tile): dQ.  Phase B (wave = key tile): dK, dV.  P is recomputed
+// from Q, K and the forward's log-sum-exp; both phases recompute the score tile in the orientation
+// whose accumulator is directly the next MFMA's A operand.
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
+                                                       const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
+                                                       const float* __restrict__ lse, bf16* __restrict__ dqkv, int S,
+                                                       int H, int heads, float scale, AttnDrop dr) {
+  constexpr int SK = NKT * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* img0 = smem;               // phase A: K     phase B: Q
+  char* img1 = smem + SK * 128;    // phase A: V     phase B: dO
+  float* mb = reinterpret_cast<float*>(smem + 2 * SK * 128);
+  float* lse_s = mb + SK;          // -lse * log2e ; -inf for q >= S
+  float* dl_s = lse_s + SK;        // delta[q]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const size_t row0 = (size_t)b * S;
+  const int ld = 3 * H;
+  const bf16* qbase = qkv + row0 * ld + h * 64;
+  const bf16* obase = ctx + row0 * H + h * 64;
+  const bf16* dobase = dctx + row0 * H + h * 64;
+  bf16* dqbase = dqkv + row0 * ld + h * 64;
+  const uint32_t bh = (uint32_t)(b * heads + h);
+  const float sl2 = scale * LOG2E;
+
+  stage_rows<SK>(img0, qbase + H, ld, S, tid);
+  stage_rows<SK>(img1, qbase + 2 * H, ld, S, tid);
+  for (int k = tid; k < SK; k += 256) {
+    mb[k] = (k < S && (keymask == nullptr || keymask[(size_t)b * S + k] != 0.f)) ? 0.f : -INFINITY;
+    lse_s[k] = (k < S) ? -lse[(size_t)bh * S + k] * LOG2E : -INFINITY;
+  }
+  // delta[q] = sum_d dO[q][d] * O[q][d] ; 4 lanes per row
+  for (int q = tid >> 2; q < SK; q += 64) {
+    float s = 0.f;
+    if (q < S) {
+      const int d0 = (tid & 3) * 16;
+#pragma unroll
+      for (int c = 0; c < 16; c += 8) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(obase + (size_t)q * H + d0 + c);
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dobase + (size_t)q * H + d0 + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)d[e];
+      }
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if ((tid & 3) == 0) dl_s[q] = s;
+  }
+  __syncthreads();
+
+  const int nqt = (S + 15) >> 4;
+  // ---------------- phase A: dQ ----------------
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q_l = qt * 16 + l15;
+    const int qrow = min(q_l, S - 1);
+    bf16x8 qf[2], df[2];
+    qf[0] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * ld + 8 * g);
+    qf[1] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * ld + 32 + 8 * g);
+    df[0] = *reinterpret_cast<const bf16x8*>(dobase + (size_t)qrow * H + 8 * g);
+    df[1] = *reinterpret_cast<const bf16x8*>(dobase + (size_t)qrow * H + 32 + 8 * g);
+    const float nl = lse_s[min(q_l, SK - 1)], dl = dl_s[min(q_l, SK - 1)];
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < NKT; ++T) {
+      f32x4 ds2[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int kt = 2 * T + hh;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(img0, kt, 0, g, l15), qf[0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(img0, kt, 1, g, l15), qf[1], a, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(img1, kt, 0, g, l15), df[0], dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(img1, kt, 1, g, l15), df[1], dp, 0, 0, 0);
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f((a[r] + m4[r]) * sl2 + nl);
+          float dpv = dp[r];
+          if (dr.thresh != 0u) {
+            const uint32_t idx = (bh * (uint32_t)S + (uint32_t)q_l) * (uint32_t)S + (uint32_t)(kt * 16 + 4 * g + r);
+            dpv = dropout_keep(dr.seed, dr.stream, idx, dr.thresh) ? dpv * dr.scale : 0.f;
+          }
+          ds2[hh][r] = pv * (dpv - dl) * scale;
+        }
+      }
+      const bf16x8 dsf = pack_frag(ds2[0], ds2[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, frag_tr(img0, T, dt, g, l15), o[dt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = qt * 16 + 4 * g + r;
+      if (q < S) {
+        bf16* dst = dqbase + (size_t)q * ld + l15;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dst[dt * 16] = (bf16)o[dt][r];
+      }
+    }
+  }
+  __syncthreads();
+  // ---------------- phase B: dK, dV ----------------
+  stage_rows<SK>(img0, qbase, ld, S, tid);
+  stage_rows<SK>(img1, dobase, H, S, tid);
+  __syncthreads();
+  const int nkt = (S + 15) >> 4;
+  for (int kt = wave; kt < nkt; kt += 4) {
+    const int k_l = kt * 16 + l15;
+    const int krow = min(k_l, S - 1);
+    bf16x8 kf[2], vf[2];
+    kf[0] = *reinterpret_cast<const bf16x8*>(qbase + H + (size_t)krow * ld + 8 * g);
+    kf[1] = *reinterpret_cast<const bf16x8*>(qbase + H + (size_t)krow * ld + 32 + 8 * g);
+    vf[0] = *reinterpret_cast<const bf16x8*>(qbase + 2 * H + (size_t)krow * ld + 8 * g);
+    vf[1] = *reinterpret_cast<const bf16x8*>(qbase + 2 * H + (size_t)krow * ld + 32 + 8 * g);
+    const float mk = mb[min(k_l, SK - 1)];
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int T = 0; T < NKT; ++T) {
+      f32x4 p2[2], ds2[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int qt = 2 * T + hh;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(img0, qt, 0, g, l15), kf[0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(img0, qt, 1, g, l15), kf[1], a, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(img1, qt, 0, g, l15), vf[0], dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(img1, qt, 1, g, l15), vf[1], dp, 0, 0, 0);
+        const f32x4 nl4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * g);
+        const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dl_s + qt * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pv = __builtin_amdgcn_exp2f((a[r] + mk) * sl2 + nl4[r]);
+          float dpv = dp[r];
+          if (dr.thresh != 0u) {
+            const uint32_t idx = (bh * (uint32_t)S + (uint32_t)(qt * 16 + 4 * g + r)) * (uint32_t)S + (uint32_t)k_l;
+            const bool keep = dropout_keep(dr.seed, dr.stream, idx, dr.thresh);
+            dpv = keep ? dpv * dr.scale : 0.f;
+            ds2[hh][r] = pv * (dpv - dl4[r]) * scale;
+            pv = keep ? pv * dr.scale : 0.f;
+          } else {
+            ds2[hh][r] = pv * (dpv - dl4[r]) * scale;
+          }
+          p2[hh][r] = pv;
+        }
+      }
+      const bf16x8 pf = pack_frag(p2[0], p2[1]);
+      const bf16x8 dsf = pack_frag(ds2[0], ds2[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr(img1, T, dt, g, l15), dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, frag_tr(img0, T, dt, g, l15), dk[dt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = kt * 16 + 4 * g + r;
+      if (k < S) {
+        bf16* dstk = dqbase + H + (size_t)k * ld + l15;
+        bf16* dstv = dqbase + 2 * H + (size_t)k * ld + l15;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dstk[dt * 16] = (bf16)dk[dt][r];
+          dstv[dt * 16] = (bf16)dv[dt][r];
+        }
+      }
+    }
+  }
+}
+
+template <int NKT>
+constexpr int attn_lds_bytes() { return NKT * 32 * 128 * 2 + NKT * 32 * 4 * 3; }
+
+}  // namespace
+
+extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
+  if (!a || !a->qkv || !a->ctx || !a->lse || a->S <= 0 || a->B <= 0 || a->H != a->heads * 64) return VAULT_EINVAL;
+  if (a->S > 192) return VAULT_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const AttnDrop dr{a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale};
+  dim3 grid(a->heads, a->B), block(256);
+  const float scale = 0.125f;  // 1/sqrt(64)
+  if (a->S <= 64) {
+    hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, attn_lds_bytes<2>(), st, reinterpret_cast<const bf16*>(a->qkv),
+                       a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr);
+  } else {
+    hipLaunchKernelGGL(attn_fwd_kernel<6>, grid, block, attn_lds_bytes<6>(), st, reinterpret_cast<const bf16*>(a->qkv),
+                       a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
+  if (!a || !a->qkv || !a->ctx || !a->lse || !a->dctx || !a->dqkv || a->S <= 0 || a->B <= 0 ||
+      a->H != a->heads * 64)
+    return VAULT_EINVAL;
+  if (a->S > 192) return VAULT_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const AttnDrop dr{a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale};
+  dim3 grid(a->heads, a->B), block(256);
+  const float scale = 0.125f;
+  if (a->S <= 64) {
+    hipLaunchKernelGGL(attn_bwd_kernel<2>, grid, block, attn_lds_bytes<2>(), st, reinterpret_cast<const bf16*>(a->qkv),
+                       a->keymask, reinterpret_cast<const bf16*>(a->ctx), reinterpret_cast<const bf16*>(a->dctx), a->lse,
+                       reinterpret_cast<bf16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_kernel<6>, grid, block, attn_lds_bytes<6>(), st, reinterpret_cast<const bf16*>(a->qkv),
+                       a->keymask, reinterpret_cast<const bf16*>(a->ctx), reinterpret_cast<const bf16*>(a->dctx), a->lse,
+                       reinterpret_cast<bf16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
+  }
+  return (int)hipGetLastError();
+}

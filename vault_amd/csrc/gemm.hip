@@ -202,6 +202,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) sc[(4 * g + r) * LDS_LD + j * 16 + l15] = acc[i][j][r];
     __builtin_amdgcn_wave_barrier();
+    if constexpr (EPI == EPI_F32_ATOMIC && TN == 4) {
+      // one wave-instruction = one full 256-byte output row: the shape float atomics run fastest at
+      float* out = reinterpret_cast<float*>(p.out);
+      const bool plain = (p.splits == 1 && p.accumulate == 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 16 + r;
+        const float val = sc[r * LDS_LD + lane];
+        if (m < p.m_valid) {
+          float* dst = out + (size_t)m * p.ldo + n0 + wn0 + lane;
+          if (plain) *dst = val; else atomicAdd(dst, val);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
     float v[SEG];
 #pragma unroll
     for (int c = 0; c < SEG; c += 4) {
