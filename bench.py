@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""Headline benchmark: train samples/sec (image+text pairs) of the ViLT-B32 + BERTweet-base
+fine-tune step (forward + backward + fused AdamW, bf16 MFMA compute / fp32 master weights), per-GPU
+batch 256, synthetic 384x384 images + 40-token captions, on N GPUs of one node (data parallel,
+RCCL all-reduce of gradients).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").  `roofline` is the dominant kernel (the
+bf16 MFMA GEMM, timed live with events on the launch stream at its largest call site, the ViLT
+FFN-in projection); `step_mfma_frac` is the whole step against the 2.5 PFLOP/s dense bf16 peak with
+BASELINE.md's 120.67 GFLOP/sample.  `cpu_baseline` times the CPU oracle (plain fp32 torch
+restatement of the reference path) on the host cores, on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from vault_amd.engine import VaultEngine  # noqa: E402
+from vault_amd.spec import LMSpec, VaultSpec, ViltSpec, build_state, synthetic_batch  # noqa: E402
+from vault_amd.train import TrainStep  # noqa: E402
+
+FLOP_PER_SAMPLE_TRAIN = 120.67e9      # BASELINE.md §2 (fwd 40.22 GF x 3)
+PEAK_BF16 = 2.5e15                    # MI355X dense bf16 MFMA, MI355X_MICROARCH.md
+
+
+def cpu_baseline(spec, seconds_budget: float = 25.0, batch: int = 8):
+    """Oracle (fp32 torch restatement of the reference path) fwd + bwd + HF-AdamW on the host."""
+    from oracle import vault_oracle as O
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    cores = torch.get_num_threads()
+    state = build_state(spec, 0)
+    P = O.to_torch_state(state, requires_grad=True)
+    names = [k for k in P]
+    m = {k: torch.zeros_like(v) for k, v in P.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in P.items()}
+    bn = synthetic_batch(spec, batch, seed=99, n_classes=3)
+    tb = O.torch_batch(bn)
+
+    def step(t):
+        for p in P.values():
+            p.grad = None
+        loss, _ = O.vault_loss(P, spec, tb)
+        loss.backward()
+        with torch.no_grad():
+            for k in names:
+                g = P[k].grad
+                if g is None:
+                    continue
+                O.hf_adamw_step(P[k], g, m[k], v2[k], 2e-5, t)
+        return float(loss.detach())
+
+    step(1)  # warm-up (allocator, thread pools)
+    t0 = time.time()
+    n = 0
+    while True:
+        step(n + 2)
+        n += 1
+        if time.time() - t0 > seconds_budget * 0.5 or n >= 3:
+            break
+    dt = time.time() - t0
+    return {"value": round(batch * n / dt, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} full fine-tune steps (fwd+bwd+AdamW, fp32) of the CPU oracle at batch {batch}, "
+                      f"same model shape and synthetic inputs; {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--freeze-lm", action="store_true")
+    ap.add_argument("--lm", default="bertweet", choices=["bertweet", "bert-base-uncased"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    lm = LMSpec.bertweet_base() if args.lm == "bertweet" else LMSpec.bert_base_uncased()
+    spec = VaultSpec(vilt=ViltSpec(), lm=lm, n_classes=3)
+    eng = VaultEngine(spec, dev, seed=0, freeze_lm=args.freeze_lm, classifier_dropout=0.1)
+    total = args.steps + args.warmup
+    stepper = TrainStep(eng, learning_rate=2e-5, warmup_ratio=0.1, total_steps=max(total, 10), process_group=pg)
+
+    B = args.batch
+    bn = synthetic_batch(spec, B, seed=1234 + rank, n_classes=3)
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in bn.items() if k != "labels"}
+    labels = torch.from_numpy(bn["labels"]).to(dev)
+
+    # live timing of the dominant kernel: events around the ViLT FFN-in GEMM launches of the timed steps
+    evs = []
+    eng.profile_tag = "vilt_ffn1_fwd"
+    eng.profile_events = None
+
+    def sync_all():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        stepper(batch, labels)
+    sync_all()
+    eng.profile_events = evs
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stepper(batch, labels)
+    sync_all()
+    dt = time.perf_counter() - t0
+    eng.profile_events = None
+    loss = float(stepper.loss.item())
+
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        sps = B * world * args.steps / dt
+        kern_ms = [s.elapsed_time(e) for s, e in evs]
+        v = spec.vilt
+        M = B * (40 + 1 + v.num_patches)
+        gemm_flops = 2.0 * M * v.intermediate_size * v.hidden_size
+        avg_ms = float(np.mean(kern_ms)) if kern_ms else float("nan")
+        achieved = gemm_flops / (avg_ms * 1e-3) / 1e12 if kern_ms else None
+        flop_per_sample = FLOP_PER_SAMPLE_TRAIN if not args.freeze_lm else 106.96e9
+        out = {
+            "metric": "train samples/sec (img+text pairs) ViLT-B32+BERTweet, bs256, 1/2/4/8 MI355X",
+            "value": round(sps, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"ViLT-B32 + {args.lm} fine-tune step (fwd+bwd+AdamW), per-GPU batch {B}, "
+                                   f"40 text tokens + 384x384 image (185-token fused sequence), "
+                                   f"{'frozen LM' if args.freeze_lm else 'all weights trained'}",
+                       "global_batch": B * world, "seq_len": 185, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<256,128,...> ViLT FFN-in forward "
+                                                    f"[{M}x{v.intermediate_size}x{v.hidden_size}]",
+                         "achieved": None if achieved is None else round(achieved, 1), "peak": 2500.0,
+                         "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / 2500.0, 4),
+                         "traffic": None, "launches_timed": len(kern_ms), "avg_launch_ms": round(avg_ms, 4)},
+            "step_mfma_frac": round(sps / world * flop_per_sample / PEAK_BF16, 4),
+            "final_loss": round(loss, 5),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(spec)
+            except Exception as e:  # pragma: no cover
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

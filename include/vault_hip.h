@@ -66,6 +66,7 @@ typedef struct vault_ln_bwd_args {
   int rows, H;
   int dy_rpg, dy_gstride, dy_goff, x_rpg, x_gstride, x_goff, dx_rpg, dx_gstride, dx_goff;
   uint32_t drop_thresh, drop_seed, drop_stream; float drop_scale;
+  int drop_on_dy;   /* 0: mask dx_bf16 (Linear -> dropout -> +res -> LN) ; 1: mask dy (LN -> dropout) */
 } vault_ln_bwd_args;
 int vault_layernorm_bwd(const vault_ln_bwd_args* args, void* stream);
 
@@ -88,6 +89,64 @@ typedef struct vault_attn_args {
 } vault_attn_args;
 int vault_attention_fwd(const vault_attn_args* args, void* stream);
 int vault_attention_bwd(const vault_attn_args* args, void* stream);
+
+
+/* ---- embeddings -----------------------------------------------------------------------------
+ * vault_position_ids: mode 1 = RoBERTa/BERTweet ids (cumsum(ids != pad) * (ids != pad) + pad,
+ * HF:models/roberta/modeling_roberta.py:142-155), mode 0 = arange (BERT). T <= 64. */
+int vault_position_ids(const int64_t* ids, int* pos, int B, int T, int mode, int pad, void* stream);
+
+/* gather: out[r] = (src ? src[r] : 0) + sum_k tab[k][index_k(r)] over up to three f32 tables of row
+ * width H (H % 256 == 0); index_k(r) = idx[k][r] (int64 if is64[k] else int32) or, when idx[k] is NULL,
+ * fixed[k] (>= 0) or r % period (fixed[k] == -2); tab[k] == NULL skips the table.
+ * Replaces the embedding sums of modeling_roberta.py:75-121 / modeling_bert.py:69-107 /
+ * modeling_vilt.py:237-269.  scatter (backward): tab[k][index_k(r)] += src[r] (float atomics). */
+typedef struct vault_gather_args {
+  const float* src; float* out;
+  const float* tab[3]; const void* idx[3]; int is64[3]; int fixed[3];
+  int period, rows, H;
+} vault_gather_args;
+int vault_gather_sum(const vault_gather_args* args, void* stream);
+int vault_scatter_add(const vault_gather_args* args, void* stream);
+
+/* pixel_values [B][C][IMG][IMG] f32 -> patch matrix [B*(IMG/ps)^2][C*ps*ps] bf16 (k = c*ps*ps + py*ps
+ * + px, row-major patch order): the unfold half of the Conv2d at modeling_vilt.py:290-300. ps % 8 == 0. */
+int vault_im2col(const float* pixel_values, void* out_bf16, int B, int C, int IMG, int ps, void* stream);
+
+/* addtab[p] = conv_bias + pos_emb[1+p] + modality_type[1] (p < P), and the CLS rows
+ * x[b*S + T] = cls_token + pos_emb[0] + modality_type[1]  (modeling_vilt.py:160-166,204-215). */
+int vault_image_consts(const float* conv_bias, const float* pos_emb, const float* mtype1, const float* cls,
+                       float* addtab, float* x, int P, int H, int B, int S, int T, void* stream);
+/* backward over the image rows of dx [B*S][H]: dpos, dmtype1, dcls, dconv_bias (+=) and the compact
+ * bf16 copy dyp [B*P][H] of the patch-row gradients (operand of the projection wgrad). */
+int vault_image_rows_bwd(const float* dx, float* dpos, float* dmtype1, float* dcls, float* dconv_bias,
+                         void* dyp_bf16, int P, int H, int B, int S, int T, void* stream);
+int vault_axpy_f32(float* dst, const float* src, float a, long long n, void* stream);
+
+/* ---- head + loss ----------------------------------------------------------------------------
+ * pooled = tanh(pre) ; logits = dropout(pooled) Wc^T + bc ; loss_sum += loss_scale * sum_b CE_b
+ * (ref: vault/models/vault/model.py:547-550,567-570 ; vault/tmsc_utils/trainer.py:241-242).
+ * bwd: dlogits = (softmax - onehot) * grad_scale unless `dlogits` is given; dWc/dbc accumulated;
+ * dpre_bf16 [B][H] = d loss / d pre.  C <= 8. */
+typedef struct vault_head_args {
+  const float* pre; const float* Wc; const float* bc; const int64_t* labels; const float* dlogits;
+  float* pooled; float* logits; float* loss_sum; float* dWc; float* dbc; void* dpre_bf16;
+  int B, H, C; float loss_scale, grad_scale;
+  uint32_t drop_thresh, drop_seed, drop_stream; float drop_scale;
+} vault_head_args;
+int vault_head_fwd(const vault_head_args* args, void* stream);
+int vault_head_bwd(const vault_head_args* args, void* stream);
+int vault_tanh_bwd(const float* pooled, const float* dpooled, void* dpre_bf16, long long n, void* stream);
+
+/* ---- optimizer ------------------------------------------------------------------------------
+ * transformers==4.48 AdamW as the reference calls it (ref: vault/tmsc_utils/trainer.py:244-254):
+ * bias_corr_factor = 1 (correct_bias=False) or sqrt(1-b2^t)/(1-b1^t); decoupled decay after the
+ * update.  g is multiplied by grad_scale first (1/world for DP averaging) and zeroed if zero_grad.
+ * Also refreshes the bf16 shadow copy used by the GEMMs.  n % 4 == 0. */
+int vault_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, float bias_corr_factor, float grad_scale,
+                     int zero_grad, void* stream);
+int vault_cast_bf16(const float* x, void* y_bf16, long long n, void* stream);
 
 #ifdef __cplusplus
 }

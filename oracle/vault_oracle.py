@@ -56,6 +56,36 @@ def to_torch_state(state: Dict[str, np.ndarray], requires_grad: bool = False) ->
     return out
 
 
+# Optional emulation of the HIP path's number format: every matmul operand (activations and
+# weights of each Linear, Q/K/V/P of attention) is rounded to bf16 before an exact fp32 product,
+# exactly where the kernels round.  Off by default (pure fp32 = the reference's arithmetic).
+_EMULATE_BF16 = False
+
+
+class emulate_bf16:
+    """``with emulate_bf16():`` - run the oracle with bf16-rounded matmul operands."""
+
+    def __enter__(self):
+        global _EMULATE_BF16
+        self._old, _EMULATE_BF16 = _EMULATE_BF16, True
+
+    def __exit__(self, *a):
+        global _EMULATE_BF16
+        _EMULATE_BF16 = self._old
+
+
+def _r(x):
+    return x.bfloat16().float() if _EMULATE_BF16 else x
+
+
+def _lin(x, w, b=None):
+    return F.linear(_r(x), _r(w), b)
+
+
+def _mm(a, b):
+    return torch.matmul(_r(a), _r(b))
+
+
 def _ln(x, w, b, eps):
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
@@ -64,16 +94,16 @@ def _mha(x, mask_add, P, pre, heads, att_name):
     """softmax(QK^T/sqrt(d) + mask) V ; returns context [B,S,H] (before output dense)."""
     B, S, H = x.shape
     d = H // heads
-    q = F.linear(x, P[f"{pre}.{att_name}.query.weight"], P[f"{pre}.{att_name}.query.bias"])
-    k = F.linear(x, P[f"{pre}.{att_name}.key.weight"], P[f"{pre}.{att_name}.key.bias"])
-    v = F.linear(x, P[f"{pre}.{att_name}.value.weight"], P[f"{pre}.{att_name}.value.bias"])
+    q = _r(_lin(x, P[f"{pre}.{att_name}.query.weight"], P[f"{pre}.{att_name}.query.bias"]))
+    k = _r(_lin(x, P[f"{pre}.{att_name}.key.weight"], P[f"{pre}.{att_name}.key.bias"]))
+    v = _r(_lin(x, P[f"{pre}.{att_name}.value.weight"], P[f"{pre}.{att_name}.value.bias"]))
     q = q.view(B, S, heads, d).transpose(1, 2)
     k = k.view(B, S, heads, d).transpose(1, 2)
     v = v.view(B, S, heads, d).transpose(1, 2)
-    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d)
+    s = _mm(q, k.transpose(-1, -2)) / math.sqrt(d)
     s = s + mask_add
     p = torch.softmax(s, dim=-1)
-    c = torch.matmul(p, v)
+    c = _mm(p, v)
     return c.permute(0, 2, 1, 3).reshape(B, S, H)
 
 
@@ -99,11 +129,11 @@ def lm_forward(P, spec, input_ids, attention_mask, token_type_ids=None, taps: Op
     for i in range(lm.num_hidden_layers):
         pre = f"bert.encoder.layer.{i}"
         c = _mha(x, mask_add, P, pre, lm.num_attention_heads, "attention.self")
-        a = F.linear(c, P[f"{pre}.attention.output.dense.weight"], P[f"{pre}.attention.output.dense.bias"])
+        a = _lin(c, P[f"{pre}.attention.output.dense.weight"], P[f"{pre}.attention.output.dense.bias"])
         x = _ln(a + x, P[f"{pre}.attention.output.LayerNorm.weight"], P[f"{pre}.attention.output.LayerNorm.bias"],
                 lm.layer_norm_eps)
-        h = F.gelu(F.linear(x, P[f"{pre}.intermediate.dense.weight"], P[f"{pre}.intermediate.dense.bias"]))
-        o = F.linear(h, P[f"{pre}.output.dense.weight"], P[f"{pre}.output.dense.bias"])
+        h = F.gelu(_r(_lin(x, P[f"{pre}.intermediate.dense.weight"], P[f"{pre}.intermediate.dense.bias"])))
+        o = _lin(h, P[f"{pre}.output.dense.weight"], P[f"{pre}.output.dense.bias"])
         x = _ln(o + x, P[f"{pre}.output.LayerNorm.weight"], P[f"{pre}.output.LayerNorm.bias"], lm.layer_norm_eps)
         if taps is not None:
             taps[f"lm_layer{i}"] = x
@@ -130,7 +160,7 @@ def vilt_embed(P, spec, text_in, attention_mask, token_type_ids, pixel_values, t
             v.layer_norm_eps)
     mt = P["embeddings.token_type_embeddings.weight"]
     text = e + mt[0]
-    pe = F.conv2d(pixel_values, P["embeddings.patch_embeddings.projection.weight"],
+    pe = F.conv2d(_r(pixel_values), _r(P["embeddings.patch_embeddings.projection.weight"]),
                   P["embeddings.patch_embeddings.projection.bias"], stride=v.patch_size)
     pe = pe.flatten(2).transpose(1, 2)                      # [B, g*g, H], row-major patch order
     pos = P["embeddings.position_embeddings"]               # [1, 1+g*g, H]
@@ -150,11 +180,11 @@ def vilt_encoder(P, spec, x, mask, taps=None):
         pre = f"encoder.layer.{i}"
         n1 = _ln(x, P[f"{pre}.layernorm_before.weight"], P[f"{pre}.layernorm_before.bias"], v.layer_norm_eps)
         c = _mha(n1, mask_add, P, pre, v.num_attention_heads, "attention.attention")
-        a = F.linear(c, P[f"{pre}.attention.output.dense.weight"], P[f"{pre}.attention.output.dense.bias"])
+        a = _lin(c, P[f"{pre}.attention.output.dense.weight"], P[f"{pre}.attention.output.dense.bias"])
         x = a + x
         n2 = _ln(x, P[f"{pre}.layernorm_after.weight"], P[f"{pre}.layernorm_after.bias"], v.layer_norm_eps)
-        h = F.gelu(F.linear(n2, P[f"{pre}.intermediate.dense.weight"], P[f"{pre}.intermediate.dense.bias"]))
-        x = F.linear(h, P[f"{pre}.output.dense.weight"], P[f"{pre}.output.dense.bias"]) + x
+        h = F.gelu(_r(_lin(n2, P[f"{pre}.intermediate.dense.weight"], P[f"{pre}.intermediate.dense.bias"])))
+        x = _lin(h, P[f"{pre}.output.dense.weight"], P[f"{pre}.output.dense.bias"]) + x
         if taps is not None:
             taps[f"vilt_layer{i}"] = x
     return x
@@ -178,7 +208,7 @@ def vault_forward(P, spec, batch: Dict[str, torch.Tensor], taps: Optional[dict] 
     x = _ln(x, P["layernorm.weight"], P["layernorm.bias"], spec.vilt.layer_norm_eps)
     out = {"last_hidden_state": x}
     if spec.add_pooling_layer:
-        pooled = torch.tanh(F.linear(x[:, 0], P["pooler.dense.weight"], P["pooler.dense.bias"]))
+        pooled = torch.tanh(_lin(x[:, 0], P["pooler.dense.weight"], P["pooler.dense.bias"]))
         out["pooler_output"] = pooled
         if spec.n_classes > 0:
             z = pooled

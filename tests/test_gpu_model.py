@@ -1,0 +1,204 @@
+"""GPU parity of the whole stacked BERT -> ViLT path (HIP engine through the C ABI) against
+  (a) the CPU oracle in fp32 (the reference's arithmetic),
+  (b) the CPU oracle with bf16-rounded matmul operands (the HIP path's number format), and
+  (c) the committed golden vectors written by the reference itself (tests/golden/*.npz).
+
+Tolerances (bf16 MFMA operands, fp32 accumulation / residual stream / LayerNorm / softmax):
+  logits: 3e-3 abs at 2+2 layers, 8e-3 abs at 12+12 layers (|logits| ~ 0.2); loss: 2e-3 abs;
+  hidden states: 1% of their max magnitude; gradients: global relative L2 error <= 6e-2 and cosine
+  >= 0.995 (the bf16-operand oracle itself sits at 3e-3 .. 4.5e-2 from the fp32 oracle on these cases).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vault_oracle as O
+from vault_amd.engine import VaultEngine
+from vault_amd.spec import LMSpec, VaultSpec, ViltSpec, build_state, synthetic_batch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _nodrop(spec):
+    if spec.lm is not None:
+        spec.lm.hidden_dropout_prob = 0.0
+        spec.lm.attention_probs_dropout_prob = 0.0
+    return spec
+
+
+def _dev(bn):
+    return {k: torch.from_numpy(v).cuda() for k, v in bn.items()}
+
+
+@pytest.mark.parametrize("kind,seed", [("roberta", 11), ("bert", 12)])
+def test_tiny_forward_backward_vs_oracle(kind, seed):
+    spec = _nodrop(VaultSpec.tiny(3, kind))
+    B = 3
+    bn = synthetic_batch(spec, B, seed=seed, n_classes=3)
+    state = build_state(spec, 0)
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    db = _dev(bn)
+    out = eng.forward(db, train=True, labels=db["labels"], need_hidden=True)
+    eng.zero_grad()
+    eng.backward()
+    torch.cuda.synchronize()
+    tb = O.torch_batch(bn)
+    P = O.to_torch_state(state, requires_grad=True)
+    loss, ref = O.vault_loss(P, spec, tb)
+    loss.backward()
+    with O.emulate_bf16():
+        refb = O.vault_forward(O.to_torch_state(state), spec, tb)
+    lg = out["logits"].cpu()
+    assert (lg - ref["logits"].detach()).abs().max() < 3e-3
+    assert (lg - refb["logits"]).abs().max() < 1e-3          # same number format: tighter
+    assert abs(float(out["loss"]) - float(loss.detach())) < 2e-3
+    hid = out["last_hidden_state"].cpu()
+    rh = ref["last_hidden_state"].detach()
+    assert (hid - rh).abs().max() < 1e-2 * rh.abs().max()
+    assert (out["pooler_output"].cpu() - ref["pooler_output"].detach()).abs().max() < 5e-3
+    # golden written by the reference itself
+    g = np.load(os.path.join(GOLD, f"tiny_{kind}.npz"))
+    assert np.abs(lg.numpy() - g["logits"]).max() < 3e-3
+    T = bn["input_ids"].shape[1]
+    assert np.abs(hid[:, : T + 1].numpy() - g["hidden_text_cls"]).max() < 1e-2 * np.abs(g["hidden_text_cls"]).max()
+    # gradients
+    num = den = dot = n1 = 0.0
+    for n in eng.params.trainable:
+        mine = eng.params.gr(n).cpu().double()
+        r = P[n].grad.double()
+        num += float((mine - r).pow(2).sum()); den += float(r.pow(2).sum())
+        dot += float((mine * r).sum()); n1 += float(mine.pow(2).sum())
+    assert (num / den) ** 0.5 < 6e-2
+    assert dot / (n1 ** 0.5 * den ** 0.5) > 0.995
+    # parameters without gradient in the reference have none here either
+    assert not eng.params.has_grad("embeddings.text_embeddings.word_embeddings.weight")
+    assert not eng.params.has_grad("embeddings.text_embeddings.position_embeddings.weight")
+
+
+def test_full_size_against_reference_golden():
+    """12+12 layers, hidden 768, B=2 (one padded caption): compare with numbers produced by the
+    reference (HuggingFace ViltModel + RobertaModel under ref VaultForTMSC) in the build container."""
+    g = np.load(os.path.join(GOLD, "full_bertweet_b2.npz"))
+    spec = _nodrop(VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3))
+    B = int(g["meta_batch"])
+    bn = synthetic_batch(spec, B, seed=int(g["meta_data_seed"]), n_classes=3)
+    eng = VaultEngine(spec, "cuda:0", seed=0, classifier_dropout=0.0)
+    db = _dev(bn)
+    out = eng.forward(db, train=True, labels=db["labels"], need_hidden=True)
+    eng.zero_grad()
+    eng.backward()
+    torch.cuda.synchronize()
+    assert np.abs(out["logits"].cpu().numpy() - g["logits"]).max() < 8e-3
+    assert abs(float(out["loss"]) - float(g["loss"])) < 2e-3
+    assert np.abs(out["pooler_output"].cpu().numpy() - g["pooler_output"]).max() < 2e-2
+    T = bn["input_ids"].shape[1]
+    h = out["last_hidden_state"][:, : T + 1].cpu().numpy()
+    assert np.abs(h - g["hidden_text_cls"]).max() < 1.5e-2 * np.abs(g["hidden_text_cls"]).max()
+    pn = np.sort(np.linalg.norm(out["last_hidden_state"][:, T + 1:].cpu().numpy(), axis=-1), axis=1)
+    np.testing.assert_allclose(pn, g["hidden_patch_sorted_norms"], rtol=5e-3)
+    # gradient norms per parameter (the analytically-zero key biases excluded)
+    names = [str(n) for n in g["grad_names"]]
+    bad = []
+    for n, rn in zip(names, g["grad_norms"]):
+        if ".key.bias" in n:
+            continue
+        mine = float(eng.params.gr(n).double().norm())
+        if abs(mine - rn) > 0.08 * rn + 1e-7:
+            bad.append((n, mine, rn))
+    assert not bad, bad[:5]
+    for k in g.files:
+        if k.startswith("grad::") and ".key.bias" not in k:
+            mine = eng.params.gr(k[6:]).cpu().numpy().reshape(g[k].shape)
+            rel = np.linalg.norm(mine - g[k]) / (np.linalg.norm(g[k]) + 1e-12)
+            assert rel < 8e-2, (k, rel)
+
+
+def test_eval_determinism_and_no_lm():
+    spec = VaultSpec.tiny(3, "roberta")
+    spec_nolm = VaultSpec(vilt=spec.vilt, lm=None, n_classes=0)
+    bn = synthetic_batch(spec_nolm, 2, seed=3)
+    state = build_state(spec_nolm, 0)
+    eng = VaultEngine(spec_nolm, "cuda:0", state=state, with_grads=False)
+    db = _dev(bn)
+    a = eng.forward(db, train=False)
+    h1 = a["last_hidden_state"].clone(); p1 = a["pooler_output"].clone()
+    b = eng.forward(db, train=False)
+    torch.cuda.synchronize()
+    assert torch.equal(h1, b["last_hidden_state"]) and torch.equal(p1, b["pooler_output"])
+    ref = O.vault_forward(O.to_torch_state(state), spec_nolm, O.torch_batch(bn))
+    assert (h1.cpu() - ref["last_hidden_state"]).abs().max() < 1e-2 * ref["last_hidden_state"].abs().max()
+    assert (p1.cpu() - ref["pooler_output"]).abs().max() < 5e-3
+
+
+def test_unsupported_inputs_raise():
+    spec = VaultSpec.tiny(3, "roberta")
+    eng = VaultEngine(spec, "cuda:0", with_grads=False)
+    bn = synthetic_batch(spec, 2, seed=3)
+    db = _dev(bn)
+    db["pixel_mask"] = db["pixel_mask"].clone()
+    db["pixel_mask"][0, :16] = 0
+    with pytest.raises(NotImplementedError):
+        eng.forward(db)
+    db2 = _dev(bn)
+    db2["pixel_values"] = db2["pixel_values"][:, :, :96, :96]
+    with pytest.raises(ValueError):
+        eng.forward(db2)
+
+
+def test_model_api_autograd_bridge():
+    from vault_amd.models.vault import VaultForTMSC, VaultModel
+    spec = _nodrop(VaultSpec.tiny(3, "roberta"))
+    bn = synthetic_batch(spec, 3, seed=11, n_classes=3)
+    with pytest.raises(RuntimeError):
+        VaultForTMSC(spec.vilt, n_classes=3, bert_config=spec.lm)(**{k: torch.from_numpy(v) for k, v in bn.items()
+                                                                     if k != "labels"})
+    model = VaultForTMSC(spec.vilt, n_classes=3, vilt_dropout_prob=0.0, bert_config=spec.lm).to("cuda")
+    kw = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
+    model.eval()
+    with torch.no_grad():
+        lg_eval = model(**kw)
+    assert lg_eval.shape == (3, 3)
+    model.train()
+    logits = model(**kw)
+    loss = torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(bn["labels"]).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    state = build_state(spec, 0)
+    P = O.to_torch_state(state, requires_grad=True)
+    rl, ref = O.vault_loss(P, spec, O.torch_batch(bn))
+    rl.backward()
+    assert (logits.detach().cpu() - ref["logits"].detach()).abs().max() < 3e-3
+    assert abs(float(loss) - float(rl.detach())) < 2e-3
+    sd = dict(model.named_parameters())
+    gw = sd["pooler.dense.weight"].grad
+    assert gw is not None
+    r = P["pooler.dense.weight"].grad
+    assert float((gw.cpu() - r).norm() / r.norm()) < 5e-2
+    assert sd["embeddings.text_embeddings.word_embeddings.weight"].grad is None
+    # zero_grad(set_to_none) + second backward gives fresh (not doubled) gradients
+    model.zero_grad(set_to_none=True)
+    logits = model(**kw)
+    torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(bn["labels"]).cuda()).backward()
+    gw2 = dict(model.named_parameters())["pooler.dense.weight"].grad
+    assert float((gw2.cpu() - r).norm() / r.norm()) < 5e-2
+    # HF input validation errors
+    with pytest.raises(ValueError):
+        model(input_ids=kw["input_ids"], attention_mask=kw["attention_mask"])
+    with pytest.raises(ValueError):
+        model(input_ids=kw["input_ids"][:2], pixel_values=kw["pixel_values"])
+    # VaultModel returns the HF output object
+    enc = VaultModel(spec.vilt, bert_config=spec.lm).to("cuda").eval()
+    with torch.no_grad():
+        o = enc(**kw)
+    assert o.last_hidden_state.shape == (3, 185, 256) and o.pooler_output.shape == (3, 256)
+    assert "pooler_output" in o.keys()
+    assert (o.pooler_output.cpu() - ref["pooler_output"].detach()).abs().max() < 5e-3
+    # state_dict round trip keeps outputs
+    sd2 = {k: v.clone() for k, v in model.state_dict().items()}
+    m2 = VaultForTMSC(spec.vilt, n_classes=3, vilt_dropout_prob=0.0, bert_config=spec.lm, _seed=1).to("cuda").eval()
+    m2.load_state_dict(sd2)
+    with torch.no_grad():
+        assert (m2(**kw) - lg_eval).abs().max() < 1e-6

@@ -1,0 +1,138 @@
+"""CPU-side tests: parameter inventory, C-ABI surface, host logic, the data-parallel bucket reducer
+(world_size 2, gloo)."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vault_oracle as O
+from vault_amd.spec import LMSpec, VaultSpec, ViltSpec, fill_param, param_entries, synthetic_batch
+from vault_amd.train import BucketReducer, linear_schedule
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_parameter_counts_match_survey():
+    def count(spec):
+        return sum(int(np.prod(s)) for _, s, _ in param_entries(spec))
+    assert count(VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3)) == 245_906_691
+    assert count(VaultSpec(vilt=ViltSpec(), lm=LMSpec.bert_base_uncased(), n_classes=3)) == 220_488_963
+
+
+def test_names_cover_reference_parameter_names():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "full_bertweet_b2.npz"))
+    ours = {n for n, _, _ in param_entries(VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3))}
+    assert {str(n) for n in g["grad_names"]} <= ours
+
+
+def test_filler_is_deterministic_and_order_free():
+    a = fill_param("encoder.layer.3.output.dense.weight", (8, 4), "normal", 0)
+    b = fill_param("encoder.layer.3.output.dense.weight", (8, 4), "normal", 0)
+    c = fill_param("encoder.layer.3.output.dense.weight", (8, 4), "normal", 1)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert abs(float(fill_param("x", (100000,), "ln_w").mean()) - 1.0) < 1e-3
+
+
+def test_synthetic_batch_contract():
+    spec = VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3)
+    b = synthetic_batch(spec, 5, seed=1)
+    assert b["input_ids"].shape == (5, 40) and b["input_ids"].dtype == np.int64
+    assert b["pixel_values"].shape == (5, 3, 384, 384) and b["pixel_values"].dtype == np.float32
+    assert (b["input_ids"][b["attention_mask"] == 0] == 1).all()      # pad id
+    assert (b["input_ids"][:, 0] == 0).all()
+    lens = b["attention_mask"].sum(1)
+    assert lens.min() >= 8 and lens.max() <= 40
+    assert "token_type_ids" not in b                                   # BERTweet tokenizer returns none
+
+
+def test_library_exports_every_declared_symbol():
+    path = os.path.join(ROOT, "vault_amd", "libvault_hip.so")
+    if not os.path.exists(path):
+        from vault_amd import build
+        build.build()
+    lib = ctypes.CDLL(path)
+    hdr = open(os.path.join(ROOT, "include", "vault_hip.h")).read()
+    names = set(re.findall(r"\b(vault_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), n
+    lib.vault_abi_version.restype = ctypes.c_int
+    assert lib.vault_abi_version() == 1
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "vault_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f"{f} imports the oracle"
+                assert "vault_oracle" not in src, f"{f} references the oracle module"
+
+
+def test_schedule_matches_oracle():
+    for s in range(0, 30):
+        assert linear_schedule(2e-5, s, 3, 25) == O.linear_schedule_lr(2e-5, s, 3, 25)
+
+
+def test_model_requires_gpu_and_keeps_reference_signature():
+    import inspect
+    from vault_amd.models.vault import VaultForTMSC, VaultModel, VaultProcessor
+    sig = inspect.signature(VaultModel.__init__)
+    assert list(sig.parameters)[1:7] == ["vilt_config", "bert_config", "freeze_lm", "vilt_dropout_prob",
+                                         "use_vilt_position_embeddings", "add_pooling_layer"]
+    sig = inspect.signature(VaultForTMSC.__init__)
+    assert list(sig.parameters)[1:6] == ["vilt_config", "n_classes", "vilt_dropout_prob", "logging_level", "bert_config"]
+    sig = inspect.signature(VaultModel.from_pretrained)
+    assert list(sig.parameters)[:4] == ["pretrained_vilt", "pretrained_bert", "freeze_lm", "use_vilt_position_embeddings"]
+    assert list(inspect.signature(VaultProcessor.from_pretrained).parameters)[:2] == ["vilt_directory", "bert_directory"]
+    spec = VaultSpec.tiny(3)
+    m = VaultForTMSC(spec.vilt, n_classes=3, bert_config=spec.lm)
+    assert set(m.state_dict()) == {n for n, _, _ in param_entries(m.spec)}
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(input_ids=torch.zeros(1, 40, dtype=torch.long), pixel_values=torch.zeros(1, 3, 192, 192))
+    with pytest.raises(ValueError):
+        m(pixel_values=torch.zeros(1, 3, 192, 192))
+
+
+# ---- data parallel: bucketed all-reduce over gloo, world_size 2 ---------------------------------
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 10_000
+    stage_lo = {"head": 9000, "vilt1": 6000, "vilt0": 3000, "vilt_embed": 2500, "lm1": 1500, "lm0": 400, "lm_embed": 0}
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    red = BucketReducer(g, stage_lo, "lm_embed", bucket_elems=2500, dist=dist)
+    launched = []
+    for tag in ["head", "vilt1", "vilt0", "vilt_embed", "lm1", "lm0", "lm_embed"]:
+        red.on_stage(tag)
+        launched = list(red.launched)
+    red.finish()
+    expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    ok = bool(torch.equal(g, expect))
+    # ranges are contiguous, descending and cover [0, n) exactly once
+    cover = sorted(launched)
+    ok = ok and cover[0][0] == 0 and cover[-1][1] == n and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    ok = ok and all(hi - lo >= 2500 for lo, hi in launched[:-1])
+    q.put((rank, ok, launched))
+    dist.destroy_process_group()
+
+
+def test_bucket_reducer_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == res[1][2]

@@ -1,0 +1,234 @@
+// Embedding-side kernels of the path (all HBM-bound gather/scatter work, 16-byte accesses):
+//   position ids, table gather-sum (+ dense source), table scatter-add (backward), patch im2col,
+//   the per-patch additive table + CLS rows of the fused [text | patch] sequence, and the backward
+//   reduction over the image rows.
+//
+// Replaces RobertaEmbeddings/BertEmbeddings (HF:models/roberta/modeling_roberta.py:75-155,
+// HF:models/bert/modeling_bert.py:69-107), ViLT TextEmbeddings on inputs_embeds
+// (HF:models/vilt/modeling_vilt.py:237-269), ViltPatchEmbeddings' unfold (modeling_vilt.py:290-300) and
+// the bookkeeping of ViltEmbeddings.visual_embed / forward for full pixel masks (modeling_vilt.py:92-219).
+#include <algorithm>
+#include "common.h"
+#include "../../include/vault_hip.h"
+
+namespace {
+
+// one wave per sample; T <= 64
+__global__ void position_ids_kernel(const long long* __restrict__ ids, int* __restrict__ pos, int T, int mode, int pad) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  int v = 0;
+  if (mode == 1) {
+    const bool valid = (t < T) && (ids[(size_t)b * T + t] != pad);
+    const unsigned long long m = __ballot(valid);
+    const int incl = __popcll(m & ((2ull << t) - 1ull));
+    v = valid ? incl + pad : pad;
+  } else {
+    v = t;
+  }
+  if (t < T) pos[(size_t)b * T + t] = v;
+}
+
+struct Gather3 {
+  const float* tab[3];
+  const void* idx[3];   // int64 (is64=1) or int32 indices per row, or null => use fixed[k]
+  int is64[3];
+  int fixed[3];         // used when idx null and >= 0; -1 = table absent; -2 = index is (row % period)
+  int period;
+};
+
+__device__ __forceinline__ long long load_idx(const Gather3& g, int k, int row) {
+  if (g.idx[k] != nullptr)
+    return g.is64[k] ? reinterpret_cast<const long long*>(g.idx[k])[row]
+                     : (long long)reinterpret_cast<const int*>(g.idx[k])[row];
+  if (g.fixed[k] == -2) return row % g.period;
+  return g.fixed[k];
+}
+
+// out[row] = (src ? src[row] : 0) + sum_k tab_k[idx_k[row]]   ; one wave per row, H % 256 == 0
+__global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict__ src, Gather3 g, float* __restrict__ out,
+                                                         int rows, int H) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  long long ix[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) ix[k] = (g.tab[k] != nullptr) ? load_idx(g, k, row) : 0;
+  for (int c = lane * 4; c < H; c += 256) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (src) a = *reinterpret_cast<const f32x4*>(src + (size_t)row * H + c);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (g.tab[k] != nullptr) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(g.tab[k] + (size_t)ix[k] * H + c);
+        a[0] += t[0]; a[1] += t[1]; a[2] += t[2]; a[3] += t[3];
+      }
+    *reinterpret_cast<f32x4*>(out + (size_t)row * H + c) = a;
+  }
+}
+
+struct Scatter3 {
+  float* tab[3];
+  const void* idx[3];
+  int is64[3];
+  int fixed[3];
+  int period;
+};
+
+// tab_k[idx_k[row]] += d[row]   (float atomics, one 256-byte segment per wave-instruction)
+__global__ __launch_bounds__(256) void scatter_add_kernel(const float* __restrict__ d, Scatter3 g, int rows, int H) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  long long ix[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    ix[k] = 0;
+    if (g.tab[k] != nullptr) {
+      if (g.idx[k] != nullptr)
+        ix[k] = g.is64[k] ? reinterpret_cast<const long long*>(g.idx[k])[row]
+                          : (long long)reinterpret_cast<const int*>(g.idx[k])[row];
+      else
+        ix[k] = (g.fixed[k] == -2) ? (row % g.period) : g.fixed[k];
+    }
+  }
+  for (int c = lane; c < H; c += 64) {
+    const float v = d[(size_t)row * H + c];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (g.tab[k] != nullptr) atomicAdd(g.tab[k] + (size_t)ix[k] * H + c, v);
+  }
+}
+
+// pixel [B][C][IMG][IMG] f32 -> A [B*P (padded)][C*ps*ps] bf16, k = c*ps*ps + py*ps + px, patches row-major
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ pix, bf16* __restrict__ out, int B, int Cn,
+                                                     int IMG, int ps, long long total_chunks) {
+  const int grid = IMG / ps;
+  const int cpr = ps / 8;                 // 8-pixel chunks per patch row
+  const int Kp = Cn * ps * ps;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total_chunks; i += (long long)gridDim.x * 256ll) {
+    // chunk order follows the OUTPUT layout (coalesced 16-byte stores)
+    const long long row = i / (Kp / 8);
+    const int kc = (int)(i - row * (Kp / 8));
+    const int b = (int)(row / (grid * grid)), p = (int)(row - (long long)b * grid * grid);
+    const int pr = p / grid, pc = p - pr * grid;
+    const int k = kc * 8;
+    const int c = k / (ps * ps), rem = k - c * ps * ps;
+    const int py = rem / ps, px = rem - py * ps;
+    (void)cpr;
+    const float* s = pix + (((size_t)b * Cn + c) * IMG + (size_t)(pr * ps + py)) * IMG + pc * ps + px;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(s);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(s + 4);
+    u32x4 w = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
+    *reinterpret_cast<u32x4*>(out + row * Kp + k) = w;
+  }
+}
+
+// addtab[p][n] = bias[n] + pos[1+p][n] + mtype1[n]  (p < P) ; x[b*S + T][n] = cls[n] + pos[0][n] + mtype1[n]
+__global__ __launch_bounds__(256) void image_consts_kernel(const float* __restrict__ bias, const float* __restrict__ pos,
+                                                           const float* __restrict__ mtype1, const float* __restrict__ cls,
+                                                           float* __restrict__ addtab, float* __restrict__ x, int P, int H,
+                                                           int B, int S, int T) {
+  const int p = blockIdx.x;  // 0..P ; p == P -> cls rows
+  for (int n = threadIdx.x; n < H; n += 256) {
+    if (p < P) {
+      addtab[(size_t)p * H + n] = bias[n] + pos[(size_t)(1 + p) * H + n] + mtype1[n];
+    } else {
+      const float v = cls[n] + pos[n] + mtype1[n];
+      for (int b = 0; b < B; ++b) x[((size_t)b * S + T) * H + n] = v;
+    }
+  }
+}
+
+// backward over the image rows of dx [B*S][H] (f32): position j in 0..P (0 = CLS):
+//   dpos[j] += sum_b dx[b, T+j] ; dmtype1 += (same) ; j==0: dcls += ; j>=1: dbias += and
+//   dyp[b*P + j-1] = bf16(dx[b, T+j])   (compact operand for the projection wgrad)
+__global__ __launch_bounds__(256) void image_rows_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dpos,
+                                                             float* __restrict__ dmtype1, float* __restrict__ dcls,
+                                                             float* __restrict__ dbias, bf16* __restrict__ dyp, int P, int H,
+                                                             int B, int S, int T, int b_per_block) {
+  const int j = blockIdx.x;
+  const int b0 = blockIdx.y * b_per_block, b1 = min(B, b0 + b_per_block);
+  for (int n = threadIdx.x; n < H; n += 256) {
+    float acc = 0.f;
+    for (int b = b0; b < b1; ++b) {
+      const float v = dx[((size_t)b * S + T + j) * H + n];
+      acc += v;
+      if (j >= 1) dyp[((size_t)b * P + (j - 1)) * H + n] = (bf16)v;
+    }
+    atomicAdd(dpos + (size_t)j * H + n, acc);
+    atomicAdd(dmtype1 + n, acc);
+    if (j == 0) atomicAdd(dcls + n, acc); else atomicAdd(dbias + n, acc);
+  }
+}
+
+__global__ void axpy_kernel(float* __restrict__ dst, const float* __restrict__ src, float a, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256ll) dst[i] += a * src[i];
+}
+
+}  // namespace
+
+extern "C" int vault_position_ids(const int64_t* ids, int* pos, int B, int T, int mode, int pad, void* stream) {
+  if (!ids || !pos || T > 64 || T <= 0 || B <= 0) return VAULT_EINVAL;
+  hipLaunchKernelGGL(position_ids_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const long long*>(ids), pos, T, mode, pad);
+  return (int)hipGetLastError();
+}
+
+extern "C" int vault_gather_sum(const vault_gather_args* a, void* stream) {
+  if (!a || !a->out || a->H % 256 || a->rows <= 0) return VAULT_EINVAL;
+  Gather3 g;
+  for (int k = 0; k < 3; ++k) {
+    g.tab[k] = a->tab[k]; g.idx[k] = a->idx[k]; g.is64[k] = a->is64[k]; g.fixed[k] = a->fixed[k];
+  }
+  g.period = a->period > 0 ? a->period : 1;
+  hipLaunchKernelGGL(gather_sum_kernel, dim3((a->rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     a->src, g, a->out, a->rows, a->H);
+  return (int)hipGetLastError();
+}
+
+extern "C" int vault_scatter_add(const vault_gather_args* a, void* stream) {
+  if (!a || !a->src || a->H % 64 || a->rows <= 0) return VAULT_EINVAL;
+  Scatter3 g;
+  for (int k = 0; k < 3; ++k) {
+    g.tab[k] = const_cast<float*>(a->tab[k]); g.idx[k] = a->idx[k]; g.is64[k] = a->is64[k]; g.fixed[k] = a->fixed[k];
+  }
+  g.period = a->period > 0 ? a->period : 1;
+  hipLaunchKernelGGL(scatter_add_kernel, dim3((a->rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     a->src, g, a->rows, a->H);
+  return (int)hipGetLastError();
+}
+
+extern "C" int vault_im2col(const float* pix, void* out_bf16, int B, int C, int IMG, int ps, void* stream) {
+  if (!pix || !out_bf16 || ps % 8 || IMG % ps || B <= 0) return VAULT_EINVAL;
+  const long long rows = (long long)B * (IMG / ps) * (IMG / ps);
+  const long long chunks = rows * (C * ps * ps / 8);
+  const int blocks = (int)std::min<long long>((chunks + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pix,
+                     reinterpret_cast<bf16*>(out_bf16), B, C, IMG, ps, chunks);
+  return (int)hipGetLastError();
+}
+
+extern "C" int vault_image_consts(const float* bias, const float* pos, const float* mtype1, const float* cls,
+                                  float* addtab, float* x, int P, int H, int B, int S, int T, void* stream) {
+  if (!bias || !pos || !mtype1 || !cls || !addtab || !x) return VAULT_EINVAL;
+  hipLaunchKernelGGL(image_consts_kernel, dim3(P + 1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), bias, pos,
+                     mtype1, cls, addtab, x, P, H, B, S, T);
+  return (int)hipGetLastError();
+}
+
+extern "C" int vault_image_rows_bwd(const float* dx, float* dpos, float* dmtype1, float* dcls, float* dbias,
+                                    void* dyp_bf16, int P, int H, int B, int S, int T, void* stream) {
+  if (!dx || !dpos || !dmtype1 || !dcls || !dbias || !dyp_bf16) return VAULT_EINVAL;
+  const int bpb = 8;
+  hipLaunchKernelGGL(image_rows_bwd_kernel, dim3(P + 1, (B + bpb - 1) / bpb), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), dx, dpos, dmtype1, dcls, dbias,
+                     reinterpret_cast<bf16*>(dyp_bf16), P, H, B, S, T, bpb);
+  return (int)hipGetLastError();
+}
+
+extern "C" int vault_axpy_f32(float* dst, const float* src, float a, long long n, void* stream) {
+  if (!dst || !src || n <= 0) return VAULT_EINVAL;
+  const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(axpy_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dst, src, a, n);
+  return (int)hipGetLastError();
+}

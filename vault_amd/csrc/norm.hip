@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                                                      bf16* __restrict__ dx_bf16, RowMap dxmap, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int rows_per_block,
                                                      uint32_t drop_thresh, uint32_t drop_seed, uint32_t drop_stream,
-                                                     float drop_scale) {
+                                                     float drop_scale, int drop_on_dy) {
   __shared__ float red[4][VPT * 256 * 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x4 gw[VPT], ag[VPT], ab[VPT];
@@ -119,6 +119,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         const float2 a = unpack_bf16x2(w.x), b = unpack_bf16x2(w.y);
         d[0] += a.x; d[1] += a.y; d[2] += b.x; d[3] += b.y;
       }
+      if (drop_on_dy && drop_thresh != 0u) {   // y = dropout(LN(x)): mask the incoming gradient
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          d[e] = dropout_keep(drop_seed, drop_stream, (uint32_t)(dr + c + e), drop_thresh) ? d[e] * drop_scale : 0.f;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         xh[j][e] = (xv[e] - mu) * rs;
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
       }
       if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + orow + c) = o;
       if (dx_bf16) {
-        if (drop_thresh != 0u) {
+        if (drop_thresh != 0u && !drop_on_dy) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             o[e] = dropout_keep(drop_seed, drop_stream, (uint32_t)(orow + c + e), drop_thresh) ? o[e] * drop_scale : 0.f;
@@ -225,7 +230,7 @@ extern "C" int vault_layernorm_bwd(const vault_ln_bwd_args* a, void* stream) {
   hipLaunchKernelGGL(ln_bwd_kernel<V>, grid, block, 0, st, reinterpret_cast<const bf16*>(a->dy_bf16), a->dy_f32, \
                      dym, a->x, xm, a->mean, a->rstd, a->gamma, a->rows, a->H, a->dres, a->dx_f32,               \
                      reinterpret_cast<bf16*>(a->dx_bf16), dxm, a->dgamma, a->dbeta, rpb, a->drop_thresh,          \
-                     a->drop_seed, a->drop_stream, a->drop_scale)
+                     a->drop_seed, a->drop_stream, a->drop_scale, a->drop_on_dy)
   switch (a->H / 256) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;

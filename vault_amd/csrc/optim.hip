@@ -1,0 +1,68 @@
+// Fused HuggingFace-4.48 AdamW over one flat parameter buffer (+ bf16 shadow weights for the GEMMs).
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= step_size * m / (sqrt(v) + eps) ; p -= lr*wd*p
+//   step_size = lr (correct_bias=False, the reference default: ref vault/tmsc_utils/trainer.py:69,244-254)
+//               or lr*sqrt(1-b2^t)/(1-b1^t), computed on the host.
+// One pass: 16 B/param read (p,g,m,v), 12 B written (p,m,v) + 2 B bf16 shadow (+4 B when zeroing g).
+#include "common.h"
+#include "../../include/vault_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16* __restrict__ pb, long long n4,
+                                                    float step_size, float lr_wd, float b1, float b2, float eps,
+                                                    float gscale, int zero_grad) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256ll) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    f32x4 gv = reinterpret_cast<f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ge = gv[e] * gscale;
+      mv[e] = mv[e] * b1 + (1.f - b1) * ge;
+      vv[e] = vv[e] * b2 + (1.f - b2) * ge * ge;
+      pv[e] = pv[e] - step_size * (mv[e] / (sqrtf(vv[e]) + eps));
+      if (lr_wd != 0.f) pv[e] = pv[e] - lr_wd * pv[e];
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (zero_grad) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (pb) {
+      uint2 w = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+      reinterpret_cast<uint2*>(pb)[i] = w;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, long long n4) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256ll) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(x)[i];
+    uint2 w = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
+    reinterpret_cast<uint2*>(y)[i] = w;
+  }
+}
+
+}  // namespace
+
+extern "C" int vault_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, long long n, float lr,
+                                float beta1, float beta2, float eps, float weight_decay, float bias_corr_factor,
+                                float grad_scale, int zero_grad, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || (n & 3)) return VAULT_EINVAL;
+  const long long n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v,
+                     reinterpret_cast<bf16*>(p_bf16), n4, lr * bias_corr_factor, lr * weight_decay, beta1, beta2, eps,
+                     grad_scale, zero_grad);
+  return (int)hipGetLastError();
+}
+
+extern "C" int vault_cast_bf16(const float* x, void* y_bf16, long long n, void* stream) {
+  if (!x || !y_bf16 || n <= 0 || (n & 3)) return VAULT_EINVAL;
+  const long long n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     reinterpret_cast<bf16*>(y_bf16), n4);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,579 @@
+"""Host-side driver of the stacked BERT -> ViLT path: owns the flat parameter/gradient buffers and
+the activation workspace in HBM and enqueues the HIP kernels of libvault_hip.so in order.
+
+PyTorch is used for device memory, streams and (in train.py) torch.distributed only; all arithmetic
+of the path runs in the hand-written kernels.  Mirrors ref: vault/models/vault/model.py:151-218
+(LM -> inputs_embeds -> ViLT) and, for backward, what autograd does for it.
+
+HBM layout
+  parameters   one flat fp32 buffer (master) + bf16 shadow + fp32 grad + Adam m, v; trainable
+               tensors first so the optimizer and the gradient all-reduce see one contiguous range;
+               q/k/v weights of a layer are adjacent, i.e. one [3H, H] matrix for the fused QKV GEMM.
+  activations  token-major [rows, features], rows padded to a multiple of 256 with zero rows
+               (GEMM tiles read them, epilogues never write them); residual stream fp32, GEMM
+               operands bf16.  The fused [text | patch] sequence of sample b is rows b*S .. b*S+S-1.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .ops import Drop, NO_DROP
+from .spec import VaultSpec, build_state, param_entries
+
+
+def _pad(n: int, m: int = 256) -> int:
+    return ((n + m - 1) // m) * m
+
+
+class ParamStore:
+    def __init__(self, spec: VaultSpec, device, state: Optional[Dict[str, np.ndarray]] = None, seed: int = 0,
+                 freeze_lm: bool = False, with_grads: bool = True):
+        self.spec, self.device, self.freeze_lm = spec, device, freeze_lm
+        entries = {n: s for n, s, _ in param_entries(spec)}
+        order = self._flat_order(spec)
+        assert set(order) == set(entries), "flat order must cover the parameter inventory"
+        no_grad = set(self.no_grad_names(spec, freeze_lm))
+        train = [n for n in order if n not in no_grad]
+        rest = [n for n in order if n in no_grad]
+        self.offsets: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        off = 0
+        for n in train:
+            self.offsets[n] = (off, entries[n])
+            off += _pad(int(np.prod(entries[n])), 64)
+        self.n_train = _pad(off, 1024)
+        off = self.n_train
+        for n in rest:
+            self.offsets[n] = (off, entries[n])
+            off += _pad(int(np.prod(entries[n])), 64)
+        self.n_total = _pad(off, 1024)
+        self.trainable = train
+        self.frozen = rest
+        host = np.zeros(self.n_total, np.float32)
+        if state is None:
+            state = build_state(spec, seed)
+        for n, (o, shp) in self.offsets.items():
+            host[o:o + int(np.prod(shp))] = np.asarray(state[n], np.float32).reshape(-1)
+        self.p = torch.from_numpy(host).to(device)
+        self.pb = torch.empty(self.n_total, dtype=torch.bfloat16, device=device)
+        ops.cast_bf16(self.p, self.pb, self.n_total)
+        self.g = self.m = self.v = None
+        if with_grads:
+            self.g = torch.zeros(self.n_train, device=device)
+            self.m = torch.zeros(self.n_train, device=device)
+            self.v = torch.zeros(self.n_train, device=device)
+
+    @staticmethod
+    def no_grad_names(spec: VaultSpec, freeze_lm: bool) -> List[str]:
+        out = []
+        if spec.lm is not None:
+            out.append("embeddings.text_embeddings.word_embeddings.weight")
+            if not spec.use_vilt_position_embeddings:
+                out.append("embeddings.text_embeddings.position_embeddings.weight")
+            if freeze_lm:
+                out += [n for n, _, _ in param_entries(spec) if n.startswith("bert.")]
+        return out
+
+    @staticmethod
+    def _layer_order(prefix: str, style: str) -> List[str]:
+        att = "attention.attention" if style == "vilt" else "attention.self"
+        o = [f"{prefix}.{att}.{n}.weight" for n in ("query", "key", "value")]
+        o += [f"{prefix}.{att}.{n}.bias" for n in ("query", "key", "value")]
+        o += [f"{prefix}.attention.output.dense.weight", f"{prefix}.attention.output.dense.bias"]
+        if style == "bert":
+            o += [f"{prefix}.attention.output.LayerNorm.weight", f"{prefix}.attention.output.LayerNorm.bias"]
+        else:
+            o += [f"{prefix}.layernorm_before.weight", f"{prefix}.layernorm_before.bias",
+                  f"{prefix}.layernorm_after.weight", f"{prefix}.layernorm_after.bias"]
+        o += [f"{prefix}.intermediate.dense.weight", f"{prefix}.intermediate.dense.bias",
+              f"{prefix}.output.dense.weight", f"{prefix}.output.dense.bias"]
+        if style == "bert":
+            o += [f"{prefix}.output.LayerNorm.weight", f"{prefix}.output.LayerNorm.bias"]
+        return o
+
+    @classmethod
+    def _flat_order(cls, spec: VaultSpec) -> List[str]:
+        o: List[str] = []
+        if spec.lm is not None:
+            o += ["bert.embeddings.word_embeddings.weight", "bert.embeddings.position_embeddings.weight",
+                  "bert.embeddings.token_type_embeddings.weight", "bert.embeddings.LayerNorm.weight",
+                  "bert.embeddings.LayerNorm.bias"]
+            for i in range(spec.lm.num_hidden_layers):
+                o += cls._layer_order(f"bert.encoder.layer.{i}", "bert")
+        o += ["embeddings.cls_token", "embeddings.position_embeddings",
+              "embeddings.text_embeddings.word_embeddings.weight",
+              "embeddings.text_embeddings.position_embeddings.weight",
+              "embeddings.text_embeddings.token_type_embeddings.weight",
+              "embeddings.text_embeddings.LayerNorm.weight", "embeddings.text_embeddings.LayerNorm.bias",
+              "embeddings.patch_embeddings.projection.weight", "embeddings.patch_embeddings.projection.bias",
+              "embeddings.token_type_embeddings.weight"]
+        for i in range(spec.vilt.num_hidden_layers):
+            o += cls._layer_order(f"encoder.layer.{i}", "vilt")
+        o += ["layernorm.weight", "layernorm.bias"]
+        if spec.add_pooling_layer:
+            o += ["pooler.dense.weight", "pooler.dense.bias"]
+        if spec.n_classes > 0:
+            o += ["classifier.1.weight", "classifier.1.bias"]
+        return o
+
+    # ---- views ------------------------------------------------------------------------------
+    def _view(self, buf, name, n_elems=None, shape=None):
+        o, shp = self.offsets[name]
+        n = int(np.prod(shp)) if n_elems is None else n_elems
+        return buf[o:o + n].view(*(shape if shape is not None else shp))
+
+    def w(self, name, **kw):
+        return self._view(self.p, name, **kw)
+
+    def wb(self, name, **kw):
+        return self._view(self.pb, name, **kw)
+
+    def gr(self, name, **kw):
+        if self.g is None or self.offsets[name][0] >= self.n_train:
+            return None
+        return self._view(self.g, name, **kw)
+
+    def has_grad(self, name) -> bool:
+        return self.g is not None and self.offsets[name][0] < self.n_train
+
+    def state_dict_numpy(self) -> Dict[str, np.ndarray]:
+        host = self.p.detach().cpu().numpy()
+        return {n: host[o:o + int(np.prod(s))].reshape(s).copy() for n, (o, s) in self.offsets.items()}
+
+    def load_numpy(self, state: Dict[str, np.ndarray]):
+        host = self.p.detach().cpu().numpy().copy()
+        for n, v in state.items():
+            o, shp = self.offsets[n]
+            host[o:o + int(np.prod(shp))] = np.asarray(v, np.float32).reshape(-1)
+        self.p.copy_(torch.from_numpy(host))
+        ops.cast_bf16(self.p, self.pb, self.n_total)
+
+
+class _LayerNames:
+    def __init__(self, prefix: str, style: str):
+        att = "attention.attention" if style == "vilt" else "attention.self"
+        self.qw, self.qb = f"{prefix}.{att}.query.weight", f"{prefix}.{att}.query.bias"
+        self.ow, self.ob = f"{prefix}.attention.output.dense.weight", f"{prefix}.attention.output.dense.bias"
+        self.iw, self.ib = f"{prefix}.intermediate.dense.weight", f"{prefix}.intermediate.dense.bias"
+        self.fw, self.fb = f"{prefix}.output.dense.weight", f"{prefix}.output.dense.bias"
+        if style == "vilt":
+            self.ln1w, self.ln1b = f"{prefix}.layernorm_before.weight", f"{prefix}.layernorm_before.bias"
+            self.ln2w, self.ln2b = f"{prefix}.layernorm_after.weight", f"{prefix}.layernorm_after.bias"
+        else:
+            self.ln1w, self.ln1b = (f"{prefix}.attention.output.LayerNorm.weight",
+                                    f"{prefix}.attention.output.LayerNorm.bias")
+            self.ln2w, self.ln2b = f"{prefix}.output.LayerNorm.weight", f"{prefix}.output.LayerNorm.bias"
+
+
+class VaultEngine:
+    """Forward / backward of VaultModel / VaultForTMSC over one batch resident in HBM."""
+
+    WGRAD_TARGET_WGS = 768
+
+    def __init__(self, spec: VaultSpec, device="cuda:0", state=None, seed: int = 0, freeze_lm: bool = False,
+                 with_grads: bool = True, classifier_dropout: float = 0.1):
+        self.spec, self.device = spec, torch.device(device)
+        self.freeze_lm = freeze_lm and spec.lm is not None
+        self.classifier_dropout = classifier_dropout
+        if spec.vilt.hidden_size % 256 or (spec.lm and spec.lm.hidden_size != spec.vilt.hidden_size):
+            raise ValueError("hidden size must be a multiple of 256 and equal for LM and ViLT")
+        if spec.vilt.hidden_size // spec.vilt.num_attention_heads != 64:
+            raise ValueError("head dimension must be 64")
+        with torch.cuda.device(self.device):
+            self.params = ParamStore(spec, self.device, state, seed, self.freeze_lm, with_grads)
+        self.vl = [_LayerNames(f"encoder.layer.{i}", "vilt") for i in range(spec.vilt.num_hidden_layers)]
+        self.ll = ([_LayerNames(f"bert.encoder.layer.{i}", "bert") for i in range(spec.lm.num_hidden_layers)]
+                   if spec.lm else [])
+        self._ws: Dict[Tuple[int, int, bool], dict] = {}
+        self.drop_seed = 0
+        self.last: Optional[dict] = None
+        # optional live kernel timing (bench.py): list receiving (start, end) torch.cuda.Event pairs
+        # recorded on the launch stream around the ViLT FFN-in forward GEMM
+        self.profile_events: Optional[list] = None
+
+    # ---- workspace --------------------------------------------------------------------------
+    def _buf(self, ws, name, shape, dtype):
+        t = ws.get(name)
+        if t is None:
+            t = torch.zeros(shape, dtype=dtype, device=self.device)
+            ws[name] = t
+        return t
+
+    def workspace(self, B: int, T: int, train: bool) -> dict:
+        key = (B, T, train)
+        if key not in self._ws:
+            self._ws[key] = {"B": B, "T": T}
+        return self._ws[key]
+
+    # ---- helpers ----------------------------------------------------------------------------
+    def _linear(self, a_bf16, wname, out, M, N, K, epi, m_valid, bias=None, **kw):
+        P = self.params
+        ops.gemm(a_bf16, P.wb(wname, n_elems=N * K, shape=(N, K)), out, M, N, K, K, K, N, 0, 0, epi, m_valid=m_valid,
+                 bias=bias, **kw)
+
+    def _dgrad(self, dy_bf16, wname, out, M, Kin, Nout, epi, m_valid, **kw):
+        # dX[M,Kin] = dY[M,Nout] . W[Nout,Kin]
+        P = self.params
+        ops.gemm(dy_bf16, P.wb(wname, n_elems=Nout * Kin, shape=(Nout, Kin)), out, M, Kin, Nout, Nout, Kin, Kin, 0, 1,
+                 epi, m_valid=m_valid, **kw)
+
+    def _wgrad(self, dy_bf16, x_bf16, wname, bname, Mtok_pad, Nout, Kin, m_valid):
+        # dW[Nout,Kin] += dY[Mtok,Nout]^T . X[Mtok,Kin] ; db[Nout] += colsum(dY)
+        P = self.params
+        gw = P.gr(wname, n_elems=Nout * Kin, shape=(Nout, Kin))
+        if gw is None:
+            return
+        tiles = (Nout // 128) * (Kin // 128)
+        nk = Mtok_pad // 64
+        splits = max(1, min(nk, (self.WGRAD_TARGET_WGS + tiles - 1) // tiles))
+        ops.gemm(dy_bf16, x_bf16, gw, Nout, Kin, Mtok_pad, Nout, Kin, Kin, 1, 1, ops.EPI_F32_ATOMIC, cfg=0, splits=splits,
+                 accumulate=1)
+        if bname is not None:
+            ops.colsum(dy_bf16, Nout, m_valid, Nout, P.gr(bname, n_elems=Nout, shape=(Nout,)))
+
+    def _drop(self, p: float, stream: int, train: bool) -> Drop:
+        return Drop(p, self.drop_seed, stream) if (train and p > 0.0) else NO_DROP
+
+    # ---- forward ----------------------------------------------------------------------------
+    def forward(self, batch: Dict[str, torch.Tensor], train: bool = False, labels: Optional[torch.Tensor] = None,
+                need_hidden: bool = True, loss_scale: Optional[float] = None) -> Dict[str, torch.Tensor]:
+        """batch tensors must already be on the device (int64 ids / mask, f32 pixels).  Returns device
+        tensors; in train mode keeps every activation needed by :meth:`backward`."""
+        with torch.cuda.device(self.device):
+            return self._forward(batch, train, labels, need_hidden, loss_scale)
+
+    def _forward(self, batch, train, labels, need_hidden, loss_scale):
+        spec, P = self.spec, self.params
+        v = spec.vilt
+        ids = batch["input_ids"]
+        B, T = ids.shape
+        H, FF, heads = v.hidden_size, v.intermediate_size, v.num_attention_heads
+        NP = v.num_patches
+        S = T + 1 + NP
+        M, Mp = B * S, _pad(B * S)
+        pm = batch.get("pixel_mask")
+        pix = batch["pixel_values"].contiguous()
+        if pix.shape[1:] != (v.num_channels, v.image_size, v.image_size):
+            raise ValueError(f"pixel_values must be [B,{v.num_channels},{v.image_size},{v.image_size}]; variable-size "
+                             "images / partial pixel masks are not implemented in this build")
+        if pix.shape[0] != B:
+            raise ValueError("The text inputs and image inputs need to have the same batch size")
+        if pm is not None and not bool((pm != 0).all()):
+            raise NotImplementedError("partial pixel_mask (padded images) is not implemented in this build")
+        am = batch.get("attention_mask")
+        amf = torch.ones(B, T, device=self.device) if am is None else am.to(torch.float32).contiguous()
+        tt = batch.get("token_type_ids")
+        ws = self.workspace(B, T, train)
+        ws.update(S=S, M=M, Mp=Mp, H=H, FF=FF, heads=heads, NP=NP, train=train)
+        buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
+        bf = torch.bfloat16
+        self.drop_seed = (self.drop_seed + 1) & 0xFFFFFFFF if train else self.drop_seed
+        ws["drop_seed"] = self.drop_seed
+        ids = ids.contiguous()
+        ws["ids"], ws["tt"] = ids, tt
+
+        # ------------------------------ language model ------------------------------
+        if spec.lm is not None:
+            lm = spec.lm
+            Ml, Mlp = B * T, _pad(B * T)
+            ws.update(Ml=Ml, Mlp=Mlp)
+            lm_tt = tt if (tt is not None and lm.type_vocab_size >= 2) else 0   # ref: model.py:174-180
+            ws["lm_tt"] = lm_tt
+            pos = buf("lm_pos", (B, T), torch.int32)
+            ops.position_ids(ids, pos, B, T, 1 if lm.kind == "roberta" else 0, lm.pad_token_id)
+            esum = buf("lm_esum", (Mlp, H))
+            ops.gather_sum(None, esum, [(P.w("bert.embeddings.word_embeddings.weight"), ids),
+                                        (P.w("bert.embeddings.position_embeddings.weight"), pos),
+                                        (P.w("bert.embeddings.token_type_embeddings.weight"), lm_tt)], Ml, H)
+            keep = train and not self.freeze_lm
+            nl = lm.num_hidden_layers
+            y = [buf(f"lm_y{i}" if keep else f"lm_y{i % 2}", (Mlp, H)) for i in range(nl + 1)]
+            yb = [buf(f"lm_yb{i}" if keep else f"lm_yb{i % 2}", (Mlp, H), bf) for i in range(nl + 1)]
+            lm_train = train   # dropout stays active in a frozen LM too (ref: model.py:189 only disables grad)
+            pdh, pda = lm.hidden_dropout_prob, lm.attention_probs_dropout_prob
+            ops.layernorm_fwd(esum, P.w("bert.embeddings.LayerNorm.weight"), P.w("bert.embeddings.LayerNorm.bias"),
+                              lm.layer_norm_eps, Ml, H, y_f32=y[0], y_bf16=yb[0], mean=buf("lm_emean", (Mlp,)),
+                              rstd=buf("lm_erstd", (Mlp,)), drop=self._drop(pdh, 1, lm_train))
+            for i, ln in enumerate(self.ll):
+                sfx = f"{i}" if keep else ""
+                qkv = buf(f"lm_qkv{sfx}", (Mlp, 3 * H), bf)
+                ctx = buf(f"lm_ctx{sfx}", (Mlp, H), bf)
+                lse = buf(f"lm_lse{sfx}", (B, heads, T))
+                h1 = buf(f"lm_h1{sfx}", (Mlp, H)); y1 = buf(f"lm_y1{sfx}", (Mlp, H)); y1b = buf(f"lm_y1b{sfx}", (Mlp, H), bf)
+                u = buf(f"lm_u{sfx}", (Mlp, FF), bf) if keep else None
+                act = buf(f"lm_act{sfx}", (Mlp, FF), bf)
+                h2 = buf(f"lm_h2{sfx}", (Mlp, H))
+                self._linear(yb[i], ln.qw, qkv, Mlp, 3 * H, H, ops.EPI_BF16, Ml, bias=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)))
+                ops.attention_fwd(qkv, amf, ctx, lse, B, T, H, heads, drop=self._drop(pda, 16 * i + 2, lm_train))
+                self._linear(ctx, ln.ow, h1, Mlp, H, H, ops.EPI_F32_RES, Ml, bias=P.w(ln.ob), res=y[i],
+                             drop=self._drop(pdh, 16 * i + 3, lm_train))
+                ops.layernorm_fwd(h1, P.w(ln.ln1w), P.w(ln.ln1b), lm.layer_norm_eps, Ml, H, y_f32=y1, y_bf16=y1b,
+                                  mean=buf(f"lm_m1{sfx}", (Mlp,)), rstd=buf(f"lm_r1{sfx}", (Mlp,)))
+                self._linear(y1b, ln.iw, act, Mlp, FF, H, ops.EPI_BF16_GELU, Ml, bias=P.w(ln.ib), out2=u)
+                self._linear(act, ln.fw, h2, Mlp, H, FF, ops.EPI_F32_RES, Ml, bias=P.w(ln.fb), res=y1,
+                             drop=self._drop(pdh, 16 * i + 4, lm_train))
+                ops.layernorm_fwd(h2, P.w(ln.ln2w), P.w(ln.ln2b), lm.layer_norm_eps, Ml, H, y_f32=y[i + 1],
+                                  y_bf16=yb[i + 1], mean=buf(f"lm_m2{sfx}", (Mlp,)), rstd=buf(f"lm_r2{sfx}", (Mlp,)))
+            text_src = y[nl]
+            use_pos = spec.use_vilt_position_embeddings
+            tables = [(P.w("embeddings.text_embeddings.token_type_embeddings.weight"), tt if tt is not None else 0)]
+        else:
+            Ml, Mlp = B * T, _pad(B * T)
+            ws.update(Ml=Ml, Mlp=Mlp)
+            text_src = None
+            use_pos = True
+            tables = [(P.w("embeddings.text_embeddings.token_type_embeddings.weight"), tt if tt is not None else 0),
+                      (P.w("embeddings.text_embeddings.word_embeddings.weight"), ids)]
+        if use_pos:
+            tables.append((P.w("embeddings.text_embeddings.position_embeddings.weight"), "mod"))
+        ws["use_pos"] = use_pos
+
+        # ------------------------------ ViLT embeddings ------------------------------
+        nv = v.num_hidden_layers
+        x = [buf(f"x{i}" if train else f"x{i % 2}", (Mp, H)) for i in range(nv + 1)]
+        vsum = buf("vt_sum", (Mlp, H))
+        ops.gather_sum(text_src, vsum, tables, Ml, H, period=T)
+        mt = P.w("embeddings.token_type_embeddings.weight")
+        ops.layernorm_fwd(vsum, P.w("embeddings.text_embeddings.LayerNorm.weight"),
+                          P.w("embeddings.text_embeddings.LayerNorm.bias"), v.layer_norm_eps, Ml, H, y_f32=x[0],
+                          ymap=(T, S, 0), post_add=mt[0], mean=buf("vt_mean", (Mlp,)), rstd=buf("vt_rstd", (Mlp,)))
+        Kp = v.num_channels * v.patch_size * v.patch_size
+        Mpp = _pad(B * NP)
+        ws.update(Kp=Kp, Mpp=Mpp)
+        apatch = buf("apatch", (Mpp, Kp), bf)
+        ops.im2col(pix, apatch, B, v.num_channels, v.image_size, v.patch_size)
+        addtab = buf("addtab", (NP, H))
+        ops.image_consts(P.w("embeddings.patch_embeddings.projection.bias"), P.w("embeddings.position_embeddings"),
+                         mt[1], P.w("embeddings.cls_token"), addtab, x[0], NP, H, B, S, T)
+        ops.gemm(apatch, P.wb("embeddings.patch_embeddings.projection.weight", shape=(H, Kp)), x[0], Mpp, H, Kp, Kp, Kp,
+                 H, 0, 0, ops.EPI_F32_PATCH, cfg=0, m_valid=B * NP, addtab=addtab, rpg=NP, gstride=S, goff=T + 1)
+        km = buf("keymask", (B, S))
+        km[:, :T] = amf
+        km[:, T:] = 1.0
+
+        # ------------------------------ ViLT encoder ------------------------------
+        for i, ln in enumerate(self.vl):
+            sfx = f"{i}" if train else ""
+            n1 = buf(f"n1{sfx}", (Mp, H), bf); qkv = buf(f"qkv{sfx}", (Mp, 3 * H), bf)
+            ctx = buf(f"ctx{sfx}", (Mp, H), bf); lse = buf(f"lse{sfx}", (B, heads, S))
+            xm = buf(f"xm{sfx}", (Mp, H)); n2 = buf(f"n2{sfx}", (Mp, H), bf)
+            u = buf(f"u{sfx}", (Mp, FF), bf) if train else None
+            act = buf(f"act{sfx}", (Mp, FF), bf)
+            ops.layernorm_fwd(x[i], P.w(ln.ln1w), P.w(ln.ln1b), v.layer_norm_eps, M, H, y_bf16=n1,
+                              mean=buf(f"m1{sfx}", (Mp,)), rstd=buf(f"r1{sfx}", (Mp,)))
+            self._linear(n1, ln.qw, qkv, Mp, 3 * H, H, ops.EPI_BF16, M, bias=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)))
+            ops.attention_fwd(qkv, km, ctx, lse, B, S, H, heads)
+            self._linear(ctx, ln.ow, xm, Mp, H, H, ops.EPI_F32_RES, M, bias=P.w(ln.ob), res=x[i])
+            ops.layernorm_fwd(xm, P.w(ln.ln2w), P.w(ln.ln2b), v.layer_norm_eps, M, H, y_bf16=n2,
+                              mean=buf(f"m2{sfx}", (Mp,)), rstd=buf(f"r2{sfx}", (Mp,)))
+            if self.profile_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            self._linear(n2, ln.iw, act, Mp, FF, H, ops.EPI_BF16_GELU, M, bias=P.w(ln.ib), out2=u)
+            if self.profile_events is not None:
+                e1.record()
+                self.profile_events.append((e0, e1))
+            self._linear(act, ln.fw, x[i + 1], Mp, H, FF, ops.EPI_F32_RES, M, bias=P.w(ln.fb), res=xm)
+
+        # ------------------------------ tail ------------------------------
+        out: Dict[str, torch.Tensor] = {}
+        xl = x[nv]
+        lw, lb = P.w("layernorm.weight"), P.w("layernorm.bias")
+        if need_hidden:
+            hid = buf("last_hidden", (Mp, H))
+            ops.layernorm_fwd(xl, lw, lb, v.layer_norm_eps, M, H, y_f32=hid, mean=buf("f_mean_all", (Mp,)),
+                              rstd=buf("f_rstd_all", (Mp,)))
+            out["last_hidden_state"] = hid[:M].view(B, S, H)
+        if spec.add_pooling_layer:
+            Bp = _pad(B)
+            ws["Bp"] = Bp
+            h0b = buf("h0b", (Bp, H), bf)
+            ops.layernorm_fwd(xl, lw, lb, v.layer_norm_eps, B, H, y_bf16=h0b, xmap=(1, S, 0), mean=buf("f_mean", (Bp,)),
+                              rstd=buf("f_rstd", (Bp,)))
+            pre = buf("pool_pre", (Bp, H))
+            self._linear(h0b, "pooler.dense.weight", pre, Bp, H, H, ops.EPI_F32_RES, B, bias=P.w("pooler.dense.bias"))
+            pooled = buf("pooled", (Bp, H))
+            if spec.n_classes > 0:
+                C = spec.n_classes
+                logits = buf("logits", (B, C))
+                loss = buf("loss", (1,))
+                loss.zero_()
+                hd = self._drop(self.classifier_dropout, 9001, train)
+                ops.head_fwd(pre, P.w("classifier.1.weight"), P.w("classifier.1.bias"), labels, pooled, logits,
+                             loss if labels is not None else None, B, H, C,
+                             (1.0 / B) if loss_scale is None else loss_scale, drop=hd)
+                out["logits"] = logits if C > 1 else logits.view(B)
+                if labels is not None:
+                    out["loss"] = loss
+                ws["labels"] = labels
+            else:
+                ops.head_fwd(pre, None, None, None, pooled, None, None, B, H, 0, 0.0)   # VaultModel: tanh only
+            out["pooler_output"] = pooled[:B]
+        ws["x"], ws["lm_y"], ws["lm_yb"] = x, (y if spec.lm is not None else None), (yb if spec.lm is not None else None)
+        self.last = ws
+        return out
+
+    # ---- backward ---------------------------------------------------------------------------
+    def zero_grad(self):
+        if self.params.g is not None:
+            self.params.g.zero_()
+
+    def backward(self, grad_scale: Optional[float] = None, dlogits: Optional[torch.Tensor] = None,
+                 dpooled: Optional[torch.Tensor] = None, dhidden: Optional[torch.Tensor] = None,
+                 after_layer=None):
+        """Accumulate parameter gradients of the last train-mode forward into the flat grad buffer.
+
+        Default (VaultForTMSC + labels): d(mean CE)/d(params), scaled by ``grad_scale`` (1/B).
+        ``dlogits`` / ``dpooled`` / ``dhidden`` inject external output gradients (autograd bridge).
+        ``after_layer(tag)`` is called after each stage so a DP driver can start all-reducing the
+        gradient range that just became final.
+        """
+        with torch.cuda.device(self.device):
+            self._backward(grad_scale, dlogits, dpooled, dhidden, after_layer)
+
+    def _backward(self, grad_scale, dlogits, dpooled, dhidden, after_layer):
+        ws = self.last
+        if ws is None or not ws.get("train"):
+            raise RuntimeError("backward() needs a preceding forward(train=True)")
+        spec, P = self.spec, self.params
+        v = spec.vilt
+        B, T, S, M, Mp, H, FF, heads, NP = (ws[k] for k in ("B", "T", "S", "M", "Mp", "H", "FF", "heads", "NP"))
+        Ml, Mlp = ws["Ml"], ws["Mlp"]
+        bf = torch.bfloat16
+        buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
+        self.drop_seed = ws["drop_seed"]
+        x = ws["x"]
+        nv = v.num_hidden_layers
+        note = after_layer if after_layer is not None else (lambda tag: None)
+
+        dx = [buf("dx_a", (Mp, H)), buf("dx_b", (Mp, H))]
+        dxb = [buf("dxb_a", (Mp, H), bf), buf("dxb_b", (Mp, H), bf)]
+        dx[0].zero_(); dxb[0].zero_()
+        # ------------------------------ tail ------------------------------
+        if spec.add_pooling_layer and (spec.n_classes > 0 or dpooled is not None):
+            Bp = ws["Bp"]
+            dpre = buf("dpre", (Bp, H), bf)
+            if spec.n_classes > 0 and dpooled is None:
+                hd = self._drop(self.classifier_dropout, 9001, True)
+                gs = (1.0 / B) if grad_scale is None else grad_scale
+                ops.head_bwd(ws["pooled"], ws["logits"], ws.get("labels"), P.w("classifier.1.weight"),
+                             P.gr("classifier.1.weight"), P.gr("classifier.1.bias"), dpre, B, H, spec.n_classes, gs,
+                             dlogits=dlogits, drop=hd)
+            else:
+                ops.tanh_bwd(ws["pooled"], dpooled.contiguous(), dpre, B * H)
+            self._wgrad(dpre, ws["h0b"], "pooler.dense.weight", "pooler.dense.bias", Bp, H, H, B)
+            dh0 = buf("dh0", (Bp, H), bf)
+            self._dgrad(dpre, "pooler.dense.weight", dh0, Bp, H, H, ops.EPI_BF16, B)
+            ops.layernorm_bwd(x[nv], ws["f_mean"], ws["f_rstd"], P.w("layernorm.weight"), B, H, dy_bf16=dh0,
+                              dx_f32=dx[0], dx_bf16=dxb[0], dgamma=P.gr("layernorm.weight"),
+                              dbeta=P.gr("layernorm.bias"), xmap=(1, S, 0), dxmap=(1, S, 0))
+        if dhidden is not None:
+            # gradient w.r.t. last_hidden_state (all rows): LN backward over all rows, added on top
+            ops.layernorm_bwd(x[nv], ws["f_mean_all"], ws["f_rstd_all"], P.w("layernorm.weight"), M, H,
+                              dy_f32=dhidden.contiguous().view(M, H), dres=dx[0], dx_f32=dx[0], dx_bf16=dxb[0],
+                              dgamma=P.gr("layernorm.weight"), dbeta=P.gr("layernorm.bias"))
+        note("head")
+
+        # ------------------------------ ViLT encoder ------------------------------
+        dU = buf("dU", (Mp, FF), bf); dN = buf("dN", (Mp, H), bf)
+        dctx = buf("dctx", (Mp, H), bf); dqkv = buf("dqkv", (Mp, 3 * H), bf)
+        km = ws["keymask"]
+        cur = 0
+        for i in reversed(range(nv)):
+            ln = self.vl[i]
+            g = lambda k: ws[f"{k}{i}"]  # noqa: E731
+            # FFN
+            self._dgrad(dxb[cur], ln.fw, dU, Mp, FF, H, ops.EPI_BF16_DGELU, M, aux=g("u"))
+            self._wgrad(dxb[cur], g("act"), ln.fw, ln.fb, Mp, H, FF, M)
+            self._dgrad(dU, ln.iw, dN, Mp, H, FF, ops.EPI_BF16, M)
+            self._wgrad(dU, g("n2"), ln.iw, ln.ib, Mp, FF, H, M)
+            nxt = cur ^ 1
+            ops.layernorm_bwd(g("xm"), g("m2"), g("r2"), P.w(ln.ln2w), M, H, dy_bf16=dN, dres=dx[cur], dx_f32=dx[nxt],
+                              dx_bf16=dxb[nxt], dgamma=P.gr(ln.ln2w), dbeta=P.gr(ln.ln2b))
+            cur = nxt
+            # attention
+            self._dgrad(dxb[cur], ln.ow, dctx, Mp, H, H, ops.EPI_BF16, M)
+            self._wgrad(dxb[cur], g("ctx"), ln.ow, ln.ob, Mp, H, H, M)
+            ops.attention_bwd(g("qkv"), km, g("ctx"), g("lse"), dctx, dqkv, B, S, H, heads)
+            self._dgrad(dqkv, ln.qw, dN, Mp, H, 3 * H, ops.EPI_BF16, M)
+            self._wgrad(dqkv, g("n1"), ln.qw, ln.qb, Mp, 3 * H, H, M)
+            nxt = cur ^ 1
+            ops.layernorm_bwd(x[i], g("m1"), g("r1"), P.w(ln.ln1w), M, H, dy_bf16=dN, dres=dx[cur], dx_f32=dx[nxt],
+                              dx_bf16=dxb[nxt], dgamma=P.gr(ln.ln1w), dbeta=P.gr(ln.ln1b))
+            cur = nxt
+            note(f"vilt{i}")
+
+        # ------------------------------ ViLT embeddings ------------------------------
+        dx0 = dx[cur]
+        Kp, Mpp = ws["Kp"], ws["Mpp"]
+        dyp = buf("dyp", (Mpp, H), bf)
+        gpos = P.gr("embeddings.position_embeddings", shape=(NP + 1, H))
+        gmt = P.gr("embeddings.token_type_embeddings.weight")
+        ops.image_rows_bwd(dx0, gpos, gmt[1], P.gr("embeddings.cls_token", shape=(H,)),
+                           P.gr("embeddings.patch_embeddings.projection.bias"), dyp, NP, H, B, S, T)
+        self._wgrad(dyp, ws["apatch"], "embeddings.patch_embeddings.projection.weight", None, Mpp, H, Kp, B * NP)
+        dvs = buf("d_vt_sum", (Mlp, H))
+        gbeta = P.gr("embeddings.text_embeddings.LayerNorm.bias")
+        ops.layernorm_bwd(ws["vt_sum"], ws["vt_mean"], ws["vt_rstd"], P.w("embeddings.text_embeddings.LayerNorm.weight"),
+                          Ml, H, dy_f32=dx0, dymap=(T, S, 0), dx_f32=dvs,
+                          dgamma=P.gr("embeddings.text_embeddings.LayerNorm.weight"), dbeta=gbeta)
+        ops.axpy(gmt[0], gbeta, 1.0, H)   # text rows: out = LN(.) + mtype[0]  =>  d mtype[0] = sum dy = dbeta
+        tt = ws["tt"]
+        gt = [(P.gr("embeddings.text_embeddings.token_type_embeddings.weight"), tt if tt is not None else 0)]
+        if spec.lm is None:
+            gt.append((P.gr("embeddings.text_embeddings.word_embeddings.weight"), ws["ids"]))
+        if ws["use_pos"]:
+            gt.append((P.gr("embeddings.text_embeddings.position_embeddings.weight"), "mod"))
+        ops.scatter_add(dvs, gt, Ml, H, period=T)
+        note("vilt_embed")
+        if spec.lm is None or self.freeze_lm:
+            return
+
+        # ------------------------------ language model ------------------------------
+        lm = spec.lm
+        nl = lm.num_hidden_layers
+        y, yb = ws["lm_y"], ws["lm_yb"]
+        amf = km[:, :T].contiguous()
+        pdh, pda = lm.hidden_dropout_prob, lm.attention_probs_dropout_prob
+        dh = buf("lm_dh", (Mlp, H)); dhb = buf("lm_dhb", (Mlp, H), bf)
+        dh1 = buf("lm_dh1", (Mlp, H)); dh1b = buf("lm_dh1b", (Mlp, H), bf)
+        ldU = buf("lm_dU", (Mlp, FF), bf); ldN = buf("lm_dN", (Mlp, H), bf)
+        ldctx = buf("lm_dctx", (Mlp, H), bf); ldqkv = buf("lm_dqkv", (Mlp, 3 * H), bf)
+        dyb = None          # bf16 part of d y2 (from the next layer's QKV dgrad)
+        dyf = dvs           # f32 part of d y2
+        for i in reversed(range(nl)):
+            ln = self.ll[i]
+            g = lambda k: ws[f"lm_{k}{i}"]  # noqa: E731
+            # y2 = LN2(h2)
+            ops.layernorm_bwd(g("h2"), g("m2"), g("r2"), P.w(ln.ln2w), Ml, H, dy_bf16=dyb, dy_f32=dyf, dx_f32=dh,
+                              dx_bf16=dhb, dgamma=P.gr(ln.ln2w), dbeta=P.gr(ln.ln2b),
+                              drop=self._drop(pdh, 16 * i + 4, True))
+            self._dgrad(dhb, ln.fw, ldU, Mlp, FF, H, ops.EPI_BF16_DGELU, Ml, aux=g("u"))
+            self._wgrad(dhb, g("act"), ln.fw, ln.fb, Mlp, H, FF, Ml)
+            self._dgrad(ldU, ln.iw, ldN, Mlp, H, FF, ops.EPI_BF16, Ml)
+            self._wgrad(ldU, g("y1b"), ln.iw, ln.ib, Mlp, FF, H, Ml)
+            # y1 = LN1(h1) ; d y1 = dgrad(bf16) + dh (residual)
+            ops.layernorm_bwd(g("h1"), g("m1"), g("r1"), P.w(ln.ln1w), Ml, H, dy_bf16=ldN, dy_f32=dh, dx_f32=dh1,
+                              dx_bf16=dh1b, dgamma=P.gr(ln.ln1w), dbeta=P.gr(ln.ln1b),
+                              drop=self._drop(pdh, 16 * i + 3, True))
+            self._dgrad(dh1b, ln.ow, ldctx, Mlp, H, H, ops.EPI_BF16, Ml)
+            self._wgrad(dh1b, g("ctx"), ln.ow, ln.ob, Mlp, H, H, Ml)
+            ops.attention_bwd(g("qkv"), amf, g("ctx"), g("lse"), ldctx, ldqkv, B, T, H, heads,
+                              drop=self._drop(pda, 16 * i + 2, True))
+            self._dgrad(ldqkv, ln.qw, ldN, Mlp, H, 3 * H, ops.EPI_BF16, Ml)
+            self._wgrad(ldqkv, yb[i], ln.qw, ln.qb, Mlp, 3 * H, H, Ml)
+            dyb, dyf = ldN, dh1   # consumed by the next iteration's LN2 backward before being overwritten
+            note(f"lm{i}")
+        # embeddings: y0 = dropout(LN(esum))
+        desum = buf("lm_desum", (Mlp, H))
+        ops.layernorm_bwd(ws["lm_esum"], ws["lm_emean"], ws["lm_erstd"], P.w("bert.embeddings.LayerNorm.weight"), Ml, H,
+                          dy_bf16=dyb, dy_f32=dyf, dx_f32=desum, dgamma=P.gr("bert.embeddings.LayerNorm.weight"),
+                          dbeta=P.gr("bert.embeddings.LayerNorm.bias"), drop=self._drop(pdh, 1, True), drop_on_dy=True)
+        ops.scatter_add(desum, [(P.gr("bert.embeddings.word_embeddings.weight"), ws["ids"]),
+                                (P.gr("bert.embeddings.position_embeddings.weight"), ws["lm_pos"]),
+                                (P.gr("bert.embeddings.token_type_embeddings.weight"), ws["lm_tt"])], Ml, H)
+        note("lm_embed")

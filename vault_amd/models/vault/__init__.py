@@ -1,0 +1,6 @@
+"""``vault_amd.models.vault`` mirrors the export list of the reference's ``vault.models.vault``
+(ref: vault/models/vault/__init__.py:6-22) for the hot path built here."""
+from .model import VaultForTMSC, VaultMixin, VaultModel
+from .processor import VaultProcessor
+
+__all__ = ["VaultModel", "VaultForTMSC", "VaultMixin", "VaultProcessor"]

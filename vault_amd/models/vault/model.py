@@ -1,0 +1,361 @@
+"""Drop-in for ``vault.models.vault.model`` (ref: vault/models/vault/model.py): same class names,
+constructor / ``from_pretrained`` / ``forward`` signatures, attribute names and ``state_dict`` keys,
+with the compute running in the hand-written HIP kernels of libvault_hip.so instead of
+HuggingFace ``ViltModel`` + ``AutoModel`` on ATen.
+
+What is kept from the reference interface
+  * ``VaultModel(vilt_config, bert_config=None, freeze_lm=False, vilt_dropout_prob=0.0,
+    use_vilt_position_embeddings=False, add_pooling_layer=True)``          (model.py:53-62, 369-372)
+  * ``VaultModel.from_pretrained(pretrained_vilt, pretrained_bert=None, freeze_lm=False,
+    use_vilt_position_embeddings=False)``                                    (model.py:92-128)
+  * ``forward(input_ids, attention_mask, token_type_ids, pixel_values, pixel_mask, ...)`` returning an
+    object with ``last_hidden_state`` / ``pooler_output`` / ``keys()``         (model.py:207-218)
+  * ``VaultForTMSC(vilt_config, n_classes=3, vilt_dropout_prob=0.1, logging_level=None,
+    bert_config=None)`` returning the logits tensor                           (model.py:512-570)
+  * ``state_dict()`` keys: HF ViLT keys at top level, ``bert.*`` for the LM, ``classifier.1.*``.
+  * HF ``ValueError``s for inconsistent inputs (HF:models/vilt/modeling_vilt.py:585-608).
+  * the reference's quirk that ``vilt_dropout_prob`` never reaches ViLT's internal dropouts
+    (typo'd config attributes, model.py:72-75): only the TMSC head uses it.
+
+Not implemented in this build (raise): ``inputs_embeds`` / ``image_embeds`` inputs, partial pixel
+masks / variable-size images, ``output_attentions`` / ``output_hidden_states``.
+
+There is no CPU or eager-PyTorch compute path: forward raises if the model is not on a GPU or the
+HIP library is missing.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+from typing import Any, Dict, Optional, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ...engine import VaultEngine
+from ...spec import LMSpec, VaultSpec, ViltSpec, build_state, param_entries
+
+try:  # the reference returns HF's ModelOutput type; use it when transformers is importable
+    from transformers.modeling_outputs import BaseModelOutputWithPooling
+except Exception:  # pragma: no cover
+    class BaseModelOutputWithPooling(dict):  # minimal stand-in with the attributes callers use
+        def __init__(self, last_hidden_state=None, pooler_output=None, hidden_states=None, attentions=None):
+            super().__init__(last_hidden_state=last_hidden_state, pooler_output=pooler_output)
+            self.last_hidden_state, self.pooler_output = last_hidden_state, pooler_output
+            self.hidden_states, self.attentions = hidden_states, attentions
+
+
+def _get(cfg: Any, name: str, default=None):
+    return getattr(cfg, name, default)
+
+
+def vilt_spec_from_config(cfg) -> ViltSpec:
+    if isinstance(cfg, ViltSpec):
+        return cfg
+    d = ViltSpec()
+    return ViltSpec(**{f: _get(cfg, f, getattr(d, f)) for f in (
+        "vocab_size", "max_position_embeddings", "type_vocab_size", "modality_type_vocab_size", "hidden_size",
+        "num_hidden_layers", "num_attention_heads", "intermediate_size", "layer_norm_eps", "image_size",
+        "patch_size", "num_channels")})
+
+
+def lm_spec_from_config(cfg) -> Optional[LMSpec]:
+    if cfg is None or isinstance(cfg, LMSpec):
+        return cfg
+    mt = _get(cfg, "model_type", "bert")
+    kind = "roberta" if mt in ("roberta", "xlm-roberta", "camembert") else "bert"
+    d = LMSpec()
+    kw = {f: _get(cfg, f, getattr(d, f)) for f in (
+        "vocab_size", "max_position_embeddings", "type_vocab_size", "hidden_size", "num_hidden_layers",
+        "num_attention_heads", "intermediate_size", "layer_norm_eps", "hidden_dropout_prob",
+        "attention_probs_dropout_prob")}
+    pad = _get(cfg, "pad_token_id", None)
+    kw["pad_token_id"] = (1 if kind == "roberta" else 0) if pad is None else pad
+    if _get(cfg, "hidden_act", "gelu") != "gelu":
+        raise NotImplementedError("only the exact-erf 'gelu' activation is implemented")
+    return LMSpec(kind=kind, **kw)
+
+
+class _Node(nn.Module):
+    """Anonymous container so that parameters sit at their HuggingFace dotted paths."""
+
+
+def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
+    mod = root
+    parts = dotted.split(".")
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], param)
+
+
+class _VaultFunction(torch.autograd.Function):
+    """Bridge to autograd: forward/backward run in the HIP engine; parameter gradients are written
+    straight into the flat gradient buffer (``p.grad`` are views of it)."""
+
+    @staticmethod
+    def forward(ctx, model, batch, want_logits, anchor, *params):
+        eng = model._engine
+        train = model.training and torch.is_grad_enabled()
+        out = eng.forward(batch, train=train, need_hidden=not want_logits or model._always_hidden)
+        ctx.model, ctx.train, ctx.want_logits = model, train, want_logits
+        if want_logits:
+            return out["logits"].clone()
+        pooled = out.get("pooler_output")
+        hid = out["last_hidden_state"].clone()
+        if pooled is None:
+            return hid
+        return hid, pooled.clone()
+
+    @staticmethod
+    def backward(ctx, *grads):
+        model = ctx.model
+        if not ctx.train:
+            raise RuntimeError("backward through a VaultModel forward that ran in eval()/no_grad mode")
+        eng = model._engine
+        model._prepare_grads()
+        if ctx.want_logits:
+            g = grads[0].contiguous().float()
+            eng.backward(dlogits=g.view(g.shape[0], -1))
+        else:
+            dh = grads[0]
+            dp = grads[1] if len(grads) > 1 else None
+            eng.backward(dhidden=None if dh is None else dh.float(), dpooled=None if dp is None else dp.float())
+        model._publish_grads()
+        return (None, None, None, None) + tuple(None for _ in range(len(ctx.needs_input_grad) - 4))
+
+
+class VaultMixin(nn.Module):
+    """Common machinery (the reference's ``VaultMixin`` prepends an LM to a HF ViLT class; here the
+    mixin owns the HIP engine)."""
+
+    argparse_args = dict(
+        vilt_model_name_or_path=dict(default="dandelin/vilt-b32-mlm", type=str,
+                                     help="model to load into Vilt parts of model"),
+        bert_model_name_or_path=dict(type=str, help="model to load into Bert parts of model, if any"),
+        vilt_dropout_prob=dict(default=0.1, type=float, help="dropout in internal Vilt layers"),
+        freeze_lm=dict(action="store_true", help="whether to freeze language model"),
+        use_vilt_position_embeddings=dict(action="store_true", help="whether to use Vilt's position embeddings"),
+    )
+    _n_classes = 0
+    _always_hidden = False
+
+    def __init__(self, vilt_config, bert_config=None, freeze_lm: bool = False, vilt_dropout_prob: float = 0.0,
+                 use_vilt_position_embeddings: bool = False, add_pooling_layer: bool = True, *, _n_classes: int = 0,
+                 _seed: int = 0, _state: Optional[Dict[str, np.ndarray]] = None):
+        super().__init__()
+        self.config = vilt_config
+        self.freeze_lm = freeze_lm
+        self.vilt_dropout_prob = vilt_dropout_prob
+        self.spec = VaultSpec(vilt=vilt_spec_from_config(vilt_config), lm=lm_spec_from_config(bert_config),
+                              n_classes=_n_classes, use_vilt_position_embeddings=use_vilt_position_embeddings,
+                              add_pooling_layer=add_pooling_layer)
+        self._engine: Optional[VaultEngine] = None
+        if self.spec.lm is None:
+            self.bert = None       # ref model.py:83-87: no LM -> plain ViLT text embeddings
+        self._names = []
+        state = _state if _state is not None else build_state(self.spec, _seed)
+        frozen = set()
+        if self.spec.lm is not None and freeze_lm:
+            frozen = {n for n, _, _ in param_entries(self.spec) if n.startswith("bert.")}
+        for n, shape, _ in param_entries(self.spec):
+            p = nn.Parameter(torch.from_numpy(np.ascontiguousarray(state[n])).clone(), requires_grad=n not in frozen)
+            _attach(self, n, p)
+            self._names.append(n)
+        lookup = dict(self.named_parameters())
+        self._params_by_name = {n: lookup[n] for n in self._names}
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        # HF checkpoints carry non-parameter buffers (position_ids, token_type_ids): ignore them
+        sd = {k: v for k, v in state_dict.items()
+              if not k.endswith("position_ids") and not k.endswith("embeddings.token_type_ids")}
+        res = super().load_state_dict(sd, strict=strict, **kw)
+        self._sync_engine_from_params()
+        return res
+
+    # ---- device binding -------------------------------------------------------------------
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        p0 = next(self.parameters())
+        if p0.device.type == "cuda":
+            self._bind(p0.device)
+        else:
+            self._engine = None
+        return self
+
+    def _bind(self, device):
+        state = {n: p.detach().float().cpu().numpy() for n, p in self._params_by_name.items()}
+        self._engine = VaultEngine(self.spec, device, state=state, freeze_lm=self.freeze_lm,
+                                   classifier_dropout=self.vilt_dropout_prob if self._n_classes else 0.0)
+        P = self._engine.params
+        for n, p in self._params_by_name.items():
+            p.data = P.w(n)
+            if P.has_grad(n):
+                p.grad = None
+
+    def _sync_engine_from_params(self):
+        """After load_state_dict (which copies into the views in place) refresh the bf16 shadow."""
+        if self._engine is not None:
+            from ... import ops
+            P = self._engine.params
+            ops.cast_bf16(P.p, P.pb, P.n_total)
+
+    def refresh_weights(self):
+        """Call after an external optimizer changed the fp32 parameters (re-derives the bf16 copies)."""
+        self._sync_engine_from_params()
+
+    def _prepare_grads(self):
+        P = self._engine.params
+        fresh = any(p.grad is None for n, p in self._params_by_name.items() if P.has_grad(n) and p.requires_grad)
+        if fresh:
+            self._engine.zero_grad()
+
+    def _publish_grads(self):
+        P = self._engine.params
+        for n, p in self._params_by_name.items():
+            if P.has_grad(n) and p.requires_grad and p.grad is None:
+                p.grad = P.gr(n)
+
+    # ---- reference API --------------------------------------------------------------------
+    def get_input_embeddings(self):
+        n = ("bert.embeddings.word_embeddings.weight" if self.spec.lm is not None
+             else "embeddings.text_embeddings.word_embeddings.weight")
+        return self._params_by_name[n]
+
+    def resize_token_embeddings(self, tokenizer_length):
+        raise NotImplementedError("resize_token_embeddings: rebuild the model with the new vocab_size")
+
+    @classmethod
+    def from_pretrained(cls, pretrained_vilt: str, pretrained_bert: Optional[str] = None, freeze_lm: bool = False,
+                        use_vilt_position_embeddings: bool = False, *args, **kwargs):
+        """Build from local checkpoint directories (``config.json`` + ``model.safetensors`` or
+        ``pytorch_model.bin``).  Mirrors ref model.py:92-128; there is no network in this build, so hub
+        names must already be local paths."""
+        vcfg, vsd = _read_checkpoint(pretrained_vilt)
+        bcfg, bsd = (None, None)
+        if pretrained_bert is not None:
+            bcfg, bsd = _read_checkpoint(pretrained_bert)
+        model = cls(_Cfg(vcfg), *args, bert_config=None if bcfg is None else _Cfg(bcfg), freeze_lm=freeze_lm,
+                    use_vilt_position_embeddings=use_vilt_position_embeddings, **kwargs)
+        own = model.state_dict()
+        new = {}
+        for k, v in vsd.items():
+            k2 = k[5:] if k.startswith("vilt.") else k
+            if k2 in own and tuple(own[k2].shape) == tuple(v.shape):
+                new[k2] = v
+        if bsd is not None:
+            for k, v in bsd.items():
+                for pre in ("roberta.", "bert.", ""):
+                    if k.startswith(pre) and ("bert." + k[len(pre):]) in own:
+                        new["bert." + k[len(pre):]] = v
+                        break
+        missing = [k for k in own if k not in new and not k.startswith("classifier.")]
+        if missing:
+            logging.getLogger(__name__).warning("from_pretrained: %d tensors keep their initial values (e.g. %s)",
+                                                len(missing), missing[:3])
+        own.update(new)
+        model.load_state_dict(own)
+        return model
+
+    def lm_preprocess(self, *args, **kwargs):
+        raise NotImplementedError("lm_preprocess is fused into forward in this build")
+
+    def _collect_batch(self, args, kwargs) -> Dict[str, torch.Tensor]:
+        names = ["input_ids", "attention_mask", "token_type_ids", "pixel_values", "pixel_mask", "inputs_embeds",
+                 "image_embeds", "image_token_type_idx", "output_attentions", "output_hidden_states", "return_dict"]
+        kw = dict(zip(names, args))
+        dup = set(kw) & set(kwargs)
+        if dup:
+            raise TypeError(f"got multiple values for {sorted(dup)}")
+        kw.update(kwargs)
+        ids, emb = kw.get("input_ids"), kw.get("inputs_embeds")
+        if ids is not None and emb is not None:
+            raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
+        if ids is None and emb is None:
+            raise ValueError("You have to specify either input_ids or inputs_embeds")
+        if emb is not None:
+            raise NotImplementedError("inputs_embeds is not implemented in this build")
+        pix, iemb = kw.get("pixel_values"), kw.get("image_embeds")
+        if pix is not None and iemb is not None:
+            raise ValueError("You cannot specify both pixel_values and image_embeds at the same time")
+        if pix is None and iemb is None:
+            raise ValueError("You have to specify either pixel_values or image_embeds")
+        if iemb is not None:
+            raise NotImplementedError("image_embeds is not implemented in this build")
+        if pix.shape[0] != ids.shape[0]:
+            raise ValueError("The text inputs and image inputs need to have the same batch size")
+        if kw.get("output_attentions") or kw.get("output_hidden_states"):
+            raise NotImplementedError("output_attentions / output_hidden_states are not implemented in this build")
+        if self._engine is None:
+            raise RuntimeError("VaultModel has no CPU path: move the model to a GPU (model.to('cuda')) first")
+        dev = self._engine.device
+        batch = {"input_ids": ids.to(dev, torch.int64), "pixel_values": pix.to(dev, torch.float32)}
+        for k in ("attention_mask", "token_type_ids", "pixel_mask"):
+            if kw.get(k) is not None:
+                batch[k] = kw[k].to(dev)
+        return batch
+
+    def _run(self, args, kwargs, want_logits: bool):
+        batch = self._collect_batch(list(args), kwargs)
+        params = [p for p in self._params_by_name.values() if p.requires_grad]
+        anchor = params[0] if params else None
+        return _VaultFunction.apply(self, batch, want_logits, anchor, *params)
+
+    def vilt_forward(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
+
+    def forward(self, *args, **kwargs):
+        out = self._run(args, kwargs, want_logits=False)
+        if isinstance(out, tuple):
+            hid, pooled = out
+        else:
+            hid, pooled = out, None
+        rd = kwargs.get("return_dict", True)
+        if rd is False:
+            return (hid, pooled)
+        return BaseModelOutputWithPooling(last_hidden_state=hid, pooler_output=pooled)
+
+
+class _Cfg:
+    """Attribute view over a config.json dict."""
+
+    def __init__(self, d: Dict[str, Any]):
+        self.__dict__.update(d)
+
+
+def _read_checkpoint(path: str):
+    if not os.path.isdir(path):
+        raise OSError(f"{path} is not a local checkpoint directory (no network access in this build)")
+    with open(os.path.join(path, "config.json")) as f:
+        cfg = json.load(f)
+    st = os.path.join(path, "model.safetensors")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        sd = load_file(st)
+    else:
+        sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+    return cfg, sd
+
+
+class VaultModel(VaultMixin):
+    """VAuLT encoder: ``BaseModelOutputWithPooling`` like ``ViltModel`` (ref model.py:369-372)."""
+
+
+class VaultForTMSC(VaultModel):
+    """VAuLT for target-oriented multimodal sentiment classification: Dropout -> Linear on the pooled
+    output, returns logits (ref model.py:512-570)."""
+
+    def __init__(self, vilt_config, n_classes: int = 3, vilt_dropout_prob: float = 0.1,
+                 logging_level: Optional[Union[int, str]] = None, bert_config=None, **kw):
+        self._n_classes = n_classes
+        super().__init__(vilt_config, add_pooling_layer=True, bert_config=bert_config,
+                         vilt_dropout_prob=vilt_dropout_prob, _n_classes=n_classes, **kw)
+        self.logger = logging.getLogger(__name__)
+        self.logger.setLevel(logging_level if logging_level else logging.WARNING)
+
+    def forward(self, *args, **kwargs) -> torch.Tensor:
+        logits = self._run(args, kwargs, want_logits=True)
+        return logits.squeeze(-1)

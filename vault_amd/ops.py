@@ -33,7 +33,7 @@ class LnBwdArgs(C.Structure):
                 ("x_rpg", C.c_int), ("x_gstride", C.c_int), ("x_goff", C.c_int),
                 ("dx_rpg", C.c_int), ("dx_gstride", C.c_int), ("dx_goff", C.c_int),
                 ("drop_thresh", C.c_uint32), ("drop_seed", C.c_uint32), ("drop_stream", C.c_uint32),
-                ("drop_scale", C.c_float)]
+                ("drop_scale", C.c_float), ("drop_on_dy", C.c_int)]
 
 
 class AttnArgs(C.Structure):
@@ -92,7 +92,8 @@ def layernorm_fwd(x, gamma, beta, eps, rows, H, *, y_bf16=None, y_f32=None, mean
 
 
 def layernorm_bwd(x, mean, rstd, gamma, rows, H, *, dy_bf16=None, dy_f32=None, dres=None, dx_f32=None, dx_bf16=None,
-                  dgamma=None, dbeta=None, dymap=(0, 0, 0), xmap=(0, 0, 0), dxmap=(0, 0, 0), drop: Drop = NO_DROP):
+                  dgamma=None, dbeta=None, dymap=(0, 0, 0), xmap=(0, 0, 0), dxmap=(0, 0, 0), drop: Drop = NO_DROP,
+                  drop_on_dy: bool = False):
     a = LnBwdArgs()
     a.dy_bf16, a.dy_f32, a.x, a.mean, a.rstd, a.gamma, a.dres = (_p(dy_bf16), _p(dy_f32), _p(x), _p(mean),
                                                                   _p(rstd), _p(gamma), _p(dres))
@@ -102,6 +103,7 @@ def layernorm_bwd(x, mean, rstd, gamma, rows, H, *, dy_bf16=None, dy_f32=None, d
     a.x_rpg, a.x_gstride, a.x_goff = xmap
     a.dx_rpg, a.dx_gstride, a.dx_goff = dxmap
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
+    a.drop_on_dy = 1 if drop_on_dy else 0
     L.check(L.load().vault_layernorm_bwd(C.byref(a), _stream()), "vault_layernorm_bwd")
 
 
@@ -127,3 +129,118 @@ def attention_fwd(qkv, keymask, ctx, lse, B, S, H, heads, drop: Drop = NO_DROP):
 def attention_bwd(qkv, keymask, ctx, lse, dctx, dqkv, B, S, H, heads, drop: Drop = NO_DROP):
     a = _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, dctx, dqkv, drop)
     L.check(L.load().vault_attention_bwd(C.byref(a), _stream()), "vault_attention_bwd")
+
+
+class GatherArgs(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("out", C.c_void_p),
+                ("tab", C.c_void_p * 3), ("idx", C.c_void_p * 3), ("is64", C.c_int * 3), ("fixed", C.c_int * 3),
+                ("period", C.c_int), ("rows", C.c_int), ("H", C.c_int)]
+
+
+class HeadArgs(C.Structure):
+    _fields_ = [("pre", C.c_void_p), ("Wc", C.c_void_p), ("bc", C.c_void_p), ("labels", C.c_void_p),
+                ("dlogits", C.c_void_p),
+                ("pooled", C.c_void_p), ("logits", C.c_void_p), ("loss_sum", C.c_void_p), ("dWc", C.c_void_p),
+                ("dbc", C.c_void_p), ("dpre_bf16", C.c_void_p),
+                ("B", C.c_int), ("H", C.c_int), ("C", C.c_int), ("loss_scale", C.c_float), ("grad_scale", C.c_float),
+                ("drop_thresh", C.c_uint32), ("drop_seed", C.c_uint32), ("drop_stream", C.c_uint32),
+                ("drop_scale", C.c_float)]
+
+
+def position_ids(ids_i64, pos_i32, B, T, mode, pad):
+    L.check(L.load().vault_position_ids(C.c_void_p(_p(ids_i64)), C.c_void_p(_p(pos_i32)), B, T, mode, pad, _stream()),
+            "vault_position_ids")
+
+
+def _gather_args(src, out, tables, rows, H, period=1):
+    """tables: list of up to 3 (table, index) with index = tensor (int64/int32) | int | "mod" (row % period)."""
+    a = GatherArgs()
+    a.src, a.out, a.rows, a.H, a.period = _p(src), _p(out), rows, H, period
+    for k in range(3):
+        if k < len(tables) and tables[k] is not None:
+            tab, idx = tables[k]
+            a.tab[k] = _p(tab)
+            if isinstance(idx, torch.Tensor):
+                a.idx[k] = _p(idx)
+                a.is64[k] = 1 if idx.dtype == torch.int64 else 0
+                a.fixed[k] = 0
+            elif idx == "mod":
+                a.idx[k], a.is64[k], a.fixed[k] = None, 0, -2
+            else:
+                a.idx[k], a.is64[k], a.fixed[k] = None, 0, int(idx)
+        else:
+            a.tab[k], a.idx[k], a.is64[k], a.fixed[k] = None, None, 0, -1
+    return a
+
+
+def gather_sum(src, out, tables, rows, H, period=1):
+    a = _gather_args(src, out, tables, rows, H, period)
+    L.check(L.load().vault_gather_sum(C.byref(a), _stream()), "vault_gather_sum")
+
+
+def scatter_add(src, grad_tables, rows, H, period=1):
+    a = _gather_args(src, None, grad_tables, rows, H, period)
+    L.check(L.load().vault_scatter_add(C.byref(a), _stream()), "vault_scatter_add")
+
+
+def im2col(pix, out_bf16, B, Cn, IMG, ps):
+    L.check(L.load().vault_im2col(C.c_void_p(_p(pix)), C.c_void_p(_p(out_bf16)), B, Cn, IMG, ps, _stream()),
+            "vault_im2col")
+
+
+def image_consts(bias, pos, mtype1, cls, addtab, x, P, H, B, S, T):
+    L.check(L.load().vault_image_consts(C.c_void_p(_p(bias)), C.c_void_p(_p(pos)), C.c_void_p(_p(mtype1)),
+                                        C.c_void_p(_p(cls)), C.c_void_p(_p(addtab)), C.c_void_p(_p(x)), P, H, B, S, T,
+                                        _stream()), "vault_image_consts")
+
+
+def image_rows_bwd(dx, dpos, dmtype1, dcls, dbias, dyp_bf16, P, H, B, S, T):
+    L.check(L.load().vault_image_rows_bwd(C.c_void_p(_p(dx)), C.c_void_p(_p(dpos)), C.c_void_p(_p(dmtype1)),
+                                          C.c_void_p(_p(dcls)), C.c_void_p(_p(dbias)), C.c_void_p(_p(dyp_bf16)), P, H,
+                                          B, S, T, _stream()), "vault_image_rows_bwd")
+
+
+def axpy(dst, src, a, n):
+    L.check(L.load().vault_axpy_f32(C.c_void_p(_p(dst)), C.c_void_p(_p(src)), C.c_float(a), C.c_longlong(n),
+                                    _stream()), "vault_axpy_f32")
+
+
+def _head_args(pre, Wc, bc, labels, pooled, logits, loss_sum, B, H, Cc, loss_scale=1.0, grad_scale=1.0, dlogits=None,
+               dWc=None, dbc=None, dpre=None, drop: Drop = NO_DROP):
+    a = HeadArgs()
+    a.pre, a.Wc, a.bc, a.labels, a.dlogits = _p(pre), _p(Wc), _p(bc), _p(labels), _p(dlogits)
+    a.pooled, a.logits, a.loss_sum, a.dWc, a.dbc, a.dpre_bf16 = (_p(pooled), _p(logits), _p(loss_sum), _p(dWc),
+                                                                 _p(dbc), _p(dpre))
+    a.B, a.H, a.C, a.loss_scale, a.grad_scale = B, H, Cc, loss_scale, grad_scale
+    a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
+    return a
+
+
+def head_fwd(pre, Wc, bc, labels, pooled, logits, loss_sum, B, H, Cc, loss_scale, drop: Drop = NO_DROP):
+    a = _head_args(pre, Wc, bc, labels, pooled, logits, loss_sum, B, H, Cc, loss_scale=loss_scale, drop=drop)
+    L.check(L.load().vault_head_fwd(C.byref(a), _stream()), "vault_head_fwd")
+
+
+def head_bwd(pooled, logits, labels, Wc, dWc, dbc, dpre, B, H, Cc, grad_scale, dlogits=None, drop: Drop = NO_DROP):
+    a = _head_args(None, Wc, None, labels, pooled, logits, None, B, H, Cc, grad_scale=grad_scale, dlogits=dlogits,
+                   dWc=dWc, dbc=dbc, dpre=dpre, drop=drop)
+    L.check(L.load().vault_head_bwd(C.byref(a), _stream()), "vault_head_bwd")
+
+
+def tanh_bwd(pooled, dpooled, dpre_bf16, n):
+    L.check(L.load().vault_tanh_bwd(C.c_void_p(_p(pooled)), C.c_void_p(_p(dpooled)), C.c_void_p(_p(dpre_bf16)),
+                                    C.c_longlong(n), _stream()), "vault_tanh_bwd")
+
+
+def adamw_step(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay, bias_corr_factor=1.0, grad_scale=1.0,
+               zero_grad=True):
+    L.check(L.load().vault_adamw_step(C.c_void_p(_p(p)), C.c_void_p(_p(g)), C.c_void_p(_p(m)), C.c_void_p(_p(v)),
+                                      C.c_void_p(_p(p_bf16)), C.c_longlong(n), C.c_float(lr), C.c_float(beta1),
+                                      C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay),
+                                      C.c_float(bias_corr_factor), C.c_float(grad_scale), C.c_int(1 if zero_grad else 0),
+                                      _stream()), "vault_adamw_step")
+
+
+def cast_bf16(x, y_bf16, n):
+    L.check(L.load().vault_cast_bf16(C.c_void_p(_p(x)), C.c_void_p(_p(y_bf16)), C.c_longlong(n), _stream()),
+            "vault_cast_bf16")

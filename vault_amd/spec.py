@@ -94,7 +94,7 @@ class VaultSpec:
         """
         vilt = ViltSpec(vocab_size=128, hidden_size=256, num_hidden_layers=2,
                         num_attention_heads=4, intermediate_size=512,
-                        image_size=96, patch_size=8)
+                        image_size=192, patch_size=16)
         if lm_kind == "roberta":
             lm = LMSpec(vocab_size=160, max_position_embeddings=50, hidden_size=256,
                         num_hidden_layers=2, num_attention_heads=4, intermediate_size=512)

@@ -1,0 +1,171 @@
+"""Data-parallel fine-tune step around the HIP engine.
+
+Restates the per-step body of the reference's loop, ref: vault/tmsc_utils/trainer.py:353-369
+(forward -> CrossEntropy -> zero_grad/backward -> AdamW step -> scheduler step) with
+  * the optimizer of trainer.py:244-254 (transformers-4.48 ``AdamW``, ``correct_bias=False`` by
+    default, eps 1e-8, decoupled weight decay on all parameters) as ONE fused HIP kernel over the
+    flat parameter buffer,
+  * the schedule of trainer.py:256-280 (linear warm-up over ``warmup_ratio`` of the steps, then
+    linear decay to 0),
+  * and - absent from the reference, which is single-device - data parallelism: one process per
+    GPU, each rank runs the step on its shard of the batch, gradients are summed with RCCL
+    all-reduce (``torch.distributed`` backend "nccl" on ROCm) over xGMI and averaged inside the
+    optimizer kernel.  The flat gradient buffer is reduced in contiguous buckets that are launched
+    from the backward pass as soon as the stages that write them have been enqueued, on a side
+    stream, so the exchange overlaps the remaining backward kernels.
+
+No loss.item() per step: the loss stays on the device (the reference syncs every step at
+trainer.py:369); read ``TrainStep.loss`` when needed.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .engine import VaultEngine
+
+
+def linear_schedule(base_lr: float, step: int, warmup_steps: int, total_steps: int) -> float:
+    """lr used by optimizer step number ``step`` (0-based) under get_linear_schedule_with_warmup."""
+    if step < warmup_steps:
+        return base_lr * float(step) / float(max(1, warmup_steps))
+    return base_lr * max(0.0, float(total_steps - step) / float(max(1, total_steps - warmup_steps)))
+
+
+class GradBuckets:
+    """Contiguous ranges of the flat gradient buffer in the order backward finalises them.
+
+    The flat layout is [LM embeddings, LM layers 0.., ViLT embeddings, ViLT layers 0.., head], and
+    backward runs head -> ViLT layers (top down) -> ViLT embeddings -> LM layers (top down) -> LM
+    embeddings, i.e. strictly descending addresses: after stage ``tag`` every gradient at or above
+    ``stage_lo[tag]`` is final.
+    """
+
+    def __init__(self, engine: VaultEngine, bucket_mb: float = 64.0):
+        P = engine.params
+        self.engine = engine
+        self.bucket_elems = int(bucket_mb * 1024 * 1024 / 4)
+        lo: Dict[str, int] = {}
+
+        def first(prefix_or_names) -> int:
+            offs = [P.offsets[n][0] for n in P.trainable
+                    if (n.startswith(prefix_or_names) if isinstance(prefix_or_names, str) else n in prefix_or_names)]
+            return min(offs) if offs else P.n_train
+
+        spec = engine.spec
+        lo["head"] = first(("layernorm.weight", "layernorm.bias", "pooler.dense.weight", "pooler.dense.bias",
+                            "classifier.1.weight", "classifier.1.bias"))
+        for i in range(spec.vilt.num_hidden_layers):
+            lo[f"vilt{i}"] = first(f"encoder.layer.{i}.")
+        lo["vilt_embed"] = first("embeddings.")
+        if spec.lm is not None and not engine.freeze_lm:
+            for i in range(spec.lm.num_hidden_layers):
+                lo[f"lm{i}"] = first(f"bert.encoder.layer.{i}.")
+            lo["lm_embed"] = 0
+        self.stage_lo = lo
+        self.last_tag = "lm_embed" if (spec.lm is not None and not engine.freeze_lm) else "vilt_embed"
+        self.n = P.n_train
+
+
+class BucketReducer:
+    """Launches an all-reduce for each contiguous gradient range as soon as it is final.
+
+    Device-agnostic on purpose (CPU tensors + gloo in the tests, HIP tensors + RCCL in production):
+    ``on_stage(tag)`` is the engine's ``after_layer`` callback, ``finish()`` waits for everything.
+    """
+
+    def __init__(self, flat_grad: torch.Tensor, stage_lo: Dict[str, int], last_tag: str, bucket_elems: int,
+                 dist, group=None, comm_stream=None, compute_device=None):
+        self.g, self.stage_lo, self.last_tag, self.bucket_elems = flat_grad, stage_lo, last_tag, bucket_elems
+        self.dist, self.group, self.comm_stream, self.device = dist, group, comm_stream, compute_device
+        self.n = flat_grad.numel()
+        self.hi = self.n
+        self.works: List = []
+        self.launched: List[Tuple[int, int]] = []
+
+    def on_stage(self, tag: str):
+        lo = self.stage_lo.get(tag)
+        if lo is None:
+            return
+        final = tag == self.last_tag
+        if final:
+            lo = 0
+        if self.hi <= lo or (not final and (self.hi - lo) < self.bucket_elems):
+            return
+        view = self.g[lo:self.hi]
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self.works.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.works.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.launched.append((lo, self.hi))
+        self.hi = lo
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works.clear()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        assert self.hi == 0, "gradient range [0, %d) was never reduced" % self.hi
+        self.hi = self.n
+        self.launched.clear()
+
+
+class TrainStep:
+    def __init__(self, engine: VaultEngine, learning_rate: float = 2e-5, adam_beta1: float = 0.9,
+                 adam_beta2: float = 0.999, adam_epsilon: float = 1e-8, weight_decay: float = 0.0,
+                 correct_bias: bool = False, warmup_ratio: float = 0.1, total_steps: int = 1000,
+                 process_group=None, bucket_mb: float = 64.0, constant_lr: bool = False):
+        self.engine = engine
+        self.lr, self.b1, self.b2, self.eps, self.wd = learning_rate, adam_beta1, adam_beta2, adam_epsilon, weight_decay
+        self.correct_bias = correct_bias
+        self.total_steps = int(total_steps)
+        self.warmup_steps = int(warmup_ratio * self.total_steps)
+        self.constant_lr = constant_lr
+        self.step_idx = 0
+        self.loss: Optional[torch.Tensor] = None
+        self.world = 1
+        self.reducer: Optional[BucketReducer] = None
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            self.world = dist.get_world_size(process_group)
+        if self.world > 1:
+            b = GradBuckets(engine, bucket_mb)
+            self.reducer = BucketReducer(engine.params.g, b.stage_lo, b.last_tag, b.bucket_elems, dist, process_group,
+                                         torch.cuda.Stream(device=engine.device), engine.device)
+
+    def current_lr(self) -> float:
+        if self.constant_lr:
+            return self.lr
+        return linear_schedule(self.lr, self.step_idx, self.warmup_steps, self.total_steps)
+
+    def __call__(self, batch: Dict[str, torch.Tensor], labels: torch.Tensor) -> torch.Tensor:
+        eng = self.engine
+        B = labels.shape[0]
+        out = eng.forward(batch, train=True, labels=labels, need_hidden=False, loss_scale=1.0 / B)
+        # gradients are zero here: the fused optimizer clears them after use (and they start at 0)
+        eng.backward(grad_scale=1.0 / B, after_layer=self.reducer.on_stage if self.reducer else None)
+        if self.reducer:
+            self.reducer.finish()
+        self.optimizer_step()
+        self.loss = out["loss"]
+        return self.loss
+
+    def optimizer_step(self):
+        eng = self.engine
+        P = eng.params
+        t = self.step_idx + 1
+        bc = 1.0
+        if self.correct_bias:
+            bc = math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+        with torch.cuda.device(eng.device):
+            ops.adamw_step(P.p, P.g, P.m, P.v, P.pb, P.n_train, self.current_lr(), self.b1, self.b2, self.eps, self.wd,
+                           bias_corr_factor=bc, grad_scale=1.0 / self.world, zero_grad=True)
+        self.step_idx += 1
