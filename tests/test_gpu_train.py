@@ -31,7 +31,7 @@ def test_adamw_kernel_matches_hf_formula(correct_bias, wd):
         torch.cuda.synchronize()
         assert float(dg.abs().max()) == 0.0          # gradients cleared by the fused kernel
     np.testing.assert_allclose(dp.cpu().numpy(), p_ref, atol=2e-7, rtol=1e-6)
-    np.testing.assert_allclose(dm.cpu().numpy(), m_ref, atol=1e-9, rtol=1e-5)
+    np.testing.assert_allclose(dm.cpu().numpy(), m_ref, atol=1e-8, rtol=1e-4)
     assert torch.equal(pb, dp.bfloat16())
 
 
@@ -41,7 +41,7 @@ def test_two_step_trajectory_vs_oracle():
     bn = synthetic_batch(spec, 4, seed=21, n_classes=3)
     state = build_state(spec, 0)
     eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
-    step = TrainStep(eng, learning_rate=1e-3, warmup_ratio=0.0, total_steps=10)
+    step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10)
     db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
     labels = torch.from_numpy(bn["labels"]).cuda()
     losses = [float(step(db, labels)) for _ in range(3)]
@@ -56,16 +56,18 @@ def test_two_step_trajectory_vs_oracle():
         loss, _ = O.vault_loss(P, spec, tb)
         loss.backward()
         ref_losses.append(float(loss.detach()))
-        lr = O.linear_schedule_lr(1e-3, t - 1, 0, 10)
+        lr = O.linear_schedule_lr(5e-5, t - 1, 0, 10)
         with torch.no_grad():
             for k, p in P.items():
                 if p.grad is not None:
                     O.hf_adamw_step(p, p.grad, m[k], v2[k], lr, t)
     assert abs(losses[0] - ref_losses[0]) < 2e-3
-    assert ref_losses[2] < ref_losses[0] - 0.05, "oracle loss should drop on a repeated batch"
-    # sign-like AdamW updates amplify bf16 gradient noise: compare the loss trajectory loosely
-    assert abs(losses[1] - ref_losses[1]) < 0.05 and abs(losses[2] - ref_losses[2]) < 0.08, (losses, ref_losses)
-    assert losses[2] < losses[0] - 0.05
+    # sign-like AdamW updates (no bias correction: |update| ~ 3.2 lr at step 1) amplify bf16 gradient
+    # noise a little: the loss trajectory must track the oracle's closely and move the same way
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) < 5e-3, (losses, ref_losses)
+    d_ref, d_mine = ref_losses[2] - ref_losses[0], losses[2] - losses[0]
+    assert d_ref < 0 and d_mine < 0 and abs(d_mine - d_ref) < 0.3 * abs(d_ref) + 2e-3, (losses, ref_losses)
     # parameters moved the same way where the reference gradient is not tiny
     w = eng.params.w("pooler.dense.weight").cpu()
     w0 = torch.from_numpy(state["pooler.dense.weight"])

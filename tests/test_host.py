@@ -54,7 +54,7 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(path):
         from vault_amd import build
         build.build()
-    lib = ctypes.CDLL(path)
+    lib = ctypes.CDLL(path)   # torch (imported above) is already in the process
     hdr = open(os.path.join(ROOT, "include", "vault_hip.h")).read()
     names = set(re.findall(r"\b(vault_[a-z0-9_]+)\s*\(", hdr))
     assert len(names) >= 18

@@ -29,6 +29,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64: it must be in the process before our library is, or the
+    # kernels would launch through a second, uninitialised HIP runtime
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -m vault_amd.build` "

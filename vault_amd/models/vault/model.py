@@ -97,9 +97,8 @@ class _VaultFunction(torch.autograd.Function):
     straight into the flat gradient buffer (``p.grad`` are views of it)."""
 
     @staticmethod
-    def forward(ctx, model, batch, want_logits, anchor, *params):
+    def forward(ctx, model, batch, want_logits, train, *params):
         eng = model._engine
-        train = model.training and torch.is_grad_enabled()
         out = eng.forward(batch, train=train, need_hidden=not want_logits or model._always_hidden)
         ctx.model, ctx.train, ctx.want_logits = model, train, want_logits
         if want_logits:
@@ -301,8 +300,8 @@ class VaultMixin(nn.Module):
     def _run(self, args, kwargs, want_logits: bool):
         batch = self._collect_batch(list(args), kwargs)
         params = [p for p in self._params_by_name.values() if p.requires_grad]
-        anchor = params[0] if params else None
-        return _VaultFunction.apply(self, batch, want_logits, anchor, *params)
+        train = self.training and torch.is_grad_enabled()   # autograd disables grad inside Function.forward
+        return _VaultFunction.apply(self, batch, want_logits, train, *params)
 
     def vilt_forward(self, *args, **kwargs):
         return self.forward(*args, **kwargs)
