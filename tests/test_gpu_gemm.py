@@ -36,8 +36,8 @@ def _rand(*shape, scale=1.0, seed=0):
     return (torch.randn(*shape, generator=g) * scale).cuda()
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2])
-@pytest.mark.parametrize("shape", [(512, 768, 768), (256, 2304, 768), (768, 768, 3072)])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", [(512, 768, 768), (256, 2304, 768), (768, 768, 3072), (256, 256, 64), (512, 256, 192), (256, 512, 320)])
 def test_forward_nt_bias(cfg, shape):
     M, N, K = shape
     A = _rand(M, K, seed=1).bfloat16()
@@ -54,7 +54,7 @@ def test_forward_nt_bias(cfg, shape):
     assert out[m_valid:].abs().max().item() == 0.0  # masked rows untouched
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
 def test_forward_gelu_and_residual(cfg):
     M, N, K = 512, 1024, 256
     A = _rand(M, K, seed=4).bfloat16()
@@ -76,7 +76,7 @@ def test_forward_gelu_and_residual(cfg):
     assert (o32 - (z + res)).abs().max().item() <= 2e-4 * z.abs().max().item()
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
 def test_dgrad_nn_and_dgelu(cfg):
     # dX[M,Kin] = dY[M,Nout] . W[Nout,Kin]  (A mode 0, B mode 1)
     M, Nout, Kin = 512, 768, 1024
@@ -96,8 +96,8 @@ def test_dgrad_nn_and_dgelu(cfg):
     assert (dX.float() - ref2).abs().max().item() <= ref2.abs().max().item() * 2 ** -7
 
 
-@pytest.mark.parametrize("cfg", [0, 2])
-@pytest.mark.parametrize("splits", [1, 3])
+@pytest.mark.parametrize("cfg", [0, 2, 3])
+@pytest.mark.parametrize("splits", [1, 3, 5])
 def test_wgrad_tn_splitk(cfg, splits):
     # dW[Nout,Kin] = dY[Mtok,Nout]^T . X[Mtok,Kin]  (A mode 1, B mode 1), contraction over tokens
     Mtok, Nout, Kin = 1024, 768, 512
@@ -139,3 +139,31 @@ def test_einval_on_bad_shapes():
     out = torch.zeros(128, 128, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(RuntimeError):
         _gemm(A, A, out, 100, 128, 64, 64, 64, 128, 0, 0, EPI_BF16)
+
+
+@pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
+def test_phase_kernel_repeatability_and_large_k(mode):
+    """The 8-phase kernel (cfg 3) relies on counted waits: run a long-K problem several times and demand
+    bit-identical results (a race shows up as run-to-run differences) that also match the reference."""
+    M, N, K = 512, 768, 3072
+    A = _rand(M, K, seed=21).bfloat16()
+    Bm = _rand(N, K, scale=0.05, seed=22).bfloat16()
+    ref = A.float() @ Bm.float().t()
+    outs = []
+    for _ in range(5):
+        if mode == "nt":
+            out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            _gemm(A, Bm, out, M, N, K, K, K, N, 0, 0, EPI_BF16, cfg=3)
+        elif mode == "nn":
+            Bt = Bm.t().contiguous()          # [K][N]
+            out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            _gemm(A, Bt, out, M, N, K, K, N, N, 0, 1, EPI_BF16, cfg=3)
+        else:
+            At, Bt = A.t().contiguous(), Bm.t().contiguous()   # [K][M], [K][N]
+            out = torch.zeros(M, N, device="cuda")
+            _gemm(At, Bt, out, M, N, K, M, N, N, 1, 1, EPI_ATOMIC, cfg=3, splits=1)
+        torch.cuda.synchronize()
+        outs.append(out.float().clone())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    assert (outs[0] - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7

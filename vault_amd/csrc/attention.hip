@@ -59,7 +59,7 @@ struct AttnDrop {
 };
 
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
                                                        bf16* __restrict__ ctx, float* __restrict__ lse, int S, int H,
                                                        int heads, float scale, AttnDrop dr) {
   constexpr int SK = NKT * 32;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 // from Q, K and the forward's log-sum-exp; both phases recompute the score tile in the orientation
 // whose accumulator is directly the next MFMA's A operand.
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
+__global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
                                                        const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
                                                        const float* __restrict__ lse, bf16* __restrict__ dqkv, int S,
                                                        int H, int heads, float scale, AttnDrop dr) {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1
     for (int T = 0; T < NKT; ++T) {
       f32x4 ds2[2];
 #pragma unroll
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
       dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
       dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
+#pragma unroll 1
     for (int T = 0; T < NKT; ++T) {
       f32x4 p2[2], ds2[2];
 #pragma unroll

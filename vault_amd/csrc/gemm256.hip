@@ -1,0 +1,292 @@
+// 256x256x64 bf16 MFMA GEMM, 4 waves (2 x 2, one per SIMD, each owning the SIMD's whole 512-entry
+// register file: 256 accumulator registers + fragments), software-pipelined in 8 phases per two K tiles.
+//
+// Same operand modes and epilogues as gemm.hip, for the large shapes of the path (M = B*185 tokens).
+// What is different from the simple double-buffered kernel:
+//   * each 64-deep K tile lives in LDS as four 16 KiB half-tiles (A0/A1 = the upper/lower 64 rows of
+//     every wave's 128 output rows, B0/B1 = the left/right 64 columns of every wave's 128 columns);
+//     two K tiles (128 KiB) form a ring of eight half-tile slots;
+//   * one half-tile (4 global_load_lds per wave) is issued per phase, six phases before its first
+//     reader, and retired with a COUNTED `s_waitcnt vmcnt(20)` (five half-tiles stay in flight across
+//     every barrier) - the L2/HBM latency is hidden behind ~1.5 K tiles of MFMA work instead of one;
+//   * each phase multiplies one quadrant (64 x 64 per wave, 32 MFMAs) while the fragments of the next
+//     quadrant are read from LDS; quadrants are walked 00,01,11,10 | 01,00,10,11 so that every
+//     fragment set is loaded exactly once per K tile and two of the four sets are always reusable.
+// Ordering rules (all formal, no timing assumptions):
+//   RAW  a half-tile is read one phase after the `vmcnt` + `s_barrier` that retired it;
+//   WAR  a slot is overwritten two phases after its ds_reads were issued, and every phase ends with
+//        `lgkmcnt(0)` before the barrier, so those reads have completed in every wave.
+#include "common.h"
+#include "gemm.h"
+#include "gemm_epi.h"
+
+namespace {
+
+constexpr int HT = 16384;      // half-tile bytes
+constexpr int BUFB = 4 * HT;   // one K tile: A0 A1 B0 B1
+
+// One asm statement: counted vmcnt (hipcc has no counted form for LDS-DMA), lgkmcnt(0), barrier.  hipcc does
+// not see these waits: fragment reads are therefore issued between the two halves of a phase's MFMA
+// cluster, after the point where hipcc places its own (already satisfied) lgkmcnt wait.
+#define WAITBAR(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// ds_read_b64_tr_b16 through asm: the builtin form makes hipcc drain every in-flight global_load_lds
+// (vmcnt(0)) in front of it, which would serialise the ring.  The data is consumed only after the
+// phase-ending WAITBAR (lgkmcnt(0)), by the MFMA asm of a later phase.
+template <int OFF>
+__device__ __forceinline__ s16x4 tr16_asm(uint32_t lds_addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "i"(OFF));
+  return v;
+}
+
+template <int A_MODE, int B_MODE, int EPI>
+__global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int g = lane >> 4, l15 = lane & 15;
+
+  const int tiles_n = p.N >> 8;
+  int tile_m, tile_n;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    tile_m = wg / tiles_n;
+    tile_n = wg - tile_m * tiles_n;
+  }
+  const int m0 = tile_m << 8, n0 = tile_n << 8;
+  const int nk_total = p.K >> 6;
+  const int per = (nk_total + p.splits - 1) / p.splits;
+  const int kt0 = blockIdx.z * per;
+  const int nk = min(nk_total, kt0 + per) - kt0;
+  if (nk <= 0) return;
+
+  // ---- staging sources: uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset, two 1-KiB pieces
+  //      per wave per half-tile
+  const char* a_base;
+  const char* b_base;
+  uint32_t a_off[4], b_off[4];
+  uint32_t a_half, b_half, a_step, b_step;   // bytes
+  if constexpr (A_MODE == 0) {
+    a_base = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda + (size_t)kt0 * 64);
+    a_half = 64u * p.lda * 2u; a_step = 128u;
+  } else {
+    a_base = reinterpret_cast<const char*>(p.A + (size_t)kt0 * 64 * p.lda + m0);
+    a_half = 128u; a_step = 64u * p.lda * 2u;
+  }
+  if constexpr (B_MODE == 0) {
+    b_base = reinterpret_cast<const char*>(p.B + (size_t)n0 * p.ldb + (size_t)kt0 * 64);
+    b_half = 64u * p.ldb * 2u; b_step = 128u;
+  } else {
+    b_base = reinterpret_cast<const char*>(p.B + (size_t)kt0 * 64 * p.ldb + n0);
+    b_half = 128u; b_step = 64u * p.ldb * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = wave * 4 + i;
+    const int r8 = lane >> 3, r = 8 * j + r8;
+    const int c = (lane & 7) ^ (((r8 >> 1) & 3) << 1);
+    const int krow = 4 * j + (lane >> 4), pos16 = lane & 15;
+    const int hk = (krow & 3) | (((krow >> 3) & 1) << 2);
+    const int cb = (pos16 >> 1) ^ hk;
+    if constexpr (A_MODE == 0) a_off[i] = (uint32_t)(((r >> 6) * 128 + (r & 63)) * p.lda + c * 8) * 2u;
+    else a_off[i] = (uint32_t)(krow * p.lda + (cb >> 2) * 128 + (cb & 3) * 16 + (pos16 & 1) * 8) * 2u;
+    if constexpr (B_MODE == 0) b_off[i] = (uint32_t)(((r >> 6) * 128 + (r & 63)) * p.ldb + c * 8) * 2u;
+    else b_off[i] = (uint32_t)(krow * p.ldb + (cb >> 2) * 128 + (cb & 3) * 16 + (pos16 & 1) * 8) * 2u;
+  }
+
+  auto issueA = [&](int h, int buf, int t) {
+    char* d = smem + buf * BUFB + h * HT + wave * 4096;
+    const char* sb = a_base + (size_t)h * a_half + (size_t)t * a_step;   // uniform
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(sb + a_off[i], d + i * 1024);
+  };
+  auto issueB = [&](int h, int buf, int t) {
+    char* d = smem + buf * BUFB + 2 * HT + h * HT + wave * 4096;
+    const char* sb = b_base + (size_t)h * b_half + (size_t)t * b_step;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(sb + b_off[i], d + i * 1024);
+  };
+
+  // ---- fragment read offsets
+  int a_o0, a_o1, b_o0, b_o1;   // mode 0: byte offsets of k-step 0 / 1 ; mode 1: base offset / swizzle key
+  {
+    const int fx = ((l15 >> 1) & 3) << 1;
+    const int q = l15 >> 2, pp = l15 & 3, hk = q | ((g & 1) << 2);
+    if constexpr (A_MODE == 0) {
+      a_o0 = (wr * 64 + l15) * 128 + ((g ^ fx) << 4);
+      a_o1 = (wr * 64 + l15) * 128 + (((4 + g) ^ fx) << 4);
+    } else {
+      a_o0 = (8 * g + q) * 256 + pp * 8;
+      a_o1 = hk;
+    }
+    if constexpr (B_MODE == 0) {
+      b_o0 = (wc * 64 + l15) * 128 + ((g ^ fx) << 4);
+      b_o1 = (wc * 64 + l15) * 128 + (((4 + g) ^ fx) << 4);
+    } else {
+      b_o0 = (8 * g + q) * 256 + pp * 8;
+      b_o1 = hk;
+    }
+  }
+  // transposed-read lane addresses (32-bit LDS byte addresses of ring buffer 0, k-step 0, first read)
+  uint32_t a_tr[4], b_tr[4];
+  if constexpr (A_MODE == 1) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+      a_tr[mt] = (uint32_t)(size_t)LDS_PTR(char, smem) + a_o0 + (((wr * 4 + mt) ^ a_o1) << 5);
+  }
+  if constexpr (B_MODE == 1) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      b_tr[nt] = (uint32_t)(size_t)LDS_PTR(char, smem) + 2 * HT + b_o0 + (((wc * 4 + nt) ^ b_o1) << 5);
+  }
+  // BUF / H are compile-time at every call site (macro-expanded), so the slot offset folds into the
+  // 16-bit DS immediate; ring buffer 1 (+64 KiB) exceeds it and is added to the address instead
+#define LOAD_TR(DST, ADDR, BUF, H)                                                                       \
+  {                                                                                                      \
+    const uint32_t ad_ = (ADDR) + (BUF) * BUFB;                                                          \
+    DST[0] = cat_tr(tr16_asm<(H) * HT>(ad_), tr16_asm<(H) * HT + 1024>(ad_));                            \
+    DST[1] = cat_tr(tr16_asm<(H) * HT + 8192>(ad_), tr16_asm<(H) * HT + 8192 + 1024>(ad_));             \
+  }
+#define LOADA(RA, BUF, H)                                                                                \
+  {                                                                                                      \
+    if constexpr (A_MODE == 0) {                                                                         \
+      const char* base_ = smem + (BUF) * BUFB + (H) * HT;                                                \
+      _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                 \
+        RA[mt][0] = *LDS_PTR(const bf16x8, base_ + a_o0 + mt * 2048);                                    \
+        RA[mt][1] = *LDS_PTR(const bf16x8, base_ + a_o1 + mt * 2048);                                    \
+      }                                                                                                  \
+    } else {                                                                                             \
+      LOAD_TR(RA[0], a_tr[0], BUF, H) LOAD_TR(RA[1], a_tr[1], BUF, H)                                    \
+      LOAD_TR(RA[2], a_tr[2], BUF, H) LOAD_TR(RA[3], a_tr[3], BUF, H)                                    \
+    }                                                                                                    \
+  }
+#define LOADB(RB, BUF, H)                                                                                \
+  {                                                                                                      \
+    if constexpr (B_MODE == 0) {                                                                         \
+      const char* base_ = smem + (BUF) * BUFB + 2 * HT + (H) * HT;                                       \
+      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                 \
+        RB[nt][0] = *LDS_PTR(const bf16x8, base_ + b_o0 + nt * 2048);                                    \
+        RB[nt][1] = *LDS_PTR(const bf16x8, base_ + b_o1 + nt * 2048);                                    \
+      }                                                                                                  \
+    } else {                                                                                             \
+      LOAD_TR(RB[0], b_tr[0], BUF, H) LOAD_TR(RB[1], b_tr[1], BUF, H)                                    \
+      LOAD_TR(RB[2], b_tr[2], BUF, H) LOAD_TR(RB[3], b_tr[3], BUF, H)                                    \
+    }                                                                                                    \
+  }
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // MFMAs are issued through inline asm with the accumulator tied in place in the AGPR half of the
+  // register file ("+a"): hipcc otherwise allocates out-of-place destinations for this many live
+  // accumulators and spills.  `volatile` keeps every cluster inside its phase.
+  auto mma = [&](int ks, int mb, int nb, bf16x8(&ra)[4][2], bf16x8(&rb)[4][2]) {
+    __builtin_amdgcn_s_setprio(1);
+    asm volatile("s_nop 1");   // a VALU-written operand needs 2 wait states before an MFMA reads it
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                     : "+a"(acc[mb + mt][nb + nt])
+                     : "v"(ra[mt][ks]), "v"(rb[nt][ks]));
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  bf16x8 RA0[4][2], RA1[4][2], RB0[4][2], RB1[4][2];
+
+  // ---- prologue: K tiles 0 and 1 in ring order, preload the first quadrant's fragments
+  issueA(0, 0, 0); issueB(0, 0, 0); issueB(1, 0, 0); issueA(1, 0, 0);
+  if (nk > 1) {
+    issueA(0, 1, 1); issueB(1, 1, 1); issueB(0, 1, 1); issueA(1, 1, 1);
+    WAITBAR(24);
+  } else {
+    WAITBAR(0);
+  }
+  LOADA(RA0, 0, 0)
+  LOADB(RB0, 0, 0)
+  if (nk > 1) { WAITBAR(20); } else { WAITBAR(0); }
+
+  // one loop iteration = two K tiles = eight phases.  FULL: both prefetch targets exist (no branches,
+  // uniform counted waits); otherwise the generic tail form (skipped issues drain with vmcnt(0)).
+#define PHASE(LOAD, ISSUE, COND, MB, NB, RA, RB) \
+  if (FULL || (COND)) { ISSUE; }                 \
+  mma(0, MB, NB, RA, RB);                        \
+  LOAD;                                          \
+  mma(1, MB, NB, RA, RB);                        \
+  if (FULL || (COND)) { WAITBAR(20); } else { WAITBAR(0); }
+#define TWO_TILES(FULLV)                                                                   \
+  {                                                                                        \
+    constexpr bool FULL = FULLV;                                                           \
+    const bool i2 = (t + 2) < nk, i3 = (t + 3) < nk;                                       \
+    PHASE(LOADB(RB1, 0, 1), issueA(0, 0, t + 2), i2, 0, 0, RA0, RB0)                       \
+    PHASE(LOADA(RA1, 0, 1), issueB(0, 0, t + 2), i2, 0, 4, RA0, RB1)                       \
+    PHASE(LOADA(RA0, 1, 0), issueB(1, 0, t + 2), i2, 4, 4, RA1, RB1)                       \
+    PHASE(LOADB(RB1, 1, 1), issueA(1, 0, t + 2), i2, 4, 0, RA1, RB0)                       \
+    if (FULL || (t + 1 < nk)) {                                                            \
+      PHASE(LOADB(RB0, 1, 0), issueA(0, 1, t + 3), i3, 0, 4, RA0, RB1)                     \
+      PHASE(LOADA(RA1, 1, 1), issueB(1, 1, t + 3), i3, 0, 0, RA0, RB0)                     \
+      PHASE(LOADA(RA0, 0, 0), issueB(0, 1, t + 3), i3, 4, 0, RA1, RB0)                     \
+      PHASE(LOADB(RB0, 0, 0), issueA(1, 1, t + 3), i3, 4, 4, RA1, RB1)                     \
+    }                                                                                      \
+  }
+  int t = 0;
+  for (; t + 3 < nk; t += 2) TWO_TILES(true)
+  for (; t < nk; t += 2) TWO_TILES(false)
+#undef TWO_TILES
+#undef PHASE
+#undef LOADA
+#undef LOADB
+#undef LOAD_TR
+  WAITBAR(0);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> accumulator reads (hazard is invisible inside asm)
+
+  gemm_epilogue<8, 8, EPI>(acc, p, smem, m0, n0, wr * 128, wc * 128, wave, lane);
+}
+
+template <int A_MODE, int B_MODE, int EPI>
+int launch256(const GemmParams& p, hipStream_t st) {
+  if ((p.M & 255) || (p.N & 255) || (p.K & 63)) return VAULT_EINVAL;
+  constexpr int LDS = 2 * BUFB;
+  auto kern = gemm256_kernel<A_MODE, B_MODE, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  dim3 grid((p.M >> 8) * (p.N >> 8), 1, p.splits);
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int vault_gemm256_launch(const GemmParams& p, int a_mode, int b_mode, int epi, hipStream_t st) {
+  const int key = a_mode * 2 + b_mode;
+#define VAULT_DISPATCH(AM, BMD)                                                  \
+  switch (epi) {                                                                 \
+    case EPI_BF16: return launch256<AM, BMD, EPI_BF16>(p, st);                   \
+    case EPI_BF16_GELU: return launch256<AM, BMD, EPI_BF16_GELU>(p, st);         \
+    case EPI_BF16_DGELU: return launch256<AM, BMD, EPI_BF16_DGELU>(p, st);       \
+    case EPI_F32_RES: return launch256<AM, BMD, EPI_F32_RES>(p, st);             \
+    case EPI_F32_PATCH: return launch256<AM, BMD, EPI_F32_PATCH>(p, st);         \
+    case EPI_F32_ATOMIC: return launch256<AM, BMD, EPI_F32_ATOMIC>(p, st);       \
+    default: return VAULT_EINVAL;                                                \
+  }
+  switch (key) {
+    case 0: VAULT_DISPATCH(0, 0)
+    case 1: VAULT_DISPATCH(0, 1)
+    case 3: VAULT_DISPATCH(1, 1)
+    default: return VAULT_EINVAL;
+  }
+#undef VAULT_DISPATCH
+}
