@@ -33,6 +33,7 @@ int vault_abi_version(void);
 typedef struct vault_gemm_args {
   const void* A; const void* B; void* out; void* out2;
   const float* bias; const float* res; const void* aux; const float* addtab;
+  float* colsum;   /* optional, bf16 epilogues: += column sums of the output over rows < m_valid */
   int M, N, K, lda, ldb, ldo, m_valid;
   int a_mode, b_mode, epi, cfg, splits, accumulate;
   int rpg, gstride, goff;
@@ -67,6 +68,7 @@ typedef struct vault_ln_bwd_args {
   int dy_rpg, dy_gstride, dy_goff, x_rpg, x_gstride, x_goff, dx_rpg, dx_gstride, dx_goff;
   uint32_t drop_thresh, drop_seed, drop_stream; float drop_scale;
   int drop_on_dy;   /* 0: mask dx_bf16 (Linear -> dropout -> +res -> LN) ; 1: mask dy (LN -> dropout) */
+  float* dbias;     /* optional: += column sums of dx_bf16 (bias gradient of the Linear fed by that branch) */
 } vault_ln_bwd_args;
 int vault_layernorm_bwd(const vault_ln_bwd_args* args, void* stream);
 
@@ -105,6 +107,7 @@ typedef struct vault_gather_args {
   const float* src; float* out;
   const float* tab[3]; const void* idx[3]; int is64[3]; int fixed[3];
   int period, rows, H;
+  const float* rowmask;   /* scatter only, optional [rows]: rows with mask 0 are skipped (their gradient is 0) */
 } vault_gather_args;
 int vault_gather_sum(const vault_gather_args* args, void* stream);
 int vault_scatter_add(const vault_gather_args* args, void* stream);

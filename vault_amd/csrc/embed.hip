@@ -74,28 +74,36 @@ struct Scatter3 {
   int period;
 };
 
-// tab_k[idx_k[row]] += d[row]   (float atomics, one 256-byte segment per wave-instruction)
-__global__ __launch_bounds__(256) void scatter_add_kernel(const float* __restrict__ d, Scatter3 g, int rows, int H) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  long long ix[3];
+// tab_k[idx_k[row]] += d[row].  A block owns a run of rows: indexed tables get one float atomic per
+// element (256-byte segments per wave-instruction; rows whose mask is 0 carry an exactly-zero gradient
+// and are skipped), single-row tables (fixed index: every row hits the same destination) are summed in
+// registers first and added once per block.
+__global__ __launch_bounds__(256) void scatter_add_kernel(const float* __restrict__ d, Scatter3 g, int rows, int H,
+                                                          const float* __restrict__ rowmask, int rows_per_block) {
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < H; c += 256) {
+    float fsum[3] = {0.f, 0.f, 0.f};
+    for (int row = r0; row < r1; ++row) {
+      if (rowmask != nullptr && rowmask[row] == 0.f) continue;
+      const float v = d[(size_t)row * H + c];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    ix[k] = 0;
-    if (g.tab[k] != nullptr) {
-      if (g.idx[k] != nullptr)
-        ix[k] = g.is64[k] ? reinterpret_cast<const long long*>(g.idx[k])[row]
-                          : (long long)reinterpret_cast<const int*>(g.idx[k])[row];
-      else
-        ix[k] = (g.fixed[k] == -2) ? (row % g.period) : g.fixed[k];
+      for (int k = 0; k < 3; ++k) {
+        if (g.tab[k] == nullptr) continue;
+        if (g.idx[k] != nullptr) {
+          const long long ix = g.is64[k] ? reinterpret_cast<const long long*>(g.idx[k])[row]
+                                         : (long long)reinterpret_cast<const int*>(g.idx[k])[row];
+          atomicAdd(g.tab[k] + (size_t)ix * H + c, v);
+        } else if (g.fixed[k] == -2) {
+          atomicAdd(g.tab[k] + (size_t)(row % g.period) * H + c, v);
+        } else {
+          fsum[k] += v;
+        }
+      }
     }
-  }
-  for (int c = lane; c < H; c += 64) {
-    const float v = d[(size_t)row * H + c];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
-      if (g.tab[k] != nullptr) atomicAdd(g.tab[k] + (size_t)ix[k] * H + c, v);
+      if (g.tab[k] != nullptr && g.idx[k] == nullptr && g.fixed[k] >= 0)
+        atomicAdd(g.tab[k] + (size_t)g.fixed[k] * H + c, fsum[k]);
   }
 }
 
@@ -193,8 +201,9 @@ extern "C" int vault_scatter_add(const vault_gather_args* a, void* stream) {
     g.tab[k] = const_cast<float*>(a->tab[k]); g.idx[k] = a->idx[k]; g.is64[k] = a->is64[k]; g.fixed[k] = a->fixed[k];
   }
   g.period = a->period > 0 ? a->period : 1;
-  hipLaunchKernelGGL(scatter_add_kernel, dim3((a->rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     a->src, g, a->rows, a->H);
+  const int rpb = 32;
+  hipLaunchKernelGGL(scatter_add_kernel, dim3((a->rows + rpb - 1) / rpb), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), a->src, g, a->rows, a->H, a->rowmask, rpb);
   return (int)hipGetLastError();
 }
 

@@ -29,6 +29,7 @@ struct GemmParams {
   const float* res;
   const __bf16* aux;
   const float* addtab;
+  float* colsum;    // bf16 epilogues: += column sums of the stored values (bias gradient), or null
   int rpg, gstride, goff;
   // inverted dropout on (acc + bias) for EPI_F32_RES; thresh == 0 disables it
   uint32_t drop_thresh, drop_seed, drop_stream;

@@ -232,8 +232,10 @@ int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, i
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return VAULT_EINVAL;
   if ((p.lda & 7) || (p.ldb & 7) || (p.ldo & 7)) return VAULT_EINVAL;
   if (cfg < 0) {
-    // default tile choice: the 8-phase 256x256 kernel when both extents allow it, else 256x128 / 128x128
-    if (p.M % 256 == 0 && p.N % 256 == 0) cfg = 3;
+    // default kernel/tile choice (measured on MI355X at M = 47360, profiles/ r01 GEMM table):
+    //   256x256 8-phase ring kernel for long contractions (K >= 1536) and all wgrads (A stored [K][M]);
+    //   256x256 double-buffered kernel for short K with wide N; 256x128 / 128x128 otherwise
+    if (p.M % 256 == 0 && p.N % 256 == 0) cfg = (p.K >= 1536 || a_mode == 1) ? 3 : 2;
     else cfg = (p.M % 256 == 0 && p.N % 128 == 0 && epi != EPI_F32_ATOMIC) ? 1 : 0;
   }
   if (cfg == 3) return vault_gemm256_launch(p, a_mode, b_mode, epi, st);

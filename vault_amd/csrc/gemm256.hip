@@ -99,17 +99,21 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     else b_off[i] = (uint32_t)(krow * p.ldb + (cb >> 2) * 128 + (cb & 3) * 16 + (pos16 & 1) * 8) * 2u;
   }
 
+  // one 1-KiB piece (i = 0..3) of a half-tile; a half-tile is 4 pieces per wave
+  auto pieceA = [&](int h, int buf, int t, int i) {
+    glds16(a_base + (size_t)h * a_half + (size_t)t * a_step + a_off[i], smem + buf * BUFB + h * HT + wave * 4096 + i * 1024);
+  };
+  auto pieceB = [&](int h, int buf, int t, int i) {
+    glds16(b_base + (size_t)h * b_half + (size_t)t * b_step + b_off[i],
+           smem + buf * BUFB + 2 * HT + h * HT + wave * 4096 + i * 1024);
+  };
   auto issueA = [&](int h, int buf, int t) {
-    char* d = smem + buf * BUFB + h * HT + wave * 4096;
-    const char* sb = a_base + (size_t)h * a_half + (size_t)t * a_step;   // uniform
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(sb + a_off[i], d + i * 1024);
+    for (int i = 0; i < 4; ++i) pieceA(h, buf, t, i);
   };
   auto issueB = [&](int h, int buf, int t) {
-    char* d = smem + buf * BUFB + 2 * HT + h * HT + wave * 4096;
-    const char* sb = b_base + (size_t)h * b_half + (size_t)t * b_step;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(sb + b_off[i], d + i * 1024);
+    for (int i = 0; i < 4; ++i) pieceB(h, buf, t, i);
   };
 
   // ---- fragment read offsets
@@ -152,32 +156,28 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     DST[0] = cat_tr(tr16_asm<(H) * HT>(ad_), tr16_asm<(H) * HT + 1024>(ad_));                            \
     DST[1] = cat_tr(tr16_asm<(H) * HT + 8192>(ad_), tr16_asm<(H) * HT + 8192 + 1024>(ad_));             \
   }
-#define LOADA(RA, BUF, H)                                                                                \
+#define LOADA_U(RA, BUF, H, U)                                                                           \
   {                                                                                                      \
     if constexpr (A_MODE == 0) {                                                                         \
       const char* base_ = smem + (BUF) * BUFB + (H) * HT;                                                \
-      _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                 \
-        RA[mt][0] = *LDS_PTR(const bf16x8, base_ + a_o0 + mt * 2048);                                    \
-        RA[mt][1] = *LDS_PTR(const bf16x8, base_ + a_o1 + mt * 2048);                                    \
-      }                                                                                                  \
+      RA[U][0] = *LDS_PTR(const bf16x8, base_ + a_o0 + (U) * 2048);                                      \
+      RA[U][1] = *LDS_PTR(const bf16x8, base_ + a_o1 + (U) * 2048);                                      \
     } else {                                                                                             \
-      LOAD_TR(RA[0], a_tr[0], BUF, H) LOAD_TR(RA[1], a_tr[1], BUF, H)                                    \
-      LOAD_TR(RA[2], a_tr[2], BUF, H) LOAD_TR(RA[3], a_tr[3], BUF, H)                                    \
+      LOAD_TR(RA[U], a_tr[U], BUF, H)                                                                    \
     }                                                                                                    \
   }
-#define LOADB(RB, BUF, H)                                                                                \
+#define LOADB_U(RB, BUF, H, U)                                                                           \
   {                                                                                                      \
     if constexpr (B_MODE == 0) {                                                                         \
       const char* base_ = smem + (BUF) * BUFB + 2 * HT + (H) * HT;                                       \
-      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                 \
-        RB[nt][0] = *LDS_PTR(const bf16x8, base_ + b_o0 + nt * 2048);                                    \
-        RB[nt][1] = *LDS_PTR(const bf16x8, base_ + b_o1 + nt * 2048);                                    \
-      }                                                                                                  \
+      RB[U][0] = *LDS_PTR(const bf16x8, base_ + b_o0 + (U) * 2048);                                      \
+      RB[U][1] = *LDS_PTR(const bf16x8, base_ + b_o1 + (U) * 2048);                                      \
     } else {                                                                                             \
-      LOAD_TR(RB[0], b_tr[0], BUF, H) LOAD_TR(RB[1], b_tr[1], BUF, H)                                    \
-      LOAD_TR(RB[2], b_tr[2], BUF, H) LOAD_TR(RB[3], b_tr[3], BUF, H)                                    \
+      LOAD_TR(RB[U], b_tr[U], BUF, H)                                                                    \
     }                                                                                                    \
   }
+#define LOADA(RA, BUF, H) { LOADA_U(RA, BUF, H, 0) LOADA_U(RA, BUF, H, 1) LOADA_U(RA, BUF, H, 2) LOADA_U(RA, BUF, H, 3) }
+#define LOADB(RB, BUF, H) { LOADB_U(RB, BUF, H, 0) LOADB_U(RB, BUF, H, 1) LOADB_U(RB, BUF, H, 2) LOADB_U(RB, BUF, H, 3) }
 
   f32x4 acc[8][8];
 #pragma unroll
@@ -188,18 +188,12 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   // MFMAs are issued through inline asm with the accumulator tied in place in the AGPR half of the
   // register file ("+a"): hipcc otherwise allocates out-of-place destinations for this many live
   // accumulators and spills.  `volatile` keeps every cluster inside its phase.
-  auto mma = [&](int ks, int mb, int nb, bf16x8(&ra)[4][2], bf16x8(&rb)[4][2]) {
-    __builtin_amdgcn_s_setprio(1);
-    asm volatile("s_nop 1");   // a VALU-written operand needs 2 wait states before an MFMA reads it
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
-                     : "+a"(acc[mb + mt][nb + nt])
-                     : "v"(ra[mt][ks]), "v"(rb[nt][ks]));
-    __builtin_amdgcn_s_setprio(0);
-  };
+  // four MFMAs (one A fragment x four B fragments) - the unit the phase body interleaves loads with
+#define MMA4(KS, MT, MB, NB, RA, RB)                                                       \
+  _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_)                                      \
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                               \
+                   : "+a"(acc[(MB) + (MT)][(NB) + nt_])                                    \
+                   : "v"(RA[MT][KS]), "v"(RB[nt_][KS]));
 
   bf16x8 RA0[4][2], RA1[4][2], RB0[4][2], RB1[4][2];
 
@@ -217,25 +211,42 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
 
   // one loop iteration = two K tiles = eight phases.  FULL: both prefetch targets exist (no branches,
   // uniform counted waits); otherwise the generic tail form (skipped issues drain with vmcnt(0)).
-#define PHASE(LOAD, ISSUE, COND, MB, NB, RA, RB) \
-  if (FULL || (COND)) { ISSUE; }                 \
-  mma(0, MB, NB, RA, RB);                        \
-  LOAD;                                          \
-  mma(1, MB, NB, RA, RB);                        \
-  if (FULL || (COND)) { WAITBAR(20); } else { WAITBAR(0); }
+  // A phase = 32 MFMAs with the next fragment set's LDS reads and one half-tile's four global_load_lds
+  // pieces spread between the 4-MFMA blocks (one wave per SIMD: anything issued in a burst would leave
+  // the matrix pipe idle for its whole issue time).
+#define PHASE(LOADU, RN, LBUF, LH, PIECE, IH, IBUF, IT, COND, MB, NB, RA, RB) \
+  {                                                                            \
+    const bool iss_ = FULL || (COND);                                          \
+    __builtin_amdgcn_s_setprio(1);                                             \
+    asm volatile("s_nop 1");                                                   \
+    MMA4(0, 0, MB, NB, RA, RB) if (iss_) PIECE(IH, IBUF, IT, 0);               \
+    MMA4(0, 1, MB, NB, RA, RB) if (iss_) PIECE(IH, IBUF, IT, 1);               \
+    LOADU(RN, LBUF, LH, 0)                                                     \
+    MMA4(0, 2, MB, NB, RA, RB) if (iss_) PIECE(IH, IBUF, IT, 2);               \
+    LOADU(RN, LBUF, LH, 1)                                                     \
+    MMA4(0, 3, MB, NB, RA, RB) if (iss_) PIECE(IH, IBUF, IT, 3);               \
+    LOADU(RN, LBUF, LH, 2)                                                     \
+    MMA4(1, 0, MB, NB, RA, RB)                                                 \
+    LOADU(RN, LBUF, LH, 3)                                                     \
+    MMA4(1, 1, MB, NB, RA, RB)                                                 \
+    MMA4(1, 2, MB, NB, RA, RB)                                                 \
+    MMA4(1, 3, MB, NB, RA, RB)                                                 \
+    __builtin_amdgcn_s_setprio(0);                                             \
+    if (iss_) { WAITBAR(20); } else { WAITBAR(0); }                            \
+  }
 #define TWO_TILES(FULLV)                                                                   \
   {                                                                                        \
     constexpr bool FULL = FULLV;                                                           \
     const bool i2 = (t + 2) < nk, i3 = (t + 3) < nk;                                       \
-    PHASE(LOADB(RB1, 0, 1), issueA(0, 0, t + 2), i2, 0, 0, RA0, RB0)                       \
-    PHASE(LOADA(RA1, 0, 1), issueB(0, 0, t + 2), i2, 0, 4, RA0, RB1)                       \
-    PHASE(LOADA(RA0, 1, 0), issueB(1, 0, t + 2), i2, 4, 4, RA1, RB1)                       \
-    PHASE(LOADB(RB1, 1, 1), issueA(1, 0, t + 2), i2, 4, 0, RA1, RB0)                       \
+    PHASE(LOADB_U, RB1, 0, 1, pieceA, 0, 0, t + 2, i2, 0, 0, RA0, RB0)                     \
+    PHASE(LOADA_U, RA1, 0, 1, pieceB, 0, 0, t + 2, i2, 0, 4, RA0, RB1)                     \
+    PHASE(LOADA_U, RA0, 1, 0, pieceB, 1, 0, t + 2, i2, 4, 4, RA1, RB1)                     \
+    PHASE(LOADB_U, RB1, 1, 1, pieceA, 1, 0, t + 2, i2, 4, 0, RA1, RB0)                     \
     if (FULL || (t + 1 < nk)) {                                                            \
-      PHASE(LOADB(RB0, 1, 0), issueA(0, 1, t + 3), i3, 0, 4, RA0, RB1)                     \
-      PHASE(LOADA(RA1, 1, 1), issueB(1, 1, t + 3), i3, 0, 0, RA0, RB0)                     \
-      PHASE(LOADA(RA0, 0, 0), issueB(0, 1, t + 3), i3, 4, 0, RA1, RB0)                     \
-      PHASE(LOADB(RB0, 0, 0), issueA(1, 1, t + 3), i3, 4, 4, RA1, RB1)                     \
+      PHASE(LOADB_U, RB0, 1, 0, pieceA, 0, 1, t + 3, i3, 0, 4, RA0, RB1)                   \
+      PHASE(LOADA_U, RA1, 1, 1, pieceB, 1, 1, t + 3, i3, 0, 0, RA0, RB0)                   \
+      PHASE(LOADA_U, RA0, 0, 0, pieceB, 0, 1, t + 3, i3, 4, 0, RA1, RB0)                   \
+      PHASE(LOADB_U, RB0, 0, 0, pieceA, 1, 1, t + 3, i3, 4, 4, RA1, RB1)                   \
     }                                                                                      \
   }
   int t = 0;
@@ -245,7 +256,10 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
 #undef PHASE
 #undef LOADA
 #undef LOADB
+#undef LOADA_U
+#undef LOADB_U
 #undef LOAD_TR
+#undef MMA4
   WAITBAR(0);
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> accumulator reads (hazard is invisible inside asm)
 

@@ -14,6 +14,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
   constexpr int LDS_LD = TN * 16 + 4;         // padded scratch row (floats)
   float* sc = reinterpret_cast<float*>(smem) + wave * (16 * LDS_LD);
   const int rr = lane >> 2, cs = (lane & 3) * SEG;
+  constexpr bool BF16_OUT = (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_DGELU);
+  float csum[BF16_OUT ? SEG : 1];
+  if constexpr (BF16_OUT) {
+#pragma unroll
+    for (int c = 0; c < SEG; ++c) csum[c] = 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -125,12 +131,31 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
         // dgrad through a dropout that sits behind this Linear's *output* in forward:
         // handled by the caller masking dY; nothing to do here.
       }
+      if constexpr (BF16_OUT) {
+#pragma unroll
+        for (int c = 0; c < SEG; ++c) csum[c] += v[c];
+      }
       bf16* out = reinterpret_cast<bf16*>(p.out) + o;
 #pragma unroll
       for (int c = 0; c < SEG; c += 8) {
         u32x4 w = {pack_bf16x2(v[c], v[c + 1]), pack_bf16x2(v[c + 2], v[c + 3]),
                    pack_bf16x2(v[c + 4], v[c + 5]), pack_bf16x2(v[c + 6], v[c + 7])};
         *reinterpret_cast<u32x4*>(out + c) = w;
+      }
+    }
+  }
+  if constexpr (BF16_OUT) {
+    if (p.colsum != nullptr) {
+      // lanes with equal (lane & 3) hold the same columns for different rows: fold the 16 of them
+#pragma unroll
+      for (int c = 0; c < SEG; ++c) {
+        float t = csum[c];
+        t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+        csum[c] = t;
+      }
+      if (lane < 4) {
+#pragma unroll
+        for (int c = 0; c < SEG; ++c) atomicAdd(p.colsum + n0 + wn0 + cs + c, csum[c]);
       }
     }
   }

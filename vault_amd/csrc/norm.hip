@@ -89,17 +89,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                                                      const float* __restrict__ gamma, int rows, int H,
                                                      const float* __restrict__ dres, float* __restrict__ dx_f32,
                                                      bf16* __restrict__ dx_bf16, RowMap dxmap, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int rows_per_block,
-                                                     uint32_t drop_thresh, uint32_t drop_seed, uint32_t drop_stream,
+                                                     float* __restrict__ dbeta, float* __restrict__ dbias,
+                                                     int rows_per_block, uint32_t drop_thresh, uint32_t drop_seed, uint32_t drop_stream,
                                                      float drop_scale, int drop_on_dy) {
-  __shared__ float red[4][VPT * 256 * 2];
+  __shared__ float red[4][VPT * 256 * 3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  f32x4 gw[VPT], ag[VPT], ab[VPT];
+  f32x4 gw[VPT], ag[VPT], ab[VPT], ac[VPT];
 #pragma unroll
   for (int j = 0; j < VPT; ++j) {
     gw[j] = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * j) * 4);
     ag[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     ab[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ac[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
@@ -157,23 +158,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         }
         uint2 w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
         *reinterpret_cast<uint2*>(dx_bf16 + orow + c) = w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ac[j][e] += o[e];   // column sums of the bf16 branch (a Linear's bias gradient)
       }
     }
   }
-  if (dgamma == nullptr) return;
+  if (dgamma == nullptr && dbias == nullptr) return;
 #pragma unroll
   for (int j = 0; j < VPT; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      red[wave][((lane + 64 * j) * 4 + e) * 2] = ag[j][e];
-      red[wave][((lane + 64 * j) * 4 + e) * 2 + 1] = ab[j][e];
+      red[wave][((lane + 64 * j) * 4 + e) * 3] = ag[j][e];
+      red[wave][((lane + 64 * j) * 4 + e) * 3 + 1] = ab[j][e];
+      red[wave][((lane + 64 * j) * 4 + e) * 3 + 2] = ac[j][e];
     }
   __syncthreads();
   for (int c = threadIdx.x; c < H; c += 256) {
-    const float sg = red[0][c * 2] + red[1][c * 2] + red[2][c * 2] + red[3][c * 2];
-    const float sb = red[0][c * 2 + 1] + red[1][c * 2 + 1] + red[2][c * 2 + 1] + red[3][c * 2 + 1];
-    atomicAdd(dgamma + c, sg);
-    atomicAdd(dbeta + c, sb);
+    if (dgamma != nullptr) {
+      atomicAdd(dgamma + c, red[0][c * 3] + red[1][c * 3] + red[2][c * 3] + red[3][c * 3]);
+      atomicAdd(dbeta + c, red[0][c * 3 + 1] + red[1][c * 3 + 1] + red[2][c * 3 + 1] + red[3][c * 3 + 1]);
+    }
+    if (dbias != nullptr)
+      atomicAdd(dbias + c, red[0][c * 3 + 2] + red[1][c * 3 + 2] + red[2][c * 3 + 2] + red[3][c * 3 + 2]);
   }
 }
 
@@ -229,7 +235,7 @@ extern "C" int vault_layernorm_bwd(const vault_ln_bwd_args* a, void* stream) {
 #define LN_BWD(V)                                                                                              \
   hipLaunchKernelGGL(ln_bwd_kernel<V>, grid, block, 0, st, reinterpret_cast<const bf16*>(a->dy_bf16), a->dy_f32, \
                      dym, a->x, xm, a->mean, a->rstd, a->gamma, a->rows, a->H, a->dres, a->dx_f32,               \
-                     reinterpret_cast<bf16*>(a->dx_bf16), dxm, a->dgamma, a->dbeta, rpb, a->drop_thresh,          \
+                     reinterpret_cast<bf16*>(a->dx_bf16), dxm, a->dgamma, a->dbeta, a->dbias, rpb, a->drop_thresh,          \
                      a->drop_seed, a->drop_stream, a->drop_scale, a->drop_on_dy)
   switch (a->H / 256) {
     case 1: LN_BWD(1); break;

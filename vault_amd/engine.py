@@ -227,11 +227,18 @@ class VaultEngine:
         gw = P.gr(wname, n_elems=Nout * Kin, shape=(Nout, Kin))
         if gw is None:
             return
-        tiles = (Nout // 128) * (Kin // 128)
         nk = Mtok_pad // 64
-        splits = max(1, min(nk, (self.WGRAD_TARGET_WGS + tiles - 1) // tiles))
-        ops.gemm(dy_bf16, x_bf16, gw, Nout, Kin, Mtok_pad, Nout, Kin, Kin, 1, 1, ops.EPI_F32_ATOMIC, cfg=0, splits=splits,
-                 accumulate=1)
+        if Nout % 256 == 0 and Kin % 256 == 0:
+            # 256x256 ring kernel; split the token contraction so that tiles x splits fills the 256 CUs once
+            tiles = (Nout // 256) * (Kin // 256)
+            splits = max(1, min(nk // 2, 256 // tiles))
+            cfg = 3
+        else:
+            tiles = (Nout // 128) * (Kin // 128)
+            splits = max(1, min(nk, (self.WGRAD_TARGET_WGS + tiles - 1) // tiles))
+            cfg = 0
+        ops.gemm(dy_bf16, x_bf16, gw, Nout, Kin, Mtok_pad, Nout, Kin, Kin, 1, 1, ops.EPI_F32_ATOMIC, cfg=cfg,
+                 splits=splits, accumulate=1)
         if bname is not None:
             ops.colsum(dy_bf16, Nout, m_valid, Nout, P.gr(bname, n_elems=Nout, shape=(Nout,)))
 
@@ -470,12 +477,14 @@ class VaultEngine:
             self._dgrad(dpre, "pooler.dense.weight", dh0, Bp, H, H, ops.EPI_BF16, B)
             ops.layernorm_bwd(x[nv], ws["f_mean"], ws["f_rstd"], P.w("layernorm.weight"), B, H, dy_bf16=dh0,
                               dx_f32=dx[0], dx_bf16=dxb[0], dgamma=P.gr("layernorm.weight"),
-                              dbeta=P.gr("layernorm.bias"), xmap=(1, S, 0), dxmap=(1, S, 0))
+                              dbeta=P.gr("layernorm.bias"), xmap=(1, S, 0), dxmap=(1, S, 0),
+                              dbias=None if dhidden is not None else P.gr(self.vl[nv - 1].fb))
         if dhidden is not None:
             # gradient w.r.t. last_hidden_state (all rows): LN backward over all rows, added on top
             ops.layernorm_bwd(x[nv], ws["f_mean_all"], ws["f_rstd_all"], P.w("layernorm.weight"), M, H,
                               dy_f32=dhidden.contiguous().view(M, H), dres=dx[0], dx_f32=dx[0], dx_bf16=dxb[0],
-                              dgamma=P.gr("layernorm.weight"), dbeta=P.gr("layernorm.bias"))
+                              dgamma=P.gr("layernorm.weight"), dbeta=P.gr("layernorm.bias"),
+                              dbias=P.gr(self.vl[nv - 1].fb))
         note("head")
 
         # ------------------------------ ViLT encoder ------------------------------
@@ -487,23 +496,26 @@ class VaultEngine:
             ln = self.vl[i]
             g = lambda k: ws[f"{k}{i}"]  # noqa: E731
             # FFN
-            self._dgrad(dxb[cur], ln.fw, dU, Mp, FF, H, ops.EPI_BF16_DGELU, M, aux=g("u"))
-            self._wgrad(dxb[cur], g("act"), ln.fw, ln.fb, Mp, H, FF, M)
+            # (bias gradients are column sums of dY: fused into the kernel that PRODUCES dY - the LayerNorm
+            #  backward for the residual-stream gradient, the GEMM epilogue for dU)
+            self._dgrad(dxb[cur], ln.fw, dU, Mp, FF, H, ops.EPI_BF16_DGELU, M, aux=g("u"), colsum=P.gr(ln.ib))
+            self._wgrad(dxb[cur], g("act"), ln.fw, None, Mp, H, FF, M)
             self._dgrad(dU, ln.iw, dN, Mp, H, FF, ops.EPI_BF16, M)
-            self._wgrad(dU, g("n2"), ln.iw, ln.ib, Mp, FF, H, M)
+            self._wgrad(dU, g("n2"), ln.iw, None, Mp, FF, H, M)
             nxt = cur ^ 1
             ops.layernorm_bwd(g("xm"), g("m2"), g("r2"), P.w(ln.ln2w), M, H, dy_bf16=dN, dres=dx[cur], dx_f32=dx[nxt],
-                              dx_bf16=dxb[nxt], dgamma=P.gr(ln.ln2w), dbeta=P.gr(ln.ln2b))
+                              dx_bf16=dxb[nxt], dgamma=P.gr(ln.ln2w), dbeta=P.gr(ln.ln2b), dbias=P.gr(ln.ob))
             cur = nxt
             # attention
             self._dgrad(dxb[cur], ln.ow, dctx, Mp, H, H, ops.EPI_BF16, M)
-            self._wgrad(dxb[cur], g("ctx"), ln.ow, ln.ob, Mp, H, H, M)
+            self._wgrad(dxb[cur], g("ctx"), ln.ow, None, Mp, H, H, M)
             ops.attention_bwd(g("qkv"), km, g("ctx"), g("lse"), dctx, dqkv, B, S, H, heads)
             self._dgrad(dqkv, ln.qw, dN, Mp, H, 3 * H, ops.EPI_BF16, M)
             self._wgrad(dqkv, g("n1"), ln.qw, ln.qb, Mp, 3 * H, H, M)
             nxt = cur ^ 1
             ops.layernorm_bwd(x[i], g("m1"), g("r1"), P.w(ln.ln1w), M, H, dy_bf16=dN, dres=dx[cur], dx_f32=dx[nxt],
-                              dx_bf16=dxb[nxt], dgamma=P.gr(ln.ln1w), dbeta=P.gr(ln.ln1b))
+                              dx_bf16=dxb[nxt], dgamma=P.gr(ln.ln1w), dbeta=P.gr(ln.ln1b),
+                              dbias=P.gr(self.vl[i - 1].fb) if i > 0 else None)
             cur = nxt
             note(f"vilt{i}")
 
@@ -551,17 +563,17 @@ class VaultEngine:
             # y2 = LN2(h2)
             ops.layernorm_bwd(g("h2"), g("m2"), g("r2"), P.w(ln.ln2w), Ml, H, dy_bf16=dyb, dy_f32=dyf, dx_f32=dh,
                               dx_bf16=dhb, dgamma=P.gr(ln.ln2w), dbeta=P.gr(ln.ln2b),
-                              drop=self._drop(pdh, 16 * i + 4, True))
-            self._dgrad(dhb, ln.fw, ldU, Mlp, FF, H, ops.EPI_BF16_DGELU, Ml, aux=g("u"))
-            self._wgrad(dhb, g("act"), ln.fw, ln.fb, Mlp, H, FF, Ml)
+                              drop=self._drop(pdh, 16 * i + 4, True), dbias=P.gr(ln.fb))
+            self._dgrad(dhb, ln.fw, ldU, Mlp, FF, H, ops.EPI_BF16_DGELU, Ml, aux=g("u"), colsum=P.gr(ln.ib))
+            self._wgrad(dhb, g("act"), ln.fw, None, Mlp, H, FF, Ml)
             self._dgrad(ldU, ln.iw, ldN, Mlp, H, FF, ops.EPI_BF16, Ml)
-            self._wgrad(ldU, g("y1b"), ln.iw, ln.ib, Mlp, FF, H, Ml)
+            self._wgrad(ldU, g("y1b"), ln.iw, None, Mlp, FF, H, Ml)
             # y1 = LN1(h1) ; d y1 = dgrad(bf16) + dh (residual)
             ops.layernorm_bwd(g("h1"), g("m1"), g("r1"), P.w(ln.ln1w), Ml, H, dy_bf16=ldN, dy_f32=dh, dx_f32=dh1,
                               dx_bf16=dh1b, dgamma=P.gr(ln.ln1w), dbeta=P.gr(ln.ln1b),
-                              drop=self._drop(pdh, 16 * i + 3, True))
+                              drop=self._drop(pdh, 16 * i + 3, True), dbias=P.gr(ln.ob))
             self._dgrad(dh1b, ln.ow, ldctx, Mlp, H, H, ops.EPI_BF16, Ml)
-            self._wgrad(dh1b, g("ctx"), ln.ow, ln.ob, Mlp, H, H, Ml)
+            self._wgrad(dh1b, g("ctx"), ln.ow, None, Mlp, H, H, Ml)
             ops.attention_bwd(g("qkv"), amf, g("ctx"), g("lse"), ldctx, ldqkv, B, T, H, heads,
                               drop=self._drop(pda, 16 * i + 2, True))
             self._dgrad(ldqkv, ln.qw, ldN, Mlp, H, 3 * H, ops.EPI_BF16, Ml)
@@ -575,5 +587,6 @@ class VaultEngine:
                           dbeta=P.gr("bert.embeddings.LayerNorm.bias"), drop=self._drop(pdh, 1, True), drop_on_dy=True)
         ops.scatter_add(desum, [(P.gr("bert.embeddings.word_embeddings.weight"), ws["ids"]),
                                 (P.gr("bert.embeddings.position_embeddings.weight"), ws["lm_pos"]),
-                                (P.gr("bert.embeddings.token_type_embeddings.weight"), ws["lm_tt"])], Ml, H)
+                                (P.gr("bert.embeddings.token_type_embeddings.weight"), ws["lm_tt"])], Ml, H,
+                        rowmask=amf)   # padded positions are masked keys everywhere: their gradient is exactly 0
         note("lm_embed")

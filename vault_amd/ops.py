@@ -33,7 +33,7 @@ class LnBwdArgs(C.Structure):
                 ("x_rpg", C.c_int), ("x_gstride", C.c_int), ("x_goff", C.c_int),
                 ("dx_rpg", C.c_int), ("dx_gstride", C.c_int), ("dx_goff", C.c_int),
                 ("drop_thresh", C.c_uint32), ("drop_seed", C.c_uint32), ("drop_stream", C.c_uint32),
-                ("drop_scale", C.c_float), ("drop_on_dy", C.c_int)]
+                ("drop_scale", C.c_float), ("drop_on_dy", C.c_int), ("dbias", C.c_void_p)]
 
 
 class AttnArgs(C.Structure):
@@ -68,10 +68,12 @@ NO_DROP = Drop()
 
 
 def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_valid=0, splits=1, accumulate=0,
-         bias=None, res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, drop: Drop = NO_DROP):
+         bias=None, res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, drop: Drop = NO_DROP,
+         colsum=None):
     a = L.GemmArgs()
     a.A, a.B, a.out, a.out2 = _p(A), _p(B), _p(out), _p(out2)
     a.bias, a.res, a.aux, a.addtab = _p(bias), _p(res), _p(aux), _p(addtab)
+    a.colsum = _p(colsum)
     a.M, a.N, a.K, a.lda, a.ldb, a.ldo, a.m_valid = M, N, K, lda, ldb, ldo, m_valid
     a.a_mode, a.b_mode, a.epi, a.cfg, a.splits, a.accumulate = a_mode, b_mode, epi, cfg, splits, accumulate
     a.rpg, a.gstride, a.goff = rpg, gstride, goff
@@ -93,7 +95,7 @@ def layernorm_fwd(x, gamma, beta, eps, rows, H, *, y_bf16=None, y_f32=None, mean
 
 def layernorm_bwd(x, mean, rstd, gamma, rows, H, *, dy_bf16=None, dy_f32=None, dres=None, dx_f32=None, dx_bf16=None,
                   dgamma=None, dbeta=None, dymap=(0, 0, 0), xmap=(0, 0, 0), dxmap=(0, 0, 0), drop: Drop = NO_DROP,
-                  drop_on_dy: bool = False):
+                  drop_on_dy: bool = False, dbias=None):
     a = LnBwdArgs()
     a.dy_bf16, a.dy_f32, a.x, a.mean, a.rstd, a.gamma, a.dres = (_p(dy_bf16), _p(dy_f32), _p(x), _p(mean),
                                                                   _p(rstd), _p(gamma), _p(dres))
@@ -104,6 +106,7 @@ def layernorm_bwd(x, mean, rstd, gamma, rows, H, *, dy_bf16=None, dy_f32=None, d
     a.dx_rpg, a.dx_gstride, a.dx_goff = dxmap
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
     a.drop_on_dy = 1 if drop_on_dy else 0
+    a.dbias = _p(dbias)
     L.check(L.load().vault_layernorm_bwd(C.byref(a), _stream()), "vault_layernorm_bwd")
 
 
@@ -134,7 +137,7 @@ def attention_bwd(qkv, keymask, ctx, lse, dctx, dqkv, B, S, H, heads, drop: Drop
 class GatherArgs(C.Structure):
     _fields_ = [("src", C.c_void_p), ("out", C.c_void_p),
                 ("tab", C.c_void_p * 3), ("idx", C.c_void_p * 3), ("is64", C.c_int * 3), ("fixed", C.c_int * 3),
-                ("period", C.c_int), ("rows", C.c_int), ("H", C.c_int)]
+                ("period", C.c_int), ("rows", C.c_int), ("H", C.c_int), ("rowmask", C.c_void_p)]
 
 
 class HeadArgs(C.Structure):
@@ -178,8 +181,9 @@ def gather_sum(src, out, tables, rows, H, period=1):
     L.check(L.load().vault_gather_sum(C.byref(a), _stream()), "vault_gather_sum")
 
 
-def scatter_add(src, grad_tables, rows, H, period=1):
+def scatter_add(src, grad_tables, rows, H, period=1, rowmask=None):
     a = _gather_args(src, None, grad_tables, rows, H, period)
+    a.rowmask = _p(rowmask)
     L.check(L.load().vault_scatter_add(C.byref(a), _stream()), "vault_scatter_add")
 
 
