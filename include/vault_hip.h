@@ -26,7 +26,7 @@ int vault_abi_version(void);
  * HF:models/roberta/modeling_roberta.py:222-398 (called from ref: vault/models/vault/model.py:190,205)
  * and the Conv2d patch projection (modeling_vilt.py:290-300).
  * a_mode 0: A is [M][K]; 1: A is [K][M].   b_mode 0: B is [N][K]; 1: B is [K][N].
- * epi: 0 bf16 out (+bias) | 1 bf16 gelu(acc+bias) (+ out2 = pre-activation) | 2 bf16 acc*gelu'(aux)
+ * epi: 0 bf16 out (+bias) | 1 bf16 gelu(acc+bias) (+ out2 = gelu'(acc+bias)) | 2 bf16 acc*aux (aux = that gelu')
  *      3 f32 out = dropout(acc+bias)+res | 4 f32 patch rows (row remap + addtab) | 5 f32 out += acc.
  * M % 128 == 0, N % 128 == 0, K % 64 == 0; buffers must be allocated to those padded sizes.
  * Rows >= m_valid are not stored.  cfg < 0 selects the tile automatically. */

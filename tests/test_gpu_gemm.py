@@ -15,7 +15,7 @@ EPI_BF16, EPI_GELU, EPI_DGELU, EPI_RES, EPI_PATCH, EPI_ATOMIC = range(6)
 
 
 def _gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, cfg=-1, m_valid=0, splits=1, bias=None,
-          res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, accumulate=0):
+          res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, accumulate=0, colsum=None):
     lib = L.load()
     a = L.GemmArgs()
     a.A, a.B, a.out = A.data_ptr(), B.data_ptr(), out.data_ptr()
@@ -24,6 +24,7 @@ def _gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, cfg=-1, m_vali
     a.res = res.data_ptr() if res is not None else None
     a.aux = aux.data_ptr() if aux is not None else None
     a.addtab = addtab.data_ptr() if addtab is not None else None
+    a.colsum = colsum.data_ptr() if colsum is not None else None
     a.M, a.N, a.K, a.lda, a.ldb, a.ldo, a.m_valid = M, N, K, lda, ldb, ldo, m_valid
     a.a_mode, a.b_mode, a.epi, a.cfg, a.splits, a.accumulate = a_mode, b_mode, epi, cfg, splits, accumulate
     a.rpg, a.gstride, a.goff = rpg, gstride, goff
@@ -66,7 +67,8 @@ def test_forward_gelu_and_residual(cfg):
     z = A.float() @ W.float().t() + bias
     ref = torch.nn.functional.gelu(z)
     torch.cuda.synchronize()
-    assert (pre.float() - z).abs().max().item() <= z.abs().max().item() * 2 ** -7
+    gprime = 0.5 * (1 + torch.erf(z / math.sqrt(2))) + z * torch.exp(-0.5 * z * z) / math.sqrt(2 * math.pi)
+    assert (pre.float() - gprime).abs().max().item() <= 2 ** -7        # out2 = gelu'(pre-activation)
     assert (out.float() - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7
     # f32 residual epilogue
     res = _rand(M, N, seed=7)
@@ -87,11 +89,9 @@ def test_dgrad_nn_and_dgelu(cfg):
     ref = dY.float() @ W.float()
     torch.cuda.synchronize()
     assert (dX.float() - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7
-    u = _rand(M, Kin, seed=10).bfloat16()
+    u = _rand(M, Kin, seed=10).bfloat16()     # stands for the stored gelu'
     _gemm(dY, W, dX, M, Kin, Nout, Nout, Kin, Kin, 0, 1, EPI_DGELU, cfg=cfg, aux=u)
-    uf = u.float()
-    dg = 0.5 * (1 + torch.erf(uf / math.sqrt(2))) + uf * torch.exp(-0.5 * uf * uf) / math.sqrt(2 * math.pi)
-    ref2 = ref * dg
+    ref2 = ref * u.float()
     torch.cuda.synchronize()
     assert (dX.float() - ref2).abs().max().item() <= ref2.abs().max().item() * 2 ** -7
 
@@ -167,3 +167,21 @@ def test_phase_kernel_repeatability_and_large_k(mode):
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
     assert (outs[0] - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+def test_fused_bias_gradient_colsum(cfg):
+    """bf16 epilogues can accumulate the column sums of what they store (rows < m_valid): the bias
+    gradient of the Linear whose dY this GEMM produces."""
+    M, Nout, Kin = 512, 768, 1024
+    dY = _rand(M, Nout, seed=31).bfloat16()
+    W = _rand(Nout, Kin, scale=0.05, seed=32).bfloat16()
+    u = _rand(M, Kin, seed=33).bfloat16()
+    dX = torch.zeros(M, Kin, dtype=torch.bfloat16, device="cuda")
+    cs = torch.full((Kin,), 2.0, device="cuda")
+    m_valid = 500
+    _gemm(dY, W, dX, M, Kin, Nout, Nout, Kin, Kin, 0, 1, EPI_DGELU, cfg=cfg, aux=u, colsum=cs, m_valid=m_valid)
+    ref = (dY.float() @ W.float()) * u.float()
+    torch.cuda.synchronize()
+    want = 2.0 + ref[:m_valid].sum(0)
+    assert (cs - want).abs().max().item() <= 2e-3 * want.abs().max().item() + 1e-2

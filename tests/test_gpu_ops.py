@@ -39,9 +39,9 @@ def test_layernorm_fwd_bwd(H, eps):
     dy32 = _rand(rows, H, seed=6)
     dres = _rand(rows, H, seed=7)
     dx32 = torch.zeros(rows, H, device="cuda"); dx16 = torch.zeros(rows, H, dtype=torch.bfloat16, device="cuda")
-    dg = torch.zeros(H, device="cuda"); db = torch.zeros(H, device="cuda")
+    dg = torch.zeros(H, device="cuda"); db = torch.zeros(H, device="cuda"); dbias = torch.ones(H, device="cuda")
     ops.layernorm_bwd(x, mean, rstd, gam, rows, H, dy_bf16=dy16, dy_f32=dy32, dres=dres, dx_f32=dx32, dx_bf16=dx16,
-                      dgamma=dg, dbeta=db)
+                      dgamma=dg, dbeta=db, dbias=dbias)
     ref.backward(dy16.float() + dy32)
     torch.cuda.synchronize()
     tol = 5e-5 * max(1.0, xr.grad.abs().max().item())
@@ -49,6 +49,8 @@ def test_layernorm_fwd_bwd(H, eps):
     assert (dx16.float() - dx32).abs().max().item() <= dx32.abs().max().item() * 2 ** -8
     assert (dg - gr.grad).abs().max().item() < 2e-4 * gr.grad.abs().max().item() + 1e-4
     assert (db - br.grad).abs().max().item() < 2e-4 * br.grad.abs().max().item() + 1e-4
+    # fused bias gradient of the Linear fed by the bf16 branch: column sums of dx
+    assert (dbias - (1 + dx32.sum(0))).abs().max().item() < 2e-3
 
 
 def test_layernorm_rowmaps():

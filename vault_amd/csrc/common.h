@@ -45,27 +45,26 @@ __device__ __forceinline__ float2 unpack_bf16x2(uint32_t u) {
   return make_float2((float)v[0], (float)v[1]);
 }
 
-// erf(x) by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): enough for values that are rounded to bf16
-// afterwards, at ~1/3 the VALU cost of the libm erff.
-__device__ __forceinline__ float fast_erf(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-  float p = 1.061405429f;
-  p = p * t - 1.453152027f;
-  p = p * t + 1.421413741f;
-  p = p * t - 0.284496736f;
-  p = p * t + 0.254829592f;
-  p = p * t;
-  const float e = __expf(-ax * ax);
-  const float r = 1.0f - p * e;
-  return copysignf(r, x);
+// Standard-normal CDF Phi(x) = 0.5 (1 + erf(x / sqrt 2)) through erf's Abramowitz-Stegun 7.1.28
+// form 1 - (1 + a1 t + ... + a6 t^6)^-16 (|err| <= 3e-7, i.e. fp32-level, and no exponential: the
+// GELU epilogues are VALU-bound, this is ~1/2 the instructions of an exp-based erf).
+__device__ __forceinline__ float norm_cdf_f(float x) {
+  const float t = fabsf(x) * 0.70710678118654752f;
+  float p = 0.0000430638f;
+  p = p * t + 0.0002765672f;
+  p = p * t + 0.0001520143f;
+  p = p * t + 0.0092705272f;
+  p = p * t + 0.0422820123f;
+  p = p * t + 0.0705230784f;
+  p = p * t + 1.0f;
+  p = p * p; p = p * p; p = p * p; p = p * p;
+  const float h = 0.5f * __builtin_amdgcn_rcpf(p);   // 0.5 * (1 - erf(|x|/sqrt2))
+  return x >= 0.f ? 1.0f - h : h;
 }
-// exact-erf GELU (HF "gelu" == torch.nn.functional.gelu, HF:activations.py:70-89)
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+// exact-erf GELU of HF "gelu" (HF:activations.py:70-89) = x Phi(x); derivative Phi(x) + x phi(x)
+__device__ __forceinline__ float gelu_f(float x) { return x * norm_cdf_f(x); }
 __device__ __forceinline__ float dgelu_f(float x) {
-  const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  return norm_cdf_f(x) + x * (0.3989422804014327f * __expf(-0.5f * x * x));
 }
 
 // counter-based keep/drop decision for dropout: a 32-bit mix of (seed, stream, element index).

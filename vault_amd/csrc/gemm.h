@@ -6,8 +6,8 @@
 
 enum GemmEpi {
   EPI_BF16 = 0,        // out_bf16 = acc (+ bias)
-  EPI_BF16_GELU = 1,   // out2_bf16 = acc + bias (optional, pre-activation) ; out_bf16 = gelu(acc + bias)
-  EPI_BF16_DGELU = 2,  // out_bf16 = acc * gelu'(aux_bf16)
+  EPI_BF16_GELU = 1,   // out_bf16 = gelu(acc + bias) ; out2_bf16 (optional) = gelu'(acc + bias)
+  EPI_BF16_DGELU = 2,  // out_bf16 = acc * aux_bf16   (aux = the gelu' stored by EPI_BF16_GELU)
   EPI_F32_RES = 3,     // out_f32 = dropout(acc + bias) + res_f32
   EPI_F32_PATCH = 4,   // out_f32[rowmap(m)] = acc + addtab[m % rpg]   (patch embedding into the fused sequence)
   EPI_F32_ATOMIC = 5,  // out_f32 += acc   (wgrad; split-K partials by float atomics)

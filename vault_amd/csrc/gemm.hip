@@ -190,7 +190,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     }
   }
 
-  gemm_epilogue<TM, TN, EPI>(acc, p, smem, m0, n0, wm0, wn0, wave, lane);
+  gemm_epilogue<TM, TN, EPI, WM, WN>(acc, p, smem, m0, n0, wm0, wn0, wave, lane);
 }
 
 template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, int EPI>

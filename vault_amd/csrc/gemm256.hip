@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   WAITBAR(0);
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> accumulator reads (hazard is invisible inside asm)
 
-  gemm_epilogue<8, 8, EPI>(acc, p, smem, m0, n0, wr * 128, wc * 128, wave, lane);
+  gemm_epilogue<8, 8, EPI, 2, 2>(acc, p, smem, m0, n0, wr * 128, wc * 128, wave, lane);
 }
 
 template <int A_MODE, int B_MODE, int EPI>

@@ -4,7 +4,7 @@
 #include "common.h"
 #include "gemm.h"
 
-template <int TM, int TN, int EPI>
+template <int TM, int TN, int EPI, int WM_, int WN_>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmParams& p, char* smem, int m0, int n0,
                                               int wm0, int wn0, int wave, int lane) {
   const int g = lane >> 4, l15 = lane & 15;
@@ -108,24 +108,35 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
     } else {
       // bf16 outputs
       if constexpr (EPI == EPI_BF16_GELU) {
+        // out2 (training only) receives gelu'(pre-activation): backward then needs one multiply per
+        // element instead of re-evaluating erf/exp (both epilogues are VALU-bound otherwise)
         if (p.out2 != nullptr) {
           bf16* o2 = reinterpret_cast<bf16*>(p.out2) + o;
 #pragma unroll
           for (int c = 0; c < SEG; c += 8) {
-            u32x4 w = {pack_bf16x2(v[c], v[c + 1]), pack_bf16x2(v[c + 2], v[c + 3]),
-                       pack_bf16x2(v[c + 4], v[c + 5]), pack_bf16x2(v[c + 6], v[c + 7])};
+            float gp[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float x = v[c + e];
+              const float cdf = norm_cdf_f(x);
+              gp[e] = cdf + x * (0.3989422804014327f * __expf(-0.5f * x * x));
+              v[c + e] = x * cdf;
+            }
+            u32x4 w = {pack_bf16x2(gp[0], gp[1]), pack_bf16x2(gp[2], gp[3]), pack_bf16x2(gp[4], gp[5]),
+                       pack_bf16x2(gp[6], gp[7])};
             *reinterpret_cast<u32x4*>(o2 + c) = w;
           }
-        }
+        } else {
 #pragma unroll
-        for (int c = 0; c < SEG; ++c) v[c] = gelu_f(v[c]);
+          for (int c = 0; c < SEG; ++c) v[c] = gelu_f(v[c]);
+        }
       } else if constexpr (EPI == EPI_BF16_DGELU) {
-        const bf16* ax = p.aux + o;
+        const bf16* ax = p.aux + o;   // gelu'(u) as stored by the forward epilogue
 #pragma unroll
         for (int c = 0; c < SEG; c += 8) {
           const bf16x8 u = *reinterpret_cast<const bf16x8*>(ax + c);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[c + e] *= dgelu_f((float)u[e]);
+          for (int e = 0; e < 8; ++e) v[c + e] *= (float)u[e];
         }
       } else if constexpr (EPI == EPI_BF16_DROPMASK) {
         // dgrad through a dropout that sits behind this Linear's *output* in forward:
@@ -145,17 +156,29 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
     }
   }
   if constexpr (BF16_OUT) {
-    if (p.colsum != nullptr) {
-      // lanes with equal (lane & 3) hold the same columns for different rows: fold the 16 of them
+    if (p.colsum != nullptr) {   // uniform across the block
+      // lanes with equal (lane & 3) hold the same columns for different rows: fold the 16 of them,
+      // then fold the WM_ waves that share columns through LDS and issue full 256-byte atomic rows
 #pragma unroll
       for (int c = 0; c < SEG; ++c) {
         float t = csum[c];
         t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
         csum[c] = t;
       }
+      __syncthreads();                                   // every wave is done with its scratch
+      float* cs_lds = reinterpret_cast<float*>(smem);    // [waves][TN*16]
       if (lane < 4) {
 #pragma unroll
-        for (int c = 0; c < SEG; ++c) atomicAdd(p.colsum + n0 + wn0 + cs + c, csum[c]);
+        for (int c = 0; c < SEG; ++c) cs_lds[wave * (TN * 16) + cs + c] = csum[c];
+      }
+      __syncthreads();
+      constexpr int BN_ = WN_ * TN * 16;
+      for (int col = threadIdx.x; col < BN_; col += WM_ * WN_ * 64) {
+        const int wcn = col / (TN * 16), cin = col - wcn * (TN * 16);
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < WM_; ++r) t += cs_lds[(r * WN_ + wcn) * (TN * 16) + cin];
+        atomicAdd(p.colsum + n0 + col, t);
       }
     }
   }

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // null).  Outputs dx_f32 = dx + dres (optional) and a bf16 copy (optionally dropout-masked for the
 // branch that sits behind a dropout in forward).  dgamma / dbeta: per-block partials + float atomics.
 template <int VPT>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy_bf16, const float* __restrict__ dy_f32,
+__global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__ dy_bf16, const float* __restrict__ dy_f32,
                                                      RowMap dymap, const float* __restrict__ x, RowMap xmap,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, int rows, int H,
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                                                      float* __restrict__ dbeta, float* __restrict__ dbias,
                                                      int rows_per_block, uint32_t drop_thresh, uint32_t drop_seed, uint32_t drop_stream,
                                                      float drop_scale, int drop_on_dy) {
-  __shared__ float red[4][VPT * 256 * 3];
+  __shared__ float red[4][VPT * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x4 gw[VPT], ag[VPT], ab[VPT], ac[VPT];
 #pragma unroll
@@ -164,22 +164,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
     }
   }
   if (dgamma == nullptr && dbias == nullptr) return;
+  // cross-wave reduction, one quantity at a time through a [4][H] buffer (12 KiB at H = 768: keeps
+  // the LDS footprint - and with it the occupancy of this HBM-bound kernel - low)
 #pragma unroll
-  for (int j = 0; j < VPT; ++j)
+  for (int qn = 0; qn < 3; ++qn) {
+    float* dst = qn == 0 ? dgamma : (qn == 1 ? dbeta : dbias);
+    if (dst == nullptr) continue;     // uniform
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      red[wave][((lane + 64 * j) * 4 + e) * 3] = ag[j][e];
-      red[wave][((lane + 64 * j) * 4 + e) * 3 + 1] = ab[j][e];
-      red[wave][((lane + 64 * j) * 4 + e) * 3 + 2] = ac[j][e];
-    }
-  __syncthreads();
-  for (int c = threadIdx.x; c < H; c += 256) {
-    if (dgamma != nullptr) {
-      atomicAdd(dgamma + c, red[0][c * 3] + red[1][c * 3] + red[2][c * 3] + red[3][c * 3]);
-      atomicAdd(dbeta + c, red[0][c * 3 + 1] + red[1][c * 3 + 1] + red[2][c * 3 + 1] + red[3][c * 3 + 1]);
-    }
-    if (dbias != nullptr)
-      atomicAdd(dbias + c, red[0][c * 3 + 2] + red[1][c * 3 + 2] + red[2][c * 3 + 2] + red[3][c * 3 + 2]);
+    for (int j = 0; j < VPT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        red[wave][(lane + 64 * j) * 4 + e] = qn == 0 ? ag[j][e] : (qn == 1 ? ab[j][e] : ac[j][e]);
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) atomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    __syncthreads();
   }
 }
 
