@@ -185,3 +185,41 @@ def test_fused_bias_gradient_colsum(cfg):
     torch.cuda.synchronize()
     want = 2.0 + ref[:m_valid].sum(0)
     assert (cs - want).abs().max().item() <= 2e-3 * want.abs().max().item() + 1e-2
+
+
+@pytest.mark.parametrize("K", [64, 192, 768, 3072])
+@pytest.mark.parametrize("mode", ["nt", "nn"])
+def test_ring_kernel_192_wide_tiles(mode, K):
+    """cfg 4 = the 8-phase ring kernel with 256x192 block tiles (used for N = 768): every epilogue it serves."""
+    M, N = 512, 768
+    m_valid = 477
+    A = _rand(M, K, seed=41).bfloat16()
+    Wnk = _rand(N, K, scale=0.05, seed=42).bfloat16()
+    ref = A.float() @ Wnk.float().t()
+    if mode == "nt":
+        Bop, ldb, bm = Wnk, K, 0
+    else:
+        Bop, ldb, bm = Wnk.t().contiguous(), N, 1
+    bias = _rand(N, seed=43)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    _gemm(A, Bop, out, M, N, K, K, ldb, N, 0, bm, EPI_BF16, cfg=4, bias=bias, m_valid=m_valid)
+    torch.cuda.synchronize()
+    r = ref + bias
+    assert (out[:m_valid].float() - r[:m_valid]).abs().max().item() <= r.abs().max().item() * 2 ** -7
+    assert out[m_valid:].abs().max().item() == 0.0
+    res = _rand(M, N, seed=44)
+    o32 = torch.zeros(M, N, device="cuda")
+    _gemm(A, Bop, o32, M, N, K, K, ldb, N, 0, bm, EPI_RES, cfg=4, bias=bias, res=res)
+    torch.cuda.synchronize()
+    assert (o32 - (r + res)).abs().max().item() <= 2e-4 * r.abs().max().item() + 1e-4
+    g = _rand(M, N, seed=45).bfloat16()
+    cs = torch.zeros(N, device="cuda")
+    _gemm(A, Bop, out, M, N, K, K, ldb, N, 0, bm, EPI_DGELU, cfg=4, aux=g, colsum=cs, m_valid=m_valid)
+    torch.cuda.synchronize()
+    r2 = ref * g.float()
+    assert (out[:m_valid].float() - r2[:m_valid]).abs().max().item() <= r2.abs().max().item() * 2 ** -7
+    assert (cs - r2[:m_valid].sum(0)).abs().max().item() <= 2e-3 * r2[:m_valid].sum(0).abs().max().item() + 1e-2
+    pre = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    _gemm(A, Bop, out, M, N, K, K, ldb, N, 0, bm, EPI_GELU, cfg=4, bias=bias, out2=pre)
+    torch.cuda.synchronize()
+    assert (out.float() - torch.nn.functional.gelu(r)).abs().max().item() <= r.abs().max().item() * 2 ** -7

@@ -223,7 +223,7 @@ int launch_modes(const GemmParams& p, int cfg, hipStream_t st) {
 
 }  // namespace
 
-int vault_gemm256_launch(const GemmParams& p, int a_mode, int b_mode, int epi, hipStream_t st);
+int vault_gemm256_launch(const GemmParams& p, int a_mode, int b_mode, int epi, int ntq, hipStream_t st);
 
 int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, int cfg, hipStream_t st) {
   GemmParams p = p_in;
@@ -234,11 +234,20 @@ int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, i
   if (cfg < 0) {
     // default kernel/tile choice (measured on MI355X at M = 47360, profiles/ r01 GEMM table):
     //   256x256 8-phase ring kernel for long contractions (K >= 1536) and all wgrads (A stored [K][M]);
+    //   its 256x192 form when that fills the last round of CUs much better (N = 768: 740 vs 555 tiles);
     //   256x256 double-buffered kernel for short K with wide N; 256x128 / 128x128 otherwise
-    if (p.M % 256 == 0 && p.N % 256 == 0) cfg = (p.K >= 1536 || a_mode == 1) ? 3 : 2;
-    else cfg = (p.M % 256 == 0 && p.N % 128 == 0 && epi != EPI_F32_ATOMIC) ? 1 : 0;
+    auto eff = [](long tiles) { return (double)tiles / (double)(((tiles + 255) / 256) * 256); };
+    if (p.M % 256 == 0 && p.N % 256 == 0) {
+      cfg = (p.K >= 1536 || a_mode == 1) ? 3 : 2;
+      if (p.N % 192 == 0 && a_mode == 0 && epi != EPI_F32_ATOMIC && p.splits == 1 &&
+          eff((long)(p.M / 256) * (p.N / 192)) > 1.1 * eff((long)(p.M / 256) * (p.N / 256)))
+        cfg = 4;
+    } else {
+      cfg = (p.M % 256 == 0 && p.N % 128 == 0 && epi != EPI_F32_ATOMIC) ? 1 : 0;
+    }
   }
-  if (cfg == 3) return vault_gemm256_launch(p, a_mode, b_mode, epi, st);
+  if (cfg == 3) return vault_gemm256_launch(p, a_mode, b_mode, epi, 4, st);
+  if (cfg == 4) return vault_gemm256_launch(p, a_mode, b_mode, epi, 3, st);
   const int key = a_mode * 2 + b_mode;
 #define VAULT_DISPATCH(AM, BMD)                                                             \
   switch (epi) {                                                                            \

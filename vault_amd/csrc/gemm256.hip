@@ -28,7 +28,7 @@ constexpr int BUFB = 4 * HT;   // one K tile: A0 A1 B0 B1
 // One asm statement: counted vmcnt (hipcc has no counted form for LDS-DMA), lgkmcnt(0), barrier.  hipcc does
 // not see these waits: fragment reads are therefore issued between the two halves of a phase's MFMA
 // cluster, after the point where hipcc places its own (already satisfied) lgkmcnt wait.
-#define WAITBAR(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define WAITBAR(N) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(N) : "memory")
 
 // ds_read_b64_tr_b16 through asm: the builtin form makes hipcc drain every in-flight global_load_lds
 // (vmcnt(0)) in front of it, which would serialise the ring.  The data is consumed only after the
@@ -40,8 +40,15 @@ __device__ __forceinline__ s16x4 tr16_asm(uint32_t lds_addr) {
   return v;
 }
 
-template <int A_MODE, int B_MODE, int EPI>
+// NTQ = 16-column MFMA tiles per wave per B half: 4 -> 256-wide block tile, 3 -> 192-wide (N = 768 gives
+// 4 x 185 = 740 tiles = 2.9 rounds of 256 CUs instead of 555 = 2.2 rounds: 96 % instead of 72 % of the
+// last round's CUs busy)
+template <int A_MODE, int B_MODE, int EPI, int NTQ>
 __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
+  constexpr int BNT = NTQ * 64;                     // block tile width
+  constexpr int PB = (B_MODE == 0) ? NTQ : 4;       // global_load_lds pieces per wave per B half-tile
+  constexpr int W32 = 3 * 4 + 2 * PB;               // pieces of the five youngest half-tiles: 3 A + 2 B
+  constexpr int W23 = 2 * 4 + 3 * PB;               //                                       2 A + 3 B
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -49,7 +56,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   const int wr = wave >> 1, wc = wave & 1;
   const int g = lane >> 4, l15 = lane & 15;
 
-  const int tiles_n = p.N >> 8;
+  const int tiles_n = p.N / BNT;
   int tile_m, tile_n;
   {
     const int nwg = gridDim.x, id = blockIdx.x;
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     tile_m = wg / tiles_n;
     tile_n = wg - tile_m * tiles_n;
   }
-  const int m0 = tile_m << 8, n0 = tile_n << 8;
+  const int m0 = tile_m << 8, n0 = tile_n * BNT;
   const int nk_total = p.K >> 6;
   const int per = (nk_total + p.splits - 1) / p.splits;
   const int kt0 = blockIdx.z * per;
@@ -80,10 +87,10 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   }
   if constexpr (B_MODE == 0) {
     b_base = reinterpret_cast<const char*>(p.B + (size_t)n0 * p.ldb + (size_t)kt0 * 64);
-    b_half = 64u * p.ldb * 2u; b_step = 128u;
+    b_half = (uint32_t)(NTQ * 16) * p.ldb * 2u; b_step = 128u;
   } else {
     b_base = reinterpret_cast<const char*>(p.B + (size_t)kt0 * 64 * p.ldb + n0);
-    b_half = 128u; b_step = 64u * p.ldb * 2u;
+    b_half = (uint32_t)(NTQ * 16) * 2u; b_step = 64u * p.ldb * 2u;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -95,8 +102,16 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     const int cb = (pos16 >> 1) ^ hk;
     if constexpr (A_MODE == 0) a_off[i] = (uint32_t)(((r >> 6) * 128 + (r & 63)) * p.lda + c * 8) * 2u;
     else a_off[i] = (uint32_t)(krow * p.lda + (cb >> 2) * 128 + (cb & 3) * 16 + (pos16 & 1) * 8) * 2u;
-    if constexpr (B_MODE == 0) b_off[i] = (uint32_t)(((r >> 6) * 128 + (r & 63)) * p.ldb + c * 8) * 2u;
-    else b_off[i] = (uint32_t)(krow * p.ldb + (cb >> 2) * 128 + (cb & 3) * 16 + (pos16 & 1) * 8) * 2u;
+    if constexpr (B_MODE == 0) {
+      // half-tile image: 2 wave-columns x NTQ*16 rows of 128 B; piece jb = wave*PB + i covers rows 8jb..8jb+7
+      const int jb = wave * PB + (i < PB ? i : PB - 1), rb = 8 * jb + r8;
+      const int wcol = rb / (NTQ * 16), within = rb - wcol * (NTQ * 16);
+      b_off[i] = (uint32_t)((wcol * (NTQ * 32) + within) * p.ldb + c * 8) * 2u;
+    } else {
+      // [64 k][8 col-blocks of 16] image, blocks wc*4 + nt; nt >= NTQ slots are never read: clamp their source
+      const int ntc = min(cb & 3, NTQ - 1);
+      b_off[i] = (uint32_t)(krow * p.ldb + (cb >> 2) * (NTQ * 32) + ntc * 16 + (pos16 & 1) * 8) * 2u;
+    }
   }
 
   // one 1-KiB piece (i = 0..3) of a half-tile; a half-tile is 4 pieces per wave
@@ -104,8 +119,9 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     glds16(a_base + (size_t)h * a_half + (size_t)t * a_step + a_off[i], smem + buf * BUFB + h * HT + wave * 4096 + i * 1024);
   };
   auto pieceB = [&](int h, int buf, int t, int i) {
-    glds16(b_base + (size_t)h * b_half + (size_t)t * b_step + b_off[i],
-           smem + buf * BUFB + 2 * HT + h * HT + wave * 4096 + i * 1024);
+    if (i < PB)
+      glds16(b_base + (size_t)h * b_half + (size_t)t * b_step + b_off[i],
+             smem + buf * BUFB + 2 * HT + h * HT + (wave * PB + i) * 1024);
   };
   auto issueA = [&](int h, int buf, int t) {
 #pragma unroll
@@ -129,8 +145,8 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
       a_o1 = hk;
     }
     if constexpr (B_MODE == 0) {
-      b_o0 = (wc * 64 + l15) * 128 + ((g ^ fx) << 4);
-      b_o1 = (wc * 64 + l15) * 128 + (((4 + g) ^ fx) << 4);
+      b_o0 = (wc * (NTQ * 16) + l15) * 128 + ((g ^ fx) << 4);
+      b_o1 = (wc * (NTQ * 16) + l15) * 128 + (((4 + g) ^ fx) << 4);
     } else {
       b_o0 = (8 * g + q) * 256 + pp * 8;
       b_o1 = hk;
@@ -167,7 +183,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     }                                                                                                    \
   }
 #define LOADB_U(RB, BUF, H, U)                                                                           \
-  {                                                                                                      \
+  if constexpr ((U) < NTQ) {                                                                             \
     if constexpr (B_MODE == 0) {                                                                         \
       const char* base_ = smem + (BUF) * BUFB + 2 * HT + (H) * HT;                                       \
       RB[U][0] = *LDS_PTR(const bf16x8, base_ + b_o0 + (U) * 2048);                                      \
@@ -179,18 +195,18 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
 #define LOADA(RA, BUF, H) { LOADA_U(RA, BUF, H, 0) LOADA_U(RA, BUF, H, 1) LOADA_U(RA, BUF, H, 2) LOADA_U(RA, BUF, H, 3) }
 #define LOADB(RB, BUF, H) { LOADB_U(RB, BUF, H, 0) LOADB_U(RB, BUF, H, 1) LOADB_U(RB, BUF, H, 2) LOADB_U(RB, BUF, H, 3) }
 
-  f32x4 acc[8][8];
+  f32x4 acc[8][2 * NTQ];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 2 * NTQ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // MFMAs are issued through inline asm with the accumulator tied in place in the AGPR half of the
   // register file ("+a"): hipcc otherwise allocates out-of-place destinations for this many live
   // accumulators and spills.  `volatile` keeps every cluster inside its phase.
   // four MFMAs (one A fragment x four B fragments) - the unit the phase body interleaves loads with
 #define MMA4(KS, MT, MB, NB, RA, RB)                                                       \
-  _Pragma("unroll") for (int nt_ = 0; nt_ < 4; ++nt_)                                      \
+  _Pragma("unroll") for (int nt_ = 0; nt_ < NTQ; ++nt_)                                    \
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                               \
                    : "+a"(acc[(MB) + (MT)][(NB) + nt_])                                    \
                    : "v"(RA[MT][KS]), "v"(RB[nt_][KS]));
@@ -201,20 +217,20 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   issueA(0, 0, 0); issueB(0, 0, 0); issueB(1, 0, 0); issueA(1, 0, 0);
   if (nk > 1) {
     issueA(0, 1, 1); issueB(1, 1, 1); issueB(0, 1, 1); issueA(1, 1, 1);
-    WAITBAR(24);
+    WAITBAR(3 * 4 + 3 * PB);
   } else {
     WAITBAR(0);
   }
   LOADA(RA0, 0, 0)
   LOADB(RB0, 0, 0)
-  if (nk > 1) { WAITBAR(20); } else { WAITBAR(0); }
+  if (nk > 1) { WAITBAR(W32); } else { WAITBAR(0); }
 
   // one loop iteration = two K tiles = eight phases.  FULL: both prefetch targets exist (no branches,
   // uniform counted waits); otherwise the generic tail form (skipped issues drain with vmcnt(0)).
   // A phase = 32 MFMAs with the next fragment set's LDS reads and one half-tile's four global_load_lds
   // pieces spread between the 4-MFMA blocks (one wave per SIMD: anything issued in a burst would leave
   // the matrix pipe idle for its whole issue time).
-#define PHASE(LOADU, RN, LBUF, LH, PIECE, IH, IBUF, IT, COND, MB, NB, RA, RB) \
+#define PHASE(WAITN, LOADU, RN, LBUF, LH, PIECE, IH, IBUF, IT, COND, MB, NB, RA, RB) \
   {                                                                            \
     const bool iss_ = FULL || (COND);                                          \
     __builtin_amdgcn_s_setprio(1);                                             \
@@ -232,21 +248,21 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     MMA4(1, 2, MB, NB, RA, RB)                                                 \
     MMA4(1, 3, MB, NB, RA, RB)                                                 \
     __builtin_amdgcn_s_setprio(0);                                             \
-    if (iss_) { WAITBAR(20); } else { WAITBAR(0); }                            \
+    if (iss_) { WAITBAR(WAITN); } else { WAITBAR(0); }                         \
   }
 #define TWO_TILES(FULLV)                                                                   \
   {                                                                                        \
     constexpr bool FULL = FULLV;                                                           \
     const bool i2 = (t + 2) < nk, i3 = (t + 3) < nk;                                       \
-    PHASE(LOADB_U, RB1, 0, 1, pieceA, 0, 0, t + 2, i2, 0, 0, RA0, RB0)                     \
-    PHASE(LOADA_U, RA1, 0, 1, pieceB, 0, 0, t + 2, i2, 0, 4, RA0, RB1)                     \
-    PHASE(LOADA_U, RA0, 1, 0, pieceB, 1, 0, t + 2, i2, 4, 4, RA1, RB1)                     \
-    PHASE(LOADB_U, RB1, 1, 1, pieceA, 1, 0, t + 2, i2, 4, 0, RA1, RB0)                     \
+    PHASE(W32, LOADB_U, RB1, 0, 1, pieceA, 0, 0, t + 2, i2, 0, 0, RA0, RB0)                \
+    PHASE(W23, LOADA_U, RA1, 0, 1, pieceB, 0, 0, t + 2, i2, 0, NTQ, RA0, RB1)              \
+    PHASE(W23, LOADA_U, RA0, 1, 0, pieceB, 1, 0, t + 2, i2, 4, NTQ, RA1, RB1)              \
+    PHASE(W32, LOADB_U, RB1, 1, 1, pieceA, 1, 0, t + 2, i2, 4, 0, RA1, RB0)                \
     if (FULL || (t + 1 < nk)) {                                                            \
-      PHASE(LOADB_U, RB0, 1, 0, pieceA, 0, 1, t + 3, i3, 0, 4, RA0, RB1)                   \
-      PHASE(LOADA_U, RA1, 1, 1, pieceB, 1, 1, t + 3, i3, 0, 0, RA0, RB0)                   \
-      PHASE(LOADA_U, RA0, 0, 0, pieceB, 0, 1, t + 3, i3, 4, 0, RA1, RB0)                   \
-      PHASE(LOADB_U, RB0, 0, 0, pieceA, 1, 1, t + 3, i3, 4, 4, RA1, RB1)                   \
+      PHASE(W32, LOADB_U, RB0, 1, 0, pieceA, 0, 1, t + 3, i3, 0, NTQ, RA0, RB1)            \
+      PHASE(W23, LOADA_U, RA1, 1, 1, pieceB, 1, 1, t + 3, i3, 0, 0, RA0, RB0)              \
+      PHASE(W23, LOADA_U, RA0, 0, 0, pieceB, 0, 1, t + 3, i3, 4, 0, RA1, RB0)              \
+      PHASE(W32, LOADB_U, RB0, 0, 0, pieceA, 1, 1, t + 3, i3, 4, NTQ, RA1, RB1)            \
     }                                                                                      \
   }
   int t = 0;
@@ -263,44 +279,53 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   WAITBAR(0);
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> accumulator reads (hazard is invisible inside asm)
 
-  gemm_epilogue<8, 8, EPI, 2, 2>(acc, p, smem, m0, n0, wr * 128, wc * 128, wave, lane);
+  gemm_epilogue<8, 2 * NTQ, EPI, 2, 2>(acc, p, smem, m0, n0, wr * 128, wc * (NTQ * 32), wave, lane);
 }
 
-template <int A_MODE, int B_MODE, int EPI>
+template <int A_MODE, int B_MODE, int EPI, int NTQ>
 int launch256(const GemmParams& p, hipStream_t st) {
-  if ((p.M & 255) || (p.N & 255) || (p.K & 63)) return VAULT_EINVAL;
+  constexpr int BNT = NTQ * 64;
+  if ((p.M & 255) || (p.N % BNT) || (p.K & 63)) return VAULT_EINVAL;
   constexpr int LDS = 2 * BUFB;
-  auto kern = gemm256_kernel<A_MODE, B_MODE, EPI>;
+  auto kern = gemm256_kernel<A_MODE, B_MODE, EPI, NTQ>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  dim3 grid((p.M >> 8) * (p.N >> 8), 1, p.splits);
+  dim3 grid((p.M >> 8) * (p.N / BNT), 1, p.splits);
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, p);
   return (int)hipGetLastError();
 }
 
-}  // namespace
-
-int vault_gemm256_launch(const GemmParams& p, int a_mode, int b_mode, int epi, hipStream_t st) {
+template <int NTQ>
+int dispatch256(const GemmParams& p, int a_mode, int b_mode, int epi, hipStream_t st) {
   const int key = a_mode * 2 + b_mode;
-#define VAULT_DISPATCH(AM, BMD)                                                  \
-  switch (epi) {                                                                 \
-    case EPI_BF16: return launch256<AM, BMD, EPI_BF16>(p, st);                   \
-    case EPI_BF16_GELU: return launch256<AM, BMD, EPI_BF16_GELU>(p, st);         \
-    case EPI_BF16_DGELU: return launch256<AM, BMD, EPI_BF16_DGELU>(p, st);       \
-    case EPI_F32_RES: return launch256<AM, BMD, EPI_F32_RES>(p, st);             \
-    case EPI_F32_PATCH: return launch256<AM, BMD, EPI_F32_PATCH>(p, st);         \
-    case EPI_F32_ATOMIC: return launch256<AM, BMD, EPI_F32_ATOMIC>(p, st);       \
-    default: return VAULT_EINVAL;                                                \
+#define VAULT_DISPATCH(AM, BMD)                                                       \
+  switch (epi) {                                                                      \
+    case EPI_BF16: return launch256<AM, BMD, EPI_BF16, NTQ>(p, st);                   \
+    case EPI_BF16_GELU: return launch256<AM, BMD, EPI_BF16_GELU, NTQ>(p, st);         \
+    case EPI_BF16_DGELU: return launch256<AM, BMD, EPI_BF16_DGELU, NTQ>(p, st);       \
+    case EPI_F32_RES: return launch256<AM, BMD, EPI_F32_RES, NTQ>(p, st);             \
+    case EPI_F32_PATCH: return launch256<AM, BMD, EPI_F32_PATCH, NTQ>(p, st);         \
+    case EPI_F32_ATOMIC:                                                              \
+      if constexpr (NTQ == 4) return launch256<AM, BMD, EPI_F32_ATOMIC, NTQ>(p, st);  \
+      else return VAULT_EINVAL;                                                       \
+    default: return VAULT_EINVAL;                                                     \
   }
   switch (key) {
     case 0: VAULT_DISPATCH(0, 0)
     case 1: VAULT_DISPATCH(0, 1)
-    case 3: VAULT_DISPATCH(1, 1)
+    case 3:
+      if constexpr (NTQ == 4) { VAULT_DISPATCH(1, 1) } else return VAULT_EINVAL;
     default: return VAULT_EINVAL;
   }
 #undef VAULT_DISPATCH
+}
+
+}  // namespace
+
+int vault_gemm256_launch(const GemmParams& p, int a_mode, int b_mode, int epi, int ntq, hipStream_t st) {
+  return ntq == 3 ? dispatch256<3>(p, a_mode, b_mode, epi, st) : dispatch256<4>(p, a_mode, b_mode, epi, st);
 }

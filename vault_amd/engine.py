@@ -231,7 +231,7 @@ class VaultEngine:
         if Nout % 256 == 0 and Kin % 256 == 0:
             # 256x256 ring kernel; split the token contraction so that tiles x splits fills the 256 CUs once
             tiles = (Nout // 256) * (Kin // 256)
-            splits = max(1, min(nk // 2, 256 // tiles))
+            splits = max(1, min(nk // 2, 256 // tiles, 16))   # >16 partial sums per element: float atomics dominate
             cfg = 3
         else:
             tiles = (Nout // 128) * (Kin // 128)
