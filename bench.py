@@ -96,9 +96,10 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     pg = None
-    if world > 1:
+    if world > 1 or os.environ.get("VAULT_FORCE_DP") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     lm = LMSpec.bertweet_base() if args.lm == "bertweet" else LMSpec.bert_base_uncased()
@@ -171,7 +172,7 @@ def main():
             except Exception as e:  # pragma: no cover
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

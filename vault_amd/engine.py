@@ -195,6 +195,17 @@ class VaultEngine:
         # recorded on the launch stream around the ViLT FFN-in forward GEMM
         self.profile_events: Optional[list] = None
 
+    def _prof_begin(self):
+        if self.profile_events is not None:
+            self._e0 = torch.cuda.Event(enable_timing=True)
+            self._e0.record()
+
+    def _prof_end(self):
+        if self.profile_events is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.profile_events.append((self._e0, e1))
+
     # ---- workspace --------------------------------------------------------------------------
     def _buf(self, ws, name, shape, dtype):
         t = ws.get(name)
@@ -253,35 +264,62 @@ class VaultEngine:
         with torch.cuda.device(self.device):
             return self._forward(batch, train, labels, need_hidden, loss_scale)
 
-    def _forward(self, batch, train, labels, need_hidden, loss_scale):
-        spec, P = self.spec, self.params
-        v = spec.vilt
+    def stage_inputs(self, batch: Dict[str, torch.Tensor], train: bool, labels: Optional[torch.Tensor] = None,
+                     validate: bool = True) -> dict:
+        """Validate the batch (HF-style errors) and copy it into the persistent input buffers of the
+        (B, T, train) workspace, so that every kernel argument of a step is pointer-stable (required for
+        tape replay).  ``validate=False`` skips the pixel-mask check (it synchronises the device)."""
+        spec, v = self.spec, self.spec.vilt
         ids = batch["input_ids"]
         B, T = ids.shape
         H, FF, heads = v.hidden_size, v.intermediate_size, v.num_attention_heads
         NP = v.num_patches
         S = T + 1 + NP
-        M, Mp = B * S, _pad(B * S)
-        pm = batch.get("pixel_mask")
-        pix = batch["pixel_values"].contiguous()
-        if pix.shape[1:] != (v.num_channels, v.image_size, v.image_size):
+        pix = batch["pixel_values"]
+        if tuple(pix.shape[1:]) != (v.num_channels, v.image_size, v.image_size):
             raise ValueError(f"pixel_values must be [B,{v.num_channels},{v.image_size},{v.image_size}]; variable-size "
                              "images / partial pixel masks are not implemented in this build")
         if pix.shape[0] != B:
             raise ValueError("The text inputs and image inputs need to have the same batch size")
-        if pm is not None and not bool((pm != 0).all()):
+        pm = batch.get("pixel_mask")
+        if validate and pm is not None and not bool((pm != 0).all()):
             raise NotImplementedError("partial pixel_mask (padded images) is not implemented in this build")
-        am = batch.get("attention_mask")
-        amf = torch.ones(B, T, device=self.device) if am is None else am.to(torch.float32).contiguous()
-        tt = batch.get("token_type_ids")
         ws = self.workspace(B, T, train)
-        ws.update(S=S, M=M, Mp=Mp, H=H, FF=FF, heads=heads, NP=NP, train=train)
+        ws.update(S=S, M=B * S, Mp=_pad(B * S), H=H, FF=FF, heads=heads, NP=NP, train=train,
+                  Ml=B * T, Mlp=_pad(B * T))
+        buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
+        buf("in_ids", (B, T), torch.int64).copy_(ids)
+        buf("in_pix", tuple(pix.shape)).copy_(pix)
+        km = buf("keymask", (B, S))
+        am = batch.get("attention_mask")
+        if am is None:
+            km.fill_(1.0)
+        else:
+            km[:, :T] = am
+            km[:, T:] = 1.0
+        buf("in_amf", (B, T)).copy_(km[:, :T])
+        tt = batch.get("token_type_ids")
+        ws["ids"], ws["pix"], ws["amf"] = ws["in_ids"], ws["in_pix"], ws["in_amf"]
+        ws["tt"] = None if tt is None else buf("in_tt", (B, T), torch.int64).copy_(tt)
+        ws["labels"] = None if labels is None else buf("in_labels", (B,), torch.int64).copy_(labels)
+        return ws
+
+    def _forward(self, batch, train, labels, need_hidden, loss_scale):
+        ws = self.stage_inputs(batch, train, labels)
+        if train:
+            self.drop_seed = (self.drop_seed + 1) & 0xFFFFFFFF
+        return self.forward_staged(ws, need_hidden, loss_scale)
+
+    def forward_staged(self, ws: dict, need_hidden: bool = True, loss_scale: Optional[float] = None):
+        """Forward over the staged inputs of ``ws`` (every launch goes through ops.* and can be taped)."""
+        spec, P = self.spec, self.params
+        v = spec.vilt
+        train = ws["train"]
+        B, T, S, M, Mp, H, FF, heads, NP = (ws[k] for k in ("B", "T", "S", "M", "Mp", "H", "FF", "heads", "NP"))
+        ids, tt, amf, pix, labels, km = ws["ids"], ws["tt"], ws["amf"], ws["pix"], ws["labels"], ws["keymask"]
         buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
         bf = torch.bfloat16
-        self.drop_seed = (self.drop_seed + 1) & 0xFFFFFFFF if train else self.drop_seed
         ws["drop_seed"] = self.drop_seed
-        ids = ids.contiguous()
-        ws["ids"], ws["tt"] = ids, tt
 
         # ------------------------------ language model ------------------------------
         if spec.lm is not None:
@@ -358,9 +396,6 @@ class VaultEngine:
                          mt[1], P.w("embeddings.cls_token"), addtab, x[0], NP, H, B, S, T)
         ops.gemm(apatch, P.wb("embeddings.patch_embeddings.projection.weight", shape=(H, Kp)), x[0], Mpp, H, Kp, Kp, Kp,
                  H, 0, 0, ops.EPI_F32_PATCH, cfg=0, m_valid=B * NP, addtab=addtab, rpg=NP, gstride=S, goff=T + 1)
-        km = buf("keymask", (B, S))
-        km[:, :T] = amf
-        km[:, T:] = 1.0
 
         # ------------------------------ ViLT encoder ------------------------------
         for i, ln in enumerate(self.vl):
@@ -377,13 +412,9 @@ class VaultEngine:
             self._linear(ctx, ln.ow, xm, Mp, H, H, ops.EPI_F32_RES, M, bias=P.w(ln.ob), res=x[i])
             ops.layernorm_fwd(xm, P.w(ln.ln2w), P.w(ln.ln2b), v.layer_norm_eps, M, H, y_bf16=n2,
                               mean=buf(f"m2{sfx}", (Mp,)), rstd=buf(f"r2{sfx}", (Mp,)))
-            if self.profile_events is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+            ops.pycall(self._prof_begin)
             self._linear(n2, ln.iw, act, Mp, FF, H, ops.EPI_BF16_GELU, M, bias=P.w(ln.ib), out2=u)
-            if self.profile_events is not None:
-                e1.record()
-                self.profile_events.append((e0, e1))
+            ops.pycall(self._prof_end)
             self._linear(act, ln.fw, x[i + 1], Mp, H, FF, ops.EPI_F32_RES, M, bias=P.w(ln.fb), res=xm)
 
         # ------------------------------ tail ------------------------------
@@ -408,7 +439,7 @@ class VaultEngine:
                 C = spec.n_classes
                 logits = buf("logits", (B, C))
                 loss = buf("loss", (1,))
-                loss.zero_()
+                ops.pycall(loss.zero_)
                 hd = self._drop(self.classifier_dropout, 9001, train)
                 ops.head_fwd(pre, P.w("classifier.1.weight"), P.w("classifier.1.bias"), labels, pooled, logits,
                              loss if labels is not None else None, B, H, C,
@@ -416,7 +447,6 @@ class VaultEngine:
                 out["logits"] = logits if C > 1 else logits.view(B)
                 if labels is not None:
                     out["loss"] = loss
-                ws["labels"] = labels
             else:
                 ops.head_fwd(pre, None, None, None, pooled, None, None, B, H, 0, 0.0)   # VaultModel: tanh only
             out["pooler_output"] = pooled[:B]
@@ -455,11 +485,15 @@ class VaultEngine:
         self.drop_seed = ws["drop_seed"]
         x = ws["x"]
         nv = v.num_hidden_layers
-        note = after_layer if after_layer is not None else (lambda tag: None)
+        if after_layer is not None:
+            note = lambda tag: ops.pycall(lambda: after_layer(tag))  # noqa: E731
+        else:
+            note = lambda tag: None  # noqa: E731
 
         dx = [buf("dx_a", (Mp, H)), buf("dx_b", (Mp, H))]
         dxb = [buf("dxb_a", (Mp, H), bf), buf("dxb_b", (Mp, H), bf)]
-        dx[0].zero_(); dxb[0].zero_()
+        ops.pycall(dx[0].zero_)
+        ops.pycall(dxb[0].zero_)
         # ------------------------------ tail ------------------------------
         if spec.add_pooling_layer and (spec.n_classes > 0 or dpooled is not None):
             Bp = ws["Bp"]
@@ -549,7 +583,7 @@ class VaultEngine:
         lm = spec.lm
         nl = lm.num_hidden_layers
         y, yb = ws["lm_y"], ws["lm_yb"]
-        amf = km[:, :T].contiguous()
+        amf = ws["amf"]
         pdh, pda = lm.hidden_dropout_prob, lm.attention_probs_dropout_prob
         dh = buf("lm_dh", (Mlp, H)); dhb = buf("lm_dhb", (Mlp, H), bf)
         dh1 = buf("lm_dh1", (Mlp, H)); dh1b = buf("lm_dh1b", (Mlp, H), bf)

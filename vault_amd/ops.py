@@ -48,6 +48,58 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+class Tape:
+    """A recorded sequence of C-ABI calls (function pointer + prepared ctypes arguments) and host
+    callbacks.  Every buffer of the engine is persistent, so a train step is the SAME call list with the
+    same pointers every time: replaying it costs a few microseconds per launch instead of re-marshalling
+    ~700 argument structs in Python.  Only the dropout seed changes between replays (``seeded``)."""
+
+    def __init__(self):
+        self.calls = []
+        self.seeded = []
+
+    def replay(self, seed: Optional[int] = None):
+        if seed is not None:
+            sd = seed & 0xFFFFFFFF
+            for a in self.seeded:
+                a.drop_seed = sd
+        for fn, args in self.calls:
+            rc = fn(*args)
+            if isinstance(rc, int) and rc != 0:
+                raise RuntimeError(f"{getattr(fn, '__name__', fn)} failed with code {rc} during replay")
+
+
+_TAPE: Optional[Tape] = None
+
+
+def start_tape() -> Tape:
+    global _TAPE
+    _TAPE = Tape()
+    return _TAPE
+
+
+def stop_tape() -> Optional[Tape]:
+    global _TAPE
+    t, _TAPE = _TAPE, None
+    return t
+
+
+def pycall(fn):
+    """Run a host-side action now and, when recording, put it on the tape (must return None / 0)."""
+    if _TAPE is not None:
+        _TAPE.calls.append((fn, ()))
+    fn()
+
+
+def _invoke(name: str, *args, struct=None, drop=None):
+    fn = getattr(L.load(), name)
+    if _TAPE is not None:
+        _TAPE.calls.append((fn, args))
+        if struct is not None and drop is not None and drop.thresh:
+            _TAPE.seeded.append(struct)
+    L.check(fn(*args), name)
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -78,7 +130,7 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_va
     a.a_mode, a.b_mode, a.epi, a.cfg, a.splits, a.accumulate = a_mode, b_mode, epi, cfg, splits, accumulate
     a.rpg, a.gstride, a.goff = rpg, gstride, goff
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
-    L.check(L.load().vault_gemm(C.byref(a), _stream()), "vault_gemm")
+    _invoke("vault_gemm", C.byref(a), _stream(), struct=a, drop=drop)
 
 
 def layernorm_fwd(x, gamma, beta, eps, rows, H, *, y_bf16=None, y_f32=None, mean=None, rstd=None, post_add=None,
@@ -90,7 +142,7 @@ def layernorm_fwd(x, gamma, beta, eps, rows, H, *, y_bf16=None, y_f32=None, mean
     a.x_rpg, a.x_gstride, a.x_goff = xmap
     a.y_rpg, a.y_gstride, a.y_goff = ymap
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
-    L.check(L.load().vault_layernorm_fwd(C.byref(a), _stream()), "vault_layernorm_fwd")
+    _invoke("vault_layernorm_fwd", C.byref(a), _stream(), struct=a, drop=drop)
 
 
 def layernorm_bwd(x, mean, rstd, gamma, rows, H, *, dy_bf16=None, dy_f32=None, dres=None, dx_f32=None, dx_bf16=None,
@@ -107,13 +159,11 @@ def layernorm_bwd(x, mean, rstd, gamma, rows, H, *, dy_bf16=None, dy_f32=None, d
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
     a.drop_on_dy = 1 if drop_on_dy else 0
     a.dbias = _p(dbias)
-    L.check(L.load().vault_layernorm_bwd(C.byref(a), _stream()), "vault_layernorm_bwd")
+    _invoke("vault_layernorm_bwd", C.byref(a), _stream(), struct=a, drop=drop)
 
 
 def colsum(x_bf16, ld, rows, N, out):
-    lib = L.load()
-    L.check(lib.vault_colsum(C.c_void_p(_p(x_bf16)), C.c_int(ld), C.c_int(rows), C.c_int(N), C.c_void_p(_p(out)),
-                             _stream()), "vault_colsum")
+    _invoke("vault_colsum", C.c_void_p(_p(x_bf16)), C.c_int(ld), C.c_int(rows), C.c_int(N), C.c_void_p(_p(out)), _stream())
 
 
 def _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, dctx=None, dqkv=None, drop: Drop = NO_DROP):
@@ -126,12 +176,12 @@ def _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, dctx=None, dqkv=None, dro
 
 def attention_fwd(qkv, keymask, ctx, lse, B, S, H, heads, drop: Drop = NO_DROP):
     a = _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, drop=drop)
-    L.check(L.load().vault_attention_fwd(C.byref(a), _stream()), "vault_attention_fwd")
+    _invoke("vault_attention_fwd", C.byref(a), _stream(), struct=a, drop=drop)
 
 
 def attention_bwd(qkv, keymask, ctx, lse, dctx, dqkv, B, S, H, heads, drop: Drop = NO_DROP):
     a = _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, dctx, dqkv, drop)
-    L.check(L.load().vault_attention_bwd(C.byref(a), _stream()), "vault_attention_bwd")
+    _invoke("vault_attention_bwd", C.byref(a), _stream(), struct=a, drop=drop)
 
 
 class GatherArgs(C.Structure):
@@ -151,8 +201,8 @@ class HeadArgs(C.Structure):
 
 
 def position_ids(ids_i64, pos_i32, B, T, mode, pad):
-    L.check(L.load().vault_position_ids(C.c_void_p(_p(ids_i64)), C.c_void_p(_p(pos_i32)), B, T, mode, pad, _stream()),
-            "vault_position_ids")
+    _invoke("vault_position_ids", C.c_void_p(_p(ids_i64)), C.c_void_p(_p(pos_i32)), C.c_int(B), C.c_int(T),
+            C.c_int(mode), C.c_int(pad), _stream())
 
 
 def _gather_args(src, out, tables, rows, H, period=1):
@@ -178,35 +228,34 @@ def _gather_args(src, out, tables, rows, H, period=1):
 
 def gather_sum(src, out, tables, rows, H, period=1):
     a = _gather_args(src, out, tables, rows, H, period)
-    L.check(L.load().vault_gather_sum(C.byref(a), _stream()), "vault_gather_sum")
+    _invoke("vault_gather_sum", C.byref(a), _stream())
 
 
 def scatter_add(src, grad_tables, rows, H, period=1, rowmask=None):
     a = _gather_args(src, None, grad_tables, rows, H, period)
     a.rowmask = _p(rowmask)
-    L.check(L.load().vault_scatter_add(C.byref(a), _stream()), "vault_scatter_add")
+    _invoke("vault_scatter_add", C.byref(a), _stream())
 
 
 def im2col(pix, out_bf16, B, Cn, IMG, ps):
-    L.check(L.load().vault_im2col(C.c_void_p(_p(pix)), C.c_void_p(_p(out_bf16)), B, Cn, IMG, ps, _stream()),
-            "vault_im2col")
+    _invoke("vault_im2col", C.c_void_p(_p(pix)), C.c_void_p(_p(out_bf16)), C.c_int(B), C.c_int(Cn), C.c_int(IMG),
+            C.c_int(ps), _stream())
 
 
 def image_consts(bias, pos, mtype1, cls, addtab, x, P, H, B, S, T):
-    L.check(L.load().vault_image_consts(C.c_void_p(_p(bias)), C.c_void_p(_p(pos)), C.c_void_p(_p(mtype1)),
-                                        C.c_void_p(_p(cls)), C.c_void_p(_p(addtab)), C.c_void_p(_p(x)), P, H, B, S, T,
-                                        _stream()), "vault_image_consts")
+    _invoke("vault_image_consts", C.c_void_p(_p(bias)), C.c_void_p(_p(pos)), C.c_void_p(_p(mtype1)),
+            C.c_void_p(_p(cls)), C.c_void_p(_p(addtab)), C.c_void_p(_p(x)), C.c_int(P), C.c_int(H), C.c_int(B),
+            C.c_int(S), C.c_int(T), _stream())
 
 
 def image_rows_bwd(dx, dpos, dmtype1, dcls, dbias, dyp_bf16, P, H, B, S, T):
-    L.check(L.load().vault_image_rows_bwd(C.c_void_p(_p(dx)), C.c_void_p(_p(dpos)), C.c_void_p(_p(dmtype1)),
-                                          C.c_void_p(_p(dcls)), C.c_void_p(_p(dbias)), C.c_void_p(_p(dyp_bf16)), P, H,
-                                          B, S, T, _stream()), "vault_image_rows_bwd")
+    _invoke("vault_image_rows_bwd", C.c_void_p(_p(dx)), C.c_void_p(_p(dpos)), C.c_void_p(_p(dmtype1)),
+            C.c_void_p(_p(dcls)), C.c_void_p(_p(dbias)), C.c_void_p(_p(dyp_bf16)), C.c_int(P), C.c_int(H), C.c_int(B),
+            C.c_int(S), C.c_int(T), _stream())
 
 
 def axpy(dst, src, a, n):
-    L.check(L.load().vault_axpy_f32(C.c_void_p(_p(dst)), C.c_void_p(_p(src)), C.c_float(a), C.c_longlong(n),
-                                    _stream()), "vault_axpy_f32")
+    _invoke("vault_axpy_f32", C.c_void_p(_p(dst)), C.c_void_p(_p(src)), C.c_float(a), C.c_longlong(n), _stream())
 
 
 def _head_args(pre, Wc, bc, labels, pooled, logits, loss_sum, B, H, Cc, loss_scale=1.0, grad_scale=1.0, dlogits=None,
@@ -222,29 +271,27 @@ def _head_args(pre, Wc, bc, labels, pooled, logits, loss_sum, B, H, Cc, loss_sca
 
 def head_fwd(pre, Wc, bc, labels, pooled, logits, loss_sum, B, H, Cc, loss_scale, drop: Drop = NO_DROP):
     a = _head_args(pre, Wc, bc, labels, pooled, logits, loss_sum, B, H, Cc, loss_scale=loss_scale, drop=drop)
-    L.check(L.load().vault_head_fwd(C.byref(a), _stream()), "vault_head_fwd")
+    _invoke("vault_head_fwd", C.byref(a), _stream(), struct=a, drop=drop)
 
 
 def head_bwd(pooled, logits, labels, Wc, dWc, dbc, dpre, B, H, Cc, grad_scale, dlogits=None, drop: Drop = NO_DROP):
     a = _head_args(None, Wc, None, labels, pooled, logits, None, B, H, Cc, grad_scale=grad_scale, dlogits=dlogits,
                    dWc=dWc, dbc=dbc, dpre=dpre, drop=drop)
-    L.check(L.load().vault_head_bwd(C.byref(a), _stream()), "vault_head_bwd")
+    _invoke("vault_head_bwd", C.byref(a), _stream(), struct=a, drop=drop)
 
 
 def tanh_bwd(pooled, dpooled, dpre_bf16, n):
-    L.check(L.load().vault_tanh_bwd(C.c_void_p(_p(pooled)), C.c_void_p(_p(dpooled)), C.c_void_p(_p(dpre_bf16)),
-                                    C.c_longlong(n), _stream()), "vault_tanh_bwd")
+    _invoke("vault_tanh_bwd", C.c_void_p(_p(pooled)), C.c_void_p(_p(dpooled)), C.c_void_p(_p(dpre_bf16)),
+            C.c_longlong(n), _stream())
 
 
 def adamw_step(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay, bias_corr_factor=1.0, grad_scale=1.0,
                zero_grad=True):
-    L.check(L.load().vault_adamw_step(C.c_void_p(_p(p)), C.c_void_p(_p(g)), C.c_void_p(_p(m)), C.c_void_p(_p(v)),
-                                      C.c_void_p(_p(p_bf16)), C.c_longlong(n), C.c_float(lr), C.c_float(beta1),
-                                      C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay),
-                                      C.c_float(bias_corr_factor), C.c_float(grad_scale), C.c_int(1 if zero_grad else 0),
-                                      _stream()), "vault_adamw_step")
+    _invoke("vault_adamw_step", C.c_void_p(_p(p)), C.c_void_p(_p(g)), C.c_void_p(_p(m)), C.c_void_p(_p(v)),
+            C.c_void_p(_p(p_bf16)), C.c_longlong(n), C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps),
+            C.c_float(weight_decay), C.c_float(bias_corr_factor), C.c_float(grad_scale),
+            C.c_int(1 if zero_grad else 0), _stream())
 
 
 def cast_bf16(x, y_bf16, n):
-    L.check(L.load().vault_cast_bf16(C.c_void_p(_p(x)), C.c_void_p(_p(y_bf16)), C.c_longlong(n), _stream()),
-            "vault_cast_bf16")
+    _invoke("vault_cast_bf16", C.c_void_p(_p(x)), C.c_void_p(_p(y_bf16)), C.c_longlong(n), _stream())

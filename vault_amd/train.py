@@ -122,7 +122,7 @@ class TrainStep:
     def __init__(self, engine: VaultEngine, learning_rate: float = 2e-5, adam_beta1: float = 0.9,
                  adam_beta2: float = 0.999, adam_epsilon: float = 1e-8, weight_decay: float = 0.0,
                  correct_bias: bool = False, warmup_ratio: float = 0.1, total_steps: int = 1000,
-                 process_group=None, bucket_mb: float = 64.0, constant_lr: bool = False):
+                 process_group=None, bucket_mb: float = 64.0, constant_lr: bool = False, use_tape: bool = True):
         self.engine = engine
         self.lr, self.b1, self.b2, self.eps, self.wd = learning_rate, adam_beta1, adam_beta2, adam_epsilon, weight_decay
         self.correct_bias = correct_bias
@@ -131,12 +131,18 @@ class TrainStep:
         self.constant_lr = constant_lr
         self.step_idx = 0
         self.loss: Optional[torch.Tensor] = None
+        self.use_tape = use_tape
+        self._tape = None
+        self._tape_key = None
+        self._loss_buf = None
         self.world = 1
         self.reducer: Optional[BucketReducer] = None
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
             self.world = dist.get_world_size(process_group)
-        if self.world > 1:
+        import os
+        # VAULT_FORCE_DP=1 exercises the bucketed all-reduce path even with a single rank (debug/testing)
+        if self.world > 1 or (os.environ.get("VAULT_FORCE_DP") == "1" and dist.is_available() and dist.is_initialized()):
             b = GradBuckets(engine, bucket_mb)
             self.reducer = BucketReducer(engine.params.g, b.stage_lo, b.last_tag, b.bucket_elems, dist, process_group,
                                          torch.cuda.Stream(device=engine.device), engine.device)
@@ -147,15 +153,32 @@ class TrainStep:
         return linear_schedule(self.lr, self.step_idx, self.warmup_steps, self.total_steps)
 
     def __call__(self, batch: Dict[str, torch.Tensor], labels: torch.Tensor) -> torch.Tensor:
+        """One optimisation step.  The first call for a (B, T) shape runs eagerly and records the call
+        tape (ops.Tape); later calls copy the batch into the persistent input buffers and replay it."""
         eng = self.engine
-        B = labels.shape[0]
-        out = eng.forward(batch, train=True, labels=labels, need_hidden=False, loss_scale=1.0 / B)
-        # gradients are zero here: the fused optimizer clears them after use (and they start at 0)
-        eng.backward(grad_scale=1.0 / B, after_layer=self.reducer.on_stage if self.reducer else None)
-        if self.reducer:
-            self.reducer.finish()
-        self.optimizer_step()
-        self.loss = out["loss"]
+        B, T = batch["input_ids"].shape
+        key = (B, T)
+        with torch.cuda.device(eng.device):
+            if self.use_tape and self._tape is not None and self._tape_key == key:
+                eng.stage_inputs(batch, True, labels, validate=False)
+                eng.drop_seed = (eng.drop_seed + 1) & 0xFFFFFFFF
+                self._tape.replay(seed=eng.drop_seed)
+            else:
+                ws = eng.stage_inputs(batch, True, labels)
+                eng.drop_seed = (eng.drop_seed + 1) & 0xFFFFFFFF
+                tape = ops.start_tape() if self.use_tape else None
+                try:
+                    out = eng.forward_staged(ws, need_hidden=False, loss_scale=1.0 / B)
+                    # gradients are zero here: the fused optimizer clears them after use (they start at 0)
+                    eng._backward(1.0 / B, None, None, None, self.reducer.on_stage if self.reducer else None)
+                finally:
+                    if self.use_tape:
+                        ops.stop_tape()
+                self._tape, self._tape_key, self._loss_buf = tape, key, out["loss"]
+            if self.reducer:
+                self.reducer.finish()
+            self.optimizer_step()
+        self.loss = self._loss_buf
         return self.loss
 
     def optimizer_step(self):
