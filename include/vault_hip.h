@@ -34,6 +34,7 @@ typedef struct vault_gemm_args {
   const void* A; const void* B; void* out; void* out2;
   const float* bias; const float* res; const void* aux; const float* addtab;
   float* colsum;   /* optional, bf16 epilogues: += column sums of the output over rows < m_valid */
+  int split3;      /* bf16 epilogues: store [hi | lo | hi] per row (ldo = 3N): A operand of a split-bf16 GEMM */
   int M, N, K, lda, ldb, ldo, m_valid;
   int a_mode, b_mode, epi, cfg, splits, accumulate;
   int rpg, gstride, goff;
@@ -55,6 +56,7 @@ typedef struct vault_ln_fwd_args {
   int rows, H; float eps;
   int x_rpg, x_gstride, x_goff, y_rpg, y_gstride, y_goff;
   uint32_t drop_thresh, drop_seed, drop_stream; float drop_scale;
+  void* y_split3;   /* optional bf16 [rows][3H] = [hi | lo | hi]: A operand of a split-bf16 (precise) GEMM */
 } vault_ln_fwd_args;
 int vault_layernorm_fwd(const vault_ln_fwd_args* args, void* stream);
 
@@ -88,6 +90,7 @@ typedef struct vault_attn_args {
   const void* dctx; void* dqkv;
   int B, S, H, heads;
   uint32_t drop_thresh, drop_seed, drop_stream; float drop_scale;
+  void* ctx_split3; /* fwd, optional bf16 [B*S][3H] = [hi | lo | hi] instead of ctx (precise path) */
 } vault_attn_args;
 int vault_attention_fwd(const vault_attn_args* args, void* stream);
 int vault_attention_bwd(const vault_attn_args* args, void* stream);
@@ -114,7 +117,7 @@ int vault_scatter_add(const vault_gather_args* args, void* stream);
 
 /* pixel_values [B][C][IMG][IMG] f32 -> patch matrix [B*(IMG/ps)^2][C*ps*ps] bf16 (k = c*ps*ps + py*ps
  * + px, row-major patch order): the unfold half of the Conv2d at modeling_vilt.py:290-300. ps % 8 == 0. */
-int vault_im2col(const float* pixel_values, void* out_bf16, int B, int C, int IMG, int ps, void* stream);
+int vault_im2col(const float* pixel_values, void* out_bf16, int B, int C, int IMG, int ps, int split3, void* stream);
 
 /* addtab[p] = conv_bias + pos_emb[1+p] + modality_type[1] (p < P), and the CLS rows
  * x[b*S + T] = cls_token + pos_emb[0] + modality_type[1]  (modeling_vilt.py:160-166,204-215). */
@@ -150,6 +153,11 @@ int vault_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, long 
                      float beta2, float eps, float weight_decay, float bias_corr_factor, float grad_scale,
                      int zero_grad, void* stream);
 int vault_cast_bf16(const float* x, void* y_bf16, long long n, void* stream);
+/* Split-bf16 operands: out[r][3K] = [hi | lo | hi] (layout 0, activations) or [hi | hi | lo] (layout 1,
+ * weights), hi = bf16(x), lo = bf16(x - hi).  One bf16 GEMM over the 3K-long contraction then equals
+ * A_hi B_hi + A_lo B_hi + A_hi B_lo: fp32-class products (2^-17) on the bf16 MFMA path - the precise
+ * inference mode used to meet the 1e-3 logits parity bar. */
+int vault_split3_bf16(const float* x, void* out_bf16, long long rows, int K, int layout, void* stream);
 
 #ifdef __cplusplus
 }

@@ -202,3 +202,41 @@ def test_model_api_autograd_bridge():
     m2.load_state_dict(sd2)
     with torch.no_grad():
         assert (m2(**kw) - lg_eval).abs().max() < 1e-6
+
+
+def test_precise_mode_meets_the_1e3_logits_bar():
+    """Split-bf16 ("bf16x3") inference: every Linear runs as A_hi W_hi + A_lo W_hi + A_hi W_lo on the bf16
+    MFMA kernels.  This is the mode that meets the north-star tolerance (logits within 1e-3 of the fp32
+    reference) at full depth; the plain bf16 mode sits at ~4e-3 there (see test above)."""
+    g = np.load(os.path.join(GOLD, "full_bertweet_b2.npz"))
+    spec = _nodrop(VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3))
+    B = int(g["meta_batch"])
+    bn = synthetic_batch(spec, B, seed=int(g["meta_data_seed"]), n_classes=3)
+    eng = VaultEngine(spec, "cuda:0", seed=0, classifier_dropout=0.0, with_grads=False)
+    db = _dev(bn)
+    out = eng.forward(db, train=False, labels=db["labels"], need_hidden=True, precise=True)
+    torch.cuda.synchronize()
+    dl = np.abs(out["logits"].cpu().numpy() - g["logits"]).max()
+    assert dl < 1e-3, dl
+    assert abs(float(out["loss"]) - float(g["loss"])) < 1e-3
+    assert np.abs(out["pooler_output"].cpu().numpy() - g["pooler_output"]).max() < 2.5e-3
+    T = bn["input_ids"].shape[1]
+    h = out["last_hidden_state"][:, : T + 1].cpu().numpy()
+    assert np.abs(h - g["hidden_text_cls"]).max() < 4e-3 * np.abs(g["hidden_text_cls"]).max()
+    # and the fast mode on the same engine still works afterwards (separate buffers)
+    out2 = eng.forward(db, train=False, need_hidden=False)
+    assert np.abs(out2["logits"].cpu().numpy() - g["logits"]).max() < 8e-3
+
+
+@pytest.mark.parametrize("kind,seed", [("roberta", 11), ("bert", 12)])
+def test_precise_mode_tiny(kind, seed):
+    spec = _nodrop(VaultSpec.tiny(3, kind))
+    bn = synthetic_batch(spec, 3, seed=seed, n_classes=3)
+    state = build_state(spec, 0)
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, with_grads=False)
+    out = eng.forward(_dev(bn), train=False, need_hidden=True, precise=True)
+    ref = O.vault_forward(O.to_torch_state(state), spec, O.torch_batch(bn))
+    torch.cuda.synchronize()
+    assert (out["logits"].cpu() - ref["logits"]).abs().max() < 3e-4
+    rh = ref["last_hidden_state"]
+    assert (out["last_hidden_state"].cpu() - rh).abs().max() < 2e-3 * rh.abs().max()

@@ -61,7 +61,7 @@ struct AttnDrop {
 template <int NKT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
                                                        bf16* __restrict__ ctx, float* __restrict__ lse, int S, int H,
-                                                       int heads, float scale, AttnDrop dr) {
+                                                       int heads, float scale, AttnDrop dr, bf16* __restrict__ ctx3) {
   constexpr int SK = NKT * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
@@ -142,9 +142,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
     for (int r = 0; r < 4; ++r) {
       const int q = qt * 16 + 4 * g + r;
       if (q < S) {
-        bf16* dst = ctx + (row0 + q) * H + h * 64 + l15;
+        if (ctx3 != nullptr) {   // precise path: [hi | lo | hi] operand of the split-bf16 projection GEMM
+          bf16* dst = ctx3 + (row0 + q) * 3 * H + h * 64 + l15;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dst[dt * 16] = (bf16)o[dt][r];
+          for (int dt = 0; dt < 4; ++dt) {
+            bf16 hi, lo;
+            split_bf16(o[dt][r], hi, lo);
+            dst[dt * 16] = hi; dst[H + dt * 16] = lo; dst[2 * H + dt * 16] = hi;
+          }
+        } else {
+          bf16* dst = ctx + (row0 + q) * H + h * 64 + l15;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) dst[dt * 16] = (bf16)o[dt][r];
+        }
       }
     }
   }
@@ -334,7 +344,8 @@ constexpr int attn_lds_bytes() { return NKT * 32 * 128 * 2 + NKT * 32 * 4 * 3; }
 }  // namespace
 
 extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
-  if (!a || !a->qkv || !a->ctx || !a->lse || a->S <= 0 || a->B <= 0 || a->H != a->heads * 64) return VAULT_EINVAL;
+  if (!a || !a->qkv || (!a->ctx && !a->ctx_split3) || !a->lse || a->S <= 0 || a->B <= 0 || a->H != a->heads * 64)
+    return VAULT_EINVAL;
   if (a->S > 192) return VAULT_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const AttnDrop dr{a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale};
@@ -342,10 +353,12 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
   const float scale = 0.125f;  // 1/sqrt(64)
   if (a->S <= 64) {
     hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, attn_lds_bytes<2>(), st, reinterpret_cast<const bf16*>(a->qkv),
-                       a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr);
+                       a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
+                       reinterpret_cast<bf16*>(a->ctx_split3));
   } else {
     hipLaunchKernelGGL(attn_fwd_kernel<6>, grid, block, attn_lds_bytes<6>(), st, reinterpret_cast<const bf16*>(a->qkv),
-                       a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr);
+                       a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
+                       reinterpret_cast<bf16*>(a->ctx_split3));
   }
   return (int)hipGetLastError();
 }

@@ -45,6 +45,14 @@ __device__ __forceinline__ float2 unpack_bf16x2(uint32_t u) {
   return make_float2((float)v[0], (float)v[1]);
 }
 
+// bf16 hi/lo split of an fp32 value: x ~= hi + lo with |x - hi - lo| <= 2^-17 |x|.  "Split-bf16" GEMMs
+// (C = A_hi B_hi + A_lo B_hi + A_hi B_lo, done as ONE bf16 GEMM over a 3x longer contraction with the
+// operands laid out [hi | lo | hi] x [hi | hi | lo]) give fp32-class products on the bf16 MFMA path.
+__device__ __forceinline__ void split_bf16(float x, bf16& hi, bf16& lo) {
+  hi = (bf16)x;
+  lo = (bf16)(x - (float)hi);
+}
+
 // Standard-normal CDF Phi(x) = 0.5 (1 + erf(x / sqrt 2)) through erf's Abramowitz-Stegun 7.1.28
 // form 1 - (1 + a1 t + ... + a6 t^6)^-16 (|err| <= 3e-7, i.e. fp32-level, and no exponential: the
 // GELU epilogues are VALU-bound, this is ~1/2 the instructions of an exp-based erf).

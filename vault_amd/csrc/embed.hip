@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(const float* __restric
 
 // pixel [B][C][IMG][IMG] f32 -> A [B*P (padded)][C*ps*ps] bf16, k = c*ps*ps + py*ps + px, patches row-major
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ pix, bf16* __restrict__ out, int B, int Cn,
-                                                     int IMG, int ps, long long total_chunks) {
+                                                     int IMG, int ps, long long total_chunks, int split3) {
   const int grid = IMG / ps;
   const int cpr = ps / 8;                 // 8-pixel chunks per patch row
   const int Kp = Cn * ps * ps;
@@ -126,6 +126,21 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ p
     const float* s = pix + (((size_t)b * Cn + c) * IMG + (size_t)(pr * ps + py)) * IMG + pc * ps + px;
     const f32x4 a = *reinterpret_cast<const f32x4*>(s);
     const f32x4 d = *reinterpret_cast<const f32x4*>(s + 4);
+    if (split3) {
+      const float xs[8] = {a[0], a[1], a[2], a[3], d[0], d[1], d[2], d[3]};
+      bf16 hi[8], lo[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split_bf16(xs[e], hi[e], lo[e]);
+      u32x4 wh = {pack_bf16x2((float)hi[0], (float)hi[1]), pack_bf16x2((float)hi[2], (float)hi[3]),
+                  pack_bf16x2((float)hi[4], (float)hi[5]), pack_bf16x2((float)hi[6], (float)hi[7])};
+      u32x4 wl = {pack_bf16x2((float)lo[0], (float)lo[1]), pack_bf16x2((float)lo[2], (float)lo[3]),
+                  pack_bf16x2((float)lo[4], (float)lo[5]), pack_bf16x2((float)lo[6], (float)lo[7])};
+      bf16* o = out + row * 3 * Kp + k;
+      *reinterpret_cast<u32x4*>(o) = wh;
+      *reinterpret_cast<u32x4*>(o + Kp) = wl;
+      *reinterpret_cast<u32x4*>(o + 2 * Kp) = wh;
+      continue;
+    }
     u32x4 w = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
     *reinterpret_cast<u32x4*>(out + row * Kp + k) = w;
   }
@@ -207,13 +222,13 @@ extern "C" int vault_scatter_add(const vault_gather_args* a, void* stream) {
   return (int)hipGetLastError();
 }
 
-extern "C" int vault_im2col(const float* pix, void* out_bf16, int B, int C, int IMG, int ps, void* stream) {
+extern "C" int vault_im2col(const float* pix, void* out_bf16, int B, int C, int IMG, int ps, int split3, void* stream) {
   if (!pix || !out_bf16 || ps % 8 || IMG % ps || B <= 0) return VAULT_EINVAL;
   const long long rows = (long long)B * (IMG / ps) * (IMG / ps);
   const long long chunks = rows * (C * ps * ps / 8);
   const int blocks = (int)std::min<long long>((chunks + 255) / 256, 256 * 16);
   hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pix,
-                     reinterpret_cast<bf16*>(out_bf16), B, C, IMG, ps, chunks);
+                     reinterpret_cast<bf16*>(out_bf16), B, C, IMG, ps, chunks, split3);
   return (int)hipGetLastError();
 }
 

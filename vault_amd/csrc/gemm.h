@@ -29,6 +29,7 @@ struct GemmParams {
   const float* res;
   const __bf16* aux;
   const float* addtab;
+  int split3;       // bf16 epilogues: store [hi | lo | hi] (row stride ldo = 3N) for the split-bf16 precise path
   float* colsum;    // bf16 epilogues: += column sums of the stored values (bias gradient), or null
   int rpg, gstride, goff;
   // inverted dropout on (acc + bias) for EPI_F32_RES; thresh == 0 disables it

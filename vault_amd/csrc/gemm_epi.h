@@ -147,6 +147,22 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
         for (int c = 0; c < SEG; ++c) csum[c] += v[c];
       }
       bf16* out = reinterpret_cast<bf16*>(p.out) + o;
+      if (p.split3) {   // precise path: this output is the next GEMM's A operand -> [hi | lo | hi], ldo = 3N
+#pragma unroll
+        for (int c = 0; c < SEG; c += 8) {
+          bf16 hi[8], lo[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) split_bf16(v[c + e], hi[e], lo[e]);
+          u32x4 wh = {pack_bf16x2((float)hi[0], (float)hi[1]), pack_bf16x2((float)hi[2], (float)hi[3]),
+                      pack_bf16x2((float)hi[4], (float)hi[5]), pack_bf16x2((float)hi[6], (float)hi[7])};
+          u32x4 wl = {pack_bf16x2((float)lo[0], (float)lo[1]), pack_bf16x2((float)lo[2], (float)lo[3]),
+                      pack_bf16x2((float)lo[4], (float)lo[5]), pack_bf16x2((float)lo[6], (float)lo[7])};
+          *reinterpret_cast<u32x4*>(out + c) = wh;
+          *reinterpret_cast<u32x4*>(out + p.N + c) = wl;
+          *reinterpret_cast<u32x4*>(out + 2 * p.N + c) = wh;
+        }
+        continue;
+      }
 #pragma unroll
       for (int c = 0; c < SEG; c += 8) {
         u32x4 w = {pack_bf16x2(v[c], v[c + 1]), pack_bf16x2(v[c + 2], v[c + 3]),

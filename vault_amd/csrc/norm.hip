@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ post_add,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
                                                      uint32_t drop_thresh, uint32_t drop_seed, uint32_t drop_stream,
-                                                     float drop_scale) {
+                                                     float drop_scale, bf16* __restrict__ y_split3) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -75,6 +75,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (y_bf16) {
       uint2 w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
       *reinterpret_cast<uint2*>(y_bf16 + orow * H + c) = w;
+    }
+    if (y_split3) {   // [hi | lo | hi] A-operand layout of the split-bf16 (precise) GEMM path
+      bf16 hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split_bf16(o[e], hi[e], lo[e]);
+      const uint2 wh = {pack_bf16x2((float)hi[0], (float)hi[1]), pack_bf16x2((float)hi[2], (float)hi[3])};
+      const uint2 wl = {pack_bf16x2((float)lo[0], (float)lo[1]), pack_bf16x2((float)lo[2], (float)lo[3])};
+      bf16* d = y_split3 + orow * 3 * H + c;
+      *reinterpret_cast<uint2*>(d) = wh;
+      *reinterpret_cast<uint2*>(d + H) = wl;
+      *reinterpret_cast<uint2*>(d + 2 * H) = wh;
     }
   }
 }
@@ -211,7 +222,7 @@ extern "C" int vault_layernorm_fwd(const vault_ln_fwd_args* a, void* stream) {
 #define LN_FWD(V)                                                                                          \
   hipLaunchKernelGGL(ln_fwd_kernel<V>, grid, block, 0, st, a->x, xm, a->gamma, a->beta, a->eps, a->rows,   \
                      a->H, reinterpret_cast<bf16*>(a->y_bf16), a->y_f32, ym, a->post_add, a->mean, a->rstd, \
-                     a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale)
+                     a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale, reinterpret_cast<bf16*>(a->y_split3))
   switch (a->H / 256) {
     case 1: LN_FWD(1); break;
     case 2: LN_FWD(2); break;

@@ -44,7 +44,36 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   }
 }
 
+// out[r][3K]: layout 0 (activation/A operand) = [hi | lo | hi], layout 1 (weight/B operand) = [hi | hi | lo]
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, bf16* __restrict__ out, long long rows,
+                                                     int K, int layout) {
+  const long long total = rows * (long long)(K / 4);
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256ll) {
+    const long long r = i / (K / 4);
+    const int c = (int)(i - r * (K / 4)) * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * K + c);
+    bf16 hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_bf16(a[e], hi[e], lo[e]);
+    bf16* o = out + r * 3 * K + c;
+    const uint2 wh = {pack_bf16x2((float)hi[0], (float)hi[1]), pack_bf16x2((float)hi[2], (float)hi[3])};
+    const uint2 wl = {pack_bf16x2((float)lo[0], (float)lo[1]), pack_bf16x2((float)lo[2], (float)lo[3])};
+    *reinterpret_cast<uint2*>(o) = wh;
+    *reinterpret_cast<uint2*>(o + K) = layout == 0 ? wl : wh;
+    *reinterpret_cast<uint2*>(o + 2 * K) = layout == 0 ? wh : wl;
+  }
+}
+
 }  // namespace
+
+extern "C" int vault_split3_bf16(const float* x, void* out_bf16, long long rows, int K, int layout, void* stream) {
+  if (!x || !out_bf16 || rows <= 0 || K <= 0 || (K & 3)) return VAULT_EINVAL;
+  const long long total = rows * (K / 4);
+  const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(split3_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     reinterpret_cast<bf16*>(out_bf16), rows, K, layout);
+  return (int)hipGetLastError();
+}
 
 extern "C" int vault_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, long long n, float lr,
                                 float beta1, float beta2, float eps, float weight_decay, float bias_corr_factor,

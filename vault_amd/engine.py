@@ -137,6 +137,28 @@ class ParamStore:
             return None
         return self._view(self.g, name, **kw)
 
+    # ---- split-bf16 (precise inference) weight shadow: [N][hi | hi | lo] per 2-D weight --------
+    def ensure_split3(self):
+        if getattr(self, "pb3", None) is None:
+            self.pb3 = torch.zeros(3 * self.n_total, dtype=torch.bfloat16, device=self.device)
+            self._pb3_fresh = False
+        if self._pb3_fresh:
+            return
+        for n, (o, shp) in self.offsets.items():
+            if len(shp) < 2 or not n.endswith("weight") or "embeddings.word" in n or "position_embeddings" in n \
+                    or "token_type_embeddings" in n:
+                continue
+            N = shp[0]
+            K = int(np.prod(shp[1:]))
+            if K % 4:
+                continue
+            ops.split3_bf16(self.p[o:o + N * K], self.pb3[3 * o:3 * o + 3 * N * K], N, K, 1)
+        self._pb3_fresh = True
+
+    def wb3(self, name, N, K):
+        o, _ = self.offsets[name]
+        return self.pb3[3 * o:3 * o + 3 * N * K].view(N, 3 * K)
+
     def has_grad(self, name) -> bool:
         return self.g is not None and self.offsets[name][0] < self.n_train
 
@@ -151,6 +173,7 @@ class ParamStore:
             host[o:o + int(np.prod(shp))] = np.asarray(v, np.float32).reshape(-1)
         self.p.copy_(torch.from_numpy(host))
         ops.cast_bf16(self.p, self.pb, self.n_total)
+        self._pb3_fresh = False
 
 
 class _LayerNames:
@@ -221,10 +244,16 @@ class VaultEngine:
         return self._ws[key]
 
     # ---- helpers ----------------------------------------------------------------------------
-    def _linear(self, a_bf16, wname, out, M, N, K, epi, m_valid, bias=None, **kw):
+    def _linear(self, a_bf16, wname, out, M, N, K, epi, m_valid, bias=None, precise=False, ldo=None, **kw):
+        """out = epilogue(A . W^T).  ``precise``: A is a [M, 3K] = [hi | lo | hi] split-bf16 operand and the
+        weight its [N, 3K] = [hi | hi | lo] counterpart: the same kernel over a 3x longer contraction."""
         P = self.params
-        ops.gemm(a_bf16, P.wb(wname, n_elems=N * K, shape=(N, K)), out, M, N, K, K, K, N, 0, 0, epi, m_valid=m_valid,
-                 bias=bias, **kw)
+        if precise:
+            ops.gemm(a_bf16, P.wb3(wname, N, K), out, M, N, 3 * K, 3 * K, 3 * K, N if ldo is None else ldo, 0, 0, epi,
+                     m_valid=m_valid, bias=bias, **kw)
+        else:
+            ops.gemm(a_bf16, P.wb(wname, n_elems=N * K, shape=(N, K)), out, M, N, K, K, K, N if ldo is None else ldo,
+                     0, 0, epi, m_valid=m_valid, bias=bias, **kw)
 
     def _dgrad(self, dy_bf16, wname, out, M, Kin, Nout, epi, m_valid, **kw):
         # dX[M,Kin] = dY[M,Nout] . W[Nout,Kin]
@@ -258,11 +287,12 @@ class VaultEngine:
 
     # ---- forward ----------------------------------------------------------------------------
     def forward(self, batch: Dict[str, torch.Tensor], train: bool = False, labels: Optional[torch.Tensor] = None,
-                need_hidden: bool = True, loss_scale: Optional[float] = None) -> Dict[str, torch.Tensor]:
+                need_hidden: bool = True, loss_scale: Optional[float] = None,
+                precise: bool = False) -> Dict[str, torch.Tensor]:
         """batch tensors must already be on the device (int64 ids / mask, f32 pixels).  Returns device
         tensors; in train mode keeps every activation needed by :meth:`backward`."""
         with torch.cuda.device(self.device):
-            return self._forward(batch, train, labels, need_hidden, loss_scale)
+            return self._forward(batch, train, labels, need_hidden, loss_scale, precise)
 
     def stage_inputs(self, batch: Dict[str, torch.Tensor], train: bool, labels: Optional[torch.Tensor] = None,
                      validate: bool = True) -> dict:
@@ -304,13 +334,18 @@ class VaultEngine:
         ws["labels"] = None if labels is None else buf("in_labels", (B,), torch.int64).copy_(labels)
         return ws
 
-    def _forward(self, batch, train, labels, need_hidden, loss_scale):
+    def _forward(self, batch, train, labels, need_hidden, loss_scale, precise=False):
+        if precise and train:
+            raise ValueError("precise (split-bf16) mode is inference-only")
         ws = self.stage_inputs(batch, train, labels)
         if train:
             self.drop_seed = (self.drop_seed + 1) & 0xFFFFFFFF
-        return self.forward_staged(ws, need_hidden, loss_scale)
+        if precise:
+            self.params.ensure_split3()
+        return self.forward_staged(ws, need_hidden, loss_scale, precise)
 
-    def forward_staged(self, ws: dict, need_hidden: bool = True, loss_scale: Optional[float] = None):
+    def forward_staged(self, ws: dict, need_hidden: bool = True, loss_scale: Optional[float] = None,
+                       precise: bool = False):
         """Forward over the staged inputs of ``ws`` (every launch goes through ops.* and can be taped)."""
         spec, P = self.spec, self.params
         v = spec.vilt
@@ -320,6 +355,8 @@ class VaultEngine:
         buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
         bf = torch.bfloat16
         ws["drop_seed"] = self.drop_seed
+        pr = precise
+        W3 = 3 if pr else 1   # operand width multiplier of the split-bf16 path
 
         # ------------------------------ language model ------------------------------
         if spec.lm is not None:
@@ -337,32 +374,41 @@ class VaultEngine:
             keep = train and not self.freeze_lm
             nl = lm.num_hidden_layers
             y = [buf(f"lm_y{i}" if keep else f"lm_y{i % 2}", (Mlp, H)) for i in range(nl + 1)]
-            yb = [buf(f"lm_yb{i}" if keep else f"lm_yb{i % 2}", (Mlp, H), bf) for i in range(nl + 1)]
+            yb = [buf((f"lm_yb{i}" if keep else f"lm_yb{i % 2}") + ("_3" if pr else ""), (Mlp, W3 * H), bf)
+                  for i in range(nl + 1)]
             lm_train = train   # dropout stays active in a frozen LM too (ref: model.py:189 only disables grad)
             pdh, pda = lm.hidden_dropout_prob, lm.attention_probs_dropout_prob
             ops.layernorm_fwd(esum, P.w("bert.embeddings.LayerNorm.weight"), P.w("bert.embeddings.LayerNorm.bias"),
-                              lm.layer_norm_eps, Ml, H, y_f32=y[0], y_bf16=yb[0], mean=buf("lm_emean", (Mlp,)),
+                              lm.layer_norm_eps, Ml, H, y_f32=y[0], y_bf16=None if pr else yb[0],
+                              y_split3=yb[0] if pr else None, mean=buf("lm_emean", (Mlp,)),
                               rstd=buf("lm_erstd", (Mlp,)), drop=self._drop(pdh, 1, lm_train))
             for i, ln in enumerate(self.ll):
                 sfx = f"{i}" if keep else ""
                 qkv = buf(f"lm_qkv{sfx}", (Mlp, 3 * H), bf)
-                ctx = buf(f"lm_ctx{sfx}", (Mlp, H), bf)
+                p3 = "_3" if pr else ""
+                ctx = buf(f"lm_ctx{sfx}{p3}", (Mlp, W3 * H), bf)
                 lse = buf(f"lm_lse{sfx}", (B, heads, T))
-                h1 = buf(f"lm_h1{sfx}", (Mlp, H)); y1 = buf(f"lm_y1{sfx}", (Mlp, H)); y1b = buf(f"lm_y1b{sfx}", (Mlp, H), bf)
+                h1 = buf(f"lm_h1{sfx}", (Mlp, H)); y1 = buf(f"lm_y1{sfx}", (Mlp, H))
+                y1b = buf(f"lm_y1b{sfx}{p3}", (Mlp, W3 * H), bf)
                 u = buf(f"lm_u{sfx}", (Mlp, FF), bf) if keep else None
-                act = buf(f"lm_act{sfx}", (Mlp, FF), bf)
+                act = buf(f"lm_act{sfx}{p3}", (Mlp, W3 * FF), bf)
                 h2 = buf(f"lm_h2{sfx}", (Mlp, H))
-                self._linear(yb[i], ln.qw, qkv, Mlp, 3 * H, H, ops.EPI_BF16, Ml, bias=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)))
-                ops.attention_fwd(qkv, amf, ctx, lse, B, T, H, heads, drop=self._drop(pda, 16 * i + 2, lm_train))
+                self._linear(yb[i], ln.qw, qkv, Mlp, 3 * H, H, ops.EPI_BF16, Ml,
+                             bias=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)), precise=pr)
+                ops.attention_fwd(qkv, amf, None if pr else ctx, lse, B, T, H, heads,
+                                  drop=self._drop(pda, 16 * i + 2, lm_train), ctx_split3=ctx if pr else None)
                 self._linear(ctx, ln.ow, h1, Mlp, H, H, ops.EPI_F32_RES, Ml, bias=P.w(ln.ob), res=y[i],
-                             drop=self._drop(pdh, 16 * i + 3, lm_train))
-                ops.layernorm_fwd(h1, P.w(ln.ln1w), P.w(ln.ln1b), lm.layer_norm_eps, Ml, H, y_f32=y1, y_bf16=y1b,
+                             drop=self._drop(pdh, 16 * i + 3, lm_train), precise=pr)
+                ops.layernorm_fwd(h1, P.w(ln.ln1w), P.w(ln.ln1b), lm.layer_norm_eps, Ml, H, y_f32=y1,
+                                  y_bf16=None if pr else y1b, y_split3=y1b if pr else None,
                                   mean=buf(f"lm_m1{sfx}", (Mlp,)), rstd=buf(f"lm_r1{sfx}", (Mlp,)))
-                self._linear(y1b, ln.iw, act, Mlp, FF, H, ops.EPI_BF16_GELU, Ml, bias=P.w(ln.ib), out2=u)
+                self._linear(y1b, ln.iw, act, Mlp, FF, H, ops.EPI_BF16_GELU, Ml, bias=P.w(ln.ib), out2=u, precise=pr,
+                             split3=pr, ldo=W3 * FF)
                 self._linear(act, ln.fw, h2, Mlp, H, FF, ops.EPI_F32_RES, Ml, bias=P.w(ln.fb), res=y1,
-                             drop=self._drop(pdh, 16 * i + 4, lm_train))
+                             drop=self._drop(pdh, 16 * i + 4, lm_train), precise=pr)
                 ops.layernorm_fwd(h2, P.w(ln.ln2w), P.w(ln.ln2b), lm.layer_norm_eps, Ml, H, y_f32=y[i + 1],
-                                  y_bf16=yb[i + 1], mean=buf(f"lm_m2{sfx}", (Mlp,)), rstd=buf(f"lm_r2{sfx}", (Mlp,)))
+                                  y_bf16=None if pr else yb[i + 1], y_split3=yb[i + 1] if pr else None,
+                                  mean=buf(f"lm_m2{sfx}", (Mlp,)), rstd=buf(f"lm_r2{sfx}", (Mlp,)))
             text_src = y[nl]
             use_pos = spec.use_vilt_position_embeddings
             tables = [(P.w("embeddings.text_embeddings.token_type_embeddings.weight"), tt if tt is not None else 0)]
@@ -389,33 +435,37 @@ class VaultEngine:
         Kp = v.num_channels * v.patch_size * v.patch_size
         Mpp = _pad(B * NP)
         ws.update(Kp=Kp, Mpp=Mpp)
-        apatch = buf("apatch", (Mpp, Kp), bf)
-        ops.im2col(pix, apatch, B, v.num_channels, v.image_size, v.patch_size)
+        apatch = buf("apatch_3" if pr else "apatch", (Mpp, W3 * Kp), bf)
+        ops.im2col(pix, apatch, B, v.num_channels, v.image_size, v.patch_size, split3=pr)
         addtab = buf("addtab", (NP, H))
         ops.image_consts(P.w("embeddings.patch_embeddings.projection.bias"), P.w("embeddings.position_embeddings"),
                          mt[1], P.w("embeddings.cls_token"), addtab, x[0], NP, H, B, S, T)
-        ops.gemm(apatch, P.wb("embeddings.patch_embeddings.projection.weight", shape=(H, Kp)), x[0], Mpp, H, Kp, Kp, Kp,
+        wpn = "embeddings.patch_embeddings.projection.weight"
+        ops.gemm(apatch, P.wb3(wpn, H, Kp) if pr else P.wb(wpn, shape=(H, Kp)), x[0], Mpp, H, W3 * Kp, W3 * Kp, W3 * Kp,
                  H, 0, 0, ops.EPI_F32_PATCH, cfg=0, m_valid=B * NP, addtab=addtab, rpg=NP, gstride=S, goff=T + 1)
 
         # ------------------------------ ViLT encoder ------------------------------
         for i, ln in enumerate(self.vl):
             sfx = f"{i}" if train else ""
-            n1 = buf(f"n1{sfx}", (Mp, H), bf); qkv = buf(f"qkv{sfx}", (Mp, 3 * H), bf)
-            ctx = buf(f"ctx{sfx}", (Mp, H), bf); lse = buf(f"lse{sfx}", (B, heads, S))
-            xm = buf(f"xm{sfx}", (Mp, H)); n2 = buf(f"n2{sfx}", (Mp, H), bf)
+            p3 = "_3" if pr else ""
+            n1 = buf(f"n1{sfx}{p3}", (Mp, W3 * H), bf); qkv = buf(f"qkv{sfx}", (Mp, 3 * H), bf)
+            ctx = buf(f"ctx{sfx}{p3}", (Mp, W3 * H), bf); lse = buf(f"lse{sfx}", (B, heads, S))
+            xm = buf(f"xm{sfx}", (Mp, H)); n2 = buf(f"n2{sfx}{p3}", (Mp, W3 * H), bf)
             u = buf(f"u{sfx}", (Mp, FF), bf) if train else None
-            act = buf(f"act{sfx}", (Mp, FF), bf)
-            ops.layernorm_fwd(x[i], P.w(ln.ln1w), P.w(ln.ln1b), v.layer_norm_eps, M, H, y_bf16=n1,
-                              mean=buf(f"m1{sfx}", (Mp,)), rstd=buf(f"r1{sfx}", (Mp,)))
-            self._linear(n1, ln.qw, qkv, Mp, 3 * H, H, ops.EPI_BF16, M, bias=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)))
-            ops.attention_fwd(qkv, km, ctx, lse, B, S, H, heads)
-            self._linear(ctx, ln.ow, xm, Mp, H, H, ops.EPI_F32_RES, M, bias=P.w(ln.ob), res=x[i])
-            ops.layernorm_fwd(xm, P.w(ln.ln2w), P.w(ln.ln2b), v.layer_norm_eps, M, H, y_bf16=n2,
-                              mean=buf(f"m2{sfx}", (Mp,)), rstd=buf(f"r2{sfx}", (Mp,)))
+            act = buf(f"act{sfx}{p3}", (Mp, W3 * FF), bf)
+            ops.layernorm_fwd(x[i], P.w(ln.ln1w), P.w(ln.ln1b), v.layer_norm_eps, M, H, y_bf16=None if pr else n1,
+                              y_split3=n1 if pr else None, mean=buf(f"m1{sfx}", (Mp,)), rstd=buf(f"r1{sfx}", (Mp,)))
+            self._linear(n1, ln.qw, qkv, Mp, 3 * H, H, ops.EPI_BF16, M, bias=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)),
+                         precise=pr)
+            ops.attention_fwd(qkv, km, None if pr else ctx, lse, B, S, H, heads, ctx_split3=ctx if pr else None)
+            self._linear(ctx, ln.ow, xm, Mp, H, H, ops.EPI_F32_RES, M, bias=P.w(ln.ob), res=x[i], precise=pr)
+            ops.layernorm_fwd(xm, P.w(ln.ln2w), P.w(ln.ln2b), v.layer_norm_eps, M, H, y_bf16=None if pr else n2,
+                              y_split3=n2 if pr else None, mean=buf(f"m2{sfx}", (Mp,)), rstd=buf(f"r2{sfx}", (Mp,)))
             ops.pycall(self._prof_begin)
-            self._linear(n2, ln.iw, act, Mp, FF, H, ops.EPI_BF16_GELU, M, bias=P.w(ln.ib), out2=u)
+            self._linear(n2, ln.iw, act, Mp, FF, H, ops.EPI_BF16_GELU, M, bias=P.w(ln.ib), out2=u, precise=pr,
+                         split3=pr, ldo=W3 * FF)
             ops.pycall(self._prof_end)
-            self._linear(act, ln.fw, x[i + 1], Mp, H, FF, ops.EPI_F32_RES, M, bias=P.w(ln.fb), res=xm)
+            self._linear(act, ln.fw, x[i + 1], Mp, H, FF, ops.EPI_F32_RES, M, bias=P.w(ln.fb), res=xm, precise=pr)
 
         # ------------------------------ tail ------------------------------
         out: Dict[str, torch.Tensor] = {}
@@ -429,11 +479,13 @@ class VaultEngine:
         if spec.add_pooling_layer:
             Bp = _pad(B)
             ws["Bp"] = Bp
-            h0b = buf("h0b", (Bp, H), bf)
-            ops.layernorm_fwd(xl, lw, lb, v.layer_norm_eps, B, H, y_bf16=h0b, xmap=(1, S, 0), mean=buf("f_mean", (Bp,)),
+            h0b = buf("h0b_3" if pr else "h0b", (Bp, W3 * H), bf)
+            ops.layernorm_fwd(xl, lw, lb, v.layer_norm_eps, B, H, y_bf16=None if pr else h0b,
+                              y_split3=h0b if pr else None, xmap=(1, S, 0), mean=buf("f_mean", (Bp,)),
                               rstd=buf("f_rstd", (Bp,)))
             pre = buf("pool_pre", (Bp, H))
-            self._linear(h0b, "pooler.dense.weight", pre, Bp, H, H, ops.EPI_F32_RES, B, bias=P.w("pooler.dense.bias"))
+            self._linear(h0b, "pooler.dense.weight", pre, Bp, H, H, ops.EPI_F32_RES, B, bias=P.w("pooler.dense.bias"),
+                         precise=pr)
             pooled = buf("pooled", (Bp, H))
             if spec.n_classes > 0:
                 C = spec.n_classes

@@ -14,7 +14,7 @@ class GemmArgs(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("B", C.c_void_p), ("out", C.c_void_p), ("out2", C.c_void_p),
         ("bias", C.c_void_p), ("res", C.c_void_p), ("aux", C.c_void_p), ("addtab", C.c_void_p),
-        ("colsum", C.c_void_p),
+        ("colsum", C.c_void_p), ("split3", C.c_int),
         ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("lda", C.c_int), ("ldb", C.c_int),
         ("ldo", C.c_int), ("m_valid", C.c_int),
         ("a_mode", C.c_int), ("b_mode", C.c_int), ("epi", C.c_int), ("cfg", C.c_int),

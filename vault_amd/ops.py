@@ -21,7 +21,7 @@ class LnFwdArgs(C.Structure):
                 ("x_rpg", C.c_int), ("x_gstride", C.c_int), ("x_goff", C.c_int),
                 ("y_rpg", C.c_int), ("y_gstride", C.c_int), ("y_goff", C.c_int),
                 ("drop_thresh", C.c_uint32), ("drop_seed", C.c_uint32), ("drop_stream", C.c_uint32),
-                ("drop_scale", C.c_float)]
+                ("drop_scale", C.c_float), ("y_split3", C.c_void_p)]
 
 
 class LnBwdArgs(C.Structure):
@@ -41,7 +41,7 @@ class AttnArgs(C.Structure):
                 ("dctx", C.c_void_p), ("dqkv", C.c_void_p),
                 ("B", C.c_int), ("S", C.c_int), ("H", C.c_int), ("heads", C.c_int),
                 ("drop_thresh", C.c_uint32), ("drop_seed", C.c_uint32), ("drop_stream", C.c_uint32),
-                ("drop_scale", C.c_float)]
+                ("drop_scale", C.c_float), ("ctx_split3", C.c_void_p)]
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -121,11 +121,12 @@ NO_DROP = Drop()
 
 def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_valid=0, splits=1, accumulate=0,
          bias=None, res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, drop: Drop = NO_DROP,
-         colsum=None):
+         colsum=None, split3=False):
     a = L.GemmArgs()
     a.A, a.B, a.out, a.out2 = _p(A), _p(B), _p(out), _p(out2)
     a.bias, a.res, a.aux, a.addtab = _p(bias), _p(res), _p(aux), _p(addtab)
     a.colsum = _p(colsum)
+    a.split3 = 1 if split3 else 0
     a.M, a.N, a.K, a.lda, a.ldb, a.ldo, a.m_valid = M, N, K, lda, ldb, ldo, m_valid
     a.a_mode, a.b_mode, a.epi, a.cfg, a.splits, a.accumulate = a_mode, b_mode, epi, cfg, splits, accumulate
     a.rpg, a.gstride, a.goff = rpg, gstride, goff
@@ -134,7 +135,7 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_va
 
 
 def layernorm_fwd(x, gamma, beta, eps, rows, H, *, y_bf16=None, y_f32=None, mean=None, rstd=None, post_add=None,
-                  xmap=(0, 0, 0), ymap=(0, 0, 0), drop: Drop = NO_DROP):
+                  xmap=(0, 0, 0), ymap=(0, 0, 0), drop: Drop = NO_DROP, y_split3=None):
     a = LnFwdArgs()
     a.x, a.gamma, a.beta, a.post_add = _p(x), _p(gamma), _p(beta), _p(post_add)
     a.y_bf16, a.y_f32, a.mean, a.rstd = _p(y_bf16), _p(y_f32), _p(mean), _p(rstd)
@@ -142,6 +143,7 @@ def layernorm_fwd(x, gamma, beta, eps, rows, H, *, y_bf16=None, y_f32=None, mean
     a.x_rpg, a.x_gstride, a.x_goff = xmap
     a.y_rpg, a.y_gstride, a.y_goff = ymap
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
+    a.y_split3 = _p(y_split3)
     _invoke("vault_layernorm_fwd", C.byref(a), _stream(), struct=a, drop=drop)
 
 
@@ -166,16 +168,17 @@ def colsum(x_bf16, ld, rows, N, out):
     _invoke("vault_colsum", C.c_void_p(_p(x_bf16)), C.c_int(ld), C.c_int(rows), C.c_int(N), C.c_void_p(_p(out)), _stream())
 
 
-def _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, dctx=None, dqkv=None, drop: Drop = NO_DROP):
+def _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, dctx=None, dqkv=None, drop: Drop = NO_DROP, ctx_split3=None):
     a = AttnArgs()
+    a.ctx_split3 = _p(ctx_split3)
     a.qkv, a.keymask, a.ctx, a.lse, a.dctx, a.dqkv = _p(qkv), _p(keymask), _p(ctx), _p(lse), _p(dctx), _p(dqkv)
     a.B, a.S, a.H, a.heads = B, S, H, heads
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
     return a
 
 
-def attention_fwd(qkv, keymask, ctx, lse, B, S, H, heads, drop: Drop = NO_DROP):
-    a = _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, drop=drop)
+def attention_fwd(qkv, keymask, ctx, lse, B, S, H, heads, drop: Drop = NO_DROP, ctx_split3=None):
+    a = _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, drop=drop, ctx_split3=ctx_split3)
     _invoke("vault_attention_fwd", C.byref(a), _stream(), struct=a, drop=drop)
 
 
@@ -237,9 +240,9 @@ def scatter_add(src, grad_tables, rows, H, period=1, rowmask=None):
     _invoke("vault_scatter_add", C.byref(a), _stream())
 
 
-def im2col(pix, out_bf16, B, Cn, IMG, ps):
+def im2col(pix, out_bf16, B, Cn, IMG, ps, split3=False):
     _invoke("vault_im2col", C.c_void_p(_p(pix)), C.c_void_p(_p(out_bf16)), C.c_int(B), C.c_int(Cn), C.c_int(IMG),
-            C.c_int(ps), _stream())
+            C.c_int(ps), C.c_int(1 if split3 else 0), _stream())
 
 
 def image_consts(bias, pos, mtype1, cls, addtab, x, P, H, B, S, T):
@@ -295,3 +298,8 @@ def adamw_step(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay, bias_
 
 def cast_bf16(x, y_bf16, n):
     _invoke("vault_cast_bf16", C.c_void_p(_p(x)), C.c_void_p(_p(y_bf16)), C.c_longlong(n), _stream())
+
+
+def split3_bf16(x_f32, out_bf16, rows, K, layout):
+    _invoke("vault_split3_bf16", C.c_void_p(_p(x_f32)), C.c_void_p(_p(out_bf16)), C.c_longlong(rows), C.c_int(K),
+            C.c_int(layout), _stream())

@@ -191,4 +191,5 @@ class TrainStep:
         with torch.cuda.device(eng.device):
             ops.adamw_step(P.p, P.g, P.m, P.v, P.pb, P.n_train, self.current_lr(), self.b1, self.b2, self.eps, self.wd,
                            bias_corr_factor=bc, grad_scale=1.0 / self.world, zero_grad=True)
+        P._pb3_fresh = False   # the split-bf16 (precise inference) shadow is stale now
         self.step_idx += 1
