@@ -158,6 +158,15 @@ def main():
         avg_ms = float(np.mean(kern_ms)) if kern_ms else float("nan")
         achieved = gemm_flops / (avg_ms * 1e-3) / 1e12 if kern_ms else None
         flop_per_sample = FLOP_PER_SAMPLE_TRAIN if not args.freeze_lm else 106.96e9
+        # HBM/fabric bytes of that kernel from PMC counters (separate rocprofv3 --pmc passes, committed
+        # under profiles/: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE); only valid for the profiled shape
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_ffn1.json")))
+            if pm.get("batch") == B:
+                traffic = pm["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "train samples/sec (img+text pairs) ViLT-B32+BERTweet, bs256, 1/2/4/8 MI355X",
             "value": round(sps, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -171,7 +180,7 @@ def main():
                                                     f"[{M}x{v.intermediate_size}x{v.hidden_size}]",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": 2500.0,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / 2500.0, 4),
-                         "traffic": None, "launches_timed": len(kern_ms), "avg_launch_ms": round(avg_ms, 4)},
+                         "traffic": traffic, "launches_timed": len(kern_ms), "avg_launch_ms": round(avg_ms, 4)},
             "step_mfma_frac": round(sps / world * flop_per_sample / PEAK_BF16, 4),
             "final_loss": round(loss, 5),
         }
