@@ -35,6 +35,25 @@ struct GemmParams {
   // inverted dropout on (acc + bias) for EPI_F32_RES; thresh == 0 disables it
   uint32_t drop_thresh, drop_seed, drop_stream;
   float drop_scale;
+  int gn;           // n-tiles per raster group (set by the launcher: B panel of a group stays L2-resident)
 };
+
+#ifdef __HIPCC__
+// Linear block id -> (tile_m, tile_n).  Blocks with equal id % 8 share an XCD (and its 4 MiB L2): each XCD
+// gets a contiguous run of the raster order; the raster walks column GROUPS of `gn` n-tiles, all m-tiles of a
+// group before the next group, so that a group's B panel (gn x BN x K) stays L2-resident while the A row
+// panels stream through once per group.
+__device__ __forceinline__ void gemm_tile_of_block(int nwg, int id, int tiles_m, int tiles_n, int gn, int& tile_m,
+                                                   int& tile_n) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  const int per_group = tiles_m * gn;
+  const int grp = wg / per_group;
+  const int rem = wg - grp * per_group;
+  const int gw = min(gn, tiles_n - grp * gn);
+  tile_m = rem / gw;
+  tile_n = grp * gn + (rem - tile_m * gw);
+}
+#endif
 
 int vault_gemm_launch(const GemmParams& p, int a_mode, int b_mode, int epi, int cfg, hipStream_t st);

@@ -16,6 +16,7 @@
 //   RAW  a half-tile is read one phase after the `vmcnt` + `s_barrier` that retired it;
 //   WAR  a slot is overwritten two phases after its ds_reads were issued, and every phase ends with
 //        `lgkmcnt(0)` before the barrier, so those reads have completed in every wave.
+#include <algorithm>
 #include "common.h"
 #include "gemm.h"
 #include "gemm_epi.h"
@@ -56,15 +57,8 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   const int wr = wave >> 1, wc = wave & 1;
   const int g = lane >> 4, l15 = lane & 15;
 
-  const int tiles_n = p.N / BNT;
   int tile_m, tile_n;
-  {
-    const int nwg = gridDim.x, id = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-    tile_m = wg / tiles_n;
-    tile_n = wg - tile_m * tiles_n;
-  }
+  gemm_tile_of_block(gridDim.x, blockIdx.x, p.M >> 8, p.N / BNT, p.gn, tile_m, tile_n);
   const int m0 = tile_m << 8, n0 = tile_n * BNT;
   const int nk_total = p.K >> 6;
   const int per = (nk_total + p.splits - 1) / p.splits;
@@ -294,8 +288,10 @@ int launch256(const GemmParams& p, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
+  GemmParams q = p;
+  q.gn = p.N / BNT;   // plain m-major raster (see gemm.hip: n-tile grouping measured slower)
   dim3 grid((p.M >> 8) * (p.N / BNT), 1, p.splits);
-  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, p);
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, q);
   return (int)hipGetLastError();
 }
 
