@@ -39,6 +39,7 @@ typedef struct vault_gemm_args {
   int a_mode, b_mode, epi, cfg, splits, accumulate;
   int rpg, gstride, goff;
   uint32_t drop_thresh, drop_seed, drop_stream; float drop_scale;
+  int gn;   /* tuning: n-tiles per raster group (0 = default, plain m-major raster) */
 } vault_gemm_args;
 int vault_gemm(const vault_gemm_args* args, void* stream);
 

@@ -18,6 +18,7 @@ extern "C" int vault_gemm(const vault_gemm_args* a, void* stream) {
   p.addtab = a->addtab; p.colsum = a->colsum; p.split3 = a->split3; p.rpg = a->rpg; p.gstride = a->gstride; p.goff = a->goff;
   p.drop_thresh = a->drop_thresh; p.drop_seed = a->drop_seed; p.drop_stream = a->drop_stream;
   p.drop_scale = a->drop_scale;
+  p.gn = a->gn;
   return vault_gemm_launch(p, a->a_mode, a->b_mode, a->epi, a->cfg, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -201,9 +201,10 @@ int launch_cfg(const GemmParams& p, hipStream_t st) {
     attr_done = true;
   }
   GemmParams q = p;
-  // one group = all n-tiles (plain m-major raster): grouping n-tiles so that the B panel fits L2 measured
-  // 5-15 % SLOWER on the path's shapes (QKV 196 -> 227 us) although it halves the fabric fetch bytes
-  q.gn = p.N / BN;
+  // raster groups of 4 n-tiles for short contractions (the group's B panel, 4 x BN x K bf16 <= 1.5 MiB, stays
+  // in the XCD's L2): in-process A/B on M = 47360, K = 768: QKV 197 -> 183 us, FFN-in 252 -> 234 us, dgrad
+  // FFN-out 290 -> 257 us (tools/gn_ab.py); no gain for K = 3072 or for the ring kernel -> plain raster there
+  q.gn = (p.gn > 0) ? std::min(p.gn, p.N / BN) : (p.K <= 1024 ? std::min(p.N / BN, 4) : p.N / BN);
   dim3 grid((p.M / BM) * (p.N / BN), 1, p.splits);
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), LDS, st, q);
   return (int)hipGetLastError();

@@ -289,7 +289,7 @@ int launch256(const GemmParams& p, hipStream_t st) {
     attr_done = true;
   }
   GemmParams q = p;
-  q.gn = p.N / BNT;   // plain m-major raster (see gemm.hip: n-tile grouping measured slower)
+  q.gn = (p.gn > 0) ? std::min(p.gn, p.N / BNT) : p.N / BNT;   // default: plain m-major raster (see gemm.hip)
   dim3 grid((p.M >> 8) * (p.N / BNT), 1, p.splits);
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, q);
   return (int)hipGetLastError();
