@@ -40,6 +40,7 @@ typedef struct vault_gemm_args {
   int rpg, gstride, goff;
   uint32_t drop_thresh, drop_seed, drop_stream; float drop_scale;
   int gn;   /* tuning: n-tiles per raster group (0 = default, plain m-major raster) */
+  int persist; /* tuning: 2 = one block per tile instead of the default persistent grid (double-buffered kernel) */
 } vault_gemm_args;
 int vault_gemm(const vault_gemm_args* args, void* stream);
 

@@ -19,6 +19,7 @@ extern "C" int vault_gemm(const vault_gemm_args* a, void* stream) {
   p.drop_thresh = a->drop_thresh; p.drop_seed = a->drop_seed; p.drop_stream = a->drop_stream;
   p.drop_scale = a->drop_scale;
   p.gn = a->gn;
+  p.persist = a->persist;
   return vault_gemm_launch(p, a->a_mode, a->b_mode, a->epi, a->cfg, reinterpret_cast<hipStream_t>(stream));
 }
 

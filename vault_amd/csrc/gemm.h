@@ -35,6 +35,7 @@ struct GemmParams {
   // inverted dropout on (acc + bias) for EPI_F32_RES; thresh == 0 disables it
   uint32_t drop_thresh, drop_seed, drop_stream;
   float drop_scale;
+  int persist;      // double-buffered kernel: persistent grid (<= resident blocks, each walks several tiles) unless 2
   int gn;           // n-tiles per raster group (set by the launcher: B panel of a group stays L2-resident)
 };
 

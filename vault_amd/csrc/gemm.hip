@@ -52,8 +52,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 
   // ---- block -> tile (XCD-aware: blocks with equal id%8 share an L2; give each XCD a
   //      contiguous run of tiles so the A row panel and the whole of B stay L2-resident)
+  //      Persistent form: the grid holds at most `resident` blocks; each walks the raster with stride
+  //      gridDim.x, so the epilogue's stores of one tile drain under the next tile's main loop.
+  const int total_tiles = (p.M / BM) * (p.N / BN);
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
   int tile_m, tile_n;
-  gemm_tile_of_block(gridDim.x, blockIdx.x, p.M / BM, p.N / BN, p.gn, tile_m, tile_n);
+  gemm_tile_of_block(total_tiles, tile, p.M / BM, p.N / BN, p.gn, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- split-K range
@@ -185,6 +189,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
   }
 
   gemm_epilogue<TM, TN, EPI, WM, WN>(acc, p, smem, m0, n0, wm0, wn0, wave, lane);
+  __syncthreads();   // epilogue scratch (LDS) is free again before the next tile stages into it
+  }
 }
 
 template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, int EPI>
@@ -205,7 +211,10 @@ int launch_cfg(const GemmParams& p, hipStream_t st) {
   // in the XCD's L2): in-process A/B on M = 47360, K = 768: QKV 197 -> 183 us, FFN-in 252 -> 234 us, dgrad
   // FFN-out 290 -> 257 us (tools/gn_ab.py); no gain for K = 3072 or for the ring kernel -> plain raster there
   q.gn = (p.gn > 0) ? std::min(p.gn, p.N / BN) : (p.K <= 1024 ? std::min(p.N / BN, 4) : p.N / BN);
-  dim3 grid((p.M / BM) * (p.N / BN), 1, p.splits);
+  // resident blocks: 256 CUs x (blocks that fit: LDS-limited, 160 KiB per CU)
+  const int resident = 256 * std::max(1, (160 * 1024) / LDS);
+  const int total = (p.M / BM) * (p.N / BN);
+  dim3 grid(p.persist != 2 ? std::min(total, resident) : total, 1, p.splits);   // persistent unless persist == 2
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), LDS, st, q);
   return (int)hipGetLastError();
 }

@@ -21,7 +21,7 @@ class GemmArgs(C.Structure):
         ("splits", C.c_int), ("accumulate", C.c_int),
         ("rpg", C.c_int), ("gstride", C.c_int), ("goff", C.c_int),
         ("drop_thresh", C.c_uint32), ("drop_seed", C.c_uint32), ("drop_stream", C.c_uint32),
-        ("drop_scale", C.c_float), ("gn", C.c_int),
+        ("drop_scale", C.c_float), ("gn", C.c_int), ("persist", C.c_int),
     ]
 
 
