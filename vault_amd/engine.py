@@ -214,8 +214,9 @@ class VaultEngine:
         self._ws: Dict[Tuple[int, int, bool], dict] = {}
         self.drop_seed = 0
         self.last: Optional[dict] = None
-        # optional live kernel timing (bench.py): list receiving (start, end) torch.cuda.Event pairs
-        # recorded on the launch stream around the ViLT FFN-in forward GEMM
+        # optional live kernel timing (bench.py): list receiving (start, end, flops) - torch.cuda.Event pairs
+        # recorded on the launch stream around every FFN-in forward GEMM launch (ViLT and LM layers: one kernel
+        # instantiation, gemm_kernel<256,256,2,4,0,0,EPI_BF16_GELU>)
         self.profile_events: Optional[list] = None
 
     def _prof_begin(self):
@@ -223,11 +224,11 @@ class VaultEngine:
             self._e0 = torch.cuda.Event(enable_timing=True)
             self._e0.record()
 
-    def _prof_end(self):
+    def _prof_end(self, flops: float = 0.0):
         if self.profile_events is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            self.profile_events.append((self._e0, e1))
+            self.profile_events.append((self._e0, e1, flops))
 
     # ---- workspace --------------------------------------------------------------------------
     def _buf(self, ws, name, shape, dtype):
@@ -402,8 +403,11 @@ class VaultEngine:
                 ops.layernorm_fwd(h1, P.w(ln.ln1w), P.w(ln.ln1b), lm.layer_norm_eps, Ml, H, y_f32=y1,
                                   y_bf16=None if pr else y1b, y_split3=y1b if pr else None,
                                   mean=buf(f"lm_m1{sfx}", (Mlp,)), rstd=buf(f"lm_r1{sfx}", (Mlp,)))
+                ops.pycall(self._prof_begin)
                 self._linear(y1b, ln.iw, act, Mlp, FF, H, ops.EPI_BF16_GELU, Ml, bias=P.w(ln.ib), out2=u, precise=pr,
                              split3=pr, ldo=W3 * FF)
+                fl_l = 2.0 * Ml * FF * H * W3
+                ops.pycall(lambda: self._prof_end(fl_l))
                 self._linear(act, ln.fw, h2, Mlp, H, FF, ops.EPI_F32_RES, Ml, bias=P.w(ln.fb), res=y1,
                              drop=self._drop(pdh, 16 * i + 4, lm_train), precise=pr)
                 ops.layernorm_fwd(h2, P.w(ln.ln2w), P.w(ln.ln2b), lm.layer_norm_eps, Ml, H, y_f32=y[i + 1],
@@ -464,7 +468,8 @@ class VaultEngine:
             ops.pycall(self._prof_begin)
             self._linear(n2, ln.iw, act, Mp, FF, H, ops.EPI_BF16_GELU, M, bias=P.w(ln.ib), out2=u, precise=pr,
                          split3=pr, ldo=W3 * FF)
-            ops.pycall(self._prof_end)
+            fl_v = 2.0 * M * FF * H * W3
+            ops.pycall(lambda: self._prof_end(fl_v))
             self._linear(act, ln.fw, x[i + 1], Mp, H, FF, ops.EPI_F32_RES, M, bias=P.w(ln.fb), res=xm, precise=pr)
 
         # ------------------------------ tail ------------------------------
