@@ -20,13 +20,23 @@ constexpr float LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ int swz_row(int row) { return (row >> 1) & 3; }  // 32-byte block XOR key
 
 // stage a [rows<=S][64] bf16 matrix (row stride ld elements) into a swizzled [SK][128 B] LDS image
-template <int SK>
+template <int SK, int NT>
 __device__ __forceinline__ void stage_rows(char* dst, const bf16* src, int ld, int S, int tid) {
-  for (int c = tid; c < SK * 8; c += 256) {
-    const int row = c >> 3, pos = c & 7;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row < S) v = *reinterpret_cast<const u32x4*>(src + (size_t)row * ld + pos * 8);
-    *reinterpret_cast<u32x4*>(dst + row * 128 + ((pos ^ (swz_row(row) << 1)) << 4)) = v;
+  // all global loads are issued before the first LDS write: one memory round trip per call instead of
+  // one per 16-byte chunk (a rolled load->store loop waits for every load separately)
+  constexpr int N = (SK * 8) / NT;
+  static_assert((SK * 8) % NT == 0, "chunk count must divide evenly");
+  u32x4 v[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int c = tid + i * NT, row = c >> 3, pos = c & 7;
+    v[i] = u32x4{0u, 0u, 0u, 0u};
+    if (row < S) v[i] = *reinterpret_cast<const u32x4*>(src + (size_t)row * ld + pos * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int c = tid + i * NT, row = c >> 3, pos = c & 7;
+    *reinterpret_cast<u32x4*>(dst + row * 128 + ((pos ^ (swz_row(row) << 1)) << 4)) = v[i];
   }
 }
 
@@ -58,8 +68,8 @@ struct AttnDrop {
   float scale;
 };
 
-template <int NKT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
+template <int NKT, int NWV, int WPE>
+__global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
                                                        bf16* __restrict__ ctx, float* __restrict__ lse, int S, int H,
                                                        int heads, float scale, AttnDrop dr, bf16* __restrict__ ctx3) {
   constexpr int SK = NKT * 32;
@@ -73,87 +83,91 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
   const size_t row0 = (size_t)b * S;
   const int ld = 3 * H;
   const bf16* qbase = qkv + row0 * ld + h * 64;
-  stage_rows<SK>(Ks, qbase + H, ld, S, tid);
-  stage_rows<SK>(Vs, qbase + 2 * H, ld, S, tid);
-  for (int k = tid; k < SK; k += 256)
+  stage_rows<SK, NWV * 64>(Ks, qbase + H, ld, S, tid);
+  stage_rows<SK, NWV * 64>(Vs, qbase + 2 * H, ld, S, tid);
+  for (int k = tid; k < SK; k += NWV * 64)
     mb[k] = (k < S && (keymask == nullptr || keymask[(size_t)b * S + k] != 0.f)) ? 0.f : -INFINITY;
   __syncthreads();
   const float sl2 = scale * LOG2E;
   const int nqt = (S + 15) >> 4;
   const uint32_t bh = (uint32_t)(b * heads + h);
-  for (int qt = wave; qt < nqt; qt += 4) {
+  for (int qt = wave; qt < nqt; qt += NWV) {
     const int qrow = min(qt * 16 + l15, S - 1);
     bf16x8 qf[2];
     qf[0] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * ld + 8 * g);
     qf[1] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * ld + 32 + 8 * g);
-    f32x4 sc[2 * NKT];
+    // pass 1: row maximum only (scores are recomputed in pass 2: the matrix pipe is nearly idle in this
+    // kernel, while keeping all 12 score tiles live costs 48 registers and the occupancy that hides LDS latency)
+    // (the key-mask bias, 0 or -inf per key = accumulator row, is the MFMA's initial accumulator: no add)
     float mx = -INFINITY;
-#pragma unroll
+#pragma unroll 3
     for (int kt = 0; kt < 2 * NKT; ++kt) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      f32x4 a = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
       a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, kt, 0, g, l15), qf[0], a, 0, 0, 0);
       a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, kt, 1, g, l15), qf[1], a, 0, 0, 0);
-      const f32x4 m4 = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        a[r] += m4[r];
-        mx = fmaxf(mx, a[r]);
-      }
-      sc[kt] = a;
+      mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 2 * NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pv = __builtin_amdgcn_exp2f((sc[kt][r] - mx) * sl2);
-        sc[kt][r] = pv;
-        sum += pv;
-      }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
+    const float mxs = mx * sl2;
     const int q_l = qt * 16 + l15;
-    if (g == 0 && q_l < S) lse[(size_t)bh * S + q_l] = mx * scale + __logf(sum);
-#pragma unroll
-    for (int kt = 0; kt < 2 * NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float pv = sc[kt][r] * inv;
-        if (dr.thresh != 0u) {
-          const uint32_t idx = (bh * (uint32_t)S + (uint32_t)q_l) * (uint32_t)S + (uint32_t)(kt * 16 + 4 * g + r);
-          pv = dropout_keep(dr.seed, dr.stream, idx, dr.thresh) ? pv * dr.scale : 0.f;
-        }
-        sc[kt][r] = pv;
-      }
+    // pass 2: p = exp2(s * sl2 - mxs), row sum, and O += P V with P straight from the accumulator layout
+    float sum = 0.f;
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1
     for (int T = 0; T < NKT; ++T) {
-      const bf16x8 pf = pack_frag(sc[2 * T], sc[2 * T + 1]);
+      f32x4 p2[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int kt = 2 * T + hh;
+        f32x4 a = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, kt, 0, g, l15), qf[0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, kt, 1, g, l15), qf[1], a, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pv = __builtin_amdgcn_exp2f(a[r] * sl2 - mxs);
+          sum += pv;
+          if (dr.thresh != 0u) {
+            const uint32_t idx = (bh * (uint32_t)S + (uint32_t)q_l) * (uint32_t)S + (uint32_t)(kt * 16 + 4 * g + r);
+            pv = dropout_keep(dr.seed, dr.stream, idx, dr.thresh) ? pv * dr.scale : 0.f;
+          }
+          p2[hh][r] = pv;
+        }
+      }
+      // O^T[d][q] += V^T[d][key] P^T[key][q]: the transposed-read V fragment is the A operand (row = d), the
+      // probabilities (accumulator layout: query on the lane) the B operand.  The result has the query on the
+      // lane and four consecutive d in its registers: 8-byte stores and a lane-local normalisation.
+      const bf16x8 pf = pack_frag(p2[0], p2[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr(Vs, T, dt, g, l15), o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Vs, T, dt, g, l15), pf, o[dt], 0, 0, 0);
     }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;       // this lane's query row (l15)
+    if (q_l < S) {
+      if (g == 0) lse[(size_t)bh * S + q_l] = mx * scale + __logf(sum);
+      if (ctx3 != nullptr) {   // precise path: [hi | lo | hi] operand of the split-bf16 projection GEMM
+        bf16* dst = ctx3 + (row0 + q_l) * 3 * H + h * 64 + 4 * g;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int q = qt * 16 + 4 * g + r;
-      if (q < S) {
-        if (ctx3 != nullptr) {   // precise path: [hi | lo | hi] operand of the split-bf16 projection GEMM
-          bf16* dst = ctx3 + (row0 + q) * 3 * H + h * 64 + l15;
+        for (int dt = 0; dt < 4; ++dt) {
+          bf16 hi[4], lo[4];
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            bf16 hi, lo;
-            split_bf16(o[dt][r], hi, lo);
-            dst[dt * 16] = hi; dst[H + dt * 16] = lo; dst[2 * H + dt * 16] = hi;
-          }
-        } else {
-          bf16* dst = ctx + (row0 + q) * H + h * 64 + l15;
+          for (int r = 0; r < 4; ++r) split_bf16(o[dt][r] * inv, hi[r], lo[r]);
+          const uint2 wh = {pack_bf16x2((float)hi[0], (float)hi[1]), pack_bf16x2((float)hi[2], (float)hi[3])};
+          const uint2 wl = {pack_bf16x2((float)lo[0], (float)lo[1]), pack_bf16x2((float)lo[2], (float)lo[3])};
+          *reinterpret_cast<uint2*>(dst + dt * 16) = wh;
+          *reinterpret_cast<uint2*>(dst + H + dt * 16) = wl;
+          *reinterpret_cast<uint2*>(dst + 2 * H + dt * 16) = wh;
+        }
+      } else {
+        bf16* dst = ctx + (row0 + q_l) * H + h * 64 + 4 * g;
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) dst[dt * 16] = (bf16)o[dt][r];
+        for (int dt = 0; dt < 4; ++dt) {
+          const uint2 w = {pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
+          *reinterpret_cast<uint2*>(dst + dt * 16) = w;
         }
       }
     }
@@ -163,8 +177,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
 // Backward.  Phase A (wave = query tile): dQ.  Phase B (wave = key tile): dK, dV.  P is recomputed
 // from Q, K and the forward's log-sum-exp; both phases recompute the score tile in the orientation
 // whose accumulator is directly the next MFMA's A operand.
-template <int NKT>
-__global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
+template <int NKT, int NWV, int WPE>
+__global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
                                                        const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
                                                        const float* __restrict__ lse, bf16* __restrict__ dqkv, int S,
                                                        int H, int heads, float scale, AttnDrop dr) {
@@ -187,14 +201,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16* __restrict
   const uint32_t bh = (uint32_t)(b * heads + h);
   const float sl2 = scale * LOG2E;
 
-  stage_rows<SK>(img0, qbase + H, ld, S, tid);
-  stage_rows<SK>(img1, qbase + 2 * H, ld, S, tid);
-  for (int k = tid; k < SK; k += 256) {
+  stage_rows<SK, NWV * 64>(img0, qbase + H, ld, S, tid);
+  stage_rows<SK, NWV * 64>(img1, qbase + 2 * H, ld, S, tid);
+  for (int k = tid; k < SK; k += NWV * 64) {
     mb[k] = (k < S && (keymask == nullptr || keymask[(size_t)b * S + k] != 0.f)) ? 0.f : -INFINITY;
     lse_s[k] = (k < S) ? -lse[(size_t)bh * S + k] * LOG2E : -INFINITY;
   }
   // delta[q] = sum_d dO[q][d] * O[q][d] ; 4 lanes per row
-  for (int q = tid >> 2; q < SK; q += 64) {
+  for (int q = tid >> 2; q < ((SK + NWV * 16 - 1) / (NWV * 16)) * (NWV * 16); q += NWV * 16) {
     float s = 0.f;
     if (q < S) {
       const int d0 = (tid & 3) * 16;
@@ -208,13 +222,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16* __restrict
     }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
-    if ((tid & 3) == 0) dl_s[q] = s;
+    if ((tid & 3) == 0 && q < SK) dl_s[q] = s;
   }
   __syncthreads();
 
   const int nqt = (S + 15) >> 4;
   // ---------------- phase A: dQ ----------------
-  for (int qt = wave; qt < nqt; qt += 4) {
+  for (int qt = wave; qt < nqt; qt += NWV) {
     const int q_l = qt * 16 + l15;
     const int qrow = min(q_l, S - 1);
     bf16x8 qf[2], df[2];
@@ -249,28 +263,28 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16* __restrict
           ds2[hh][r] = pv * (dpv - dl) * scale;
         }
       }
+      // dQ^T[d][q] += K^T[d][key] dS^T[key][q] (query stays on the lane: 8-byte stores)
       const bf16x8 dsf = pack_frag(ds2[0], ds2[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, frag_tr(img0, T, dt, g, l15), o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(img0, T, dt, g, l15), dsf, o[dt], 0, 0, 0);
     }
+    if (q_l < S) {
+      bf16* dst = dqbase + (size_t)q_l * ld + 4 * g;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int q = qt * 16 + 4 * g + r;
-      if (q < S) {
-        bf16* dst = dqbase + (size_t)q * ld + l15;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dst[dt * 16] = (bf16)o[dt][r];
+      for (int dt = 0; dt < 4; ++dt) {
+        const uint2 w = {pack_bf16x2(o[dt][0], o[dt][1]), pack_bf16x2(o[dt][2], o[dt][3])};
+        *reinterpret_cast<uint2*>(dst + dt * 16) = w;
       }
     }
   }
   __syncthreads();
   // ---------------- phase B: dK, dV ----------------
-  stage_rows<SK>(img0, qbase, ld, S, tid);
-  stage_rows<SK>(img1, dobase, H, S, tid);
+  stage_rows<SK, NWV * 64>(img0, qbase, ld, S, tid);
+  stage_rows<SK, NWV * 64>(img1, dobase, H, S, tid);
   __syncthreads();
   const int nkt = (S + 15) >> 4;
-  for (int kt = wave; kt < nkt; kt += 4) {
+  for (int kt = wave; kt < nkt; kt += NWV) {
     const int k_l = kt * 16 + l15;
     const int krow = min(k_l, S - 1);
     bf16x8 kf[2], vf[2];
@@ -316,23 +330,22 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(const bf16* __restrict
       }
       const bf16x8 pf = pack_frag(p2[0], p2[1]);
       const bf16x8 dsf = pack_frag(ds2[0], ds2[1]);
+      // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]  (key on the lane)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, frag_tr(img1, T, dt, g, l15), dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, frag_tr(img0, T, dt, g, l15), dk[dt], 0, 0, 0);
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(img1, T, dt, g, l15), pf, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(img0, T, dt, g, l15), dsf, dk[dt], 0, 0, 0);
       }
     }
+    if (k_l < S) {
+      bf16* dstk = dqbase + H + (size_t)k_l * ld + 4 * g;
+      bf16* dstv = dqbase + 2 * H + (size_t)k_l * ld + 4 * g;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k = kt * 16 + 4 * g + r;
-      if (k < S) {
-        bf16* dstk = dqbase + H + (size_t)k * ld + l15;
-        bf16* dstv = dqbase + 2 * H + (size_t)k * ld + l15;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          dstk[dt * 16] = (bf16)dk[dt][r];
-          dstv[dt * 16] = (bf16)dv[dt][r];
-        }
+      for (int dt = 0; dt < 4; ++dt) {
+        const uint2 wk = {pack_bf16x2(dk[dt][0], dk[dt][1]), pack_bf16x2(dk[dt][2], dk[dt][3])};
+        const uint2 wv = {pack_bf16x2(dv[dt][0], dv[dt][1]), pack_bf16x2(dv[dt][2], dv[dt][3])};
+        *reinterpret_cast<uint2*>(dstk + dt * 16) = wk;
+        *reinterpret_cast<uint2*>(dstv + dt * 16) = wv;
       }
     }
   }
@@ -352,11 +365,11 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
   dim3 grid(a->heads, a->B), block(256);
   const float scale = 0.125f;  // 1/sqrt(64)
   if (a->S <= 64) {
-    hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, attn_lds_bytes<2>(), st, reinterpret_cast<const bf16*>(a->qkv),
+    hipLaunchKernelGGL((attn_fwd_kernel<2, 4, 3>), grid, dim3(256), attn_lds_bytes<2>(), st, reinterpret_cast<const bf16*>(a->qkv),
                        a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
                        reinterpret_cast<bf16*>(a->ctx_split3));
   } else {
-    hipLaunchKernelGGL(attn_fwd_kernel<6>, grid, block, attn_lds_bytes<6>(), st, reinterpret_cast<const bf16*>(a->qkv),
+    hipLaunchKernelGGL((attn_fwd_kernel<6, 12, 6>), grid, dim3(768), attn_lds_bytes<6>(), st, reinterpret_cast<const bf16*>(a->qkv),
                        a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
                        reinterpret_cast<bf16*>(a->ctx_split3));
   }
@@ -373,11 +386,11 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
   dim3 grid(a->heads, a->B), block(256);
   const float scale = 0.125f;
   if (a->S <= 64) {
-    hipLaunchKernelGGL(attn_bwd_kernel<2>, grid, block, attn_lds_bytes<2>(), st, reinterpret_cast<const bf16*>(a->qkv),
+    hipLaunchKernelGGL((attn_bwd_kernel<2, 4, 3>), grid, dim3(256), attn_lds_bytes<2>(), st, reinterpret_cast<const bf16*>(a->qkv),
                        a->keymask, reinterpret_cast<const bf16*>(a->ctx), reinterpret_cast<const bf16*>(a->dctx), a->lse,
                        reinterpret_cast<bf16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
   } else {
-    hipLaunchKernelGGL(attn_bwd_kernel<6>, grid, block, attn_lds_bytes<6>(), st, reinterpret_cast<const bf16*>(a->qkv),
+    hipLaunchKernelGGL((attn_bwd_kernel<6, 4, 3>), grid, dim3(256), attn_lds_bytes<6>(), st, reinterpret_cast<const bf16*>(a->qkv),
                        a->keymask, reinterpret_cast<const bf16*>(a->ctx), reinterpret_cast<const bf16*>(a->dctx), a->lse,
                        reinterpret_cast<bf16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
   }
