@@ -223,3 +223,67 @@ def test_ring_kernel_192_wide_tiles(mode, K):
     _gemm(A, Bop, out, M, N, K, K, ldb, N, 0, bm, EPI_GELU, cfg=4, bias=bias, out2=pre)
     torch.cuda.synchronize()
     assert (out.float() - torch.nn.functional.gelu(r)).abs().max().item() <= r.abs().max().item() * 2 ** -7
+
+
+# ---- persistent ring kernel: > 256 work items, so blocks walk several tiles and the epilogue of one tile
+#      overlaps the staging / first phases of the next (counted waits that allow for the stores in flight)
+@pytest.mark.parametrize("cfg", [3, 4])
+@pytest.mark.parametrize("K", [64, 192, 256, 832])
+@pytest.mark.parametrize("epi", ["bf16", "gelu", "res"])
+def test_ring_kernel_persistent_overlap_forward(cfg, K, epi):
+    M, N = 256 * 43, (1536 if cfg == 4 else 2048)      # 43 x 8 = 344 tiles > 256 blocks
+    A = _rand(M, K, seed=31).bfloat16()
+    W = _rand(N, K, scale=0.05, seed=32).bfloat16()
+    bias = _rand(N, seed=33)
+    m_valid = M - 300                                   # last TWO tile rows are partial / one fully masked row block
+    z = A.float() @ W.float().t() + bias
+    for rep in range(3):                                # repeat: a racy wait shows as run-to-run differences
+        if epi == "bf16":
+            out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_BF16, cfg=cfg, bias=bias, m_valid=m_valid)
+            ref, tol = z, z.abs().max().item() * 2 ** -7
+        elif epi == "gelu":
+            out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            pre = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_GELU, cfg=cfg, bias=bias, out2=pre, m_valid=m_valid)
+            ref = torch.nn.functional.gelu(z); tol = ref.abs().max().item() * 2 ** -7
+            gprime = 0.5 * (1 + torch.erf(z / math.sqrt(2))) + z * torch.exp(-0.5 * z * z) / math.sqrt(2 * math.pi)
+            assert (pre[:m_valid].float() - gprime[:m_valid]).abs().max().item() <= 2 ** -7
+        else:
+            res = _rand(M, N, seed=34)
+            out = torch.zeros(M, N, device="cuda")
+            _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_RES, cfg=cfg, bias=bias, res=res, m_valid=m_valid)
+            ref, tol = z + res, 2e-4 * z.abs().max().item()
+        torch.cuda.synchronize()
+        assert (out[:m_valid].float() - ref[:m_valid]).abs().max().item() <= tol
+        assert out[m_valid:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("cfg", [3, 4])
+def test_ring_kernel_persistent_overlap_dgrad_colsum(cfg):
+    M, K, N = 256 * 43, 512, (1536 if cfg == 4 else 2048)
+    dY = _rand(M, K, seed=41).bfloat16()
+    W = _rand(K, N, scale=0.05, seed=42).bfloat16()     # [K][N]: b_mode 1
+    aux = _rand(M, N, seed=43).bfloat16()
+    ref = (dY.float() @ W.float()) * aux.float()
+    for rep in range(2):
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        cs = torch.zeros(N, device="cuda")
+        _gemm(dY, W, out, M, N, K, K, N, N, 0, 1, EPI_DGELU, cfg=cfg, aux=aux, colsum=cs)
+        torch.cuda.synchronize()
+        assert (out.float() - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7
+        csr = out.float().sum(0)
+        assert (cs - csr).abs().max().item() <= 2e-3 * csr.abs().max().item() + 1e-2
+
+
+@pytest.mark.parametrize("splits", [1, 3, 8])
+def test_ring_kernel_persistent_wgrad(splits):
+    # out[M][N] (+)= A[K][M]^T B[K][N]: 12 x 12 = 144 tiles x splits work items
+    M, N, K = 3072, 3072, 1280
+    A = _rand(K, M, seed=51).bfloat16()
+    B = _rand(K, N, scale=0.05, seed=52).bfloat16()
+    ref = A.float().t() @ B.float()
+    out = torch.zeros(M, N, device="cuda")
+    _gemm(A, B, out, M, N, K, M, N, N, 1, 1, EPI_ATOMIC, cfg=3, splits=splits)
+    torch.cuda.synchronize()
+    assert (out - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()

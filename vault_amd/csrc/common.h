@@ -98,5 +98,13 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// lane id recomputed from the hardware (never hoisted, never kept live): persistent kernels use it instead of
+// holding threadIdx-derived registers across their whole tile loop
+__device__ __forceinline__ int lane_id_volatile() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 #define VAULT_OK 0
 #define VAULT_EINVAL 22

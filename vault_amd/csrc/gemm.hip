@@ -240,20 +240,23 @@ int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, i
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return VAULT_EINVAL;
   if ((p.lda & 7) || (p.ldb & 7) || (p.ldo & 7)) return VAULT_EINVAL;
   if (cfg < 0) {
-    // default kernel/tile choice (measured on MI355X at M = 47360, profiles/ r01 GEMM table):
-    //   256x256 8-phase ring kernel for long contractions (K >= 1536) and all wgrads (A stored [K][M]);
-    //   its 256x192 form when that fills the last round of CUs much better (N = 768: 740 vs 555 tiles);
-    //   256x256 double-buffered kernel for short K with wide N; 256x128 / 128x128 otherwise
+    // default kernel/tile choice (measured on MI355X at M = 47360, tools/gemm_bench.py + tools/k_sweep.py):
+    //   256x256 persistent ring kernel from K = 512 up and for all wgrads (A stored [K][M]): its epilogue
+    //   overlaps the next tile, the double-buffered kernel only wins for very short contractions;
+    //   the 256x192 form of the ring kernel when that fills the last round of CUs better
+    //   (N = 768: 740 vs 555 tiles, N = 2304: 2220 vs 1665); 256x128 / 128x128 otherwise
     auto eff = [](long tiles) { return (double)tiles / (double)(((tiles + 255) / 256) * 256); };
     if (p.M % 256 == 0 && p.N % 256 == 0) {
-      cfg = (p.K >= 1536 || a_mode == 1) ? 3 : 2;
-      if (p.N % 192 == 0 && a_mode == 0 && epi != EPI_F32_ATOMIC && p.splits == 1 &&
-          eff((long)(p.M / 256) * (p.N / 192)) > 1.1 * eff((long)(p.M / 256) * (p.N / 256)))
+      cfg = (p.K >= 512 || a_mode == 1) ? 3 : 2;
+      if (p.N % 192 == 0 && a_mode == 0 && epi != EPI_F32_ATOMIC && p.splits == 1 && p.K >= 512 &&
+          eff((long)(p.M / 256) * (p.N / 192)) > 1.02 * eff((long)(p.M / 256) * (p.N / 256)))
         cfg = 4;
     } else {
       cfg = (p.M % 256 == 0 && p.N % 128 == 0 && epi != EPI_F32_ATOMIC) ? 1 : 0;
     }
   }
+  // the ring kernel's residual epilogue always loads its residual operand: without one use the simple kernel
+  if ((cfg == 3 || cfg == 4) && epi == EPI_F32_RES && p.res == nullptr) cfg = (p.N % 256 == 0) ? 2 : 1;
   if (cfg == 3) return vault_gemm256_launch(p, a_mode, b_mode, epi, 4, st);
   if (cfg == 4) return vault_gemm256_launch(p, a_mode, b_mode, epi, 3, st);
   const int key = a_mode * 2 + b_mode;

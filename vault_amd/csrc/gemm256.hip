@@ -12,6 +12,13 @@
 //   * each phase multiplies one quadrant (64 x 64 per wave, 32 MFMAs) while the fragments of the next
 //     quadrant are read from LDS; quadrants are walked 00,01,11,10 | 01,00,10,11 so that every
 //     fragment set is loaded exactly once per K tile and two of the four sets are always reusable.
+// The grid is persistent (<= 256 blocks, block b walks work items b, b + grid, ...).  The epilogue of one
+// tile overlaps the start of the next: its LDS scratch lies outside the ring, one half-tile of the next
+// tile's first two K tiles is issued per 16-row epilogue step, and the global stores of the epilogue are
+// never waited for explicitly - VMEM operations retire in issue order, so the counted waits of the next
+// tile's first five phases simply allow for the stores that are certain to have been issued behind the
+// half-tile they retire (a lower bound: `SPS` per epilogue step of a fully valid tile, else none).  The
+// stores drain to L2/HBM while the matrix pipe is already working on the next tile.
 // Ordering rules (all formal, no timing assumptions):
 //   RAW  a half-tile is read one phase after the `vmcnt` + `s_barrier` that retired it;
 //   WAR  a slot is overwritten two phases after its ds_reads were issued, and every phase ends with
@@ -55,37 +62,43 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  const int g = lane >> 4, l15 = lane & 15;
+  constexpr int TN = 2 * NTQ;
+  constexpr bool F32OUT = (EPI == EPI_F32_RES || EPI == EPI_F32_PATCH);
+  // VMEM operations every wave is certain to issue in one 16-row epilogue step of a fully valid tile
+  constexpr int SPS = (EPI == EPI_F32_ATOMIC) ? 16 * (TN * 16 / 64) : (F32OUT ? TN : TN / 2);
+#define CAPW(N, STEPS) (((N) + (STEPS) * SPS) > 63 ? 63 : ((N) + (STEPS) * SPS))
 
-  int tile_m, tile_n;
-  gemm_tile_of_block(gridDim.x, blockIdx.x, p.M >> 8, p.N / BNT, p.gn, tile_m, tile_n);
-  const int m0 = tile_m << 8, n0 = tile_n * BNT;
+  // ---- work items: (split z, tile) pairs, z-major; every split owns >= 1 K tile (launcher)
+  const int tiles_m = p.M >> 8, tiles_n = p.N / BNT, ntiles = tiles_m * tiles_n;
+  const int nwork = ntiles * p.splits;
   const int nk_total = p.K >> 6;
   const int per = (nk_total + p.splits - 1) / p.splits;
-  const int kt0 = blockIdx.z * per;
-  const int nk = min(nk_total, kt0 + per) - kt0;
-  if (nk <= 0) return;
 
   // ---- staging sources: uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset, two 1-KiB pieces
   //      per wave per half-tile
+  int m0, n0, nk;
   const char* a_base;
   const char* b_base;
   uint32_t a_off[4], b_off[4];
   uint32_t a_half, b_half, a_step, b_step;   // bytes
-  if constexpr (A_MODE == 0) {
-    a_base = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda + (size_t)kt0 * 64);
-    a_half = 64u * p.lda * 2u; a_step = 128u;
-  } else {
-    a_base = reinterpret_cast<const char*>(p.A + (size_t)kt0 * 64 * p.lda + m0);
-    a_half = 128u; a_step = 64u * p.lda * 2u;
-  }
-  if constexpr (B_MODE == 0) {
-    b_base = reinterpret_cast<const char*>(p.B + (size_t)n0 * p.ldb + (size_t)kt0 * 64);
-    b_half = (uint32_t)(NTQ * 16) * p.ldb * 2u; b_step = 128u;
-  } else {
-    b_base = reinterpret_cast<const char*>(p.B + (size_t)kt0 * 64 * p.ldb + n0);
-    b_half = (uint32_t)(NTQ * 16) * 2u; b_step = 64u * p.ldb * 2u;
-  }
+  if constexpr (A_MODE == 0) { a_half = 64u * p.lda * 2u; a_step = 128u; }
+  else { a_half = 128u; a_step = 64u * p.lda * 2u; }
+  if constexpr (B_MODE == 0) { b_half = (uint32_t)(NTQ * 16) * p.ldb * 2u; b_step = 128u; }
+  else { b_half = (uint32_t)(NTQ * 16) * 2u; b_step = 64u * p.ldb * 2u; }
+  auto setup = [&](int w) {
+    const int z = w / ntiles, tl = w - z * ntiles;
+    int tile_m, tile_n;
+    gemm_tile_of_block(ntiles, tl, tiles_m, tiles_n, p.gn, tile_m, tile_n);
+    m0 = tile_m << 8; n0 = tile_n * BNT;
+    const int kt0 = z * per;
+    nk = min(nk_total, kt0 + per) - kt0;
+    if constexpr (A_MODE == 0) a_base = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda + (size_t)kt0 * 64);
+    else a_base = reinterpret_cast<const char*>(p.A + (size_t)kt0 * 64 * p.lda + m0);
+    if constexpr (B_MODE == 0) b_base = reinterpret_cast<const char*>(p.B + (size_t)n0 * p.ldb + (size_t)kt0 * 64);
+    else b_base = reinterpret_cast<const char*>(p.B + (size_t)kt0 * 64 * p.ldb + n0);
+  };
+  int w = blockIdx.x;
+  setup(w);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int j = wave * 4 + i;
@@ -109,13 +122,21 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   }
 
   // one 1-KiB piece (i = 0..3) of a half-tile; a half-tile is 4 pieces per wave
+  // The per-lane offset passes through an opaque move at every use: hipcc otherwise hoists its 64-bit
+  // extension out of the persistent loop (8 register pairs live across everything) instead of folding the
+  // 32-bit offset into the SGPR-base addressing form.
   auto pieceA = [&](int h, int buf, int t, int i) {
-    glds16(a_base + (size_t)h * a_half + (size_t)t * a_step + a_off[i], smem + buf * BUFB + h * HT + wave * 4096 + i * 1024);
+    uint32_t o = a_off[i];
+    asm volatile("" : "+v"(o));
+    glds16(a_base + (size_t)h * a_half + (size_t)t * a_step + o, smem + buf * BUFB + h * HT + wave * 4096 + i * 1024);
   };
   auto pieceB = [&](int h, int buf, int t, int i) {
-    if (i < PB)
-      glds16(b_base + (size_t)h * b_half + (size_t)t * b_step + b_off[i],
+    if (i < PB) {
+      uint32_t o = b_off[i];
+      asm volatile("" : "+v"(o));
+      glds16(b_base + (size_t)h * b_half + (size_t)t * b_step + o,
              smem + buf * BUFB + 2 * HT + h * HT + (wave * PB + i) * 1024);
+    }
   };
   auto issueA = [&](int h, int buf, int t) {
 #pragma unroll
@@ -126,38 +147,6 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     for (int i = 0; i < 4; ++i) pieceB(h, buf, t, i);
   };
 
-  // ---- fragment read offsets
-  int a_o0, a_o1, b_o0, b_o1;   // mode 0: byte offsets of k-step 0 / 1 ; mode 1: base offset / swizzle key
-  {
-    const int fx = ((l15 >> 1) & 3) << 1;
-    const int q = l15 >> 2, pp = l15 & 3, hk = q | ((g & 1) << 2);
-    if constexpr (A_MODE == 0) {
-      a_o0 = (wr * 64 + l15) * 128 + ((g ^ fx) << 4);
-      a_o1 = (wr * 64 + l15) * 128 + (((4 + g) ^ fx) << 4);
-    } else {
-      a_o0 = (8 * g + q) * 256 + pp * 8;
-      a_o1 = hk;
-    }
-    if constexpr (B_MODE == 0) {
-      b_o0 = (wc * (NTQ * 16) + l15) * 128 + ((g ^ fx) << 4);
-      b_o1 = (wc * (NTQ * 16) + l15) * 128 + (((4 + g) ^ fx) << 4);
-    } else {
-      b_o0 = (8 * g + q) * 256 + pp * 8;
-      b_o1 = hk;
-    }
-  }
-  // transposed-read lane addresses (32-bit LDS byte addresses of ring buffer 0, k-step 0, first read)
-  uint32_t a_tr[4], b_tr[4];
-  if constexpr (A_MODE == 1) {
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-      a_tr[mt] = (uint32_t)(size_t)LDS_PTR(char, smem) + a_o0 + (((wr * 4 + mt) ^ a_o1) << 5);
-  }
-  if constexpr (B_MODE == 1) {
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-      b_tr[nt] = (uint32_t)(size_t)LDS_PTR(char, smem) + 2 * HT + b_o0 + (((wc * 4 + nt) ^ b_o1) << 5);
-  }
   // BUF / H are compile-time at every call site (macro-expanded), so the slot offset folds into the
   // 16-bit DS immediate; ring buffer 1 (+64 KiB) exceeds it and is added to the address instead
 #define LOAD_TR(DST, ADDR, BUF, H)                                                                       \
@@ -190,11 +179,6 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
 #define LOADB(RB, BUF, H) { LOADB_U(RB, BUF, H, 0) LOADB_U(RB, BUF, H, 1) LOADB_U(RB, BUF, H, 2) LOADB_U(RB, BUF, H, 3) }
 
   f32x4 acc[8][2 * NTQ];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 2 * NTQ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   // MFMAs are issued through inline asm with the accumulator tied in place in the AGPR half of the
   // register file ("+a"): hipcc otherwise allocates out-of-place destinations for this many live
   // accumulators and spills.  `volatile` keeps every cluster inside its phase.
@@ -207,17 +191,21 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
 
   bf16x8 RA0[4][2], RA1[4][2], RB0[4][2], RB1[4][2];
 
-  // ---- prologue: K tiles 0 and 1 in ring order, preload the first quadrant's fragments
-  issueA(0, 0, 0); issueB(0, 0, 0); issueB(1, 0, 0); issueA(1, 0, 0);
-  if (nk > 1) {
-    issueA(0, 1, 1); issueB(1, 1, 1); issueB(0, 1, 1); issueA(1, 1, 1);
-    WAITBAR(3 * 4 + 3 * PB);
-  } else {
-    WAITBAR(0);
-  }
-  LOADA(RA0, 0, 0)
-  LOADB(RB0, 0, 0)
-  if (nk > 1) { WAITBAR(W32); } else { WAITBAR(0); }
+  // the first two K tiles of the current work item in ring order, one half-tile per call (h8 = 0..7)
+  auto stage_first = [&](int h8) {
+    switch (h8) {
+      case 0: issueA(0, 0, 0); break;
+      case 1: issueB(0, 0, 0); break;
+      case 2: issueB(1, 0, 0); break;
+      case 3: issueA(1, 0, 0); break;
+      case 4: if (nk > 1) issueA(0, 1, 1); break;
+      case 5: if (nk > 1) issueB(1, 1, 1); break;
+      case 6: if (nk > 1) issueB(0, 1, 1); break;
+      default: if (nk > 1) issueA(1, 1, 1); break;
+    }
+  };
+#pragma unroll
+  for (int h8 = 0; h8 < 8; ++h8) stage_first(h8);
 
   // one loop iteration = two K tiles = eight phases.  FULL: both prefetch targets exist (no branches,
   // uniform counted waits); otherwise the generic tail form (skipped issues drain with vmcnt(0)).
@@ -244,24 +232,97 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     __builtin_amdgcn_s_setprio(0);                                             \
     if (iss_) { WAITBAR(WAITN); } else { WAITBAR(0); }                         \
   }
-#define TWO_TILES(FULLV)                                                                   \
+#define TWO_TILES(FULLV, O5, O4, O3, O2, O1)                                                                  \
   {                                                                                        \
     constexpr bool FULL = FULLV;                                                           \
     const bool i2 = (t + 2) < nk, i3 = (t + 3) < nk;                                       \
-    PHASE(W32, LOADB_U, RB1, 0, 1, pieceA, 0, 0, t + 2, i2, 0, 0, RA0, RB0)                \
-    PHASE(W23, LOADA_U, RA1, 0, 1, pieceB, 0, 0, t + 2, i2, 0, NTQ, RA0, RB1)              \
-    PHASE(W23, LOADA_U, RA0, 1, 0, pieceB, 1, 0, t + 2, i2, 4, NTQ, RA1, RB1)              \
-    PHASE(W32, LOADB_U, RB1, 1, 1, pieceA, 1, 0, t + 2, i2, 4, 0, RA1, RB0)                \
+    PHASE(CAPW(W32, O5), LOADB_U, RB1, 0, 1, pieceA, 0, 0, t + 2, i2, 0, 0, RA0, RB0)                \
+    PHASE(CAPW(W23, O4), LOADA_U, RA1, 0, 1, pieceB, 0, 0, t + 2, i2, 0, NTQ, RA0, RB1)              \
+    PHASE(CAPW(W23, O3), LOADA_U, RA0, 1, 0, pieceB, 1, 0, t + 2, i2, 4, NTQ, RA1, RB1)              \
+    PHASE(CAPW(W32, O2), LOADB_U, RB1, 1, 1, pieceA, 1, 0, t + 2, i2, 4, 0, RA1, RB0)                \
     if (FULL || (t + 1 < nk)) {                                                            \
-      PHASE(W32, LOADB_U, RB0, 1, 0, pieceA, 0, 1, t + 3, i3, 0, NTQ, RA0, RB1)            \
+      PHASE(CAPW(W32, O1), LOADB_U, RB0, 1, 0, pieceA, 0, 1, t + 3, i3, 0, NTQ, RA0, RB1)            \
       PHASE(W23, LOADA_U, RA1, 1, 1, pieceB, 1, 1, t + 3, i3, 0, 0, RA0, RB0)              \
       PHASE(W23, LOADA_U, RA0, 0, 0, pieceB, 0, 1, t + 3, i3, 4, 0, RA1, RB0)              \
       PHASE(W32, LOADB_U, RB0, 0, 0, pieceA, 1, 1, t + 3, i3, 4, NTQ, RA1, RB1)            \
     }                                                                                      \
   }
-  int t = 0;
-  for (; t + 3 < nk; t += 2) TWO_TILES(true)
-  for (; t < nk; t += 2) TWO_TILES(false)
+  bool behind_stores = false;   // the staged half-tiles were issued between the steps of a fully valid tile's epilogue
+  while (true) {
+    // ---- fragment read offsets: recomputed per work item from an opaque copy of the lane id, so that they
+    //      are not live across the epilogue (where they would spill: the reload would wait for the stores)
+    const int ln_ = lane_id_volatile();
+    const int g = ln_ >> 4, l15 = ln_ & 15;
+    int a_o0, a_o1, b_o0, b_o1;   // mode 0: byte offsets of k-step 0 / 1 ; mode 1: base offset / swizzle key
+    {
+      const int fx = ((l15 >> 1) & 3) << 1;
+      const int q = l15 >> 2, pp = l15 & 3, hk = q | ((g & 1) << 2);
+      if constexpr (A_MODE == 0) {
+        a_o0 = (wr * 64 + l15) * 128 + ((g ^ fx) << 4);
+        a_o1 = (wr * 64 + l15) * 128 + (((4 + g) ^ fx) << 4);
+      } else {
+        a_o0 = (8 * g + q) * 256 + pp * 8;
+        a_o1 = hk;
+      }
+      if constexpr (B_MODE == 0) {
+        b_o0 = (wc * (NTQ * 16) + l15) * 128 + ((g ^ fx) << 4);
+        b_o1 = (wc * (NTQ * 16) + l15) * 128 + (((4 + g) ^ fx) << 4);
+      } else {
+        b_o0 = (8 * g + q) * 256 + pp * 8;
+        b_o1 = hk;
+      }
+    }
+    // transposed-read lane addresses (32-bit LDS byte addresses of ring buffer 0, k-step 0, first read)
+    uint32_t a_tr[4], b_tr[4];
+    if constexpr (A_MODE == 1) {
+  #pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        a_tr[mt] = (uint32_t)(size_t)LDS_PTR(char, smem) + a_o0 + (((wr * 4 + mt) ^ a_o1) << 5);
+    }
+    if constexpr (B_MODE == 1) {
+  #pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        b_tr[nt] = (uint32_t)(size_t)LDS_PTR(char, smem) + 2 * HT + b_o0 + (((wc * 4 + nt) ^ b_o1) << 5);
+    }
+    // ---- retire K tile 0's first half-tiles, preload the first quadrant's fragments
+    const bool ovl = behind_stores && nk >= 4;
+    if (nk > 1) {
+      if (ovl) { WAITBAR(CAPW(3 * 4 + 3 * PB, 7)); } else { WAITBAR(3 * 4 + 3 * PB); }
+    } else {
+      WAITBAR(0);
+    }
+    LOADA(RA0, 0, 0)
+    LOADB(RB0, 0, 0)
+    if (nk > 1) {
+      if (ovl) { WAITBAR(CAPW(W32, 6)); } else { WAITBAR(W32); }
+    } else {
+      WAITBAR(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * NTQ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int t = 0;
+    if (ovl) {
+      TWO_TILES(true, 5, 4, 3, 2, 1)
+      t = 2;
+    }
+    for (; t + 3 < nk; t += 2) TWO_TILES(true, 0, 0, 0, 0, 0)
+    for (; t < nk; t += 2) TWO_TILES(false, 0, 0, 0, 0, 0)
+    WAITBAR(0);   // every wave has read its last fragments: the ring may be refilled
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> accumulator reads (hazard is invisible inside asm)
+
+    const int em0 = m0, en0 = n0;
+    const int wnext = w + gridDim.x;
+    const bool more = wnext < nwork;
+    if (more) setup(wnext);
+    gemm_epilogue<8, TN, EPI, 2, 2, true>(acc, p, smem + 2 * BUFB, em0, en0, wr * 128, wc * (NTQ * 32), wave, lane,
+                                          [&](int step) { if (more) stage_first(step); }, more ? 4 : 0);
+    if (!more) break;
+    behind_stores = (em0 + 256 <= p.m_valid);
+    w = wnext;
+  }
 #undef TWO_TILES
 #undef PHASE
 #undef LOADA
@@ -270,17 +331,14 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
 #undef LOADB_U
 #undef LOAD_TR
 #undef MMA4
-  WAITBAR(0);
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> accumulator reads (hazard is invisible inside asm)
-
-  gemm_epilogue<8, 2 * NTQ, EPI, 2, 2>(acc, p, smem, m0, n0, wr * 128, wc * (NTQ * 32), wave, lane);
+#undef CAPW
 }
 
 template <int A_MODE, int B_MODE, int EPI, int NTQ>
 int launch256(const GemmParams& p, hipStream_t st) {
   constexpr int BNT = NTQ * 64;
   if ((p.M & 255) || (p.N % BNT) || (p.K & 63)) return VAULT_EINVAL;
-  constexpr int LDS = 2 * BUFB;
+  constexpr int LDS = 2 * BUFB + 4 * 16 * ((NTQ == 4 ? 64 : 96) + 4) * 4;   // ring + epilogue scratch (gemm_epi.h: 16 x LD floats per wave)
   auto kern = gemm256_kernel<A_MODE, B_MODE, EPI, NTQ>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -290,7 +348,11 @@ int launch256(const GemmParams& p, hipStream_t st) {
   }
   GemmParams q = p;
   q.gn = (p.gn > 0) ? std::min(p.gn, p.N / BNT) : p.N / BNT;   // default: plain m-major raster (see gemm.hip)
-  dim3 grid((p.M >> 8) * (p.N / BNT), 1, p.splits);
+  const int nk_total = p.K >> 6;
+  const int per = (nk_total + p.splits - 1) / p.splits;
+  q.splits = (nk_total + per - 1) / per;                        // every split owns at least one K tile
+  const int nwork = (p.M >> 8) * (p.N / BNT) * q.splits;
+  dim3 grid(std::min(nwork, 256), 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, q);
   return (int)hipGetLastError();
 }
