@@ -8,10 +8,12 @@ RCCL all-reduce of gradients).
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").  `roofline` is the dominant kernel (the
-bf16 MFMA GEMM, timed live with events on the launch stream at its largest call site, the ViLT
-FFN-in projection); `step_mfma_frac` is the whole step against the 2.5 PFLOP/s dense bf16 peak with
-BASELINE.md's 120.67 GFLOP/sample.  `cpu_baseline` times the CPU oracle (plain fp32 torch
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").  `roofline` is the dominant kernel of the
+step by GPU time (rocprofv3 --stats, profiles/): the weight-gradient instantiation of the bf16 MFMA ring
+GEMM, gemm256_kernel<1,1,EPI_F32_ATOMIC,4>, timed live with events on the launch stream around all of its
+launches in every 4th timed step; `roofline_ffn1` is the same for the FFN-in forward instantiation (the
+largest single GEMM call site); `step_mfma_frac` is the whole step against the 2.5 PFLOP/s dense bf16 peak
+with BASELINE.md's 120.67 GFLOP/sample.  `cpu_baseline` times the CPU oracle (plain fp32 torch
 restatement of the reference path) on the host cores, on a bounded sample.
 """
 from __future__ import annotations
@@ -122,9 +124,9 @@ def main():
     batch = {k: torch.from_numpy(v).to(dev) for k, v in bn.items() if k != "labels"}
     labels = torch.from_numpy(bn["labels"]).to(dev)
 
-    # live timing of the dominant kernel: events around the ViLT FFN-in GEMM launches of the timed steps
-    evs = []
-    eng.profile_tag = "vilt_ffn1_fwd"
+    # live timing of the dominant kernels: event pairs on the launch stream around their launches, in every 4th
+    # timed step (an event pair costs ~1-2 us of stream time: sampling keeps `value` undisturbed)
+    evs = {"wgrad": [], "ffn1": []}
     eng.profile_events = None
 
     def sync_all():
@@ -135,9 +137,9 @@ def main():
     for _ in range(args.warmup):
         stepper(batch, labels)
     sync_all()
-    eng.profile_events = evs
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        eng.profile_events = evs if (k % 4 == 0) else None
         stepper(batch, labels)
     sync_all()
     dt = time.perf_counter() - t0
@@ -151,24 +153,37 @@ def main():
 
     if rank == 0:
         sps = B * world * args.steps / dt
-        # dominant kernel = the FFN-in forward GEMM instantiation (12 ViLT launches at M = B*185 and 12 LM launches
-        # at M = B*40 per step): achieved = algorithmic FLOPs of all timed launches / their total duration
-        kern_ms = [s.elapsed_time(e) for s, e, _ in evs]
-        kern_fl = [f for _, _, f in evs]
         v = spec.vilt
         M = B * (40 + 1 + v.num_patches)
-        avg_ms = float(np.mean(kern_ms)) if kern_ms else float("nan")
-        achieved = sum(kern_fl) / (sum(kern_ms) * 1e-3) / 1e12 if kern_ms else None
         flop_per_sample = FLOP_PER_SAMPLE_TRAIN if not args.freeze_lm else 106.96e9
-        # HBM/fabric bytes of that kernel from PMC counters (separate rocprofv3 --pmc passes, committed
-        # under profiles/: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE); only valid for the profiled shape
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_ffn1.json")))
-            if pm.get("batch") == B:
-                traffic = pm["traffic_bytes_per_launch_avg"]
-        except Exception:
+
+        def roof(site, kernel, pmc_file):
+            """achieved = algorithmic FLOPs of all timed launches / the sum of their durations"""
+            ms = [s_.elapsed_time(e_) for s_, e_, _ in evs[site]]
+            fl = [f for _, _, f in evs[site]]
+            if not ms:
+                return {"bound": "mfma", "kernel": kernel, "achieved": None, "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": None, "traffic": None, "launches_timed": 0}
+            achieved = sum(fl) / (sum(ms) * 1e-3) / 1e12
+            # HBM/fabric bytes of that kernel from PMC counters (separate rocprofv3 --pmc passes, committed under
+            # profiles/: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE), average per launch; only for the profiled batch
             traffic = None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+                if pm.get("batch") == B and pm.get("lm") == args.lm and not args.freeze_lm:
+                    traffic = pm["traffic_bytes_per_launch_avg"]
+            except Exception:
+                traffic = None
+            return {"bound": "mfma", "kernel": kernel, "flop_per_launch_avg": round(float(np.mean(fl)) / 1e9, 2),
+                    "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
+                    "traffic": traffic, "launches_timed": len(ms), "avg_launch_ms": round(float(np.mean(ms)), 4)}
+
+        r_wgrad = roof("wgrad", "gemm256_kernel<1,1,5,4> (A[K][M]^T B[K][N], EPI_F32_ATOMIC, split-K): every weight-gradient "
+                                f"GEMM of the step, dW[N x K] += dY[{M} | {B * 40} tokens][N]^T X[tokens][K]",
+                       "r01_pmc_gemm_wgrad.json")
+        r_ffn1 = roof("ffn1", "gemm256_kernel<0,0,1,4> (EPI_BF16_GELU): FFN-in forward, ViLT "
+                              f"[{M}x{v.intermediate_size}x{v.hidden_size}] + LM [{B * 40}x{v.intermediate_size}x{v.hidden_size}]",
+                      "r01_pmc_gemm_ffn1.json")
         out = {
             "metric": "train samples/sec (img+text pairs) ViLT-B32+BERTweet, bs256, 1/2/4/8 MI355X",
             "value": round(sps, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -178,13 +193,7 @@ def main():
                                    f"40 text tokens + 384x384 image (185-token fused sequence), "
                                    f"{'frozen LM' if args.freeze_lm else 'all weights trained'}",
                        "global_batch": B * world, "seq_len": 185, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<256,256,2,4,0,0,1> (EPI_BF16_GELU): FFN-in forward, ViLT "
-                                                    f"[{M}x{v.intermediate_size}x{v.hidden_size}] + LM "
-                                                    f"[{B * 40}x{v.intermediate_size}x{v.hidden_size}] launches",
-                         "flop_per_launch_avg": None if not kern_fl else round(float(np.mean(kern_fl)) / 1e9, 2),
-                         "achieved": None if achieved is None else round(achieved, 1), "peak": 2500.0,
-                         "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / 2500.0, 4),
-                         "traffic": traffic, "launches_timed": len(kern_ms), "avg_launch_ms": round(avg_ms, 4)},
+            "roofline": r_wgrad, "roofline_ffn1": r_ffn1,
             "step_mfma_frac": round(sps / world * flop_per_sample / PEAK_BF16, 4),
             "final_loss": round(loss, 5),
         }

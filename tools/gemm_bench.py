@@ -6,7 +6,9 @@ sys.path.insert(0, ".")
 from tests.test_gpu_gemm import _gemm, EPI_BF16, EPI_GELU, EPI_DGELU, EPI_RES, EPI_ATOMIC
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-M = ((B * 185 + 255) // 256) * 256
+SEQ = int(sys.argv[2]) if len(sys.argv) > 2 else 185      # 185: ViLT fused sequence, 40: LM tokens
+CFGS = tuple(int(c) for c in sys.argv[3].split(",")) if len(sys.argv) > 3 else (2, 3, 4)
+M = ((B * SEQ + 255) // 256) * 256
 H, FF = 768, 3072
 
 
@@ -37,7 +39,7 @@ o_h = torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
 dW = torch.zeros(FF, H, device="cuda")
 
 cases = []
-for cfg in (2, 3, 4):
+for cfg in CFGS:
     cases += [
         (f"fwd qkv   cfg{cfg}", 2 * M * 3 * H * H, lambda cfg=cfg: _gemm(X, Wqkv, o_qkv, M, 3 * H, H, H, H, 3 * H, 0, 0, EPI_BF16, cfg=cfg, bias=bias_q)),
         (f"fwd proj  cfg{cfg}", 2 * M * H * H, lambda cfg=cfg: _gemm(X, Wo, o_h32, M, H, H, H, H, H, 0, 0, EPI_RES, cfg=cfg, bias=bias_h, res=res)),

@@ -75,6 +75,32 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return norm_cdf_f(x) + x * (0.3989422804014327f * __expf(-0.5f * x * x));
 }
 
+// Two-at-a-time forms for the GEMM epilogues (v_pk_fma_f32 / v_pk_mul_f32 process a register pair per
+// issue slot; the GELU epilogues are VALU-bound): same polynomial, Phi = 0.5 + copysign(0.5 - h, x).
+__device__ __forceinline__ f32x2 norm_cdf_f2(f32x2 x) {
+  const f32x2 a = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+  const f32x2 t = a * 0.70710678118654752f;
+  f32x2 p = {0.0000430638f, 0.0000430638f};
+  p = p * t + 0.0002765672f;
+  p = p * t + 0.0001520143f;
+  p = p * t + 0.0092705272f;
+  p = p * t + 0.0422820123f;
+  p = p * t + 0.0705230784f;
+  p = p * t + 1.0f;
+  p = p * p; p = p * p; p = p * p; p = p * p;
+  const f32x2 r = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
+  const f32x2 d = 0.5f - 0.5f * r;   // 0.5 erf(|x|/sqrt2) >= 0
+  return f32x2{0.5f + __builtin_copysignf(d[0], x[0]), 0.5f + __builtin_copysignf(d[1], x[1])};
+}
+// y = gelu(x), dy = gelu'(x) = Phi(x) + x phi(x)
+__device__ __forceinline__ void gelu_fwd_f2(f32x2 x, f32x2& y, f32x2& dy) {
+  const f32x2 cdf = norm_cdf_f2(x);
+  const f32x2 q = (x * x) * (-0.5f * 1.4426950408889634f);
+  const f32x2 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+  y = x * cdf;
+  dy = cdf + x * (e * 0.3989422804014327f);
+}
+
 // counter-based keep/drop decision for dropout: a 32-bit mix of (seed, stream, element index).
 // The same function regenerates the mask in backward, so no mask tensor is stored.
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {

@@ -11,7 +11,7 @@ enum GemmEpi {
   EPI_F32_RES = 3,     // out_f32 = dropout(acc + bias) + res_f32
   EPI_F32_PATCH = 4,   // out_f32[rowmap(m)] = acc + addtab[m % rpg]   (patch embedding into the fused sequence)
   EPI_F32_ATOMIC = 5,  // out_f32 += acc   (wgrad; split-K partials by float atomics)
-  EPI_BF16_DROPMASK = 6,
+  EPI_BF16_GELU_INF = 6,  // internal (ring kernel): EPI_BF16_GELU without the gelu' output, picked by the launcher when out2 == null
 };
 
 struct GemmParams {

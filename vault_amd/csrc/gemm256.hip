@@ -38,6 +38,14 @@ constexpr int BUFB = 4 * HT;   // one K tile: A0 A1 B0 B1
 // cluster, after the point where hipcc places its own (already satisfied) lgkmcnt wait.
 #define WAITBAR(N) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(N) : "memory")
 
+// The same with the count selected by a uniform flag INSIDE the asm statement (relative branches): a C++ branch
+// here would cut the loop body into basic blocks, and hipcc then shuffles the accumulators between register
+// files at the block boundaries.
+#define WAITBAR2(FLAG, NF, N)                                                                                  \
+  asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 2\n\ts_waitcnt vmcnt(%1) lgkmcnt(0)\n\ts_branch 1\n"     \
+               "\ts_waitcnt vmcnt(%2) lgkmcnt(0)\n\ts_barrier" ::"s"(__builtin_amdgcn_readfirstlane((int)(FLAG))), "i"(NF), "i"(N) \
+               : "memory", "scc")   /* branch operands = dwords to skip: [wait NF, s_branch] / [wait N] */
+
 // ds_read_b64_tr_b16 through asm: the builtin form makes hipcc drain every in-flight global_load_lds
 // (vmcnt(0)) in front of it, which would serialise the ring.  The data is consumed only after the
 // phase-ending WAITBAR (lgkmcnt(0)), by the MFMA asm of a later phase.
@@ -193,36 +201,39 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
 
   // the first two K tiles of the current work item in ring order, one half-tile per call (h8 = 0..7)
   auto stage_first = [&](int h8) {
+    const int t1 = nk > 1 ? 1 : 0;   // single-K-tile items stage tile 0 twice (never read): no branches, uniform waits
     switch (h8) {
       case 0: issueA(0, 0, 0); break;
       case 1: issueB(0, 0, 0); break;
       case 2: issueB(1, 0, 0); break;
       case 3: issueA(1, 0, 0); break;
-      case 4: if (nk > 1) issueA(0, 1, 1); break;
-      case 5: if (nk > 1) issueB(1, 1, 1); break;
-      case 6: if (nk > 1) issueB(0, 1, 1); break;
-      default: if (nk > 1) issueA(1, 1, 1); break;
+      case 4: issueA(0, 1, t1); break;
+      case 5: issueB(1, 1, t1); break;
+      case 6: issueB(0, 1, t1); break;
+      default: issueA(1, 1, t1); break;
     }
   };
 #pragma unroll
   for (int h8 = 0; h8 < 8; ++h8) stage_first(h8);
 
-  // one loop iteration = two K tiles = eight phases.  FULL: both prefetch targets exist (no branches,
-  // uniform counted waits); otherwise the generic tail form (skipped issues drain with vmcnt(0)).
-  // A phase = 32 MFMAs with the next fragment set's LDS reads and one half-tile's four global_load_lds
-  // pieces spread between the 4-MFMA blocks (one wave per SIMD: anything issued in a burst would leave
-  // the matrix pipe idle for its whole issue time).
-#define PHASE(WAITN, LOADU, RN, LBUF, LH, PIECE, IH, IBUF, IT, COND, MB, NB, RA, RB) \
+  // one loop iteration = two K tiles = eight phases.  A phase = 32 MFMAs with the next fragment set's LDS
+  // reads and one half-tile's four global_load_lds pieces spread between the 4-MFMA blocks (one wave per
+  // SIMD: anything issued in a burst would leave the matrix pipe idle for its whole issue time).
+  // There is ONE copy of the loop body (instruction cache: main loop + epilogue must fit 64 KiB):
+  //   * every phase always issues its half-tile; past the end of the contraction the K tile index is clamped
+  //     (a duplicate of the last tile lands in a slot nobody reads), so the counted waits never change;
+  //   * FIRST (first iteration behind an overlapped epilogue) selects the store-tolerant wait of phases 1-5
+  //     by a uniform branch.
+#define PHASE(WAITN, WAITF, LOADU, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB) \
   {                                                                            \
-    const bool iss_ = FULL || (COND);                                          \
     __builtin_amdgcn_s_setprio(1);                                             \
     asm volatile("s_nop 1");                                                   \
-    MMA4(0, 0, MB, NB, RA, RB) if (iss_) PIECE(IH, IBUF, IT, 0);               \
-    MMA4(0, 1, MB, NB, RA, RB) if (iss_) PIECE(IH, IBUF, IT, 1);               \
+    MMA4(0, 0, MB, NB, RA, RB) PIECE(IH, IBUF, IT, 0);                         \
+    MMA4(0, 1, MB, NB, RA, RB) PIECE(IH, IBUF, IT, 1);                         \
     LOADU(RN, LBUF, LH, 0)                                                     \
-    MMA4(0, 2, MB, NB, RA, RB) if (iss_) PIECE(IH, IBUF, IT, 2);               \
+    MMA4(0, 2, MB, NB, RA, RB) PIECE(IH, IBUF, IT, 2);                         \
     LOADU(RN, LBUF, LH, 1)                                                     \
-    MMA4(0, 3, MB, NB, RA, RB) if (iss_) PIECE(IH, IBUF, IT, 3);               \
+    MMA4(0, 3, MB, NB, RA, RB) PIECE(IH, IBUF, IT, 3);                         \
     LOADU(RN, LBUF, LH, 2)                                                     \
     MMA4(1, 0, MB, NB, RA, RB)                                                 \
     LOADU(RN, LBUF, LH, 3)                                                     \
@@ -230,23 +241,18 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     MMA4(1, 2, MB, NB, RA, RB)                                                 \
     MMA4(1, 3, MB, NB, RA, RB)                                                 \
     __builtin_amdgcn_s_setprio(0);                                             \
-    if (iss_) { WAITBAR(WAITN); } else { WAITBAR(0); }                         \
+    if constexpr ((WAITF) != (WAITN)) { WAITBAR2(first, WAITF, WAITN); } else { WAITBAR(WAITN); } \
   }
-#define TWO_TILES(FULLV, O5, O4, O3, O2, O1)                                                                  \
-  {                                                                                        \
-    constexpr bool FULL = FULLV;                                                           \
-    const bool i2 = (t + 2) < nk, i3 = (t + 3) < nk;                                       \
-    PHASE(CAPW(W32, O5), LOADB_U, RB1, 0, 1, pieceA, 0, 0, t + 2, i2, 0, 0, RA0, RB0)                \
-    PHASE(CAPW(W23, O4), LOADA_U, RA1, 0, 1, pieceB, 0, 0, t + 2, i2, 0, NTQ, RA0, RB1)              \
-    PHASE(CAPW(W23, O3), LOADA_U, RA0, 1, 0, pieceB, 1, 0, t + 2, i2, 4, NTQ, RA1, RB1)              \
-    PHASE(CAPW(W32, O2), LOADB_U, RB1, 1, 1, pieceA, 1, 0, t + 2, i2, 4, 0, RA1, RB0)                \
-    if (FULL || (t + 1 < nk)) {                                                            \
-      PHASE(CAPW(W32, O1), LOADB_U, RB0, 1, 0, pieceA, 0, 1, t + 3, i3, 0, NTQ, RA0, RB1)            \
-      PHASE(W23, LOADA_U, RA1, 1, 1, pieceB, 1, 1, t + 3, i3, 0, 0, RA0, RB0)              \
-      PHASE(W23, LOADA_U, RA0, 0, 0, pieceB, 0, 1, t + 3, i3, 4, 0, RA1, RB0)              \
-      PHASE(W32, LOADB_U, RB0, 0, 0, pieceA, 1, 1, t + 3, i3, 4, NTQ, RA1, RB1)            \
-    }                                                                                      \
-  }
+#define HALF_A                                                                                       \
+    PHASE(W32, CAPW(W32, 5), LOADB_U, RB1, 0, 1, pieceA, 0, 0, t2, 0, 0, RA0, RB0)                   \
+    PHASE(W23, CAPW(W23, 4), LOADA_U, RA1, 0, 1, pieceB, 0, 0, t2, 0, NTQ, RA0, RB1)                 \
+    PHASE(W23, CAPW(W23, 3), LOADA_U, RA0, 1, 0, pieceB, 1, 0, t2, 4, NTQ, RA1, RB1)                 \
+    PHASE(W32, CAPW(W32, 2), LOADB_U, RB1, 1, 1, pieceA, 1, 0, t2, 4, 0, RA1, RB0)
+#define HALF_B                                                                                       \
+    PHASE(W32, CAPW(W32, 1), LOADB_U, RB0, 1, 0, pieceA, 0, 1, t3, 0, NTQ, RA0, RB1)                 \
+    PHASE(W23, W23, LOADA_U, RA1, 1, 1, pieceB, 1, 1, t3, 0, 0, RA0, RB0)                            \
+    PHASE(W23, W23, LOADA_U, RA0, 0, 0, pieceB, 0, 1, t3, 4, 0, RA1, RB0)                            \
+    PHASE(W32, W32, LOADB_U, RB0, 0, 0, pieceA, 1, 1, t3, 4, NTQ, RA1, RB1)
   bool behind_stores = false;   // the staged half-tiles were issued between the steps of a fully valid tile's epilogue
   while (true) {
     // ---- fragment read offsets: recomputed per work item from an opaque copy of the lane id, so that they
@@ -284,32 +290,31 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
       for (int nt = 0; nt < 4; ++nt)
         b_tr[nt] = (uint32_t)(size_t)LDS_PTR(char, smem) + 2 * HT + b_o0 + (((wc * 4 + nt) ^ b_o1) << 5);
     }
-    // ---- retire K tile 0's first half-tiles, preload the first quadrant's fragments
-    const bool ovl = behind_stores && nk >= 4;
-    if (nk > 1) {
-      if (ovl) { WAITBAR(CAPW(3 * 4 + 3 * PB, 7)); } else { WAITBAR(3 * 4 + 3 * PB); }
-    } else {
-      WAITBAR(0);
-    }
+    // ---- retire K tile 0's first half-tiles, preload the first quadrant's fragments ("ovl": the staged
+    //      half-tiles were issued between the steps of a fully valid tile's epilogue, whose stores sit behind them)
+    const bool ovl = behind_stores;
+    if (ovl) { WAITBAR(CAPW(3 * 4 + 3 * PB, 7)); } else { WAITBAR(3 * 4 + 3 * PB); }
     LOADA(RA0, 0, 0)
     LOADB(RB0, 0, 0)
-    if (nk > 1) {
-      if (ovl) { WAITBAR(CAPW(W32, 6)); } else { WAITBAR(W32); }
-    } else {
-      WAITBAR(0);
-    }
+    if (ovl) { WAITBAR(CAPW(W32, 6)); } else { WAITBAR(W32); }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 2 * NTQ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int t = 0;
-    if (ovl) {
-      TWO_TILES(true, 5, 4, 3, 2, 1)
-      t = 2;
+#pragma clang loop unroll(disable)
+    for (; t + 1 < nk; t += 2) {   // two K tiles per iteration, straight-line body
+      const bool first = ovl && (t == 0);
+      const int t2 = min(t + 2, nk - 1), t3 = min(t + 3, nk - 1);
+      HALF_A
+      HALF_B
     }
-    for (; t + 3 < nk; t += 2) TWO_TILES(true, 0, 0, 0, 0, 0)
-    for (; t < nk; t += 2) TWO_TILES(false, 0, 0, 0, 0, 0)
+    if (t < nk) {                  // odd contraction length: one more K tile
+      const bool first = ovl && (t == 0);
+      const int t2 = nk - 1;
+      HALF_A
+    }
     WAITBAR(0);   // every wave has read its last fragments: the ring may be refilled
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> accumulator reads (hazard is invisible inside asm)
 
@@ -323,7 +328,8 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     behind_stores = (em0 + 256 <= p.m_valid);
     w = wnext;
   }
-#undef TWO_TILES
+#undef HALF_A
+#undef HALF_B
 #undef PHASE
 #undef LOADA
 #undef LOADB
@@ -363,7 +369,9 @@ int dispatch256(const GemmParams& p, int a_mode, int b_mode, int epi, hipStream_
 #define VAULT_DISPATCH(AM, BMD)                                                       \
   switch (epi) {                                                                      \
     case EPI_BF16: return launch256<AM, BMD, EPI_BF16, NTQ>(p, st);                   \
-    case EPI_BF16_GELU: return launch256<AM, BMD, EPI_BF16_GELU, NTQ>(p, st);         \
+    case EPI_BF16_GELU:                                                               \
+      if (p.out2 != nullptr) return launch256<AM, BMD, EPI_BF16_GELU, NTQ>(p, st);    \
+      else return launch256<AM, BMD, EPI_BF16_GELU_INF, NTQ>(p, st);                  \
     case EPI_BF16_DGELU: return launch256<AM, BMD, EPI_BF16_DGELU, NTQ>(p, st);       \
     case EPI_F32_RES: return launch256<AM, BMD, EPI_F32_RES, NTQ>(p, st);             \
     case EPI_F32_PATCH: return launch256<AM, BMD, EPI_F32_PATCH, NTQ>(p, st);         \

@@ -26,7 +26,7 @@ template <int TM, int TN, int EPI, int WM_, int WN_, bool ASYNC = false, typenam
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmParams& p, char* smem, int m0, int n0,
                                               int wm0, int wn0, int wave, int lane, Hook hook = Hook(),
                                               int hook0_ops = 0) {
-  constexpr bool BF16_OUT = (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_DGELU);
+  constexpr bool BF16_OUT = (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_GELU_INF || EPI == EPI_BF16_DGELU);
   constexpr bool ATOMIC = (EPI == EPI_F32_ATOMIC);
   constexpr bool PRE_F32 = (EPI == EPI_F32_RES || EPI == EPI_F32_PATCH);   // per-row f32 operand to prefetch
   constexpr bool PRE_B16 = (EPI == EPI_BF16_DGELU);                         // per-row bf16 operand to prefetch
@@ -279,20 +279,21 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
         for (int e = 0; e < EL; e += 4)
           *reinterpret_cast<f32x4*>(out + ecol(e)) = f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
       } else if constexpr (BF16_OUT) {
-        if constexpr (EPI == EPI_BF16_GELU) {
+        if constexpr (EPI == EPI_BF16_GELU || EPI == EPI_BF16_GELU_INF) {
           // out2 (training only) receives gelu'(pre-activation): backward then needs one multiply per
-          // element instead of re-evaluating erf/exp (both epilogues are VALU-bound otherwise)
-          if (p.out2 != nullptr) {
+          // element instead of re-evaluating erf/exp (both epilogues are VALU-bound otherwise).  The ring
+          // kernel instantiates the two forms separately (its launcher looks at out2): half the epilogue code.
+          if (EPI == EPI_BF16_GELU && (ASYNC || p.out2 != nullptr)) {
             bf16* o2 = reinterpret_cast<bf16*>(p.out2) + o;
 #pragma unroll
             for (int c = 0; c < EL; c += 8) {
               float gp[8];
 #pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float x = v[c + e];
-                const float cdf = norm_cdf_f(x);
-                gp[e] = cdf + x * (0.3989422804014327f * __expf(-0.5f * x * x));
-                v[c + e] = x * cdf;
+              for (int e = 0; e < 8; e += 2) {
+                f32x2 y2, d2;
+                gelu_fwd_f2(f32x2{v[c + e], v[c + e + 1]}, y2, d2);
+                gp[e] = d2[0]; gp[e + 1] = d2[1];
+                v[c + e] = y2[0]; v[c + e + 1] = y2[1];
               }
               u32x4 w = {pack_bf16x2(gp[0], gp[1]), pack_bf16x2(gp[2], gp[3]), pack_bf16x2(gp[4], gp[5]),
                          pack_bf16x2(gp[6], gp[7])};
@@ -300,7 +301,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
             }
           } else {
 #pragma unroll
-            for (int e = 0; e < EL; ++e) v[e] = gelu_f(v[e]);
+            for (int e = 0; e < EL; e += 2) {
+              const f32x2 x2 = {v[e], v[e + 1]};
+              const f32x2 y2 = x2 * norm_cdf_f2(x2);
+              v[e] = y2[0]; v[e + 1] = y2[1];
+            }
           }
         } else if constexpr (EPI == EPI_BF16_DGELU) {
 #pragma unroll

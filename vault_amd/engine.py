@@ -214,21 +214,24 @@ class VaultEngine:
         self._ws: Dict[Tuple[int, int, bool], dict] = {}
         self.drop_seed = 0
         self.last: Optional[dict] = None
-        # optional live kernel timing (bench.py): list receiving (start, end, flops) - torch.cuda.Event pairs
-        # recorded on the launch stream around every FFN-in forward GEMM launch (ViLT and LM layers: one kernel
-        # instantiation, gemm_kernel<256,256,2,4,0,0,EPI_BF16_GELU>)
-        self.profile_events: Optional[list] = None
+        # optional live kernel timing (bench.py): {site: [(start, end, flops), ...]} of torch.cuda.Event pairs recorded
+        # on the launch stream around every launch of a kernel instantiation.  Sites: "wgrad" = the ring kernel's
+        # weight-gradient form gemm256_kernel<1,1,EPI_F32_ATOMIC,4> (every _wgrad launch that takes it), "ffn1" =
+        # the FFN-in forward GEMM gemm256_kernel<0,0,EPI_BF16_GELU,4> (ViLT and LM layers).
+        self.profile_events: Optional[Dict[str, list]] = None
+        self._e0: Dict[str, torch.cuda.Event] = {}
 
-    def _prof_begin(self):
-        if self.profile_events is not None:
-            self._e0 = torch.cuda.Event(enable_timing=True)
-            self._e0.record()
+    def _prof_begin(self, site: str):
+        if self.profile_events is not None and site in self.profile_events:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._e0[site] = e0
 
-    def _prof_end(self, flops: float = 0.0):
-        if self.profile_events is not None:
+    def _prof_end(self, site: str, flops: float = 0.0):
+        if self.profile_events is not None and site in self.profile_events:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            self.profile_events.append((self._e0, e1, flops))
+            self.profile_events[site].append((self._e0[site], e1, flops))
 
     # ---- workspace --------------------------------------------------------------------------
     def _buf(self, ws, name, shape, dtype):
@@ -278,8 +281,13 @@ class VaultEngine:
             tiles = (Nout // 128) * (Kin // 128)
             splits = max(1, min(nk, (self.WGRAD_TARGET_WGS + tiles - 1) // tiles))
             cfg = 0
+        if cfg == 3:
+            ops.pycall(lambda: self._prof_begin("wgrad"))
         ops.gemm(dy_bf16, x_bf16, gw, Nout, Kin, Mtok_pad, Nout, Kin, Kin, 1, 1, ops.EPI_F32_ATOMIC, cfg=cfg,
                  splits=splits, accumulate=1)
+        if cfg == 3:
+            fl = 2.0 * m_valid * Nout * Kin
+            ops.pycall(lambda: self._prof_end("wgrad", fl))
         if bname is not None:
             ops.colsum(dy_bf16, Nout, m_valid, Nout, P.gr(bname, n_elems=Nout, shape=(Nout,)))
 
@@ -403,11 +411,11 @@ class VaultEngine:
                 ops.layernorm_fwd(h1, P.w(ln.ln1w), P.w(ln.ln1b), lm.layer_norm_eps, Ml, H, y_f32=y1,
                                   y_bf16=None if pr else y1b, y_split3=y1b if pr else None,
                                   mean=buf(f"lm_m1{sfx}", (Mlp,)), rstd=buf(f"lm_r1{sfx}", (Mlp,)))
-                ops.pycall(self._prof_begin)
+                ops.pycall(lambda: self._prof_begin("ffn1"))
                 self._linear(y1b, ln.iw, act, Mlp, FF, H, ops.EPI_BF16_GELU, Ml, bias=P.w(ln.ib), out2=u, precise=pr,
                              split3=pr, ldo=W3 * FF)
                 fl_l = 2.0 * Ml * FF * H * W3
-                ops.pycall(lambda: self._prof_end(fl_l))
+                ops.pycall(lambda: self._prof_end("ffn1", fl_l))
                 self._linear(act, ln.fw, h2, Mlp, H, FF, ops.EPI_F32_RES, Ml, bias=P.w(ln.fb), res=y1,
                              drop=self._drop(pdh, 16 * i + 4, lm_train), precise=pr)
                 ops.layernorm_fwd(h2, P.w(ln.ln2w), P.w(ln.ln2b), lm.layer_norm_eps, Ml, H, y_f32=y[i + 1],
@@ -465,11 +473,11 @@ class VaultEngine:
             self._linear(ctx, ln.ow, xm, Mp, H, H, ops.EPI_F32_RES, M, bias=P.w(ln.ob), res=x[i], precise=pr)
             ops.layernorm_fwd(xm, P.w(ln.ln2w), P.w(ln.ln2b), v.layer_norm_eps, M, H, y_bf16=None if pr else n2,
                               y_split3=n2 if pr else None, mean=buf(f"m2{sfx}", (Mp,)), rstd=buf(f"r2{sfx}", (Mp,)))
-            ops.pycall(self._prof_begin)
+            ops.pycall(lambda: self._prof_begin("ffn1"))
             self._linear(n2, ln.iw, act, Mp, FF, H, ops.EPI_BF16_GELU, M, bias=P.w(ln.ib), out2=u, precise=pr,
                          split3=pr, ldo=W3 * FF)
             fl_v = 2.0 * M * FF * H * W3
-            ops.pycall(lambda: self._prof_end(fl_v))
+            ops.pycall(lambda: self._prof_end("ffn1", fl_v))
             self._linear(act, ln.fw, x[i + 1], Mp, H, FF, ops.EPI_F32_RES, M, bias=P.w(ln.fb), res=xm, precise=pr)
 
         # ------------------------------ tail ------------------------------
