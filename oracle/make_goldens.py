@@ -26,7 +26,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from vault_amd.spec import LMSpec, VaultSpec, ViltSpec, build_state, param_entries, synthetic_batch  # noqa: E402
+from vault_amd.spec import (LMSpec, VaultSpec, ViltSpec, build_state, param_entries, synthetic_batch,  # noqa: E402
+                            synthetic_ragged_batch)
 
 REF = "/root/reference"
 
@@ -106,8 +107,23 @@ def run_reference(model, spec, batch_np):
         kw["token_type_ids"] = torch.from_numpy(batch_np["token_type_ids"])
     torch.manual_seed(0)
     model.zero_grad(set_to_none=True)
+    # the image part of the attention mask (which of the randomly ordered patch rows are real patches) is internal to
+    # ViltEmbeddings.visual_embed: capture its return value
+    captured = {}
+    emb = model.embeddings
+    orig_ve = emb.visual_embed
+
+    def spy(*a, **k):
+        r = orig_ve(*a, **k)
+        captured["x_mask"] = r[1].detach().clone()
+        return r
+
+    emb.visual_embed = spy
     # VaultForTMSC.forward returns logits only; grab the encoder output through the mixin
-    enc = super(type(model), model).forward(**kw)
+    try:
+        enc = super(type(model), model).forward(**kw)
+    finally:
+        emb.visual_embed = orig_ve
     logits = model.classifier(enc.pooler_output).squeeze(-1)
     loss = torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(batch_np["labels"]))
     loss.backward()
@@ -116,11 +132,17 @@ def run_reference(model, spec, batch_np):
         "logits": logits.detach().numpy(),
         "pooler_output": enc.pooler_output.detach().numpy(),
         "hidden_text_cls": enc.last_hidden_state[:, : T + 1].detach().numpy(),
-        # patch tokens come back in a random order (D3): store an order-free summary
-        "hidden_patch_sorted_norms": np.sort(
-            enc.last_hidden_state[:, T + 1:].detach().norm(dim=-1).numpy(), axis=1),
         "loss": np.float32(loss.item()),
     }
+    # patch tokens come back in a random order (D3): store an order-free summary - of the REAL patches only when the
+    # batch holds padded images (masked padding rows are arbitrary)
+    pn = enc.last_hidden_state[:, T + 1:].detach().norm(dim=-1).numpy()
+    xm = captured["x_mask"][:, 1:].numpy() != 0
+    if xm.all():
+        out["hidden_patch_sorted_norms"] = np.sort(pn, axis=1)
+    else:
+        out["valid_patch_counts"] = xm.sum(axis=1).astype(np.int64)
+        out["hidden_valid_patch_sorted_norms"] = np.concatenate([np.sort(pn[b][xm[b]]) for b in range(pn.shape[0])])
     names, norms = [], []
     small = {}
     for k, p in model.named_parameters():
@@ -150,6 +172,13 @@ CASES = {
     "tiny_bert": (lambda: VaultSpec.tiny(3, "bert"), 3, 12),
     "full_bertweet_b2": (lambda: VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3), 2, 13),
 }
+# padded batches of different image sizes: name -> (spec factory, valid (h, w) per sample, canvas, seed).
+# tiny: patch 16, position table 12 x 12; canvas 192 x 256 = 12 x 16 patches: one full-canvas image (192 patches: the
+# sequence is longer than the table), one small image (10 x 7 patches, 122 masked padding rows), one square image
+RAGGED_CASES = {
+    "tiny_roberta_ragged": (lambda: VaultSpec.tiny(3, "roberta"), [(192, 256), (160, 112), (192, 192)], (192, 256), 21),
+    "tiny_bert_ragged_small": (lambda: VaultSpec.tiny(3, "bert"), [(96, 160), (128, 64), (80, 80), (128, 160)], (128, 160), 22),
+}
 
 
 def main():
@@ -171,6 +200,20 @@ def main():
         np.savez_compressed(path, **out)
         print(name, "loss", out["loss"], "logits", out["logits"].ravel()[:6], "->", path,
               f"{os.path.getsize(path)/1024:.0f} KiB")
+    for name, (mk, valid_hw, pad_hw, dseed) in RAGGED_CASES.items():
+        if only and name not in only:
+            continue
+        spec = mk()
+        model, _ = build_reference_model(ref, spec, seed=0)
+        batch = synthetic_ragged_batch(spec, valid_hw, pad_hw, seed=dseed, n_classes=spec.n_classes)
+        out = run_reference(model, spec, batch)
+        out["meta_valid_hw"] = np.array(valid_hw, np.int64)
+        out["meta_pad_hw"] = np.array(pad_hw, np.int64)
+        out["meta_data_seed"] = np.int64(dseed)
+        path = os.path.join(outdir, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(name, "loss", out["loss"], "logits", out["logits"].ravel()[:6], "valid", out.get("valid_patch_counts"),
+              "->", path, f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
 if __name__ == "__main__":

@@ -140,7 +140,7 @@ def lm_forward(P, spec, input_ids, attention_mask, token_type_ids=None, taps: Op
     return x
 
 
-def vilt_embed(P, spec, text_in, attention_mask, token_type_ids, pixel_values, taps=None):
+def vilt_embed(P, spec, text_in, attention_mask, token_type_ids, pixel_values, taps=None, pixel_mask=None):
     """text_in: LM output [B,T,H] (inputs_embeds) or int64 ids [B,T] when no LM is used."""
     v = spec.vilt
     B = pixel_values.shape[0]
@@ -162,14 +162,39 @@ def vilt_embed(P, spec, text_in, attention_mask, token_type_ids, pixel_values, t
     text = e + mt[0]
     pe = F.conv2d(_r(pixel_values), _r(P["embeddings.patch_embeddings.projection.weight"]),
                   P["embeddings.patch_embeddings.projection.bias"], stride=v.patch_size)
-    pe = pe.flatten(2).transpose(1, 2)                      # [B, g*g, H], row-major patch order
+    gh, gw = pe.shape[2], pe.shape[3]
+    pe = pe.flatten(2).transpose(1, 2)                      # [B, gh*gw, H], row-major patch order
     pos = P["embeddings.position_embeddings"]               # [1, 1+g*g, H]
-    img = torch.cat([P["embeddings.cls_token"].expand(B, -1, -1), pe], dim=1) + pos
+    g = v.image_size // v.patch_size
+    full = pixel_mask is None or (gh == g and gw == g and bool((pixel_mask != 0).all()))
+    if full:
+        img = torch.cat([P["embeddings.cls_token"].expand(B, -1, -1), pe], dim=1) + pos
+        img_mask = torch.ones((B, img.shape[1]), dtype=attention_mask.dtype)
+    else:
+        # padded / non-square images (HF:models/vilt/modeling_vilt.py:92-178): per-image bilinear resize of the
+        # g x g position table to the image's own h x w patch grid (align_corners=True, zero outside), patch
+        # selection by vault_amd.spec.select_patches (deterministic stand-in for the reference's multinomial)
+        from vault_amd.spec import select_patches
+        sel, valid, hw, _, L = select_patches(pixel_mask.numpy(), v.patch_size, -1)
+        spatial = pos[:, 1:, :].transpose(1, 2).reshape(1, -1, g, g)
+        rows = []
+        for b in range(B):
+            h, w = int(hw[b, 0]), int(hw[b, 1])
+            pr = F.interpolate(spatial, size=(h, w), mode="bilinear", align_corners=True)
+            pr = F.pad(pr, (0, gw - w, 0, gh - h)).flatten(2).transpose(1, 2)[0]      # [gh*gw, H]
+            idx = torch.from_numpy(sel[b].astype(np.int64))
+            rows.append(pe[b][idx] + pr[idx])
+        patches = torch.stack(rows, dim=0)                                              # [B, L, H]
+        cls = P["embeddings.cls_token"].expand(B, -1, -1) + pos[:, :1, :]
+        img = torch.cat([cls, patches], dim=1)
+        img_mask = torch.cat([torch.ones((B, 1), dtype=attention_mask.dtype),
+                              torch.from_numpy(valid.astype(np.int64)).to(attention_mask.dtype)], dim=1)
     img = img + mt[1]
     x = torch.cat([text, img], dim=1)
     if taps is not None:
         taps["vilt_embed"] = x
-    mask = torch.cat([attention_mask, torch.ones((B, img.shape[1]), dtype=attention_mask.dtype)], dim=1)
+        taps["image_mask"] = img_mask
+    mask = torch.cat([attention_mask, img_mask], dim=1)
     return x, mask
 
 
@@ -203,7 +228,7 @@ def vault_forward(P, spec, batch: Dict[str, torch.Tensor], taps: Optional[dict] 
         text_in = lm_forward(P, spec, ids, am, tt, taps)
     else:
         text_in = ids
-    x, mask = vilt_embed(P, spec, text_in, am, tt, pix, taps)
+    x, mask = vilt_embed(P, spec, text_in, am, tt, pix, taps, pixel_mask=batch.get("pixel_mask"))
     x = vilt_encoder(P, spec, x, mask, taps)
     x = _ln(x, P["layernorm.weight"], P["layernorm.bias"], spec.vilt.layer_norm_eps)
     out = {"last_hidden_state": x}

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import vault_oracle as O
-from vault_amd.spec import LMSpec, VaultSpec, ViltSpec, build_state, synthetic_batch
+from vault_amd.spec import LMSpec, VaultSpec, ViltSpec, build_state, select_patches, synthetic_batch, synthetic_ragged_batch
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -60,6 +60,62 @@ def test_oracle_matches_reference_golden(name):
     for k in g.files:
         if k.startswith("grad::"):
             np.testing.assert_allclose(P[k[6:]].grad.numpy(), g[k], atol=2e-6, rtol=1e-3)
+
+
+RAGGED = {
+    "tiny_roberta_ragged": lambda: VaultSpec.tiny(3, "roberta"),
+    "tiny_bert_ragged_small": lambda: VaultSpec.tiny(3, "bert"),
+}
+
+
+@pytest.mark.parametrize("name", list(RAGGED))
+def test_oracle_matches_reference_golden_padded_images(name):
+    """Batches of differently sized, padded images (pixel_mask != 1; canvas != the pre-training grid): per-image
+    bilinear resize of the position table, patch selection, masked padding rows.  The reference orders the
+    patches at random; every quantity compared here is invariant to that order."""
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    spec = RAGGED[name]()
+    torch.set_num_threads(8)
+    valid_hw = [tuple(int(x) for x in r) for r in g["meta_valid_hw"]]
+    pad_hw = tuple(int(x) for x in g["meta_pad_hw"])
+    bn = synthetic_ragged_batch(spec, valid_hw, pad_hw, seed=int(g["meta_data_seed"]), n_classes=spec.n_classes)
+    batch = O.torch_batch(bn)
+    P = O.to_torch_state(build_state(spec, 0), requires_grad=True)
+    loss, out = O.vault_loss(P, spec, batch)
+    loss.backward()
+    T = batch["input_ids"].shape[1]
+    sel, valid, hw, grid, L = select_patches(bn["pixel_mask"], spec.vilt.patch_size)
+    assert out["last_hidden_state"].shape[1] == T + 1 + L
+    np.testing.assert_array_equal(valid.sum(axis=1), g["valid_patch_counts"])
+    np.testing.assert_allclose(out["logits"].detach().numpy(), g["logits"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(out["pooler_output"].detach().numpy(), g["pooler_output"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(out["last_hidden_state"][:, : T + 1].detach().numpy(), g["hidden_text_cls"],
+                               atol=1e-4, rtol=0)
+    pn = out["last_hidden_state"][:, T + 1:].detach().norm(dim=-1).numpy()
+    mine = np.concatenate([np.sort(pn[b][valid[b] != 0]) for b in range(pn.shape[0])])
+    np.testing.assert_allclose(mine, g["hidden_valid_patch_sorted_norms"], rtol=1e-5)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5
+    names = [str(n) for n in g["grad_names"]]
+    for n, ref_norm in zip(names, g["grad_norms"]):
+        assert P[n].grad is not None, n
+        assert abs(float(P[n].grad.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 2e-8, n
+    for k in g.files:
+        if k.startswith("grad::"):
+            np.testing.assert_allclose(P[k[6:]].grad.numpy(), g[k], atol=2e-6, rtol=1e-3)
+
+
+def test_select_patches_edge_cases():
+    # all-valid square canvas: identity order, nothing masked
+    sel, valid, hw, grid, L = select_patches(np.ones((2, 64, 64), np.int64), 16)
+    assert grid == (4, 4) and L == 16 and (sel == np.arange(16)).all() and valid.all() and (hw == 4).all()
+    # one 2x3-patch image next to a full one: valid patches first (row-major), then cyclic masked padding
+    pm = np.zeros((2, 64, 64), np.int64); pm[0] = 1; pm[1, :32, :48] = 1
+    sel, valid, hw, grid, L = select_patches(pm, 16)
+    assert L == 16 and list(sel[1, :6]) == [0, 1, 2, 4, 5, 6] and valid[1].sum() == 6 and tuple(hw[1]) == (2, 3)
+    assert set(sel[1, 6:]) <= set(range(16)) - {0, 1, 2, 4, 5, 6}
+    # max_image_length caps the sequence
+    sel, valid, hw, grid, L = select_patches(pm, 16, max_image_length=5)
+    assert L == 5 and valid.all()
 
 
 def test_adamw_formula_float64():

@@ -241,3 +241,68 @@ def synthetic_batch(spec: VaultSpec, batch: int, seed: int = 1234, text_len: int
     if lm is not None and lm.type_vocab_size > 1:
         out["token_type_ids"] = np.zeros((batch, text_len), np.int64)
     return out
+
+
+def synthetic_ragged_batch(spec: VaultSpec, valid_hw, pad_hw, seed: int = 1234, text_len: int = 40,
+                           n_classes: int = 3) -> Dict[str, np.ndarray]:
+    """Like :func:`synthetic_batch`, but with images of different sizes padded to a common
+    ``pad_hw = (Hp, Wp)`` canvas the way the HF ViLT image processor pads a batch: sample b holds a
+    ``valid_hw[b] = (h, w)`` pixel image in the top-left corner, zeros elsewhere, and ``pixel_mask`` marks the
+    image (ref: vault/models/vault/dataset.py:323-347 calls that processor per item)."""
+    B = len(valid_hw)
+    out = synthetic_batch(spec, B, seed=seed, text_len=text_len, n_classes=n_classes)
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+    Hp, Wp = pad_hw
+    pix = np.zeros((B, spec.vilt.num_channels, Hp, Wp), np.float32)
+    pm = np.zeros((B, Hp, Wp), np.int64)
+    for b, (h, w) in enumerate(valid_hw):
+        pix[b, :, :h, :w] = np.clip(rng.standard_normal((spec.vilt.num_channels, h, w), dtype=np.float32), -1.0, 1.0)
+        pm[b, :h, :w] = 1
+    out["pixel_values"], out["pixel_mask"] = pix, pm
+    return out
+
+
+def select_patches(pixel_mask: np.ndarray, patch_size: int, max_image_length: int = -1):
+    """Host-side patch bookkeeping of ``ViltEmbeddings.visual_embed`` (HF:models/vilt/modeling_vilt.py:92-160)
+    with a DETERMINISTIC choice where the reference draws at random (``torch.multinomial``): valid patches in
+    row-major order, then - for images with fewer valid patches than the longest one of the batch - masked
+    padding patches taken cyclically from the image's non-valid ones.  Every random outcome of the reference is
+    a permutation of the valid part plus arbitrary masked padding, which valid tokens never attend to.
+
+    pixel_mask [B, Hp, Wp] (0/1) ->
+      sel   int32 [B, L]   patch slot (row * gw + col on the gh x gw patch grid of the padded canvas)
+      valid int32 [B, L]   1 = real patch, 0 = padding (masked key)
+      hw    int32 [B, 2]   valid patch rows / cols of each image (its position table is resized to h x w)
+      (gh, gw), L
+    """
+    pm = np.asarray(pixel_mask)
+    B, Hp, Wp = pm.shape
+    gh, gw = Hp // patch_size, Wp // patch_size
+    # nn.functional.interpolate(mode="nearest") to (gh, gw): source index floor(dst * Hp / gh)
+    ri = (np.arange(gh) * Hp) // gh
+    ci = (np.arange(gw) * Wp) // gw
+    xm = (pm[:, ri][:, :, ci] != 0).astype(np.int64)          # [B, gh, gw]
+    x_h = xm.sum(axis=1)[:, 0]
+    x_w = xm.sum(axis=2)[:, 0]
+    eff = x_h * x_w
+    L = int(eff.max())
+    if isinstance(max_image_length, int) and max_image_length > 0:
+        L = min(L, int(max_image_length))
+    sel = np.zeros((B, L), np.int32)
+    valid = np.zeros((B, L), np.int32)
+    flat = xm.reshape(B, -1)
+    for b in range(B):
+        v = np.flatnonzero(flat[b] != 0)
+        nv = np.flatnonzero(flat[b] == 0)
+        if len(v) >= L:
+            sel[b] = v[:L]
+            valid[b] = 1
+        else:
+            pad = L - len(v)
+            if len(nv) == 0:
+                raise ValueError("pixel_mask: an image with fewer valid patches than the batch maximum has no padding patch")
+            sel[b, :len(v)] = v
+            sel[b, len(v):] = nv[np.arange(pad) % len(nv)]
+            valid[b, :len(v)] = 1
+    hw = np.stack([x_h, x_w], axis=1).astype(np.int32)
+    return sel, valid, hw, (gh, gw), L
