@@ -117,7 +117,8 @@ def main():
     spec = VaultSpec(vilt=ViltSpec(), lm=lm, n_classes=3)
     eng = VaultEngine(spec, dev, seed=0, freeze_lm=args.freeze_lm, classifier_dropout=0.1)
     total = args.steps + args.warmup
-    stepper = TrainStep(eng, learning_rate=2e-5, warmup_ratio=0.1, total_steps=max(total, 10), process_group=pg)
+    stepper = TrainStep(eng, learning_rate=2e-5, warmup_ratio=0.1, total_steps=max(total, 10), process_group=pg,
+                       assume_full_pixel_mask=True)   # synthetic 384x384 images, all-ones masks: no per-step mask check
 
     B = args.batch
     bn = synthetic_batch(spec, B, seed=1234 + rank, n_classes=3)

@@ -129,6 +129,27 @@ int vault_image_consts(const float* conv_bias, const float* pos_emb, const float
  * bf16 copy dyp [B*P][H] of the patch-row gradients (operand of the projection wgrad). */
 int vault_image_rows_bwd(const float* dx, float* dpos, float* dmtype1, float* dcls, float* dconv_bias,
                          void* dyp_bf16, int P, int H, int B, int S, int T, void* stream);
+
+/* ---- padded batches of differently sized images (pixel_mask != 1 and/or a canvas that is not the pre-training
+ * grid): the device half of ViltEmbeddings.visual_embed, HF modeling_vilt.py:92-178, reached from the reference
+ * through VaultMixin.vilt_forward (ref: vault/models/vault/model.py:204-205) with the per-item processor
+ * output of ref: vault/models/vault/dataset.py:323-347.  The host picks the patch slots that enter the sequence
+ * (vault_amd.spec.select_patches: the reference draws the order / the masked padding at random, here it is
+ * deterministic): sel int32 [B][L] = slot (row * gw + col) on the (HP/ps) x (WP/ps) grid of the canvas,
+ * hw int32 [B][2] = patch rows / cols of each image; G x G = grid of the position table (image_size / ps). */
+/* unfold the selected patches: A [B*L][C*ps*ps] bf16 (split3: [hi | lo | hi], 3x wide) */
+int vault_im2col_sel(const float* pixel_values, void* out_bf16, const int* sel, int B, int L, int C, int HP, int WP,
+                     int ps, int split3, void* stream);
+/* addtab[l] = conv_bias + modality_type[1] for all L rows; CLS rows x[b*S + T] = cls + pos_emb[0] + modality_type[1] */
+int vault_image_sel_consts(const float* conv_bias, const float* pos_emb, const float* mtype1, const float* cls,
+                           float* addtab, float* x, int L, int H, int B, int S, int T, void* stream);
+/* x[b*S + T + 1 + l] += bilinear_resize(pos_emb[1:], to hw[b], align_corners)[sel[b][l]]  (0 outside the image) */
+int vault_image_pos_sel_fwd(float* x, const float* pos_emb, const int* sel, const int* hw, int B, int L, int S, int T,
+                            int H, int gw, int G, void* stream);
+/* backward of the three above over dx [B*S][H]: dpos (transposed interpolation), dmtype1, dcls, dconv_bias (+=),
+ * dyp [B*L][H] bf16 = patch-row gradients (operand of the projection wgrad) */
+int vault_image_sel_bwd(const float* dx, float* dpos, float* dmtype1, float* dcls, float* dconv_bias, void* dyp_bf16,
+                        const int* sel, const int* hw, int B, int L, int S, int T, int H, int gw, int G, void* stream);
 int vault_axpy_f32(float* dst, const float* src, float a, long long n, void* stream);
 
 /* ---- head + loss ----------------------------------------------------------------------------

@@ -16,7 +16,8 @@ import torch
 
 from oracle import vault_oracle as O
 from vault_amd.engine import VaultEngine
-from vault_amd.spec import LMSpec, VaultSpec, ViltSpec, build_state, synthetic_batch
+from vault_amd.spec import (LMSpec, VaultSpec, ViltSpec, build_state, select_patches, synthetic_batch,
+                            synthetic_ragged_batch)
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -78,6 +79,59 @@ def test_tiny_forward_backward_vs_oracle(kind, seed):
     assert not eng.params.has_grad("embeddings.text_embeddings.position_embeddings.weight")
 
 
+@pytest.mark.parametrize("name,kind", [("tiny_roberta_ragged", "roberta"), ("tiny_bert_ragged_small", "bert")])
+def test_padded_image_batches_vs_oracle_and_reference_golden(name, kind):
+    """Batches of differently sized images padded to a non-square canvas (pixel_mask != 1): selected patches only,
+    per-image resize of the position table, masked padding rows; the fused sequence of the first case is 233
+    tokens long (the 320-key attention instantiation)."""
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    spec = _nodrop(VaultSpec.tiny(3, kind))
+    valid_hw = [tuple(int(x) for x in r) for r in g["meta_valid_hw"]]
+    pad_hw = tuple(int(x) for x in g["meta_pad_hw"])
+    bn = synthetic_ragged_batch(spec, valid_hw, pad_hw, seed=int(g["meta_data_seed"]), n_classes=3)
+    B = len(valid_hw)
+    state = build_state(spec, 0)
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    db = _dev(bn)
+    out = eng.forward(db, train=True, labels=db["labels"], need_hidden=True)
+    eng.zero_grad()
+    eng.backward()
+    torch.cuda.synchronize()
+    tb = O.torch_batch(bn)
+    P = O.to_torch_state(state, requires_grad=True)
+    loss, ref = O.vault_loss(P, spec, tb)
+    loss.backward()
+    lg = out["logits"].cpu()
+    assert (lg - ref["logits"].detach()).abs().max() < 3e-3
+    assert np.abs(lg.numpy() - g["logits"]).max() < 3e-3                      # the reference itself
+    assert abs(float(out["loss"]) - float(g["loss"])) < 2e-3
+    assert (out["pooler_output"].cpu() - ref["pooler_output"].detach()).abs().max() < 5e-3
+    T = bn["input_ids"].shape[1]
+    sel, valid, hw, grid, L = select_patches(bn["pixel_mask"], spec.vilt.patch_size)
+    hid = out["last_hidden_state"].cpu()
+    rh = ref["last_hidden_state"].detach()
+    assert hid.shape[1] >= T + 1 + L                                          # the engine may append masked padding rows
+    scale = float(rh.abs().max())
+    assert np.abs(hid[:, : T + 1].numpy() - g["hidden_text_cls"]).max() < 1e-2 * scale
+    for b in range(B):                                                        # real patches, same (row-major) order
+        nvb = int(valid[b].sum())
+        assert (hid[b, T + 1: T + 1 + nvb] - rh[b, T + 1: T + 1 + nvb]).abs().max() < 1e-2 * scale
+    num = den = dot = n1 = 0.0
+    for n in eng.params.trainable:
+        mine = eng.params.gr(n).cpu().double()
+        r = P[n].grad.double()
+        num += float((mine - r).pow(2).sum()); den += float(r.pow(2).sum())
+        dot += float((mine * r).sum()); n1 += float(mine.pow(2).sum())
+    assert (num / den) ** 0.5 < 6e-2
+    assert dot / (n1 ** 0.5 * den ** 0.5) > 0.995
+    # the position table's gradient flows through the transposed interpolation
+    gp = eng.params.gr("embeddings.position_embeddings").cpu().double().reshape(-1)
+    rp = P["embeddings.position_embeddings"].grad.double().reshape(-1)
+    assert float((gp - rp).norm() / rp.norm()) < 6e-2
+    np.testing.assert_allclose(float(gp.norm()), float(g["grad_norms"][list(g["grad_names"]).index(
+        "embeddings.position_embeddings")]), rtol=6e-2)
+
+
 def test_full_size_against_reference_golden():
     """12+12 layers, hidden 768, B=2 (one padded caption): compare with numbers produced by the
     reference (HuggingFace ViltModel + RobertaModel under ref VaultForTMSC) in the build container."""
@@ -137,15 +191,19 @@ def test_unsupported_inputs_raise():
     spec = VaultSpec.tiny(3, "roberta")
     eng = VaultEngine(spec, "cuda:0", with_grads=False)
     bn = synthetic_batch(spec, 2, seed=3)
-    db = _dev(bn)
-    db["pixel_mask"] = db["pixel_mask"].clone()
-    db["pixel_mask"][0, :16] = 0
-    with pytest.raises(NotImplementedError):
-        eng.forward(db)
     db2 = _dev(bn)
-    db2["pixel_values"] = db2["pixel_values"][:, :, :96, :96]
+    db2["pixel_values"] = db2["pixel_values"][:, :, :90, :96]          # not a multiple of the patch size
     with pytest.raises(ValueError):
         eng.forward(db2)
+    db3 = _dev(bn)
+    db3["pixel_values"] = torch.zeros(2, 3, 320, 320, device="cuda")   # 400 patches: beyond the 320-key attention
+    db3["pixel_mask"] = torch.ones(2, 320, 320, dtype=torch.int64, device="cuda")
+    with pytest.raises(ValueError):
+        eng.forward(db3)
+    db4 = _dev(bn)
+    db4["pixel_values"] = db4["pixel_values"][:1]                      # batch mismatch (HF error)
+    with pytest.raises(ValueError):
+        eng.forward(db4)
 
 
 def test_model_api_autograd_bridge():

@@ -119,3 +119,42 @@ def test_tape_replay_matches_eager_steps():
     # sign-like AdamW steps flip on ~0 gradients whose float-atomic sums differ in the last bit: compare in bulk
     d = (res[False][1] - res[True][1]).abs()
     assert float(d.mean()) < 1e-6 and float((d > 1e-5).float().mean()) < 0.02
+
+
+
+def test_train_step_on_padded_image_batches_mixed_with_square_ones():
+    """The fine-tune step on batches of differently sized, padded images (general image path, one tape per image
+    geometry) interleaved with ordinary square batches: same trajectory with and without tape replay, and the
+    loss goes down when one padded batch is repeated."""
+    from vault_amd.spec import synthetic_ragged_batch
+    spec = VaultSpec.tiny(3, "bert")
+    state = build_state(spec, 0)
+    geos = [([(96, 160), (128, 64), (80, 80), (128, 160)], (128, 160)),
+            ([(128, 160), (64, 64), (96, 96), (32, 160)], (128, 160)),      # same canvas, other image sizes
+            None,                                                             # square all-valid batch
+            ([(96, 160), (128, 64), (80, 80), (128, 160)], (128, 160))]
+    batches = []
+    for i, gspec in enumerate(geos):
+        if gspec is None:
+            batches.append(synthetic_batch(spec, 4, seed=70 + i, n_classes=3))
+        else:
+            batches.append(synthetic_ragged_batch(spec, gspec[0], gspec[1], seed=70 + i, n_classes=3))
+    res = {}
+    for use_tape in (False, True):
+        eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+        step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10, use_tape=use_tape)
+        losses = []
+        for bn in batches:
+            db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
+            losses.append(float(step(db, torch.from_numpy(bn["labels"]).cuda())))
+        res[use_tape] = losses
+    la, lb = res[False], res[True]
+    assert max(abs(a - b) for a, b in zip(la, lb)) < 5e-4, (la, lb)
+    # repeat one padded batch: the loss must fall
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    step = TrainStep(eng, learning_rate=2e-4, warmup_ratio=0.0, total_steps=100, constant_lr=True)
+    bn = batches[0]
+    db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
+    lab = torch.from_numpy(bn["labels"]).cuda()
+    ls = [float(step(db, lab)) for _ in range(12)]
+    assert ls[-1] < ls[0] - 0.05, ls

@@ -1,5 +1,6 @@
 // Multi-head self-attention forward/backward for short sequences (S <= 32*NKT keys: the fused
-// [text | patch] sequence S = 185 -> NKT = 6, the text-only LM sequence S = 40 -> NKT = 2), d = 64.
+// [text | patch] sequence S = 185 -> NKT = 6, the text-only LM sequence S = 40 -> NKT = 2, padded batches of
+// larger images (up to 384 x 640 -> S = 281) -> NKT = 10), d = 64.
 //
 // One workgroup per (batch, head).  The whole K and V of the head live in LDS (XOR-swizzled 128-byte
 // rows); scores are computed transposed (S^T = K Q^T) so that the softmax'd tile is, register for
@@ -359,7 +360,7 @@ constexpr int attn_lds_bytes() { return NKT * 32 * 128 * 2 + NKT * 32 * 4 * 3; }
 extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
   if (!a || !a->qkv || (!a->ctx && !a->ctx_split3) || !a->lse || a->S <= 0 || a->B <= 0 || a->H != a->heads * 64)
     return VAULT_EINVAL;
-  if (a->S > 192) return VAULT_EINVAL;
+  if (a->S > 320) return VAULT_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const AttnDrop dr{a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale};
   dim3 grid(a->heads, a->B), block(256);
@@ -368,8 +369,20 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
     hipLaunchKernelGGL((attn_fwd_kernel<2, 4, 3>), grid, dim3(256), attn_lds_bytes<2>(), st, reinterpret_cast<const bf16*>(a->qkv),
                        a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
                        reinterpret_cast<bf16*>(a->ctx_split3));
-  } else {
+  } else if (a->S <= 192) {
     hipLaunchKernelGGL((attn_fwd_kernel<6, 12, 6>), grid, dim3(768), attn_lds_bytes<6>(), st, reinterpret_cast<const bf16*>(a->qkv),
+                       a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
+                       reinterpret_cast<bf16*>(a->ctx_split3));
+  } else {   // long sequences of padded, larger images: K/V image 80 KiB -> one block per CU
+    auto kern = attn_fwd_kernel<10, 4, 1>;
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         attn_lds_bytes<10>());
+      if (e != hipSuccess) return (int)e;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), attn_lds_bytes<10>(), st, reinterpret_cast<const bf16*>(a->qkv),
                        a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
                        reinterpret_cast<bf16*>(a->ctx_split3));
   }
@@ -380,7 +393,7 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
   if (!a || !a->qkv || !a->ctx || !a->lse || !a->dctx || !a->dqkv || a->S <= 0 || a->B <= 0 ||
       a->H != a->heads * 64)
     return VAULT_EINVAL;
-  if (a->S > 192) return VAULT_EINVAL;
+  if (a->S > 320) return VAULT_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const AttnDrop dr{a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale};
   dim3 grid(a->heads, a->B), block(256);
@@ -389,8 +402,20 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
     hipLaunchKernelGGL((attn_bwd_kernel<2, 4, 3>), grid, dim3(256), attn_lds_bytes<2>(), st, reinterpret_cast<const bf16*>(a->qkv),
                        a->keymask, reinterpret_cast<const bf16*>(a->ctx), reinterpret_cast<const bf16*>(a->dctx), a->lse,
                        reinterpret_cast<bf16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
-  } else {
+  } else if (a->S <= 192) {
     hipLaunchKernelGGL((attn_bwd_kernel<6, 4, 3>), grid, dim3(256), attn_lds_bytes<6>(), st, reinterpret_cast<const bf16*>(a->qkv),
+                       a->keymask, reinterpret_cast<const bf16*>(a->ctx), reinterpret_cast<const bf16*>(a->dctx), a->lse,
+                       reinterpret_cast<bf16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
+  } else {
+    auto kern = attn_bwd_kernel<10, 4, 1>;
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         attn_lds_bytes<10>());
+      if (e != hipSuccess) return (int)e;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), attn_lds_bytes<10>(), st, reinterpret_cast<const bf16*>(a->qkv),
                        a->keymask, reinterpret_cast<const bf16*>(a->ctx), reinterpret_cast<const bf16*>(a->dctx), a->lse,
                        reinterpret_cast<bf16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
   }

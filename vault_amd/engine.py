@@ -23,7 +23,7 @@ import torch
 
 from . import ops
 from .ops import Drop, NO_DROP
-from .spec import VaultSpec, build_state, param_entries
+from .spec import select_patches, VaultSpec, build_state, param_entries
 
 
 def _pad(n: int, m: int = 256) -> int:
@@ -211,7 +211,7 @@ class VaultEngine:
         self.vl = [_LayerNames(f"encoder.layer.{i}", "vilt") for i in range(spec.vilt.num_hidden_layers)]
         self.ll = ([_LayerNames(f"bert.encoder.layer.{i}", "bert") for i in range(spec.lm.num_hidden_layers)]
                    if spec.lm else [])
-        self._ws: Dict[Tuple[int, int, bool], dict] = {}
+        self._ws: Dict[tuple, dict] = {}
         self.drop_seed = 0
         self.last: Optional[dict] = None
         # optional live kernel timing (bench.py): {site: [(start, end, flops), ...]} of torch.cuda.Event pairs recorded
@@ -241,10 +241,18 @@ class VaultEngine:
             ws[name] = t
         return t
 
-    def workspace(self, B: int, T: int, train: bool) -> dict:
-        key = (B, T, train)
+    MAX_RAGGED_WORKSPACES = 2   # padded-image geometries kept alive (each owns every activation buffer of a step)
+
+    def workspace(self, B: int, T: int, train: bool, geom: Tuple[int, int, int] = (0, 0, 0)) -> dict:
+        """Buffers of one (batch, text length, mode, image geometry); geom = (L, HP, WP) for padded batches of
+        differently sized images, (0, 0, 0) for the square pre-training canvas with all-valid masks."""
+        key = (B, T, train) + tuple(geom)
         if key not in self._ws:
-            self._ws[key] = {"B": B, "T": T}
+            if geom != (0, 0, 0):
+                old = [k for k in self._ws if k[3:] != (0, 0, 0)]
+                while len(old) >= self.MAX_RAGGED_WORKSPACES:
+                    self._ws.pop(old.pop(0))
+            self._ws[key] = {"B": B, "T": T, "key": key}
         return self._ws[key]
 
     # ---- helpers ----------------------------------------------------------------------------
@@ -312,20 +320,42 @@ class VaultEngine:
         ids = batch["input_ids"]
         B, T = ids.shape
         H, FF, heads = v.hidden_size, v.intermediate_size, v.num_attention_heads
-        NP = v.num_patches
-        S = T + 1 + NP
         pix = batch["pixel_values"]
-        if tuple(pix.shape[1:]) != (v.num_channels, v.image_size, v.image_size):
-            raise ValueError(f"pixel_values must be [B,{v.num_channels},{v.image_size},{v.image_size}]; variable-size "
-                             "images / partial pixel masks are not implemented in this build")
+        if pix.dim() != 4 or pix.shape[1] != v.num_channels or pix.shape[2] % v.patch_size or pix.shape[3] % v.patch_size:
+            raise ValueError(f"pixel_values must be [B,{v.num_channels},HP,WP] with HP, WP multiples of the patch size "
+                             f"{v.patch_size}")
         if pix.shape[0] != B:
             raise ValueError("The text inputs and image inputs need to have the same batch size")
         pm = batch.get("pixel_mask")
-        if validate and pm is not None and not bool((pm != 0).all()):
-            raise NotImplementedError("partial pixel_mask (padded images) is not implemented in this build")
-        ws = self.workspace(B, T, train)
+        HP, WP = int(pix.shape[2]), int(pix.shape[3])
+        square = (HP == v.image_size and WP == v.image_size)
+        # padded batches of differently sized images (HF visual_embed, modeling_vilt.py:92-178): the patch bookkeeping
+        # runs on the host (like the reference's own python loops over the batch), the arithmetic on the device.
+        # ``validate=False`` on the square canvas means "the caller vouches for an all-ones pixel_mask" (no sync).
+        ragged = (not square) or (validate and pm is not None and not bool((pm != 0).all()))
+        geom = (0, 0, 0)
+        if ragged:
+            pm_h = np.ones((B, HP, WP), np.int64) if pm is None else pm.detach().cpu().numpy()
+            if pm_h.shape != (B, HP, WP):
+                raise ValueError("pixel_mask must be [B,HP,WP] like pixel_values")
+            sel, valid, hw, (gh, gw), L0 = select_patches(pm_h, v.patch_size, getattr(v, "max_image_length", -1))
+            # round the image part up to a multiple of 8 rows with more masked padding (fewer distinct geometries);
+            # the attention kernels hold at most 320 keys
+            cap = 320 - T - 1
+            if L0 > cap:
+                raise ValueError(f"fused sequence {T + 1 + L0} exceeds the attention kernels' 320 keys")
+            L = min(((L0 + 7) // 8) * 8, cap)
+            if L > L0:   # extra rows repeat the last slot and are masked like any padding
+                sel = np.concatenate([sel, np.repeat(sel[:, -1:], L - L0, axis=1)], axis=1)
+                valid = np.concatenate([valid, np.zeros((B, L - L0), np.int32)], axis=1)
+            geom = (L, HP, WP)
+            NP = L
+        else:
+            NP = v.num_patches
+        S = T + 1 + NP
+        ws = self.workspace(B, T, train, geom)
         ws.update(S=S, M=B * S, Mp=_pad(B * S), H=H, FF=FF, heads=heads, NP=NP, train=train,
-                  Ml=B * T, Mlp=_pad(B * T))
+                  Ml=B * T, Mlp=_pad(B * T), ragged=ragged, HP=HP, WP=WP)
         buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
         buf("in_ids", (B, T), torch.int64).copy_(ids)
         buf("in_pix", tuple(pix.shape)).copy_(pix)
@@ -336,6 +366,12 @@ class VaultEngine:
         else:
             km[:, :T] = am
             km[:, T:] = 1.0
+        if ragged:
+            ws["gw"] = gw
+            buf("in_sel", (B, NP), torch.int32).copy_(torch.from_numpy(np.ascontiguousarray(sel)))
+            buf("in_hw", (B, 2), torch.int32).copy_(torch.from_numpy(np.ascontiguousarray(hw)))
+            km[:, T + 1:] = torch.from_numpy(valid.astype(np.float32)).to(km.device)
+            ws["sel"], ws["hw"], ws["n_valid"] = ws["in_sel"], ws["in_hw"], valid.sum(axis=1)
         buf("in_amf", (B, T)).copy_(km[:, :T])
         tt = batch.get("token_type_ids")
         ws["ids"], ws["pix"], ws["amf"] = ws["in_ids"], ws["in_pix"], ws["in_amf"]
@@ -448,13 +484,22 @@ class VaultEngine:
         Mpp = _pad(B * NP)
         ws.update(Kp=Kp, Mpp=Mpp)
         apatch = buf("apatch_3" if pr else "apatch", (Mpp, W3 * Kp), bf)
-        ops.im2col(pix, apatch, B, v.num_channels, v.image_size, v.patch_size, split3=pr)
         addtab = buf("addtab", (NP, H))
-        ops.image_consts(P.w("embeddings.patch_embeddings.projection.bias"), P.w("embeddings.position_embeddings"),
-                         mt[1], P.w("embeddings.cls_token"), addtab, x[0], NP, H, B, S, T)
         wpn = "embeddings.patch_embeddings.projection.weight"
+        if ws["ragged"]:
+            # padded batch of differently sized images: selected patch slots only, per-image resized position table
+            ops.im2col_sel(pix, apatch, ws["sel"], B, NP, v.num_channels, ws["HP"], ws["WP"], v.patch_size, split3=pr)
+            ops.image_sel_consts(P.w("embeddings.patch_embeddings.projection.bias"), P.w("embeddings.position_embeddings"),
+                                 mt[1], P.w("embeddings.cls_token"), addtab, x[0], NP, H, B, S, T)
+        else:
+            ops.im2col(pix, apatch, B, v.num_channels, v.image_size, v.patch_size, split3=pr)
+            ops.image_consts(P.w("embeddings.patch_embeddings.projection.bias"), P.w("embeddings.position_embeddings"),
+                             mt[1], P.w("embeddings.cls_token"), addtab, x[0], NP, H, B, S, T)
         ops.gemm(apatch, P.wb3(wpn, H, Kp) if pr else P.wb(wpn, shape=(H, Kp)), x[0], Mpp, H, W3 * Kp, W3 * Kp, W3 * Kp,
                  H, 0, 0, ops.EPI_F32_PATCH, cfg=0, m_valid=B * NP, addtab=addtab, rpg=NP, gstride=S, goff=T + 1)
+        if ws["ragged"]:
+            ops.image_pos_sel_fwd(x[0], P.w("embeddings.position_embeddings"), ws["sel"], ws["hw"], B, NP, S, T, H,
+                                  ws["gw"], v.image_size // v.patch_size)
 
         # ------------------------------ ViLT encoder ------------------------------
         for i, ln in enumerate(self.vl):
@@ -622,10 +667,15 @@ class VaultEngine:
         dx0 = dx[cur]
         Kp, Mpp = ws["Kp"], ws["Mpp"]
         dyp = buf("dyp", (Mpp, H), bf)
-        gpos = P.gr("embeddings.position_embeddings", shape=(NP + 1, H))
+        gpos = P.gr("embeddings.position_embeddings", shape=(v.num_patches + 1, H))
         gmt = P.gr("embeddings.token_type_embeddings.weight")
-        ops.image_rows_bwd(dx0, gpos, gmt[1], P.gr("embeddings.cls_token", shape=(H,)),
-                           P.gr("embeddings.patch_embeddings.projection.bias"), dyp, NP, H, B, S, T)
+        if ws["ragged"]:
+            ops.image_sel_bwd(dx0, gpos, gmt[1], P.gr("embeddings.cls_token", shape=(H,)),
+                              P.gr("embeddings.patch_embeddings.projection.bias"), dyp, ws["sel"], ws["hw"], B, NP, S, T, H,
+                              ws["gw"], v.image_size // v.patch_size)
+        else:
+            ops.image_rows_bwd(dx0, gpos, gmt[1], P.gr("embeddings.cls_token", shape=(H,)),
+                               P.gr("embeddings.patch_embeddings.projection.bias"), dyp, NP, H, B, S, T)
         self._wgrad(dyp, ws["apatch"], "embeddings.patch_embeddings.projection.weight", None, Mpp, H, Kp, B * NP)
         dvs = buf("d_vt_sum", (Mlp, H))
         gbeta = P.gr("embeddings.text_embeddings.LayerNorm.bias")

@@ -17,8 +17,12 @@ What is kept from the reference interface
   * the reference's quirk that ``vilt_dropout_prob`` never reaches ViLT's internal dropouts
     (typo'd config attributes, model.py:72-75): only the TMSC head uses it.
 
-Not implemented in this build (raise): ``inputs_embeds`` / ``image_embeds`` inputs, partial pixel
-masks / variable-size images, ``output_attentions`` / ``output_hidden_states``.
+Padded batches of differently sized images (``pixel_mask`` with zeros, canvases other than the square
+pre-training one, up to 320 fused tokens) take the general image path of the engine: the order of the patch
+rows in ``last_hidden_state`` is row-major (the reference's is random), padding rows are masked.
+
+Not implemented in this build (raise): ``inputs_embeds`` / ``image_embeds`` inputs,
+``output_attentions`` / ``output_hidden_states``.
 
 There is no CPU or eager-PyTorch compute path: forward raises if the model is not on a GPU or the
 HIP library is missing.
@@ -58,7 +62,7 @@ def vilt_spec_from_config(cfg) -> ViltSpec:
     return ViltSpec(**{f: _get(cfg, f, getattr(d, f)) for f in (
         "vocab_size", "max_position_embeddings", "type_vocab_size", "modality_type_vocab_size", "hidden_size",
         "num_hidden_layers", "num_attention_heads", "intermediate_size", "layer_norm_eps", "image_size",
-        "patch_size", "num_channels")})
+        "patch_size", "num_channels", "max_image_length")})
 
 
 def lm_spec_from_config(cfg) -> Optional[LMSpec]:

@@ -257,6 +257,28 @@ def image_rows_bwd(dx, dpos, dmtype1, dcls, dbias, dyp_bf16, P, H, B, S, T):
             C.c_int(S), C.c_int(T), _stream())
 
 
+def im2col_sel(pix, out_bf16, sel, B, L, Cn, HP, WP, ps, split3=False):
+    _invoke("vault_im2col_sel", C.c_void_p(_p(pix)), C.c_void_p(_p(out_bf16)), C.c_void_p(_p(sel)), C.c_int(B), C.c_int(L),
+            C.c_int(Cn), C.c_int(HP), C.c_int(WP), C.c_int(ps), C.c_int(1 if split3 else 0), _stream())
+
+
+def image_sel_consts(bias, pos, mtype1, cls, addtab, x, L, H, B, S, T):
+    _invoke("vault_image_sel_consts", C.c_void_p(_p(bias)), C.c_void_p(_p(pos)), C.c_void_p(_p(mtype1)),
+            C.c_void_p(_p(cls)), C.c_void_p(_p(addtab)), C.c_void_p(_p(x)), C.c_int(L), C.c_int(H), C.c_int(B),
+            C.c_int(S), C.c_int(T), _stream())
+
+
+def image_pos_sel_fwd(x, pos, sel, hw, B, L, S, T, H, gw, G):
+    _invoke("vault_image_pos_sel_fwd", C.c_void_p(_p(x)), C.c_void_p(_p(pos)), C.c_void_p(_p(sel)), C.c_void_p(_p(hw)),
+            C.c_int(B), C.c_int(L), C.c_int(S), C.c_int(T), C.c_int(H), C.c_int(gw), C.c_int(G), _stream())
+
+
+def image_sel_bwd(dx, dpos, dmtype1, dcls, dbias, dyp_bf16, sel, hw, B, L, S, T, H, gw, G):
+    _invoke("vault_image_sel_bwd", C.c_void_p(_p(dx)), C.c_void_p(_p(dpos)), C.c_void_p(_p(dmtype1)), C.c_void_p(_p(dcls)),
+            C.c_void_p(_p(dbias)), C.c_void_p(_p(dyp_bf16)), C.c_void_p(_p(sel)), C.c_void_p(_p(hw)), C.c_int(B),
+            C.c_int(L), C.c_int(S), C.c_int(T), C.c_int(H), C.c_int(gw), C.c_int(G), _stream())
+
+
 def axpy(dst, src, a, n):
     _invoke("vault_axpy_f32", C.c_void_p(_p(dst)), C.c_void_p(_p(src)), C.c_float(a), C.c_longlong(n), _stream())
 

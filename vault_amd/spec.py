@@ -66,6 +66,7 @@ class ViltSpec:
     image_size: int = 384
     patch_size: int = 32
     num_channels: int = 3
+    max_image_length: int = -1     # ViltConfig.max_image_length: cap on the image part of the sequence (-1: none)
 
     @property
     def grid(self) -> int:

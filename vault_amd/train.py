@@ -122,7 +122,8 @@ class TrainStep:
     def __init__(self, engine: VaultEngine, learning_rate: float = 2e-5, adam_beta1: float = 0.9,
                  adam_beta2: float = 0.999, adam_epsilon: float = 1e-8, weight_decay: float = 0.0,
                  correct_bias: bool = False, warmup_ratio: float = 0.1, total_steps: int = 1000,
-                 process_group=None, bucket_mb: float = 64.0, constant_lr: bool = False, use_tape: bool = True):
+                 process_group=None, bucket_mb: float = 64.0, constant_lr: bool = False, use_tape: bool = True,
+                 assume_full_pixel_mask: bool = False):
         self.engine = engine
         self.lr, self.b1, self.b2, self.eps, self.wd = learning_rate, adam_beta1, adam_beta2, adam_epsilon, weight_decay
         self.correct_bias = correct_bias
@@ -134,6 +135,10 @@ class TrainStep:
         self.use_tape = use_tape
         self._tape = None
         self._tape_key = None
+        self._tape_ws = None
+        # True: the caller vouches that every pixel_mask is all ones on the square pre-training canvas (no device
+        # sync per step); False: the mask is checked each step and padded batches take the general image path
+        self.assume_full_pixel_mask = assume_full_pixel_mask
         self._loss_buf = None
         self.world = 1
         self.reducer: Optional[BucketReducer] = None
@@ -157,14 +162,15 @@ class TrainStep:
         tape (ops.Tape); later calls copy the batch into the persistent input buffers and replay it."""
         eng = self.engine
         B, T = batch["input_ids"].shape
-        key = (B, T)
         with torch.cuda.device(eng.device):
-            if self.use_tape and self._tape is not None and self._tape_key == key:
-                eng.stage_inputs(batch, True, labels, validate=False)
+            # staging decides the image geometry (square all-valid canvas, or a padded batch of differently sized
+            # images: host-side patch selection); every geometry has its own workspace, hence its own tape
+            ws = eng.stage_inputs(batch, True, labels, validate=not self.assume_full_pixel_mask)
+            key = ws["key"]
+            if self.use_tape and self._tape is not None and self._tape_key == key and self._tape_ws is ws:
                 eng.drop_seed = (eng.drop_seed + 1) & 0xFFFFFFFF
                 self._tape.replay(seed=eng.drop_seed)
             else:
-                ws = eng.stage_inputs(batch, True, labels)
                 eng.drop_seed = (eng.drop_seed + 1) & 0xFFFFFFFF
                 tape = ops.start_tape() if self.use_tape else None
                 try:
@@ -174,7 +180,7 @@ class TrainStep:
                 finally:
                     if self.use_tape:
                         ops.stop_tape()
-                self._tape, self._tape_key, self._loss_buf = tape, key, out["loss"]
+                self._tape, self._tape_key, self._tape_ws, self._loss_buf = tape, key, ws, out["loss"]
             if self.reducer:
                 self.reducer.finish()
             self.optimizer_step()
