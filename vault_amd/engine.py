@@ -332,13 +332,19 @@ class VaultEngine:
         # padded batches of differently sized images (HF visual_embed, modeling_vilt.py:92-178): the patch bookkeeping
         # runs on the host (like the reference's own python loops over the batch), the arithmetic on the device.
         # ``validate=False`` on the square canvas means "the caller vouches for an all-ones pixel_mask" (no sync).
-        ragged = (not square) or (validate and pm is not None and not bool((pm != 0).all()))
+        if pm is not None and tuple(pm.shape) != (B, HP, WP):
+            raise ValueError("pixel_mask must be [B,HP,WP] like pixel_values")
+        # only the patch grid of the mask matters (nearest-neighbour interpolation reads pixel_mask[:, ::ps, ::ps]):
+        # subsample on the device, bring B x gh x gw bytes to the host
+        grid_h = None
+        if pm is not None and (validate or not square):
+            grid_h = (pm[:, ::v.patch_size, ::v.patch_size] != 0).to(torch.uint8).cpu().numpy()
+        ragged = (not square) or (grid_h is not None and not bool(grid_h.all()))
         geom = (0, 0, 0)
         if ragged:
-            pm_h = np.ones((B, HP, WP), np.int64) if pm is None else pm.detach().cpu().numpy()
-            if pm_h.shape != (B, HP, WP):
-                raise ValueError("pixel_mask must be [B,HP,WP] like pixel_values")
-            sel, valid, hw, (gh, gw), L0 = select_patches(pm_h, v.patch_size, getattr(v, "max_image_length", -1))
+            if grid_h is None:
+                grid_h = np.ones((B, HP // v.patch_size, WP // v.patch_size), np.uint8)
+            sel, valid, hw, (gh, gw), L0 = select_patches(grid_h, 1, getattr(v, "max_image_length", -1))
             # round the image part up to a multiple of 8 rows with more masked padding (fewer distinct geometries);
             # the attention kernels hold at most 320 keys
             cap = 320 - T - 1

@@ -278,11 +278,17 @@ def select_patches(pixel_mask: np.ndarray, patch_size: int, max_image_length: in
     """
     pm = np.asarray(pixel_mask)
     B, Hp, Wp = pm.shape
-    gh, gw = Hp // patch_size, Wp // patch_size
-    # nn.functional.interpolate(mode="nearest") to (gh, gw): source index floor(dst * Hp / gh)
-    ri = (np.arange(gh) * Hp) // gh
-    ci = (np.arange(gw) * Wp) // gw
-    xm = (pm[:, ri][:, :, ci] != 0).astype(np.int64)          # [B, gh, gw]
+    if patch_size == 1:
+        # already on the patch grid (the engine subsamples on the device: pixel_mask[:, ::ps, ::ps] is exactly what
+        # nearest-neighbour interpolation to the grid reads)
+        gh, gw = Hp, Wp
+        xm = (pm != 0).astype(np.int64)
+    else:
+        gh, gw = Hp // patch_size, Wp // patch_size
+        # nn.functional.interpolate(mode="nearest") to (gh, gw): source index floor(dst * Hp / gh)
+        ri = (np.arange(gh) * Hp) // gh
+        ci = (np.arange(gw) * Wp) // gw
+        xm = (pm[:, ri][:, :, ci] != 0).astype(np.int64)          # [B, gh, gw]
     x_h = xm.sum(axis=1)[:, 0]
     x_w = xm.sum(axis=2)[:, 0]
     eff = x_h * x_w
