@@ -280,7 +280,14 @@ class VaultEngine:
         if gw is None:
             return
         nk = Mtok_pad // 64
-        if Nout % 256 == 0 and Kin % 256 == 0:
+        if Mtok_pad <= 16384 and Nout % 128 == 0 and Kin % 128 == 0:
+            # short contractions (the LM's 40-token sequences: 10240 rows at B = 256): 128x128 tiles with few splits
+            # beat the 256x256 ring kernel, whose tiles x splits cannot fill the chip without very short K ranges
+            # (tools/wgrad_sweep.py; in-step A/B on one box: +1.0 % samples/s)
+            tiles = (Nout // 128) * (Kin // 128)
+            splits = 7 if tiles <= 36 else (4 if tiles <= 108 else 3)
+            cfg = 0
+        elif Nout % 256 == 0 and Kin % 256 == 0:
             # 256x256 ring kernel; split the token contraction so that tiles x splits fills the 256 CUs once
             tiles = (Nout // 256) * (Kin // 256)
             splits = max(1, min(nk // 2, 256 // tiles, 16))   # >16 partial sums per element: float atomics dominate
