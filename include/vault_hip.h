@@ -29,7 +29,10 @@ int vault_abi_version(void);
  * epi: 0 bf16 out (+bias) | 1 bf16 gelu(acc+bias) (+ out2 = gelu'(acc+bias)) | 2 bf16 acc*aux (aux = that gelu')
  *      3 f32 out = dropout(acc+bias)+res | 4 f32 patch rows (row remap + addtab) | 5 f32 out += acc.
  * M % 128 == 0, N % 128 == 0, K % 64 == 0; buffers must be allocated to those padded sizes.
- * Rows >= m_valid are not stored.  cfg < 0 selects the tile automatically. */
+ * Rows >= m_valid are not stored.  cfg < 0 selects the kernel/tile automatically; explicit values: 0 / 1 / 2 =
+ * double-buffered kernel with 128x128 / 256x128 / 256x256 tiles, 3 / 4 = persistent ring kernel with
+ * 256x256 / 256x192 tiles (M % 256 == 0, N % 256 / 192 == 0; its residual epilogue needs `res`, without one
+ * the launcher takes the double-buffered kernel). */
 typedef struct vault_gemm_args {
   const void* A; const void* B; void* out; void* out2;
   const float* bias; const float* res; const void* aux; const float* addtab;
