@@ -243,7 +243,7 @@ extern "C" int vault_image_consts(const float* bias, const float* pos, const flo
 extern "C" int vault_image_rows_bwd(const float* dx, float* dpos, float* dmtype1, float* dcls, float* dbias,
                                     void* dyp_bf16, int P, int H, int B, int S, int T, void* stream) {
   if (!dx || !dpos || !dmtype1 || !dcls || !dbias || !dyp_bf16) return VAULT_EINVAL;
-  const int bpb = 8;
+  const int bpb = 32;   // samples per block: fewer blocks hammer the shared dmtype1 / dbias / dcls addresses with atomics
   hipLaunchKernelGGL(image_rows_bwd_kernel, dim3(P + 1, (B + bpb - 1) / bpb), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), dx, dpos, dmtype1, dcls, dbias,
                      reinterpret_cast<bf16*>(dyp_bf16), P, H, B, S, T, bpb);

@@ -188,7 +188,7 @@ extern "C" int vault_image_sel_bwd(const float* dx, float* dpos, float* dmtype1,
                                    const int* sel, const int* hw, int B, int L, int S, int T, int H, int gw, int G,
                                    void* stream) {
   if (!dx || !dpos || !dmtype1 || !dcls || !dbias || !dyp_bf16 || !sel || !hw || B <= 0 || L <= 0) return VAULT_EINVAL;
-  const int bpb = 8;
+  const int bpb = 32;   // samples per block: fewer blocks hammer the shared dmtype1 / dbias / dcls addresses with atomics
   hipLaunchKernelGGL(image_sel_bwd_kernel, dim3(L + 1, (B + bpb - 1) / bpb), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), dx, dpos, dmtype1, dcls, dbias, reinterpret_cast<bf16*>(dyp_bf16),
                      sel, hw, L, H, B, S, T, gw, G, bpb);

@@ -509,7 +509,7 @@ class VaultEngine:
             ops.image_consts(P.w("embeddings.patch_embeddings.projection.bias"), P.w("embeddings.position_embeddings"),
                              mt[1], P.w("embeddings.cls_token"), addtab, x[0], NP, H, B, S, T)
         ops.gemm(apatch, P.wb3(wpn, H, Kp) if pr else P.wb(wpn, shape=(H, Kp)), x[0], Mpp, H, W3 * Kp, W3 * Kp, W3 * Kp,
-                 H, 0, 0, ops.EPI_F32_PATCH, cfg=0, m_valid=B * NP, addtab=addtab, rpg=NP, gstride=S, goff=T + 1)
+                 H, 0, 0, ops.EPI_F32_PATCH, m_valid=B * NP, addtab=addtab, rpg=NP, gstride=S, goff=T + 1)
         if ws["ragged"]:
             ops.image_pos_sel_fwd(x[0], P.w("embeddings.position_embeddings"), ws["sel"], ws["hw"], B, NP, S, T, H,
                                   ws["gw"], v.image_size // v.patch_size)
