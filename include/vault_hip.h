@@ -43,7 +43,9 @@ typedef struct vault_gemm_args {
   int rpg, gstride, goff;
   uint32_t drop_thresh, drop_seed, drop_stream; float drop_scale;
   int gn;   /* tuning: n-tiles per raster group (0 = default, plain m-major raster) */
-  int persist; /* tuning: 2 = one block per tile instead of the default persistent grid (double-buffered kernel) */
+  int persist; /* scheduling: bit 0 = ring kernel hands tiles out dynamically (per-XCD ticket counters), bit 1 = the
+                  double-buffered kernel launches one block per tile instead of its persistent grid; 3 when the GEMMs
+                  share the GPU with another kernel (RCCL collectives of a data-parallel step), 0 otherwise */
 } vault_gemm_args;
 int vault_gemm(const vault_gemm_args* args, void* stream);
 

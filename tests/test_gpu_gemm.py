@@ -15,7 +15,7 @@ EPI_BF16, EPI_GELU, EPI_DGELU, EPI_RES, EPI_PATCH, EPI_ATOMIC = range(6)
 
 
 def _gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, cfg=-1, m_valid=0, splits=1, bias=None,
-          res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, accumulate=0, colsum=None):
+          res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, accumulate=0, colsum=None, persist=0):
     lib = L.load()
     a = L.GemmArgs()
     a.A, a.B, a.out = A.data_ptr(), B.data_ptr(), out.data_ptr()
@@ -28,6 +28,7 @@ def _gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, cfg=-1, m_vali
     a.M, a.N, a.K, a.lda, a.ldb, a.ldo, a.m_valid = M, N, K, lda, ldb, ldo, m_valid
     a.a_mode, a.b_mode, a.epi, a.cfg, a.splits, a.accumulate = a_mode, b_mode, epi, cfg, splits, accumulate
     a.rpg, a.gstride, a.goff = rpg, gstride, goff
+    a.persist = persist
     st = torch.cuda.current_stream().cuda_stream
     L.check(lib.vault_gemm(C.byref(a), C.c_void_p(st)), "vault_gemm")
 
@@ -287,3 +288,45 @@ def test_ring_kernel_persistent_wgrad(splits):
     _gemm(A, B, out, M, N, K, M, N, N, 1, 1, EPI_ATOMIC, cfg=3, splits=splits)
     torch.cuda.synchronize()
     assert (out - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+
+@pytest.mark.parametrize("cfg", [3, 4])
+@pytest.mark.parametrize("epi", ["bf16", "res"])
+def test_ring_kernel_dynamic_scheduler(cfg, epi):
+    """persist = 1: work items handed out by per-XCD ticket counters (with stealing) instead of the static
+    block -> items walk; many back-to-back launches also exercise the self-reset of the counters."""
+    M, N, K = 256 * 43, (1536 if cfg == 4 else 2048), 320
+    A = _rand(M, K, seed=61).bfloat16()
+    W = _rand(N, K, scale=0.05, seed=62).bfloat16()
+    bias = _rand(N, seed=63)
+    z = A.float() @ W.float().t() + bias
+    res = _rand(M, N, seed=64)
+    for rep in range(6):
+        if epi == "bf16":
+            out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_BF16, cfg=cfg, bias=bias, persist=1)
+            ref, tol = z, z.abs().max().item() * 2 ** -7
+        else:
+            out = torch.zeros(M, N, device="cuda")
+            _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_RES, cfg=cfg, bias=bias, res=res, persist=1)
+            ref, tol = z + res, 2e-4 * z.abs().max().item()
+        # a small launch in between: fewer work items than blocks (every block exits after its static item)
+        o2 = torch.zeros(512, 512, dtype=torch.bfloat16, device="cuda")
+        _gemm(A[:512], W[:512], o2, 512, 512, K, K, K, 512, 0, 0, EPI_BF16, cfg=3, persist=1)
+        torch.cuda.synchronize()
+        assert (out.float() - ref).abs().max().item() <= tol
+        r2 = A[:512].float() @ W[:512].float().t()
+        assert (o2.float() - r2).abs().max().item() <= r2.abs().max().item() * 2 ** -7
+
+
+def test_ring_kernel_dynamic_scheduler_wgrad_splits():
+    M, N, K = 3072, 3072, 1280
+    A = _rand(K, M, seed=71).bfloat16()
+    B = _rand(K, N, scale=0.05, seed=72).bfloat16()
+    ref = A.float().t() @ B.float()
+    for splits in (1, 3, 8):
+        out = torch.zeros(M, N, device="cuda")
+        _gemm(A, B, out, M, N, K, M, N, N, 1, 1, EPI_ATOMIC, cfg=3, splits=splits, persist=1)
+        torch.cuda.synchronize()
+        assert (out - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()

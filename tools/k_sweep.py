@@ -19,4 +19,5 @@ for K in (64, 128, 256, 768, 1536, 3072):
         L.check(L.load().vault_gemm(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm")
     print(f"K={K:5d}", " ".join(f"cfg{c}:{t(lambda: run(c)):7.1f}us" for c in (0, 2, 3)), "| persistent",
           " ".join(f"cfg{c}:{t(lambda: run(c, 1)):7.1f}us" for c in (0, 2)),
-          "| no-store (m_valid=256)", " ".join(f"cfg{c}:{t(lambda: run(c, 0, 256)):7.1f}us" for c in (2, 3)))
+          "| no-store (m_valid=256)", " ".join(f"cfg{c}:{t(lambda: run(c, 0, 256)):7.1f}us" for c in (2, 3)),
+          f"| cfg3 dynamic scheduler: {t(lambda: run(3, 1)):7.1f}us")

@@ -35,7 +35,9 @@ struct GemmParams {
   // inverted dropout on (acc + bias) for EPI_F32_RES; thresh == 0 disables it
   uint32_t drop_thresh, drop_seed, drop_stream;
   float drop_scale;
-  int persist;      // double-buffered kernel: persistent grid (<= resident blocks, each walks several tiles) unless 2
+  int persist;      // bit 0: ring kernel hands its work items out dynamically (ticket counters); bit 1: double-buffered
+                    // kernel launches one block per tile instead of its persistent grid.  3 = both: for GEMMs that share
+                    // the GPU with another kernel (RCCL collectives of a data-parallel step)
   int gn;           // n-tiles per raster group (set by the launcher: B panel of a group stays L2-resident)
 };
 

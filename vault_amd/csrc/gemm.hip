@@ -214,7 +214,7 @@ int launch_cfg(const GemmParams& p, hipStream_t st) {
   // resident blocks: 256 CUs x (blocks that fit: LDS-limited, 160 KiB per CU)
   const int resident = 256 * std::max(1, (160 * 1024) / LDS);
   const int total = (p.M / BM) * (p.N / BN);
-  dim3 grid(p.persist != 2 ? std::min(total, resident) : total, 1, p.splits);   // persistent unless persist == 2
+  dim3 grid((p.persist & 2) == 0 ? std::min(total, resident) : total, 1, p.splits);   // persistent unless (persist & 2)
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), LDS, st, q);
   return (int)hipGetLastError();
 }

@@ -12,7 +12,12 @@
 //   * each phase multiplies one quadrant (64 x 64 per wave, 32 MFMAs) while the fragments of the next
 //     quadrant are read from LDS; quadrants are walked 00,01,11,10 | 01,00,10,11 so that every
 //     fragment set is loaded exactly once per K tile and two of the four sets are always reusable.
-// The grid is persistent (<= 256 blocks, block b walks work items b, b + grid, ...).  The epilogue of one
+// The grid is persistent (<= 256 blocks): block b walks work items b, b + grid, ...  With (GemmParams.persist & 1)
+// the items are handed out DYNAMICALLY instead: the items with id % 8 == x belong to XCD x (contiguous tile runs
+// per L2, see gemm_tile_of_block); block b starts with item b and then draws tickets from its XCD's counter (one
+// returning atomic per tile), stealing from the other XCDs' counters when its own is exhausted.  A block that
+// cannot get a CU at launch (another kernel - an RCCL collective on a second stream - holds it) then costs its
+// share of throughput, not a second pass over a statically assigned tile list: the mode for data-parallel runs.  The epilogue of one
 // tile overlaps the start of the next: its LDS scratch lies outside the ring, one half-tile of the next
 // tile's first two K tiles is issued per 16-row epilogue step, and the global stores of the epilogue are
 // never waited for explicitly - VMEM operations retire in issue order, so the counted waits of the next
@@ -29,6 +34,11 @@
 #include "gemm_epi.h"
 
 namespace {
+
+// Dynamic tile scheduler state (one per device code object; kernels of ONE stream are serialised, which is how the
+// engine launches them): two sets of eight per-XCD ticket counters.  Launch k draws from set k & 1 and clears the
+// other set for launch k + 1 (no end-of-kernel reset, no "last block" bookkeeping).
+__device__ unsigned int g_ring_tickets[2][8];
 
 constexpr int HT = 16384;      // half-tile bytes
 constexpr int BUFB = 4 * HT;   // one K tile: A0 A1 B0 B1
@@ -71,6 +81,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   constexpr int TN = 2 * NTQ;
+  constexpr int SCRATCH_BYTES = 4 * 16 * ((NTQ == 4 ? 64 : 96) + 4) * 4;   // epilogue scratch (gemm_epi.h), then 16 B scheduler word
   constexpr bool F32OUT = (EPI == EPI_F32_RES || EPI == EPI_F32_PATCH);
   // VMEM operations every wave is certain to issue in one 16-row epilogue step of a fully valid tile
   constexpr int SPS = (EPI == EPI_F32_ATOMIC) ? 16 * (TN * 16 / 64) : (F32OUT ? TN : TN / 2);
@@ -107,6 +118,17 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   };
   int w = blockIdx.x;
   setup(w);
+  // dynamic scheduler: items of XCD x are x + 8 j ; the first n_static_x of them are the blocks' own start items
+  const int xcd = blockIdx.x & 7;
+  auto items_of = [&](int x) { return x < nwork ? (nwork - x + 7) >> 3 : 0; };          // j < items_of(x)
+  auto static_of = [&](int x) { return x < (int)gridDim.x ? ((int)gridDim.x - x + 7) >> 3 : 0; };
+  // a ticket stands for TICKET_ITEMS consecutive items of an XCD's list: one returning atomic per that many tiles
+  constexpr int TICKET_ITEMS = 2;
+  int pend_w = -1;           // thread 0: second item of the current ticket, not yet started
+  int last_tk = 0;           // thread 0: last ticket drawn from the own list
+  const bool dyn = (p.persist & 1) != 0;   // dynamic hand-out of work items (else: block b walks b, b + grid, ...)
+  unsigned int* const tickets = g_ring_tickets[(p.persist >> 8) & 1];   // bit 8: launch parity (set by the launcher)
+  if (dyn && blockIdx.x == 0 && tid < 8) g_ring_tickets[((p.persist >> 8) & 1) ^ 1][tid] = 0u;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int j = wave * 4 + i;
@@ -319,8 +341,58 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> accumulator reads (hazard is invisible inside asm)
 
     const int em0 = m0, en0 = n0;
-    const int wnext = w + gridDim.x;
-    const bool more = wnext < nwork;
+    // ---- next work item: own XCD's ticket, else steal; broadcast through LDS
+    int* sched_lds = reinterpret_cast<int*>(smem + 2 * BUFB + SCRATCH_BYTES);
+    if (!dyn) {
+      if (tid == 0) *sched_lds = (w + (int)gridDim.x < nwork) ? w + (int)gridDim.x : -1;
+    } else if (tid == 0) {
+      // dynamic mode.  The returning atomic is drawn HERE, where wave 0 has nothing in flight (a wait for its
+      // result anywhere else would also wait for staging loads or for the previous tile's stores): about one
+      // L2 round trip per TICKET_ITEMS tiles on the critical path.
+      int wn = -1;
+      const bool drew = pend_w < 0;
+      if (!drew) {                      // second item of the ticket in hand
+        wn = pend_w;
+        pend_w = -1;
+      } else {
+        auto tickets_of = [&](int x) { return (items_of(x) - static_of(x) + TICKET_ITEMS - 1) / TICKET_ITEMS; };
+        auto take = [&](int x, unsigned int tk) {   // items x + 8 j, j = static_of(x) + TICKET_ITEMS * tk + {0, 1}
+          const int j = static_of(x) + TICKET_ITEMS * (int)tk;
+          if (j < items_of(x)) {
+            wn = x + 8 * j;
+            if (j + 1 < items_of(x)) pend_w = x + 8 * (j + 1);
+          }
+        };
+        // Far from the end of this XCD's list (judged by the last ticket this block drew): draw directly.
+        if (last_tk + 2 * static_of(xcd) < tickets_of(xcd)) {
+          const unsigned int tk = atomicAdd(tickets + xcd, 1u);
+          last_tk = (int)tk;
+          take(xcd, tk);
+        }
+        // Near the end: one batch of plain (device-scope) loads first - every block finds its list exhausted at
+        // about the same time, and 256 failing atomics on the same few addresses would serialise in L2.
+        for (int attempt = 0; attempt < 4 && wn < 0; ++attempt) {
+          unsigned int cnt[8];
+#pragma unroll
+          for (int y = 0; y < 8; ++y) cnt[y] = __hip_atomic_load(tickets + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          int best = -1, best_left = 0;
+#pragma unroll
+          for (int y = 0; y < 8; ++y) {
+            const int left = tickets_of(y) - (int)cnt[y];
+            // own list first; otherwise steal from the list with the most tickets left
+            if (left > 0 && (y == xcd || (best != xcd && left > best_left))) { best = y; best_left = left; }
+          }
+          if (best < 0) break;
+          const unsigned int tk = atomicAdd(tickets + best, 1u);
+          if (best == xcd) last_tk = (int)tk;
+          take(best, tk);
+        }
+      }
+      *sched_lds = wn;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int wnext = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(sched_lds));
+    const bool more = wnext >= 0;
     if (more) setup(wnext);
     gemm_epilogue<8, TN, EPI, 2, 2, true>(acc, p, smem + 2 * BUFB, em0, en0, wr * 128, wc * (NTQ * 32), wave, lane,
                                           [&](int step) { if (more) stage_first(step); }, more ? 4 : 0);
@@ -340,11 +412,17 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
 #undef CAPW
 }
 
+// launch parity of the dynamic scheduler's counter sets: ONE sequence for every instantiation of the kernel
+inline int next_parity() {
+  static unsigned seq = 0;
+  return (int)(seq++ & 1u);
+}
+
 template <int A_MODE, int B_MODE, int EPI, int NTQ>
 int launch256(const GemmParams& p, hipStream_t st) {
   constexpr int BNT = NTQ * 64;
   if ((p.M & 255) || (p.N % BNT) || (p.K & 63)) return VAULT_EINVAL;
-  constexpr int LDS = 2 * BUFB + 4 * 16 * ((NTQ == 4 ? 64 : 96) + 4) * 4;   // ring + epilogue scratch (gemm_epi.h: 16 x LD floats per wave)
+  constexpr int LDS = 2 * BUFB + 4 * 16 * ((NTQ == 4 ? 64 : 96) + 4) * 4 + 16;   // ring + epilogue scratch (gemm_epi.h: 16 x LD floats per wave) + scheduler word
   auto kern = gemm256_kernel<A_MODE, B_MODE, EPI, NTQ>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -359,6 +437,7 @@ int launch256(const GemmParams& p, hipStream_t st) {
   q.splits = (nk_total + per - 1) / per;                        // every split owns at least one K tile
   const int nwork = (p.M >> 8) * (p.N / BNT) * q.splits;
   dim3 grid(std::min(nwork, 256), 1, 1);
+  q.persist = (p.persist & 0xff) | (((p.persist & 1) ? next_parity() : 0) << 8);   // the sequence counts dynamic launches only
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, q);
   return (int)hipGetLastError();
 }

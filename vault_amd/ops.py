@@ -119,6 +119,13 @@ class Drop:
 NO_DROP = Drop()
 
 
+# GEMM scheduling mode (vault_gemm_args.persist): 3 while the GEMMs share the GPU with RCCL collectives on another
+# stream (train.TrainStep sets it for world size > 1): tiles are handed out dynamically / one block per tile, so a CU
+# held by the collective costs its share of throughput instead of a second pass over a static tile list
+# (tools/contention_test.py: 196-230 us instead of 271-281 us with 8-64 CUs held, 189 us alone)
+GEMM_SCHED = int(__import__("os").environ.get("VAULT_GEMM_SCHED", "0"))   # env: exercise the mode on one GPU
+
+
 def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_valid=0, splits=1, accumulate=0,
          bias=None, res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, drop: Drop = NO_DROP,
          colsum=None, split3=False):
@@ -130,6 +137,7 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_va
     a.M, a.N, a.K, a.lda, a.ldb, a.ldo, a.m_valid = M, N, K, lda, ldb, ldo, m_valid
     a.a_mode, a.b_mode, a.epi, a.cfg, a.splits, a.accumulate = a_mode, b_mode, epi, cfg, splits, accumulate
     a.rpg, a.gstride, a.goff = rpg, gstride, goff
+    a.persist = GEMM_SCHED
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
     _invoke("vault_gemm", C.byref(a), _stream(), struct=a, drop=drop)
 

@@ -147,6 +147,11 @@ class TrainStep:
             self.world = dist.get_world_size(process_group)
         import os
         # VAULT_FORCE_DP=1 exercises the bucketed all-reduce path even with a single rank (debug/testing)
+        if self.world > 1:
+            # the gradient all-reduce (RCCL kernels on a side stream) shares the CUs with the backward GEMMs: hand the
+            # GEMM tiles out dynamically so that a CU held by the collective does not stall a static tile walk.
+            # (The tape records the argument structs: this must be set before the first step is recorded.)
+            ops.GEMM_SCHED = 3
         if self.world > 1 or (os.environ.get("VAULT_FORCE_DP") == "1" and dist.is_available() and dist.is_initialized()):
             b = GradBuckets(engine, bucket_mb)
             self.reducer = BucketReducer(engine.params.g, b.stage_lo, b.last_tag, b.bucket_elems, dist, process_group,
