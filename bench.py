@@ -11,7 +11,7 @@ RCCL all-reduce of gradients).
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").  `roofline` is the dominant kernel of the
 step by GPU time (rocprofv3 --stats, profiles/): the weight-gradient instantiation of the bf16 MFMA ring
 GEMM, gemm256_kernel<1,1,EPI_F32_ATOMIC,4>, timed live with events on the launch stream around all of its
-launches in every 4th timed step; `roofline_ffn1` is the same for the FFN-in forward instantiation (the
+launches (ViLT layers + patch projection) in every 4th timed step; `roofline_ffn1` is the same for the FFN-in forward instantiation (the
 largest single GEMM call site); `step_mfma_frac` is the whole step against the 2.5 PFLOP/s dense bf16 peak
 with BASELINE.md's 120.67 GFLOP/sample.  `cpu_baseline` times the CPU oracle (plain fp32 torch
 restatement of the reference path) on the host cores, on a bounded sample.
@@ -179,8 +179,9 @@ def main():
                     "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
                     "traffic": traffic, "launches_timed": len(ms), "avg_launch_ms": round(float(np.mean(ms)), 4)}
 
-        r_wgrad = roof("wgrad", "gemm256_kernel<1,1,5,4> (A[K][M]^T B[K][N], EPI_F32_ATOMIC, split-K): every weight-gradient "
-                                f"GEMM of the step, dW[N x K] += dY[{M} | {B * 40} tokens][N]^T X[tokens][K]",
+        r_wgrad = roof("wgrad", "gemm256_kernel<1,1,5,4> (A[K][M]^T B[K][N], EPI_F32_ATOMIC, split-K): the weight-gradient GEMMs "
+                                f"of the ViLT layers and the patch projection, dW[N x K] += dY[{M} tokens][N]^T X[tokens][K] "
+                                "(the LM's 40-token contractions take the 128x128 double-buffered kernel)",
                        "r01_pmc_gemm_wgrad.json")
         r_ffn1 = roof("ffn1", "gemm256_kernel<0,0,1,4> (EPI_BF16_GELU): FFN-in forward, ViLT "
                               f"[{M}x{v.intermediate_size}x{v.hidden_size}] + LM [{B * 40}x{v.intermediate_size}x{v.hidden_size}]",

@@ -46,16 +46,23 @@ struct GemmParams {
 // gets a contiguous run of the raster order; the raster walks column GROUPS of `gn` n-tiles, all m-tiles of a
 // group before the next group, so that a group's B panel (gn x BN x K) stays L2-resident while the A row
 // panels stream through once per group.
-__device__ __forceinline__ void gemm_tile_of_block(int nwg, int id, int tiles_m, int tiles_n, int gn, int& tile_m,
-                                                   int& tile_n) {
-  const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
-  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+// XCD-contiguous renumbering: ids with equal id % 8 run on one XCD; give each XCD a contiguous run of `n` items
+__device__ __forceinline__ int gemm_xcd_contiguous(int n, int id) {
+  const int q = n >> 3, r = n & 7, xcd = id & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+}
+// raster position -> tile: column groups of `gn` n-tiles, all m-tiles of a group before the next group
+__device__ __forceinline__ void gemm_raster(int wg, int tiles_m, int tiles_n, int gn, int& tile_m, int& tile_n) {
   const int per_group = tiles_m * gn;
   const int grp = wg / per_group;
   const int rem = wg - grp * per_group;
   const int gw = min(gn, tiles_n - grp * gn);
   tile_m = rem / gw;
   tile_n = grp * gn + (rem - tile_m * gw);
+}
+__device__ __forceinline__ void gemm_tile_of_block(int nwg, int id, int tiles_m, int tiles_n, int gn, int& tile_m,
+                                                   int& tile_n) {
+  gemm_raster(gemm_xcd_contiguous(nwg, id), tiles_m, tiles_n, gn, tile_m, tile_n);
 }
 #endif
 

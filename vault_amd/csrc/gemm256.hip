@@ -105,9 +105,13 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   if constexpr (B_MODE == 0) { b_half = (uint32_t)(NTQ * 16) * p.ldb * 2u; b_step = 128u; }
   else { b_half = (uint32_t)(NTQ * 16) * 2u; b_step = 64u * p.ldb * 2u; }
   auto setup = [&](int w) {
-    const int z = w / ntiles, tl = w - z * ntiles;
+    // the XCD-contiguous renumbering runs over the WHOLE work list (z-major): with split-K an XCD then works on
+    // one or two K ranges only, so the A / B panels of a range are fetched into one or two L2s instead of all
+    // eight (weight gradients, 36 tiles x 7 splits: L2 fill 970 -> ~460 MB per launch by this count)
+    const int lin = gemm_xcd_contiguous(nwork, w);
+    const int z = lin / ntiles, tl = lin - z * ntiles;
     int tile_m, tile_n;
-    gemm_tile_of_block(ntiles, tl, tiles_m, tiles_n, p.gn, tile_m, tile_n);
+    gemm_raster(tl, tiles_m, tiles_n, p.gn, tile_m, tile_n);
     m0 = tile_m << 8; n0 = tile_n * BNT;
     const int kt0 = z * per;
     nk = min(nk_total, kt0 + per) - kt0;
