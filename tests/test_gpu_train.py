@@ -158,3 +158,61 @@ def test_train_step_on_padded_image_batches_mixed_with_square_ones():
     lab = torch.from_numpy(bn["labels"]).cuda()
     ls = [float(step(db, lab)) for _ in range(12)]
     assert ls[-1] < ls[0] - 0.05, ls
+
+
+
+def _dp_worker(rank, world, port, out_path, kind, nsteps, use_tape):
+    """One data-parallel rank (both ranks share cuda:0; gloo carries the device tensors): its half of every batch."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        spec = VaultSpec.tiny(3, kind)
+        spec.lm.hidden_dropout_prob = 0.0
+        spec.lm.attention_probs_dropout_prob = 0.0
+        eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0), classifier_dropout=0.0)
+        step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10, use_tape=use_tape, bucket_mb=0.25)
+        assert step.world == world and step.reducer is not None and ops.GEMM_SCHED == 3
+        losses = []
+        for i in range(nsteps):
+            bn = synthetic_batch(spec, 8, seed=90 + i, n_classes=3)
+            lo, hi = rank * 4, rank * 4 + 4
+            db = {k: torch.from_numpy(v[lo:hi]).cuda() for k, v in bn.items() if k != "labels"}
+            losses.append(float(step(db, torch.from_numpy(bn["labels"][lo:hi]).cuda())))
+        torch.cuda.synchronize()
+        torch.save({"p": eng.params.p.cpu(), "losses": losses}, f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_tape", [False, True])
+def test_data_parallel_two_ranks_equal_one_rank_on_the_global_batch(tmp_path, use_tape):
+    """The whole N > 1 path on real kernels: two processes (sharing the one GPU, gloo as the transport) each step
+    half of a global batch of 8 - bucketed gradient all-reduce from inside backward on a side stream, dynamic GEMM
+    scheduling, AdamW dividing by the world size - and must land where ONE process stepping the 8 samples lands."""
+    import torch.multiprocessing as mp
+    nsteps = 3
+    out = str(tmp_path / "dp")
+    port = 29600 + (1 if use_tape else 0)
+    mp.spawn(_dp_worker, args=(2, port, out, "roberta", nsteps, use_tape), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["p"], r1["p"])                       # replicas stay bit-identical
+    spec = VaultSpec.tiny(3, "roberta")
+    spec.lm.hidden_dropout_prob = 0.0
+    spec.lm.attention_probs_dropout_prob = 0.0
+    eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0), classifier_dropout=0.0)
+    step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10, use_tape=False)
+    ref_losses = []
+    for i in range(nsteps):
+        bn = synthetic_batch(spec, 8, seed=90 + i, n_classes=3)
+        db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
+        ref_losses.append(float(step(db, torch.from_numpy(bn["labels"]).cuda())))
+    torch.cuda.synchronize()
+    # the global mean loss is the mean of the two local means
+    for a, b, c in zip(r0["losses"], r1["losses"], ref_losses):
+        assert abs(0.5 * (a + b) - c) < 5e-4, (a, b, c)
+    d = (r0["p"] - eng.params.p.cpu()).abs()
+    # same tolerance as tape-vs-eager: float-atomic summation order + sign-like AdamW steps on ~0 gradients
+    assert float(d.mean()) < 1e-6 and float((d > 1e-5).float().mean()) < 0.02
