@@ -392,6 +392,18 @@ class VaultEngine:
         ws["labels"] = None if labels is None else buf("in_labels", (B,), torch.int64).copy_(labels)
         return ws
 
+    def input_buffers(self, B: int, T: int, train: bool = True) -> Dict[str, torch.Tensor]:
+        """The persistent input staging buffers of the (B, T) workspace on the square pre-training canvas
+        (``input_ids``, ``pixel_values``, ``labels``).  A data loader may write its host->device copies straight into
+        them and pass these very tensors to :meth:`stage_inputs` / ``TrainStep``: staging then copies nothing
+        (``Tensor.copy_`` onto itself is a no-op), which saves one device-to-device pass over the pixels per step."""
+        v = self.spec.vilt
+        ws = self.workspace(B, T, train)
+        buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
+        return {"input_ids": buf("in_ids", (B, T), torch.int64),
+                "pixel_values": buf("in_pix", (B, v.num_channels, v.image_size, v.image_size)),
+                "labels": buf("in_labels", (B,), torch.int64)}
+
     def _forward(self, batch, train, labels, need_hidden, loss_scale, precise=False):
         if precise and train:
             raise ValueError("precise (split-bf16) mode is inference-only")
