@@ -110,39 +110,40 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(const float* __restric
 // pixel [B][C][IMG][IMG] f32 -> A [B*P (padded)][C*ps*ps] bf16, k = c*ps*ps + py*ps + px, patches row-major
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ pix, bf16* __restrict__ out, int B, int Cn,
                                                      int IMG, int ps, long long total_chunks, int split3) {
+  // one block per output row (patch): the row -> (sample, patch row, patch column) split is scalar work, the
+  // per-chunk index math stays in 32 bits (64-bit divisions per 16-byte chunk made this kernel VALU-bound)
   const int grid = IMG / ps;
-  const int cpr = ps / 8;                 // 8-pixel chunks per patch row
-  const int Kp = Cn * ps * ps;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total_chunks; i += (long long)gridDim.x * 256ll) {
-    // chunk order follows the OUTPUT layout (coalesced 16-byte stores)
-    const long long row = i / (Kp / 8);
-    const int kc = (int)(i - row * (Kp / 8));
-    const int b = (int)(row / (grid * grid)), p = (int)(row - (long long)b * grid * grid);
+  const int Kp = Cn * ps * ps, pp = ps * ps;
+  const int rows = (int)(total_chunks / (Kp / 8));
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int b = row / (grid * grid), p = row - b * grid * grid;
     const int pr = p / grid, pc = p - pr * grid;
-    const int k = kc * 8;
-    const int c = k / (ps * ps), rem = k - c * ps * ps;
-    const int py = rem / ps, px = rem - py * ps;
-    (void)cpr;
-    const float* s = pix + (((size_t)b * Cn + c) * IMG + (size_t)(pr * ps + py)) * IMG + pc * ps + px;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(s);
-    const f32x4 d = *reinterpret_cast<const f32x4*>(s + 4);
-    if (split3) {
-      const float xs[8] = {a[0], a[1], a[2], a[3], d[0], d[1], d[2], d[3]};
-      bf16 hi[8], lo[8];
+    const float* base = pix + ((size_t)b * Cn * IMG + (size_t)pr * ps) * IMG + pc * ps;
+    bf16* orow = out + (size_t)row * (split3 ? 3 * Kp : Kp);
+    for (int kc = threadIdx.x; kc < Kp / 8; kc += 256) {
+      const int k = kc * 8;
+      const int c = k / pp, rem = k - c * pp;
+      const int py = rem / ps, px = rem - py * ps;
+      const float* s = base + ((size_t)c * IMG + py) * IMG + px;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(s);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(s + 4);
+      if (split3) {
+        const float xs[8] = {a[0], a[1], a[2], a[3], d[0], d[1], d[2], d[3]};
+        bf16 hi[8], lo[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) split_bf16(xs[e], hi[e], lo[e]);
-      u32x4 wh = {pack_bf16x2((float)hi[0], (float)hi[1]), pack_bf16x2((float)hi[2], (float)hi[3]),
-                  pack_bf16x2((float)hi[4], (float)hi[5]), pack_bf16x2((float)hi[6], (float)hi[7])};
-      u32x4 wl = {pack_bf16x2((float)lo[0], (float)lo[1]), pack_bf16x2((float)lo[2], (float)lo[3]),
-                  pack_bf16x2((float)lo[4], (float)lo[5]), pack_bf16x2((float)lo[6], (float)lo[7])};
-      bf16* o = out + row * 3 * Kp + k;
-      *reinterpret_cast<u32x4*>(o) = wh;
-      *reinterpret_cast<u32x4*>(o + Kp) = wl;
-      *reinterpret_cast<u32x4*>(o + 2 * Kp) = wh;
-      continue;
+        for (int e = 0; e < 8; ++e) split_bf16(xs[e], hi[e], lo[e]);
+        u32x4 wh = {pack_bf16x2((float)hi[0], (float)hi[1]), pack_bf16x2((float)hi[2], (float)hi[3]),
+                    pack_bf16x2((float)hi[4], (float)hi[5]), pack_bf16x2((float)hi[6], (float)hi[7])};
+        u32x4 wl = {pack_bf16x2((float)lo[0], (float)lo[1]), pack_bf16x2((float)lo[2], (float)lo[3]),
+                    pack_bf16x2((float)lo[4], (float)lo[5]), pack_bf16x2((float)lo[6], (float)lo[7])};
+        *reinterpret_cast<u32x4*>(orow + k) = wh;
+        *reinterpret_cast<u32x4*>(orow + Kp + k) = wl;
+        *reinterpret_cast<u32x4*>(orow + 2 * Kp + k) = wh;
+        continue;
+      }
+      u32x4 w = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
+      *reinterpret_cast<u32x4*>(orow + k) = w;
     }
-    u32x4 w = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
-    *reinterpret_cast<u32x4*>(out + row * Kp + k) = w;
   }
 }
 
@@ -226,7 +227,7 @@ extern "C" int vault_im2col(const float* pix, void* out_bf16, int B, int C, int 
   if (!pix || !out_bf16 || ps % 8 || IMG % ps || B <= 0) return VAULT_EINVAL;
   const long long rows = (long long)B * (IMG / ps) * (IMG / ps);
   const long long chunks = rows * (C * ps * ps / 8);
-  const int blocks = (int)std::min<long long>((chunks + 255) / 256, 256 * 16);
+  const int blocks = (int)std::min<long long>(rows, 256 * 64);
   hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pix,
                      reinterpret_cast<bf16*>(out_bf16), B, C, IMG, ps, chunks, split3);
   return (int)hipGetLastError();
