@@ -107,6 +107,17 @@ class BucketReducer:
         self.launched.append((lo, self.hi))
         self.hi = lo
 
+    def finish_upper(self) -> int:
+        """Wait for every launched all-reduce except the LAST one (the lowest addresses: it is launched when
+        backward ends, nothing is left to hide it behind) and return its upper bound x: gradients in [x, n) are
+        final and reduced, so the optimizer can already run on them while [0, x) is still on the wire."""
+        if len(self.works) < 2:
+            return self.n if not self.works else self.launched[-1][1]
+        for w in self.works[:-1]:
+            w.wait()
+        del self.works[:-1]
+        return self.launched[-1][1]
+
     def finish(self):
         for w in self.works:
             w.wait()
@@ -187,20 +198,36 @@ class TrainStep:
                         ops.stop_tape()
                 self._tape, self._tape_key, self._tape_ws, self._loss_buf = tape, key, ws, out["loss"]
             if self.reducer:
-                self.reducer.finish()
-            self.optimizer_step()
+                # optimizer on the already reduced upper part of the flat buffer while the last bucket (LM / ViLT
+                # embeddings: the lowest addresses) is still being all-reduced, then on the rest
+                x = self.reducer.finish_upper()
+                if 0 < x < eng.params.n_train:
+                    self.optimizer_step(lo=x, hi=eng.params.n_train, advance=False)
+                    self.reducer.finish()
+                    self.optimizer_step(lo=0, hi=x)
+                else:
+                    self.reducer.finish()
+                    self.optimizer_step()
+            else:
+                self.optimizer_step()
         self.loss = self._loss_buf
         return self.loss
 
-    def optimizer_step(self):
+    def optimizer_step(self, lo: int = 0, hi: Optional[int] = None, advance: bool = True):
+        """Fused HF-AdamW over elements [lo, hi) of the flat parameter buffer (default: all trainable ones);
+        ``advance=False`` leaves the step counter alone (first part of a split update)."""
         eng = self.engine
         P = eng.params
+        hi = P.n_train if hi is None else hi
         t = self.step_idx + 1
         bc = 1.0
         if self.correct_bias:
             bc = math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
         with torch.cuda.device(eng.device):
-            ops.adamw_step(P.p, P.g, P.m, P.v, P.pb, P.n_train, self.current_lr(), self.b1, self.b2, self.eps, self.wd,
-                           bias_corr_factor=bc, grad_scale=1.0 / self.world, zero_grad=True)
-        P._pb3_fresh = False   # the split-bf16 (precise inference) shadow is stale now
-        self.step_idx += 1
+            if hi > lo:
+                ops.adamw_step(P.p[lo:hi], P.g[lo:hi], P.m[lo:hi], P.v[lo:hi], P.pb[lo:hi], hi - lo, self.current_lr(),
+                               self.b1, self.b2, self.eps, self.wd, bias_corr_factor=bc, grad_scale=1.0 / self.world,
+                               zero_grad=True)
+        if advance:
+            P._pb3_fresh = False   # the split-bf16 (precise inference) shadow is stale now
+            self.step_idx += 1
