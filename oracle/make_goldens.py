@@ -181,6 +181,62 @@ RAGGED_CASES = {
 }
 
 
+def flag_case_inputs(spec, B, dseed):
+    """Inputs + fixed output-gradient weights of the VaultModel flag case (shared with the tests)."""
+    batch = synthetic_batch(spec, B, seed=dseed, n_classes=3)
+    rng = np.random.Generator(np.random.PCG64(dseed + 1))
+    T = batch["input_ids"].shape[1]
+    batch["token_type_ids"] = (rng.random((B, T)) < 0.4).astype(np.int64) * batch["attention_mask"]
+    wp = rng.standard_normal((B, spec.vilt.hidden_size)).astype(np.float32)
+    wh = rng.standard_normal((B, T + 1, spec.vilt.hidden_size)).astype(np.float32) * 0.1
+    return batch, wp, wh
+
+
+def run_reference_vaultmodel_flags(ref, name, outdir):
+    """Headless VaultModel with freeze_lm=True and use_vilt_position_embeddings=True (ref: model.py:53-91): the LM
+    receives no gradient, ViLT's own text position table is used and trained, BERT token types 0/1 are live.
+    Scalar objective: <pooler_output, Wp> + <last_hidden_state[:, :T+1], Wh> with fixed Wp, Wh."""
+    spec = VaultSpec.tiny(0, "bert")
+    spec.use_vilt_position_embeddings = True
+    vc, lc = hf_configs(spec)
+    model = ref.VaultModel(vc, bert_config=lc, freeze_lm=True, vilt_dropout_prob=0.0,
+                           use_vilt_position_embeddings=True).eval()
+    state = build_state(spec, 0)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in state.items():
+            assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
+            sd[k].copy_(torch.from_numpy(v))
+    B, dseed = 3, 31
+    batch, wp, wh = flag_case_inputs(spec, B, dseed)
+    kw = {k: torch.from_numpy(batch[k]) for k in ("input_ids", "attention_mask", "token_type_ids", "pixel_values",
+                                                  "pixel_mask")}
+    torch.manual_seed(0)
+    enc = model(**kw)
+    T = batch["input_ids"].shape[1]
+    obj = (enc.pooler_output * torch.from_numpy(wp)).sum() + (enc.last_hidden_state[:, : T + 1] * torch.from_numpy(wh)).sum()
+    obj.backward()
+    out = {"pooler_output": enc.pooler_output.detach().numpy(),
+           "hidden_text_cls": enc.last_hidden_state[:, : T + 1].detach().numpy(),
+           "hidden_patch_sorted_norms": np.sort(enc.last_hidden_state[:, T + 1:].detach().norm(dim=-1).numpy(), axis=1),
+           "objective": np.float32(obj.item()), "meta_batch": np.int64(B), "meta_data_seed": np.int64(dseed)}
+    names, norms = [], []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(k)
+        norms.append(float(p.grad.double().norm()))
+        if k in ("embeddings.text_embeddings.position_embeddings.weight", "embeddings.cls_token",
+                 "embeddings.text_embeddings.token_type_embeddings.weight", "pooler.dense.bias"):
+            out["grad::" + k] = p.grad.detach().numpy().copy()
+    assert not any(n.startswith("bert.") for n in names), "freeze_lm: the LM must not receive gradients"
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array(norms, np.float64)
+    path = os.path.join(outdir, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, "objective", out["objective"], "n grads", len(names), "->", path, f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
 def main():
     ref = import_reference()
     outdir = os.path.join(ROOT, "tests", "golden")
@@ -200,6 +256,8 @@ def main():
         np.savez_compressed(path, **out)
         print(name, "loss", out["loss"], "logits", out["logits"].ravel()[:6], "->", path,
               f"{os.path.getsize(path)/1024:.0f} KiB")
+    if not only or "tiny_bert_vaultmodel_flags" in only:
+        run_reference_vaultmodel_flags(ref, "tiny_bert_vaultmodel_flags", outdir)
     for name, (mk, valid_hw, pad_hw, dseed) in RAGGED_CASES.items():
         if only and name not in only:
             continue

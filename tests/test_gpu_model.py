@@ -132,6 +132,49 @@ def test_padded_image_batches_vs_oracle_and_reference_golden(name, kind):
         "embeddings.position_embeddings")]), rtol=6e-2)
 
 
+def test_vaultmodel_flags_freeze_lm_and_vilt_position_embeddings_vs_reference_golden():
+    """Headless VaultModel with freeze_lm=True and use_vilt_position_embeddings=True, BERT token types 0/1: output
+    gradients injected at pooler_output / last_hidden_state (the autograd-bridge entry), compared with the
+    reference-generated golden and the oracle."""
+    from oracle.make_goldens import flag_case_inputs
+    g = np.load(os.path.join(GOLD, "tiny_bert_vaultmodel_flags.npz"))
+    spec = VaultSpec.tiny(0, "bert")
+    spec.use_vilt_position_embeddings = True
+    spec.lm.hidden_dropout_prob = 0.0            # (the golden is an eval-mode run: a frozen LM still drops out in train mode)
+    spec.lm.attention_probs_dropout_prob = 0.0
+    B = int(g["meta_batch"])
+    bn, wp, wh = flag_case_inputs(spec, B, int(g["meta_data_seed"]))
+    state = build_state(spec, 0)
+    eng = VaultEngine(spec, "cuda:0", state=state, freeze_lm=True)
+    db = _dev(bn)
+    out = eng.forward(db, train=True, need_hidden=True)
+    T = bn["input_ids"].shape[1]
+    S = out["last_hidden_state"].shape[1]
+    dh = torch.zeros(B, S, spec.vilt.hidden_size, device="cuda")
+    dh[:, : T + 1] = torch.from_numpy(wh).cuda()
+    eng.zero_grad()
+    eng.backward(dpooled=torch.from_numpy(wp).cuda(), dhidden=dh)
+    torch.cuda.synchronize()
+    scale = float(np.abs(g["hidden_text_cls"]).max())
+    assert np.abs(out["pooler_output"].cpu().numpy() - g["pooler_output"]).max() < 5e-3
+    assert np.abs(out["last_hidden_state"][:, : T + 1].cpu().numpy() - g["hidden_text_cls"]).max() < 1e-2 * scale
+    names = [str(n) for n in g["grad_names"]]
+    # frozen LM: no gradient storage for it at all; ViLT's text position table is trained under the flag
+    assert not any(eng.params.has_grad(n) for n in eng.params.offsets if n.startswith("bert."))
+    assert eng.params.has_grad("embeddings.text_embeddings.position_embeddings.weight")
+    num = den = 0.0
+    for n, ref_norm in zip(names, g["grad_norms"]):
+        mine = float(eng.params.gr(n).double().norm())
+        num += (mine - ref_norm) ** 2; den += ref_norm ** 2
+        # (key-bias gradients are analytically zero: bf16 rounding noise of ~1e-3 absolute is all there is)
+        assert abs(mine - ref_norm) <= 8e-2 * ref_norm + 2e-3, (n, mine, ref_norm)
+    assert (num / den) ** 0.5 < 3e-2
+    for k in g.files:
+        if k.startswith("grad::"):
+            mine = eng.params.gr(k[6:]).cpu().numpy().reshape(g[k].shape)
+            assert np.linalg.norm(mine - g[k]) <= 6e-2 * np.linalg.norm(g[k]) + 1e-5, k
+
+
 def test_full_size_against_reference_golden():
     """12+12 layers, hidden 768, B=2 (one padded caption): compare with numbers produced by the
     reference (HuggingFace ViltModel + RobertaModel under ref VaultForTMSC) in the build container."""

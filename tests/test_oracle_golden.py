@@ -104,6 +104,40 @@ def test_oracle_matches_reference_golden_padded_images(name):
             np.testing.assert_allclose(P[k[6:]].grad.numpy(), g[k], atol=2e-6, rtol=1e-3)
 
 
+def test_oracle_matches_reference_golden_vaultmodel_flags():
+    """Headless VaultModel, freeze_lm=True, use_vilt_position_embeddings=True, BERT token types 0/1
+    (ref: vault/models/vault/model.py:53-91)."""
+    from oracle.make_goldens import flag_case_inputs
+    g = np.load(os.path.join(GOLD, "tiny_bert_vaultmodel_flags.npz"))
+    spec = VaultSpec.tiny(0, "bert")
+    spec.use_vilt_position_embeddings = True
+    torch.set_num_threads(8)
+    bn, wp, wh = flag_case_inputs(spec, int(g["meta_batch"]), int(g["meta_data_seed"]))
+    P = O.to_torch_state(build_state(spec, 0), requires_grad=True)
+    for k, v in P.items():
+        if k.startswith("bert."):
+            v.requires_grad_(False)           # freeze_lm
+    out = O.vault_forward(P, spec, O.torch_batch(bn))
+    T = bn["input_ids"].shape[1]
+    obj = (out["pooler_output"] * torch.from_numpy(wp)).sum() + \
+        (out["last_hidden_state"][:, : T + 1] * torch.from_numpy(wh)).sum()
+    obj.backward()
+    np.testing.assert_allclose(out["pooler_output"].detach().numpy(), g["pooler_output"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(out["last_hidden_state"][:, : T + 1].detach().numpy(), g["hidden_text_cls"], atol=1e-4, rtol=0)
+    assert abs(float(obj.detach()) - float(g["objective"])) < 1e-4
+    names = [str(n) for n in g["grad_names"]]
+    for n, ref_norm in zip(names, g["grad_norms"]):
+        assert P[n].grad is not None, n
+        assert abs(float(P[n].grad.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 2e-8, n
+    for k, p_ in P.items():
+        if k not in names:
+            assert p_.grad is None or float(p_.grad.abs().max()) == 0.0, k
+    assert "embeddings.text_embeddings.position_embeddings.weight" in names      # used and trained under the flag
+    for k in g.files:
+        if k.startswith("grad::"):
+            np.testing.assert_allclose(P[k[6:]].grad.numpy(), g[k], atol=2e-6, rtol=1e-3)
+
+
 def test_select_patches_edge_cases():
     # all-valid square canvas: identity order, nothing masked
     sel, valid, hw, grid, L = select_patches(np.ones((2, 64, 64), np.int64), 16)
