@@ -237,6 +237,55 @@ def run_reference_vaultmodel_flags(ref, name, outdir):
     print(name, "objective", out["objective"], "n grads", len(names), "->", path, f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
+def run_reference_itr(ref, name, outdir):
+    """VaultForImageAndTextRetrieval (ref: model.py:375-405; HF ViltForImageAndTextRetrieval: Linear(H, 1) on the pooled
+    output, encoder under the `vilt.` prefix).  Objective: <logits, w>."""
+    spec = VaultSpec.tiny(1, "roberta")
+    vc, lc = hf_configs(spec)
+    model = ref.VaultForImageAndTextRetrieval(vc, bert_config=lc).eval()
+    state = build_state(spec, 0)
+    sd = model.state_dict()
+
+    def ext(n):   # build name -> reference state_dict key
+        if n.startswith("bert."):
+            return n
+        if n.startswith("classifier.1."):
+            return "rank_output." + n[len("classifier.1."):]
+        return "vilt." + n
+
+    with torch.no_grad():
+        for k, v in state.items():
+            assert tuple(sd[ext(k)].shape) == tuple(v.shape), (k, sd[ext(k)].shape, v.shape)
+            sd[ext(k)].copy_(torch.from_numpy(v))
+        model.vilt.embeddings.text_embeddings.position_embeddings.weight.zero_()   # D1
+    unexpected = [k for k in sd if k not in {ext(n) for n in state} and "position_ids" not in k and "token_type_ids" not in k]
+    assert not unexpected, unexpected[:5]
+    B, dseed = 3, 41
+    batch = synthetic_batch(spec, B, seed=dseed, n_classes=1)
+    rng = np.random.Generator(np.random.PCG64(dseed + 1))
+    w = rng.standard_normal((B, 1)).astype(np.float32)
+    kw = {k: torch.from_numpy(batch[k]) for k in ("input_ids", "attention_mask", "pixel_values", "pixel_mask")}
+    torch.manual_seed(0)
+    out = model(**kw)
+    obj = (out.logits * torch.from_numpy(w)).sum()
+    obj.backward()
+    res = {"logits": out.logits.detach().numpy(), "objective": np.float32(obj.item()), "w": w,
+           "meta_batch": np.int64(B), "meta_data_seed": np.int64(dseed)}
+    names, norms = [], []
+    for k, p in model.named_parameters():
+        if p.grad is None or k == "vilt.embeddings.text_embeddings.position_embeddings.weight":
+            continue
+        names.append(k)
+        norms.append(float(p.grad.double().norm()))
+        if k in ("rank_output.weight", "rank_output.bias", "vilt.pooler.dense.bias", "vilt.embeddings.cls_token"):
+            res["grad::" + k] = p.grad.detach().numpy().copy()
+    res["grad_names"] = np.array(names)
+    res["grad_norms"] = np.array(norms, np.float64)
+    path = os.path.join(outdir, f"{name}.npz")
+    np.savez_compressed(path, **res)
+    print(name, "logits", res["logits"].ravel(), "n grads", len(names), "->", path, f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
 def main():
     ref = import_reference()
     outdir = os.path.join(ROOT, "tests", "golden")
@@ -256,6 +305,8 @@ def main():
         np.savez_compressed(path, **out)
         print(name, "loss", out["loss"], "logits", out["logits"].ravel()[:6], "->", path,
               f"{os.path.getsize(path)/1024:.0f} KiB")
+    if not only or "tiny_roberta_itr" in only:
+        run_reference_itr(ref, "tiny_roberta_itr", outdir)
     if not only or "tiny_bert_vaultmodel_flags" in only:
         run_reference_vaultmodel_flags(ref, "tiny_bert_vaultmodel_flags", outdir)
     for name, (mk, valid_hw, pad_hw, dseed) in RAGGED_CASES.items():

@@ -98,6 +98,42 @@ def test_model_requires_gpu_and_keeps_reference_signature():
         m(pixel_values=torch.zeros(1, 3, 192, 192))
 
 
+def test_itr_head_class_keys_and_itm_checkpoint_adoption(tmp_path):
+    """VaultForImageAndTextRetrieval: encoder keys under ``vilt.``, ``rank_output`` head; from_pretrained of an ITM
+    pre-training checkpoint takes row 1 of ``itm_score.fc`` for it (ref: vault/models/vault/model.py:375-405)."""
+    import json
+    from safetensors.torch import save_file
+    from vault_amd.models.vault import VaultForImageAndTextRetrieval
+    spec = VaultSpec.tiny(1, "roberta")
+    m = VaultForImageAndTextRetrieval(spec.vilt, bert_config=spec.lm)
+    keys = set(m.state_dict())
+    assert {"rank_output.weight", "rank_output.bias", "vilt.pooler.dense.weight", "vilt.embeddings.cls_token",
+            "bert.embeddings.word_embeddings.weight"} <= keys
+    assert not any(k.startswith(("classifier.", "embeddings.", "encoder.")) for k in keys)
+    assert tuple(m.state_dict()["rank_output.weight"].shape) == (1, spec.vilt.hidden_size)
+    with pytest.raises(NotImplementedError):
+        m(input_ids=torch.zeros(1, 40, dtype=torch.long), pixel_values=torch.zeros(1, 3, 192, 192),
+          labels=torch.zeros(1))
+    # a base-ViLT style ITM checkpoint: keys under "vilt.", 2-way itm_score head
+    d = tmp_path / "vilt-itm"
+    d.mkdir()
+    v = spec.vilt
+    cfg = {f: getattr(v, f) for f in ("vocab_size", "max_position_embeddings", "type_vocab_size", "modality_type_vocab_size",
+                                      "hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size",
+                                      "layer_norm_eps", "image_size", "patch_size", "num_channels")}
+    json.dump(cfg, open(d / "config.json", "w"))
+    nolm = VaultForImageAndTextRetrieval(v)          # ViLT-only twin provides tensors of the right shapes
+    sd = {k: (t.clone() + 0.5) for k, t in nolm.state_dict().items() if k.startswith("vilt.")}
+    sd["itm_score.fc.weight"] = torch.arange(2 * v.hidden_size, dtype=torch.float32).view(2, -1)
+    sd["itm_score.fc.bias"] = torch.tensor([3.0, 7.0])
+    save_file(sd, str(d / "model.safetensors"))
+    loaded = VaultForImageAndTextRetrieval.from_pretrained(str(d))
+    got = loaded.state_dict()
+    assert torch.equal(got["rank_output.weight"], sd["itm_score.fc.weight"][1:])
+    assert torch.equal(got["rank_output.bias"], sd["itm_score.fc.bias"][1:])
+    assert torch.equal(got["vilt.pooler.dense.weight"], sd["vilt.pooler.dense.weight"])
+
+
 # ---- data parallel: bucketed all-reduce over gloo, world_size 2 ---------------------------------
 def _dp_worker(rank, world, port, q):
     import torch.distributed as dist

@@ -138,6 +138,33 @@ def test_oracle_matches_reference_golden_vaultmodel_flags():
             np.testing.assert_allclose(P[k[6:]].grad.numpy(), g[k], atol=2e-6, rtol=1e-3)
 
 
+def test_oracle_matches_reference_golden_itr_head():
+    """VaultForImageAndTextRetrieval (rank head on the pooled output) as run by the reference."""
+    g = np.load(os.path.join(GOLD, "tiny_roberta_itr.npz"))
+    spec = VaultSpec.tiny(1, "roberta")
+    torch.set_num_threads(8)
+    bn = synthetic_batch(spec, int(g["meta_batch"]), seed=int(g["meta_data_seed"]), n_classes=1)
+    P = O.to_torch_state(build_state(spec, 0), requires_grad=True)
+    out = O.vault_forward(P, spec, O.torch_batch(bn))
+    logits = out["logits"].reshape(-1, 1)
+    obj = (logits * torch.from_numpy(g["w"])).sum()
+    obj.backward()
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits"], atol=2e-5, rtol=0)
+
+    def internal(k):   # reference state_dict key -> build name
+        if k.startswith("vilt."):
+            return k[5:]
+        return k.replace("rank_output.", "classifier.1.")
+
+    for k, ref_norm in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        n = internal(k)
+        assert P[n].grad is not None, n
+        assert abs(float(P[n].grad.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 2e-8, n
+    for k in g.files:
+        if k.startswith("grad::"):
+            np.testing.assert_allclose(P[internal(k[6:])].grad.numpy().reshape(g[k].shape), g[k], atol=2e-6, rtol=1e-3)
+
+
 def test_select_patches_edge_cases():
     # all-valid square canvas: identity order, nothing masked
     sel, valid, hw, grid, L = select_patches(np.ones((2, 64, 64), np.int64), 16)

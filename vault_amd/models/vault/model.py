@@ -51,6 +51,15 @@ except Exception:  # pragma: no cover
             self.hidden_states, self.attentions = hidden_states, attentions
 
 
+try:
+    from transformers.modeling_outputs import SequenceClassifierOutput as _SequenceClassifierOutput
+except Exception:  # pragma: no cover
+    class _SequenceClassifierOutput(dict):
+        def __init__(self, loss=None, logits=None):
+            super().__init__(loss=loss, logits=logits)
+            self.loss, self.logits = loss, logits
+
+
 def _get(cfg: Any, name: str, default=None):
     return getattr(cfg, name, default)
 
@@ -145,6 +154,7 @@ class VaultMixin(nn.Module):
         use_vilt_position_embeddings=dict(action="store_true", help="whether to use Vilt's position embeddings"),
     )
     _n_classes = 0
+    _head_dropout = True
     _always_hidden = False
     #: inference only: run every Linear as a split-bf16 ("bf16x3") GEMM - fp32-class products on the bf16
     #: MFMA path, ~3x the GEMM time - to meet the 1e-3 logits parity bar against the fp32 reference
@@ -170,10 +180,16 @@ class VaultMixin(nn.Module):
             frozen = {n for n, _, _ in param_entries(self.spec) if n.startswith("bert.")}
         for n, shape, _ in param_entries(self.spec):
             p = nn.Parameter(torch.from_numpy(np.ascontiguousarray(state[n])).clone(), requires_grad=n not in frozen)
-            _attach(self, n, p)
+            _attach(self, self._ext_name(n), p)
             self._names.append(n)
         lookup = dict(self.named_parameters())
-        self._params_by_name = {n: lookup[n] for n in self._names}
+        self._params_by_name = {n: lookup[self._ext_name(n)] for n in self._names}
+
+    #: classes built on a HF ``ViltFor...`` head model keep the encoder under ``vilt.`` and name their head
+    #: differently: engine-internal name -> state_dict key
+    @staticmethod
+    def _ext_name(n: str) -> str:
+        return n
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         # HF checkpoints carry non-parameter buffers (position_ids, token_type_ids): ignore them
@@ -196,7 +212,7 @@ class VaultMixin(nn.Module):
     def _bind(self, device):
         state = {n: p.detach().float().cpu().numpy() for n, p in self._params_by_name.items()}
         self._engine = VaultEngine(self.spec, device, state=state, freeze_lm=self.freeze_lm,
-                                   classifier_dropout=self.vilt_dropout_prob if self._n_classes else 0.0)
+                                   classifier_dropout=self.vilt_dropout_prob if (self._n_classes and self._head_dropout) else 0.0)
         P = self._engine.params
         for n, p in self._params_by_name.items():
             p.data = P.w(n)
@@ -251,23 +267,32 @@ class VaultMixin(nn.Module):
                     use_vilt_position_embeddings=use_vilt_position_embeddings, **kwargs)
         own = model.state_dict()
         new = {}
+        ext = {n: model._ext_name(n) for n in model._names}
+        by_ext = set(ext.values())
         for k, v in vsd.items():
-            k2 = k[5:] if k.startswith("vilt.") else k
-            if k2 in own and tuple(own[k2].shape) == tuple(v.shape):
-                new[k2] = v
+            # checkpoints of head models keep the encoder under "vilt.", base ViLT checkpoints at top level
+            for cand in (k, k[5:] if k.startswith("vilt.") else "vilt." + k):
+                tgt = cand if cand in by_ext else ext.get(cand)
+                if tgt is not None and tuple(own[tgt].shape) == tuple(v.shape):
+                    new[tgt] = v
+                    break
         if bsd is not None:
             for k, v in bsd.items():
                 for pre in ("roberta.", "bert.", ""):
                     if k.startswith(pre) and ("bert." + k[len(pre):]) in own:
                         new["bert." + k[len(pre):]] = v
                         break
-        missing = [k for k in own if k not in new and not k.startswith("classifier.")]
+        model._adopt_checkpoint_heads(vsd, new, own)
+        missing = [k for k in own if k not in new and not k.startswith(("classifier.", "rank_output."))]
         if missing:
             logging.getLogger(__name__).warning("from_pretrained: %d tensors keep their initial values (e.g. %s)",
                                                 len(missing), missing[:3])
         own.update(new)
         model.load_state_dict(own)
         return model
+
+    def _adopt_checkpoint_heads(self, ckpt_sd, new, own):
+        """Hook: map head tensors of a pre-training checkpoint onto this class's head (see the ITR class)."""
 
     def lm_preprocess(self, *args, **kwargs):
         raise NotImplementedError("lm_preprocess is fused into forward in this build")
@@ -368,3 +393,43 @@ class VaultForTMSC(VaultModel):
     def forward(self, *args, **kwargs) -> torch.Tensor:
         logits = self._run(args, kwargs, want_logits=True)
         return logits.squeeze(-1)
+
+
+class VaultForImageAndTextRetrieval(VaultMixin):
+    """VAuLT for image-text retrieval (ref model.py:375-405 on HF ``ViltForImageAndTextRetrieval``): ``rank_output``
+    = Linear(hidden, 1) on the pooled output; ``state_dict`` keys ``vilt.*`` / ``bert.*`` / ``rank_output.*``.
+    ``from_pretrained`` of an ITM pre-training checkpoint (``"itm"`` in its name) initialises ``rank_output`` from
+    row 1 of ``itm_score.fc`` like the reference.  Like HF, passing ``labels`` raises (no training loss defined);
+    gradients flow through ``logits``."""
+
+    _n_classes = 1
+    _head_dropout = False
+
+    @staticmethod
+    def _ext_name(n: str) -> str:
+        if n.startswith("bert."):
+            return n
+        if n.startswith("classifier.1."):
+            return "rank_output." + n[len("classifier.1."):]
+        return "vilt." + n
+
+    def __init__(self, vilt_config, bert_config=None, freeze_lm: bool = False, vilt_dropout_prob: float = 0.0,
+                 use_vilt_position_embeddings: bool = False, **kw):
+        kw.pop("__from_pretrained__", None)
+        super().__init__(vilt_config, bert_config=bert_config, freeze_lm=freeze_lm, vilt_dropout_prob=vilt_dropout_prob,
+                         use_vilt_position_embeddings=use_vilt_position_embeddings, add_pooling_layer=True,
+                         _n_classes=1, **kw)
+
+    def _adopt_checkpoint_heads(self, ckpt_sd, new, own):
+        w, b = ckpt_sd.get("itm_score.fc.weight"), ckpt_sd.get("itm_score.fc.bias")
+        if "rank_output.weight" not in new and w is not None and b is not None and w.shape[0] == 2:
+            new["rank_output.weight"], new["rank_output.bias"] = w[1:].clone(), b[1:].clone()
+
+    def forward(self, *args, labels=None, **kwargs):
+        if labels is not None:
+            raise NotImplementedError("Training is not yet supported.")
+        logits = self._run(args, kwargs, want_logits=True)
+        logits = logits.reshape(logits.shape[0], 1)
+        if kwargs.get("return_dict", True) is False:
+            return (logits,)
+        return _SequenceClassifierOutput(loss=None, logits=logits)
