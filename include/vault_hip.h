@@ -51,7 +51,7 @@ int vault_gemm(const vault_gemm_args* args, void* stream);
 
 
 /* ---- LayerNorm ----------------------------------------------------------------------------
- * fp32 statistics, one wave per row, H % 256 == 0, H <= 1024.  Replaces nn.LayerNorm at
+ * fp32 statistics, one wave per row, H in {256, 512, 768, 1024, 1536}.  Replaces nn.LayerNorm at
  * HF:models/vilt/modeling_vilt.py:431-447,637, HF:models/roberta/modeling_roberta.py:339,397 and
  * the embedding LayerNorms (modeling_vilt.py:267, modeling_roberta.py:119).
  * Row maps: logical row r lives at physical row (r / rpg) * gstride + goff + r % rpg (rpg == 0:
@@ -171,6 +171,11 @@ typedef struct vault_head_args {
 int vault_head_fwd(const vault_head_args* args, void* stream);
 int vault_head_bwd(const vault_head_args* args, void* stream);
 int vault_tanh_bwd(const float* pooled, const float* dpooled, void* dpre_bf16, long long n, void* stream);
+/* elementwise exact-erf GELU of the MLP task heads (HF ViltForQuestionAnswering.classifier, modeling_vilt.py: Linear -
+ * LayerNorm - GELU - Linear on the pooled output; reached through ref: vault/models/vault/model.py:472-509):
+ * y_bf16 = gelu(x) ; dx = dy * gelu'(x) */
+int vault_gelu_fwd(const float* x, void* y_bf16, long long n, void* stream);
+int vault_gelu_bwd(const float* x, const float* dy, float* dx, long long n, void* stream);
 
 /* ---- optimizer ------------------------------------------------------------------------------
  * transformers==4.48 AdamW as the reference calls it (ref: vault/tmsc_utils/trainer.py:244-254):

@@ -286,6 +286,54 @@ def run_reference_itr(ref, name, outdir):
     print(name, "logits", res["logits"].ravel(), "n grads", len(names), "->", path, f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
+def run_reference_vqa(ref, name, outdir):
+    """VaultForQuestionAnswering (ref: model.py:472-509 on HF ViltForQuestionAnswering: Linear(H, 2H) - LayerNorm - GELU -
+    Linear(2H, n_classes) on the pooled output, loss = BCE-with-logits * n_classes).  n_classes = 10 exercises
+    ``renew_classifier``; the loss is the reference's own."""
+    L = 10
+    spec = VaultSpec.tiny(L, "roberta")
+    spec.head = "mlp"
+    vc, lc = hf_configs(spec)
+    model = ref.VaultForQuestionAnswering(vc, bert_config=lc, n_classes=L).eval()
+    state = build_state(spec, 0)
+    sd = model.state_dict()
+
+    def ext(n):
+        return n if n.startswith(("bert.", "classifier.")) else "vilt." + n
+
+    with torch.no_grad():
+        for k, v in state.items():
+            assert tuple(sd[ext(k)].shape) == tuple(v.shape), (k, sd[ext(k)].shape, v.shape)
+            sd[ext(k)].copy_(torch.from_numpy(v))
+        model.vilt.embeddings.text_embeddings.position_embeddings.weight.zero_()   # D1
+    unexpected = [k for k in sd if k not in {ext(n) for n in state} and "position_ids" not in k and "token_type_ids" not in k]
+    assert not unexpected, unexpected[:5]
+    B, dseed = 3, 51
+    batch = synthetic_batch(spec, B, seed=dseed, n_classes=1)
+    rng = np.random.Generator(np.random.PCG64(dseed + 1))
+    labels = (rng.random((B, L)) < 0.3).astype(np.float32) * rng.random((B, L)).astype(np.float32)   # soft VQA scores
+    kw = {k: torch.from_numpy(batch[k]) for k in ("input_ids", "attention_mask", "pixel_values", "pixel_mask")}
+    torch.manual_seed(0)
+    out = model(**kw, labels=torch.from_numpy(labels))
+    out.loss.backward()
+    res = {"logits": out.logits.detach().numpy(), "loss": np.float32(out.loss.item()), "labels": labels,
+           "meta_batch": np.int64(B), "meta_data_seed": np.int64(dseed)}
+    names, norms = [], []
+    for k, p in model.named_parameters():
+        if p.grad is None or k == "vilt.embeddings.text_embeddings.position_embeddings.weight":
+            continue
+        names.append(k)
+        norms.append(float(p.grad.double().norm()))
+        if (k.startswith("classifier.") and k != "classifier.0.weight") or k in ("vilt.pooler.dense.bias",):
+            res["grad::" + k] = p.grad.detach().numpy().copy()
+    res["grad_names"] = np.array(names)
+    res["grad_norms"] = np.array(norms, np.float64)
+    path = os.path.join(outdir, f"{name}.npz")
+    np.savez_compressed(path, **res)
+    print(name, "loss", res["loss"], "logits", res["logits"].ravel()[:4], "n grads", len(names), "->", path,
+          f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
 def main():
     ref = import_reference()
     outdir = os.path.join(ROOT, "tests", "golden")
@@ -305,6 +353,8 @@ def main():
         np.savez_compressed(path, **out)
         print(name, "loss", out["loss"], "logits", out["logits"].ravel()[:6], "->", path,
               f"{os.path.getsize(path)/1024:.0f} KiB")
+    if not only or "tiny_roberta_vqa" in only:
+        run_reference_vqa(ref, "tiny_roberta_vqa", outdir)
     if not only or "tiny_roberta_itr" in only:
         run_reference_itr(ref, "tiny_roberta_itr", outdir)
     if not only or "tiny_bert_vaultmodel_flags" in only:

@@ -235,7 +235,12 @@ def vault_forward(P, spec, batch: Dict[str, torch.Tensor], taps: Optional[dict] 
     if spec.add_pooling_layer:
         pooled = torch.tanh(_lin(x[:, 0], P["pooler.dense.weight"], P["pooler.dense.bias"]))
         out["pooler_output"] = pooled
-        if spec.n_classes > 0:
+        if spec.n_classes > 0 and getattr(spec, "head", "linear") == "mlp":
+            # HF ViltForQuestionAnswering.classifier (modeling_vilt.py): Linear(H, 2H) - LayerNorm(2H) - GELU - Linear
+            h = _lin(pooled, P["classifier.0.weight"], P["classifier.0.bias"])
+            h = _ln(h, P["classifier.1.weight"], P["classifier.1.bias"], 1e-5)
+            out["logits"] = _lin(F.gelu(_r(h)), P["classifier.3.weight"], P["classifier.3.bias"])
+        elif spec.n_classes > 0:
             z = pooled
             if classifier_keep_mask is not None:
                 z = z * classifier_keep_mask / (1.0 - classifier_p)

@@ -203,6 +203,36 @@ def test_itr_head_model_class_vs_reference_golden():
             assert np.linalg.norm(mine - g[k]) <= 0.15 * np.linalg.norm(g[k]) + 1e-6, k
 
 
+def test_vqa_head_model_class_vs_reference_golden():
+    """VaultForQuestionAnswering (MLP head through GEMM / LayerNorm / GELU kernels, output projection padded to 256
+    columns) through the nn.Module API, loss and gradients against the reference's own run."""
+    from vault_amd.models.vault import VaultForQuestionAnswering
+    g = np.load(os.path.join(GOLD, "tiny_roberta_vqa.npz"))
+    L = g["labels"].shape[1]
+    spec = _nodrop(VaultSpec.tiny(L, "roberta"))
+    bn = synthetic_batch(spec, int(g["meta_batch"]), seed=int(g["meta_data_seed"]), n_classes=1)
+    m = VaultForQuestionAnswering(spec.vilt, bert_config=spec.lm, n_classes=L).to("cuda").train()
+    assert {"classifier.0.weight", "classifier.1.bias", "classifier.3.weight", "vilt.pooler.dense.weight"} <= set(m.state_dict())
+    kw = {k: torch.from_numpy(bn[k]).cuda() for k in ("input_ids", "attention_mask", "pixel_values", "pixel_mask")}
+    out = m(**kw, labels=torch.from_numpy(g["labels"]).cuda())
+    out.loss.backward()
+    torch.cuda.synchronize()
+    assert tuple(out.logits.shape) == (int(g["meta_batch"]), L)
+    assert np.abs(out.logits.detach().cpu().numpy() - g["logits"]).max() < 5e-3
+    assert abs(float(out.loss) - float(g["loss"])) < 5e-3
+    sd = dict(m.named_parameters())
+    num = den = 0.0
+    for k, ref_norm in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        assert sd[k].grad is not None, k
+        mine = float(sd[k].grad.double().norm())
+        num += (mine - ref_norm) ** 2; den += ref_norm ** 2
+    assert (num / den) ** 0.5 < 3e-2
+    for k in g.files:
+        if k.startswith("grad::"):
+            mine = sd[k[6:]].grad.cpu().numpy().reshape(g[k].shape)
+            assert np.linalg.norm(mine - g[k]) <= 6e-2 * np.linalg.norm(g[k]) + 1e-6, k
+
+
 def test_full_size_against_reference_golden():
     """12+12 layers, hidden 768, B=2 (one padded caption): compare with numbers produced by the
     reference (HuggingFace ViltModel + RobertaModel under ref VaultForTMSC) in the build container."""

@@ -165,6 +165,31 @@ def test_oracle_matches_reference_golden_itr_head():
             np.testing.assert_allclose(P[internal(k[6:])].grad.numpy().reshape(g[k].shape), g[k], atol=2e-6, rtol=1e-3)
 
 
+def test_oracle_matches_reference_golden_vqa_head():
+    """VaultForQuestionAnswering (MLP head on the pooled output, BCE-with-logits * n_classes) as run by the reference."""
+    g = np.load(os.path.join(GOLD, "tiny_roberta_vqa.npz"))
+    L = g["labels"].shape[1]
+    spec = VaultSpec.tiny(L, "roberta")
+    spec.head = "mlp"
+    torch.set_num_threads(8)
+    bn = synthetic_batch(spec, int(g["meta_batch"]), seed=int(g["meta_data_seed"]), n_classes=1)
+    P = O.to_torch_state(build_state(spec, 0), requires_grad=True)
+    out = O.vault_forward(P, spec, O.torch_batch(bn))
+    labels = torch.from_numpy(g["labels"])
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out["logits"], labels) * L
+    loss.backward()
+    np.testing.assert_allclose(out["logits"].detach().numpy(), g["logits"], atol=2e-5, rtol=0)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4
+    internal = lambda k: k[5:] if k.startswith("vilt.") else k   # noqa: E731
+    for k, ref_norm in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        n = internal(k)
+        assert P[n].grad is not None, n
+        assert abs(float(P[n].grad.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 2e-8, n
+    for k in g.files:
+        if k.startswith("grad::"):
+            np.testing.assert_allclose(P[internal(k[6:])].grad.numpy().reshape(g[k].shape), g[k], atol=2e-6, rtol=1e-3)
+
+
 def test_select_patches_edge_cases():
     # all-valid square canvas: identity order, nothing masked
     sel, valid, hw, grid, L = select_patches(np.ones((2, 64, 64), np.int64), 16)

@@ -113,7 +113,32 @@ __global__ void tanh_bwd_kernel(const float* __restrict__ pooled, const float* _
   }
 }
 
+// y_bf16 = gelu(x)   /   dx = dy * gelu'(x)      (MLP task heads: Linear - LayerNorm - GELU - Linear on the pooled output)
+__global__ void gelu_fwd_kernel(const float* __restrict__ x, bf16* __restrict__ y, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256ll) y[i] = (bf16)gelu_f(x[i]);
+}
+__global__ void gelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256ll)
+    dx[i] = dy[i] * dgelu_f(x[i]);
+}
+
 }  // namespace
+
+extern "C" int vault_gelu_fwd(const float* x, void* y_bf16, long long n, void* stream) {
+  if (!x || !y_bf16 || n <= 0) return VAULT_EINVAL;
+  const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     reinterpret_cast<bf16*>(y_bf16), n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int vault_gelu_bwd(const float* x, const float* dy, float* dx, long long n, void* stream) {
+  if (!x || !dy || !dx || n <= 0) return VAULT_EINVAL;
+  const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, dy, dx, n);
+  return (int)hipGetLastError();
+}
 
 extern "C" int vault_head_fwd(const vault_head_args* a, void* stream) {
   if (!a || !a->pre || !a->pooled || a->B <= 0 || a->C > MAXC || a->C < 0) return VAULT_EINVAL;

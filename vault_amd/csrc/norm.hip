@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ in
 }  // namespace
 
 extern "C" int vault_layernorm_fwd(const vault_ln_fwd_args* a, void* stream) {
-  if (!a || a->H % 256 || a->H > 1024 || a->rows <= 0) return VAULT_EINVAL;
+  if (!a || a->H % 256 || (a->H > 1024 && a->H != 1536) || a->rows <= 0) return VAULT_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const RowMap xm{a->x_rpg, a->x_gstride, a->x_goff}, ym{a->y_rpg, a->y_gstride, a->y_goff};
   dim3 grid((a->rows + 3) / 4), block(256);
@@ -228,13 +228,14 @@ extern "C" int vault_layernorm_fwd(const vault_ln_fwd_args* a, void* stream) {
     case 2: LN_FWD(2); break;
     case 3: LN_FWD(3); break;
     case 4: LN_FWD(4); break;
+    case 6: LN_FWD(6); break;
   }
 #undef LN_FWD
   return (int)hipGetLastError();
 }
 
 extern "C" int vault_layernorm_bwd(const vault_ln_bwd_args* a, void* stream) {
-  if (!a || a->H % 256 || a->H > 1024 || a->rows <= 0) return VAULT_EINVAL;
+  if (!a || a->H % 256 || (a->H > 1024 && a->H != 1536) || a->rows <= 0) return VAULT_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const RowMap dym{a->dy_rpg, a->dy_gstride, a->dy_goff}, xm{a->x_rpg, a->x_gstride, a->x_goff},
       dxm{a->dx_rpg, a->dx_gstride, a->dx_goff};
@@ -251,6 +252,7 @@ extern "C" int vault_layernorm_bwd(const vault_ln_bwd_args* a, void* stream) {
     case 2: LN_BWD(2); break;
     case 3: LN_BWD(3); break;
     case 4: LN_BWD(4); break;
+    case 6: LN_BWD(6); break;
   }
 #undef LN_BWD
   return (int)hipGetLastError();

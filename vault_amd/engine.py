@@ -53,17 +53,20 @@ class ParamStore:
         self.n_total = _pad(off, 1024)
         self.trainable = train
         self.frozen = rest
-        host = np.zeros(self.n_total, np.float32)
+        # the MLP head's output projection is used as a GEMM operand padded to a multiple of 256 rows: readable (zero)
+        # slack behind the buffers, never part of [0, n_train) that the optimizer and the all-reduce walk
+        self.slack = 256 * 2 * spec.vilt.hidden_size + 1024 if (spec.n_classes > 0 and spec.head == "mlp") else 0
+        host = np.zeros(self.n_total + self.slack, np.float32)
         if state is None:
             state = build_state(spec, seed)
         for n, (o, shp) in self.offsets.items():
             host[o:o + int(np.prod(shp))] = np.asarray(state[n], np.float32).reshape(-1)
         self.p = torch.from_numpy(host).to(device)
-        self.pb = torch.empty(self.n_total, dtype=torch.bfloat16, device=device)
+        self.pb = torch.zeros(self.n_total + self.slack, dtype=torch.bfloat16, device=device)
         ops.cast_bf16(self.p, self.pb, self.n_total)
         self.g = self.m = self.v = None
         if with_grads:
-            self.g = torch.zeros(self.n_train, device=device)
+            self.g = torch.zeros(self.n_train + self.slack, device=device)
             self.m = torch.zeros(self.n_train, device=device)
             self.v = torch.zeros(self.n_train, device=device)
 
@@ -116,7 +119,11 @@ class ParamStore:
         o += ["layernorm.weight", "layernorm.bias"]
         if spec.add_pooling_layer:
             o += ["pooler.dense.weight", "pooler.dense.bias"]
-        if spec.n_classes > 0:
+        if spec.n_classes > 0 and spec.head == "mlp":
+            # the output projection last: its [n_classes, 2H] matrix is read (never written) as 256-row padded
+            o += ["classifier.0.weight", "classifier.0.bias", "classifier.1.weight", "classifier.1.bias",
+                  "classifier.3.weight", "classifier.3.bias"]
+        elif spec.n_classes > 0:
             o += ["classifier.1.weight", "classifier.1.bias"]
         return o
 
@@ -273,7 +280,7 @@ class VaultEngine:
         ops.gemm(dy_bf16, P.wb(wname, n_elems=Nout * Kin, shape=(Nout, Kin)), out, M, Kin, Nout, Nout, Kin, Kin, 0, 1,
                  epi, m_valid=m_valid, **kw)
 
-    def _wgrad(self, dy_bf16, x_bf16, wname, bname, Mtok_pad, Nout, Kin, m_valid):
+    def _wgrad(self, dy_bf16, x_bf16, wname, bname, Mtok_pad, Nout, Kin, m_valid, out_rows=0):
         # dW[Nout,Kin] += dY[Mtok,Nout]^T . X[Mtok,Kin] ; db[Nout] += colsum(dY)
         P = self.params
         gw = P.gr(wname, n_elems=Nout * Kin, shape=(Nout, Kin))
@@ -299,7 +306,7 @@ class VaultEngine:
         if cfg == 3:
             ops.pycall(lambda: self._prof_begin("wgrad"))
         ops.gemm(dy_bf16, x_bf16, gw, Nout, Kin, Mtok_pad, Nout, Kin, Kin, 1, 1, ops.EPI_F32_ATOMIC, cfg=cfg,
-                 splits=splits, accumulate=1)
+                 splits=splits, accumulate=1, m_valid=out_rows)   # out_rows: rows of dW that exist (0 = all Nout)
         if cfg == 3:
             fl = 2.0 * m_valid * Nout * Kin
             ops.pycall(lambda: self._prof_end("wgrad", fl))
@@ -570,7 +577,26 @@ class VaultEngine:
             self._linear(h0b, "pooler.dense.weight", pre, Bp, H, H, ops.EPI_F32_RES, B, bias=P.w("pooler.dense.bias"),
                          precise=pr)
             pooled = buf("pooled", (Bp, H))
-            if spec.n_classes > 0:
+            if spec.n_classes > 0 and spec.head == "mlp":
+                # HF ViltForQuestionAnswering.classifier: Linear(H, 2H) - LayerNorm(2H, eps 1e-5) - GELU - Linear(2H, L).
+                # The output projection runs with L padded to 256 columns (readable slack behind the parameter buffers).
+                L, H2 = spec.n_classes, 2 * H
+                Lp = _pad(L)
+                ops.head_fwd(pre, None, None, None, pooled, None, None, B, H, 0, 0.0)   # tanh
+                pooled_b = buf("pooled_b", (Bp, H), bf)
+                ops.cast_bf16(pooled, pooled_b, Bp * H)
+                h1 = buf("mlp_h1", (Bp, H2))
+                self._linear(pooled_b, "classifier.0.weight", h1, Bp, H2, H, ops.EPI_F32_RES, B, bias=P.w("classifier.0.bias"))
+                n1 = buf("mlp_n1", (Bp, H2))
+                ops.layernorm_fwd(h1, P.w("classifier.1.weight"), P.w("classifier.1.bias"), 1e-5, B, H2, y_f32=n1,
+                                  mean=buf("mlp_mean", (Bp,)), rstd=buf("mlp_rstd", (Bp,)))
+                a1 = buf("mlp_a1", (Bp, H2), bf)
+                ops.gelu_fwd(n1, a1, Bp * H2)
+                lg = buf("mlp_logits", (Bp, Lp))
+                ops.gemm(a1, P.wb("classifier.3.weight", n_elems=Lp * H2, shape=(Lp, H2)), lg, Bp, Lp, H2, H2, H2, Lp, 0, 0,
+                         ops.EPI_F32_RES, m_valid=B, bias=P.w("classifier.3.bias", n_elems=Lp, shape=(Lp,)))
+                out["logits"] = lg[:B, :L]
+            elif spec.n_classes > 0:
                 C = spec.n_classes
                 logits = buf("logits", (B, C))
                 loss = buf("loss", (1,))
@@ -633,7 +659,34 @@ class VaultEngine:
         if spec.add_pooling_layer and (spec.n_classes > 0 or dpooled is not None):
             Bp = ws["Bp"]
             dpre = buf("dpre", (Bp, H), bf)
-            if spec.n_classes > 0 and dpooled is None:
+            if spec.n_classes > 0 and spec.head == "mlp" and dpooled is None:
+                if dlogits is None:
+                    raise ValueError("the MLP head has no built-in loss: pass dlogits (the autograd bridge does)")
+                L, H2 = spec.n_classes, 2 * H
+                Lp = _pad(L)
+                dl32 = buf("mlp_dlogits", (Bp, Lp))
+                ops.pycall(dl32.zero_)
+                dl32[:B, :L].copy_(dlogits.view(B, L))
+                dlb = buf("mlp_dlogits_b", (Bp, Lp), bf)
+                ops.cast_bf16(dl32, dlb, Bp * Lp)
+                # output projection: weight gradient rows >= L are never written (m_valid), its bias gradient is the
+                # column sum (the padded columns are zero and land in the slack behind the gradient buffer)
+                self._wgrad(dlb, ws["mlp_a1"], "classifier.3.weight", "classifier.3.bias", Bp, Lp, H2, B, out_rows=L)
+                da1 = buf("mlp_da1", (Bp, H2))
+                ops.gemm(dlb, P.wb("classifier.3.weight", n_elems=Lp * H2, shape=(Lp, H2)), da1, Bp, H2, Lp, Lp, H2, H2, 0, 1,
+                         ops.EPI_F32_RES, m_valid=B)
+                dn1 = buf("mlp_dn1", (Bp, H2))
+                ops.gelu_bwd(ws["mlp_n1"], da1, dn1, Bp * H2)
+                dh1b = buf("mlp_dh1b", (Bp, H2), bf)
+                ops.layernorm_bwd(ws["mlp_h1"], ws["mlp_mean"], ws["mlp_rstd"], P.w("classifier.1.weight"), B, H2,
+                                  dy_f32=dn1, dx_bf16=dh1b, dgamma=P.gr("classifier.1.weight"),
+                                  dbeta=P.gr("classifier.1.bias"), dbias=P.gr("classifier.0.bias"))
+                self._wgrad(dh1b, ws["pooled_b"], "classifier.0.weight", None, Bp, H2, H, B)
+                dpl = buf("mlp_dpooled", (Bp, H))
+                ops.gemm(dh1b, P.wb("classifier.0.weight", shape=(H2, H)), dpl, Bp, H, H2, H2, H, H, 0, 1, ops.EPI_F32_RES,
+                         m_valid=B)
+                ops.tanh_bwd(ws["pooled"], dpl, dpre, B * H)
+            elif spec.n_classes > 0 and dpooled is None:
                 hd = self._drop(self.classifier_dropout, 9001, True)
                 gs = (1.0 / B) if grad_scale is None else grad_scale
                 ops.head_bwd(ws["pooled"], ws["logits"], ws.get("labels"), P.w("classifier.1.weight"),

@@ -162,14 +162,14 @@ class VaultMixin(nn.Module):
 
     def __init__(self, vilt_config, bert_config=None, freeze_lm: bool = False, vilt_dropout_prob: float = 0.0,
                  use_vilt_position_embeddings: bool = False, add_pooling_layer: bool = True, *, _n_classes: int = 0,
-                 _seed: int = 0, _state: Optional[Dict[str, np.ndarray]] = None):
+                 _seed: int = 0, _state: Optional[Dict[str, np.ndarray]] = None, _head: str = "linear"):
         super().__init__()
         self.config = vilt_config
         self.freeze_lm = freeze_lm
         self.vilt_dropout_prob = vilt_dropout_prob
         self.spec = VaultSpec(vilt=vilt_spec_from_config(vilt_config), lm=lm_spec_from_config(bert_config),
                               n_classes=_n_classes, use_vilt_position_embeddings=use_vilt_position_embeddings,
-                              add_pooling_layer=add_pooling_layer)
+                              add_pooling_layer=add_pooling_layer, head=_head)
         self._engine: Optional[VaultEngine] = None
         if self.spec.lm is None:
             self.bert = None       # ref model.py:83-87: no LM -> plain ViLT text embeddings
@@ -284,6 +284,7 @@ class VaultMixin(nn.Module):
                         break
         model._adopt_checkpoint_heads(vsd, new, own)
         missing = [k for k in own if k not in new and not k.startswith(("classifier.", "rank_output."))]
+        model._loaded_keys = set(new)
         if missing:
             logging.getLogger(__name__).warning("from_pretrained: %d tensors keep their initial values (e.g. %s)",
                                                 len(missing), missing[:3])
@@ -433,3 +434,51 @@ class VaultForImageAndTextRetrieval(VaultMixin):
         if kwargs.get("return_dict", True) is False:
             return (logits,)
         return _SequenceClassifierOutput(loss=None, logits=logits)
+
+
+class VaultForQuestionAnswering(VaultMixin):
+    """VAuLT for visual question answering (ref model.py:472-509 on HF ``ViltForQuestionAnswering``): classifier =
+    Linear(H, 2H) - LayerNorm(2H) - GELU - Linear(2H, num_labels) on the pooled output, all of it on the HIP path;
+    ``loss`` = BCE-with-logits x num_labels when ``labels`` (soft scores [B, num_labels]) are given, like HF.
+    ``n_classes`` replaces the label count of the config (ref ``renew_classifier``: a freshly initialised output
+    projection); ``state_dict`` keys ``vilt.*`` / ``bert.*`` / ``classifier.{0,1,3}.*``."""
+
+    _head_dropout = False
+
+    @staticmethod
+    def _ext_name(n: str) -> str:
+        return n if n.startswith(("bert.", "classifier.")) else "vilt." + n
+
+    def __init__(self, config, bert_config=None, freeze_lm: bool = False, vilt_dropout_prob: float = 0.0,
+                 use_vilt_position_embeddings: bool = False, n_classes: Optional[int] = None, **kw):
+        num_labels = n_classes if n_classes is not None else _get(config, "num_labels", None)
+        if num_labels is None:
+            id2label = _get(config, "id2label", None)
+            num_labels = len(id2label) if id2label else 2
+        self._n_classes = int(num_labels)
+        super().__init__(config, bert_config=bert_config, freeze_lm=freeze_lm, vilt_dropout_prob=vilt_dropout_prob,
+                         use_vilt_position_embeddings=use_vilt_position_embeddings, add_pooling_layer=True,
+                         _n_classes=self._n_classes, _head="mlp", **kw)
+
+    @classmethod
+    def from_pretrained(cls, *args, **kwargs):
+        n_classes = kwargs.pop("n_classes", None)
+        model = super().from_pretrained(*args, n_classes=n_classes, **kwargs)
+        if n_classes is not None and "classifier.3.weight" not in getattr(model, "_loaded_keys", ()):
+            print("Substituting current classifier, you should probably TRAIN this model on a down-stream task to be able "
+                  "to use it for predictions and inference.")
+        return model
+
+    def renew_classifier(self, num_labels: int):
+        raise NotImplementedError("renew_classifier: build the model with n_classes=<num_labels> "
+                                  "(the head lives in the engine's flat parameter buffer)")
+
+    def forward(self, *args, labels=None, **kwargs):
+        logits = self._run(args, kwargs, want_logits=True)
+        loss = None
+        if labels is not None:
+            labels = labels.to(logits.device, logits.dtype)
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, labels) * labels.shape[1]
+        if kwargs.get("return_dict", True) is False:
+            return (logits,) if loss is None else (loss, logits)
+        return _SequenceClassifierOutput(loss=loss, logits=logits)

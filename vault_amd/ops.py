@@ -318,6 +318,14 @@ def tanh_bwd(pooled, dpooled, dpre_bf16, n):
             C.c_longlong(n), _stream())
 
 
+def gelu_fwd(x, y_bf16, n):
+    _invoke("vault_gelu_fwd", C.c_void_p(_p(x)), C.c_void_p(_p(y_bf16)), C.c_longlong(n), _stream())
+
+
+def gelu_bwd(x, dy, dx, n):
+    _invoke("vault_gelu_bwd", C.c_void_p(_p(x)), C.c_void_p(_p(dy)), C.c_void_p(_p(dx)), C.c_longlong(n), _stream())
+
+
 def adamw_step(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay, bias_corr_factor=1.0, grad_scale=1.0,
                zero_grad=True):
     _invoke("vault_adamw_step", C.c_void_p(_p(p)), C.c_void_p(_p(g)), C.c_void_p(_p(m)), C.c_void_p(_p(v)),

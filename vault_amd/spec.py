@@ -82,6 +82,8 @@ class VaultSpec:
     vilt: ViltSpec = dataclasses.field(default_factory=ViltSpec)
     lm: Optional[LMSpec] = dataclasses.field(default_factory=LMSpec)
     n_classes: int = 0                 # 0 => VaultModel (no classifier head)
+    head: str = "linear"               # "linear": Dropout-Linear on the pooled output (TMSC, retrieval rank head);
+                                       # "mlp": Linear(H,2H)-LayerNorm-GELU-Linear(2H,n_classes) (HF VQA head)
     use_vilt_position_embeddings: bool = False
     add_pooling_layer: bool = True
 
@@ -178,7 +180,11 @@ def param_entries(spec: VaultSpec) -> List[ParamEntry]:
         ]
         for i in range(lm.num_hidden_layers):
             e += _layer_entries(f"bert.encoder.layer.{i}", HL, lm.intermediate_size, "bert")
-    if spec.n_classes > 0:
+    if spec.n_classes > 0 and spec.head == "mlp":
+        e += [("classifier.0.weight", (2 * H, H), "normal"), ("classifier.0.bias", (2 * H,), "normal"),
+              ("classifier.1.weight", (2 * H,), "ln_w"), ("classifier.1.bias", (2 * H,), "normal"),
+              ("classifier.3.weight", (spec.n_classes, 2 * H), "normal"), ("classifier.3.bias", (spec.n_classes,), "normal")]
+    elif spec.n_classes > 0:
         e += [("classifier.1.weight", (spec.n_classes, H), "normal"),
               ("classifier.1.bias", (spec.n_classes,), "normal")]
     return e

@@ -165,7 +165,7 @@ class TrainStep:
             ops.GEMM_SCHED = 3
         if self.world > 1 or (os.environ.get("VAULT_FORCE_DP") == "1" and dist.is_available() and dist.is_initialized()):
             b = GradBuckets(engine, bucket_mb)
-            self.reducer = BucketReducer(engine.params.g, b.stage_lo, b.last_tag, b.bucket_elems, dist, process_group,
+            self.reducer = BucketReducer(engine.params.g[:engine.params.n_train], b.stage_lo, b.last_tag, b.bucket_elems, dist, process_group,
                                          torch.cuda.Stream(device=engine.device), engine.device)
 
     def current_lr(self) -> float:
