@@ -21,6 +21,6 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 n = 10
 for _ in range(n): loss = step(db, lab)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-ws = [w for k, w in eng._ws.items() if k[3:] != (0, 0, 0)][0]
+ws = [w for k, w in eng._ws.items() if len(k) == 7 and k[3:6] != (0, 0, 0)][0]
 print(f"B={B} canvas 384x640 S={ws['S']} valid patches/sample mean {ws['n_valid'].mean():.1f}: {dt*1e3:.2f} ms/step, "
       f"{B/dt:.1f} samples/s, loss {float(loss):.4f} (per-step host patch selection + mask check included)")

@@ -55,7 +55,7 @@ class ParamStore:
         self.frozen = rest
         # the MLP head's output projection is used as a GEMM operand padded to a multiple of 256 rows: readable (zero)
         # slack behind the buffers, never part of [0, n_train) that the optimizer and the all-reduce walk
-        self.slack = 256 * 2 * spec.vilt.hidden_size + 1024 if (spec.n_classes > 0 and spec.head == "mlp") else 0
+        self.slack = 256 * spec.mlp_dims[1] + 1024 if (spec.n_classes > 0 and spec.head == "mlp") else 0
         host = np.zeros(self.n_total + self.slack, np.float32)
         if state is None:
             state = build_state(spec, seed)
@@ -250,13 +250,14 @@ class VaultEngine:
 
     MAX_RAGGED_WORKSPACES = 2   # padded-image geometries kept alive (each owns every activation buffer of a step)
 
-    def workspace(self, B: int, T: int, train: bool, geom: Tuple[int, int, int] = (0, 0, 0)) -> dict:
+    def workspace(self, B: int, T: int, train: bool, geom: Tuple[int, int, int] = (0, 0, 0), tag: int = 0) -> dict:
         """Buffers of one (batch, text length, mode, image geometry); geom = (L, HP, WP) for padded batches of
-        differently sized images, (0, 0, 0) for the square pre-training canvas with all-valid masks."""
-        key = (B, T, train) + tuple(geom)
+        differently sized images, (0, 0, 0) for the square pre-training canvas with all-valid masks.  ``tag``
+        separates the activation sets of several encoder passes that are alive at once (multi-image heads)."""
+        key = (B, T, train) + tuple(geom) + (tag,)
         if key not in self._ws:
             if geom != (0, 0, 0):
-                old = [k for k in self._ws if k[3:] != (0, 0, 0)]
+                old = [k for k in self._ws if len(k) == 7 and k[3:6] != (0, 0, 0)]
                 while len(old) >= self.MAX_RAGGED_WORKSPACES:
                     self._ws.pop(old.pop(0))
             self._ws[key] = {"B": B, "T": T, "key": key}
@@ -319,14 +320,19 @@ class VaultEngine:
     # ---- forward ----------------------------------------------------------------------------
     def forward(self, batch: Dict[str, torch.Tensor], train: bool = False, labels: Optional[torch.Tensor] = None,
                 need_hidden: bool = True, loss_scale: Optional[float] = None,
-                precise: bool = False) -> Dict[str, torch.Tensor]:
+                precise: bool = False, ws_tag: int = 0, image_token_type_idx: int = 1,
+                advance_seed: bool = True) -> Dict[str, torch.Tensor]:
         """batch tensors must already be on the device (int64 ids / mask, f32 pixels).  Returns device
-        tensors; in train mode keeps every activation needed by :meth:`backward`."""
+        tensors; in train mode keeps every activation needed by :meth:`backward` (in the workspace ``self.last``).
+        ``ws_tag`` / ``image_token_type_idx`` / ``advance_seed=False``: further encoder passes over other images of
+        the same samples (HF ``ViltForImagesAndTextClassification``: modality type i + 1 for image i, one LM pass -
+        here one per image with identical dropout masks)."""
         with torch.cuda.device(self.device):
-            return self._forward(batch, train, labels, need_hidden, loss_scale, precise)
+            return self._forward(batch, train, labels, need_hidden, loss_scale, precise, ws_tag, image_token_type_idx,
+                                 advance_seed)
 
     def stage_inputs(self, batch: Dict[str, torch.Tensor], train: bool, labels: Optional[torch.Tensor] = None,
-                     validate: bool = True) -> dict:
+                     validate: bool = True, ws_tag: int = 0) -> dict:
         """Validate the batch (HF-style errors) and copy it into the persistent input buffers of the
         (B, T, train) workspace, so that every kernel argument of a step is pointer-stable (required for
         tape replay).  ``validate=False`` skips the pixel-mask check (it synchronises the device)."""
@@ -373,7 +379,7 @@ class VaultEngine:
         else:
             NP = v.num_patches
         S = T + 1 + NP
-        ws = self.workspace(B, T, train, geom)
+        ws = self.workspace(B, T, train, geom, ws_tag)
         ws.update(S=S, M=B * S, Mp=_pad(B * S), H=H, FF=FF, heads=heads, NP=NP, train=train,
                   Ml=B * T, Mlp=_pad(B * T), ragged=ragged, HP=HP, WP=WP)
         buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
@@ -411,11 +417,15 @@ class VaultEngine:
                 "pixel_values": buf("in_pix", (B, v.num_channels, v.image_size, v.image_size)),
                 "labels": buf("in_labels", (B,), torch.int64)}
 
-    def _forward(self, batch, train, labels, need_hidden, loss_scale, precise=False):
+    def _forward(self, batch, train, labels, need_hidden, loss_scale, precise=False, ws_tag=0, image_type_idx=1,
+                 advance_seed=True):
         if precise and train:
             raise ValueError("precise (split-bf16) mode is inference-only")
-        ws = self.stage_inputs(batch, train, labels)
-        if train:
+        if not 0 < image_type_idx < self.spec.vilt.modality_type_vocab_size:
+            raise ValueError("image_token_type_idx outside the modality type table")
+        ws = self.stage_inputs(batch, train, labels, ws_tag=ws_tag)
+        ws["img_type"] = image_type_idx
+        if train and advance_seed:
             self.drop_seed = (self.drop_seed + 1) & 0xFFFFFFFF
         if precise:
             self.params.ensure_split3()
@@ -522,11 +532,11 @@ class VaultEngine:
             # padded batch of differently sized images: selected patch slots only, per-image resized position table
             ops.im2col_sel(pix, apatch, ws["sel"], B, NP, v.num_channels, ws["HP"], ws["WP"], v.patch_size, split3=pr)
             ops.image_sel_consts(P.w("embeddings.patch_embeddings.projection.bias"), P.w("embeddings.position_embeddings"),
-                                 mt[1], P.w("embeddings.cls_token"), addtab, x[0], NP, H, B, S, T)
+                                 mt[ws.get("img_type", 1)], P.w("embeddings.cls_token"), addtab, x[0], NP, H, B, S, T)
         else:
             ops.im2col(pix, apatch, B, v.num_channels, v.image_size, v.patch_size, split3=pr)
             ops.image_consts(P.w("embeddings.patch_embeddings.projection.bias"), P.w("embeddings.position_embeddings"),
-                             mt[1], P.w("embeddings.cls_token"), addtab, x[0], NP, H, B, S, T)
+                             mt[ws.get("img_type", 1)], P.w("embeddings.cls_token"), addtab, x[0], NP, H, B, S, T)
         ops.gemm(apatch, P.wb3(wpn, H, Kp) if pr else P.wb(wpn, shape=(H, Kp)), x[0], Mpp, H, W3 * Kp, W3 * Kp, W3 * Kp,
                  H, 0, 0, ops.EPI_F32_PATCH, m_valid=B * NP, addtab=addtab, rpg=NP, gstride=S, goff=T + 1)
         if ws["ragged"]:
@@ -578,24 +588,9 @@ class VaultEngine:
                          precise=pr)
             pooled = buf("pooled", (Bp, H))
             if spec.n_classes > 0 and spec.head == "mlp":
-                # HF ViltForQuestionAnswering.classifier: Linear(H, 2H) - LayerNorm(2H, eps 1e-5) - GELU - Linear(2H, L).
-                # The output projection runs with L padded to 256 columns (readable slack behind the parameter buffers).
-                L, H2 = spec.n_classes, 2 * H
-                Lp = _pad(L)
                 ops.head_fwd(pre, None, None, None, pooled, None, None, B, H, 0, 0.0)   # tanh
-                pooled_b = buf("pooled_b", (Bp, H), bf)
-                ops.cast_bf16(pooled, pooled_b, Bp * H)
-                h1 = buf("mlp_h1", (Bp, H2))
-                self._linear(pooled_b, "classifier.0.weight", h1, Bp, H2, H, ops.EPI_F32_RES, B, bias=P.w("classifier.0.bias"))
-                n1 = buf("mlp_n1", (Bp, H2))
-                ops.layernorm_fwd(h1, P.w("classifier.1.weight"), P.w("classifier.1.bias"), 1e-5, B, H2, y_f32=n1,
-                                  mean=buf("mlp_mean", (Bp,)), rstd=buf("mlp_rstd", (Bp,)))
-                a1 = buf("mlp_a1", (Bp, H2), bf)
-                ops.gelu_fwd(n1, a1, Bp * H2)
-                lg = buf("mlp_logits", (Bp, Lp))
-                ops.gemm(a1, P.wb("classifier.3.weight", n_elems=Lp * H2, shape=(Lp, H2)), lg, Bp, Lp, H2, H2, H2, Lp, 0, 0,
-                         ops.EPI_F32_RES, m_valid=B, bias=P.w("classifier.3.bias", n_elems=Lp, shape=(Lp,)))
-                out["logits"] = lg[:B, :L]
+                if spec.num_images == 1:     # (multi-image heads run on the concatenated pooled outputs: mlp_head_forward)
+                    out["logits"] = self._mlp_forward(ws, pooled, B)
             elif spec.n_classes > 0:
                 C = spec.n_classes
                 logits = buf("logits", (B, C))
@@ -615,6 +610,76 @@ class VaultEngine:
         self.last = ws
         return out
 
+    # ---- MLP task head (HF ViltForQuestionAnswering / ViltForImagesAndTextClassification .classifier) ------------
+    def _mlp_forward(self, ws: dict, x_f32: torch.Tensor, B: int) -> torch.Tensor:
+        """logits = Linear(GELU(LayerNorm(Linear(x))))  for x [>= B rows, H_in] f32; Linear(H_in, H_mid) -
+        LayerNorm(H_mid, eps 1e-5) - GELU - Linear(H_mid, L).  The output projection runs with L padded to 256 columns
+        (readable slack behind the parameter buffers).  Buffers live in ``ws``."""
+        spec, P = self.spec, self.params
+        Hin, Hm = spec.mlp_dims
+        L = spec.n_classes
+        Lp, Bp = _pad(L), _pad(B)
+        bf = torch.bfloat16
+        buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
+        xb = buf("mlp_xb", (Bp, Hin), bf)
+        ops.cast_bf16(x_f32, xb, B * Hin)
+        h1 = buf("mlp_h1", (Bp, Hm))
+        self._linear(xb, "classifier.0.weight", h1, Bp, Hm, Hin, ops.EPI_F32_RES, B, bias=P.w("classifier.0.bias"))
+        n1 = buf("mlp_n1", (Bp, Hm))
+        ops.layernorm_fwd(h1, P.w("classifier.1.weight"), P.w("classifier.1.bias"), 1e-5, B, Hm, y_f32=n1,
+                          mean=buf("mlp_mean", (Bp,)), rstd=buf("mlp_rstd", (Bp,)))
+        a1 = buf("mlp_a1", (Bp, Hm), bf)
+        ops.gelu_fwd(n1, a1, Bp * Hm)
+        lg = buf("mlp_logits", (Bp, Lp))
+        ops.gemm(a1, P.wb("classifier.3.weight", n_elems=Lp * Hm, shape=(Lp, Hm)), lg, Bp, Lp, Hm, Hm, Hm, Lp, 0, 0,
+                 ops.EPI_F32_RES, m_valid=B, bias=P.w("classifier.3.bias", n_elems=Lp, shape=(Lp,)))
+        return lg[:B, :L]
+
+    def _mlp_backward(self, ws: dict, dlogits: torch.Tensor, B: int) -> torch.Tensor:
+        """Parameter gradients of the MLP head (+=) and d/dx [Bp, H_in] f32 of the last :meth:`_mlp_forward` on ``ws``."""
+        spec, P = self.spec, self.params
+        Hin, Hm = spec.mlp_dims
+        L = spec.n_classes
+        Lp, Bp = _pad(L), _pad(B)
+        bf = torch.bfloat16
+        buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
+        dl32 = buf("mlp_dlogits", (Bp, Lp))
+        ops.pycall(dl32.zero_)
+        dl32[:B, :L].copy_(dlogits.reshape(B, L))
+        dlb = buf("mlp_dlogits_b", (Bp, Lp), bf)
+        ops.cast_bf16(dl32, dlb, Bp * Lp)
+        # output projection: weight-gradient rows >= L are never written (m_valid); its bias gradient is the column sum
+        # (the padded columns are zero and land in the slack behind the gradient buffer)
+        self._wgrad(dlb, ws["mlp_a1"], "classifier.3.weight", "classifier.3.bias", Bp, Lp, Hm, B, out_rows=L)
+        da1 = buf("mlp_da1", (Bp, Hm))
+        ops.gemm(dlb, P.wb("classifier.3.weight", n_elems=Lp * Hm, shape=(Lp, Hm)), da1, Bp, Hm, Lp, Lp, Hm, Hm, 0, 1,
+                 ops.EPI_F32_RES, m_valid=B)
+        dn1 = buf("mlp_dn1", (Bp, Hm))
+        ops.gelu_bwd(ws["mlp_n1"], da1, dn1, Bp * Hm)
+        dh1b = buf("mlp_dh1b", (Bp, Hm), bf)
+        ops.layernorm_bwd(ws["mlp_h1"], ws["mlp_mean"], ws["mlp_rstd"], P.w("classifier.1.weight"), B, Hm, dy_f32=dn1,
+                          dx_bf16=dh1b, dgamma=P.gr("classifier.1.weight"), dbeta=P.gr("classifier.1.bias"),
+                          dbias=P.gr("classifier.0.bias"))
+        self._wgrad(dh1b, ws["mlp_xb"], "classifier.0.weight", None, Bp, Hm, Hin, B)
+        dx = buf("mlp_dx", (Bp, Hin))
+        ops.gemm(dh1b, P.wb("classifier.0.weight", shape=(Hm, Hin)), dx, Bp, Hin, Hm, Hm, Hin, Hin, 0, 1, ops.EPI_F32_RES,
+                 m_valid=B)
+        return dx
+
+    def mlp_head_forward(self, x_f32: torch.Tensor, train: bool = True) -> torch.Tensor:
+        """The MLP head on an external input [B, H_in] (concatenated pooled outputs of several encoder passes)."""
+        with torch.cuda.device(self.device):
+            B = x_f32.shape[0]
+            ws = self._ws.setdefault(("mlp_head", B), {})
+            xin = self._buf(ws, "mlp_xin", (_pad(B), self.spec.mlp_dims[0]), torch.float32)
+            xin[:B].copy_(x_f32)
+            return self._mlp_forward(ws, xin, B)
+
+    def mlp_head_backward(self, dlogits: torch.Tensor) -> torch.Tensor:
+        with torch.cuda.device(self.device):
+            B = dlogits.shape[0]
+            return self._mlp_backward(self._ws[("mlp_head", B)], dlogits.contiguous().float(), B)[:B]
+
     # ---- backward ---------------------------------------------------------------------------
     def zero_grad(self):
         if self.params.g is not None:
@@ -622,7 +687,7 @@ class VaultEngine:
 
     def backward(self, grad_scale: Optional[float] = None, dlogits: Optional[torch.Tensor] = None,
                  dpooled: Optional[torch.Tensor] = None, dhidden: Optional[torch.Tensor] = None,
-                 after_layer=None):
+                 after_layer=None, ws: Optional[dict] = None):
         """Accumulate parameter gradients of the last train-mode forward into the flat grad buffer.
 
         Default (VaultForTMSC + labels): d(mean CE)/d(params), scaled by ``grad_scale`` (1/B).
@@ -631,10 +696,10 @@ class VaultEngine:
         gradient range that just became final.
         """
         with torch.cuda.device(self.device):
-            self._backward(grad_scale, dlogits, dpooled, dhidden, after_layer)
+            self._backward(grad_scale, dlogits, dpooled, dhidden, after_layer, ws)
 
-    def _backward(self, grad_scale, dlogits, dpooled, dhidden, after_layer):
-        ws = self.last
+    def _backward(self, grad_scale, dlogits, dpooled, dhidden, after_layer, ws=None):
+        ws = self.last if ws is None else ws
         if ws is None or not ws.get("train"):
             raise RuntimeError("backward() needs a preceding forward(train=True)")
         spec, P = self.spec, self.params
@@ -662,30 +727,7 @@ class VaultEngine:
             if spec.n_classes > 0 and spec.head == "mlp" and dpooled is None:
                 if dlogits is None:
                     raise ValueError("the MLP head has no built-in loss: pass dlogits (the autograd bridge does)")
-                L, H2 = spec.n_classes, 2 * H
-                Lp = _pad(L)
-                dl32 = buf("mlp_dlogits", (Bp, Lp))
-                ops.pycall(dl32.zero_)
-                dl32[:B, :L].copy_(dlogits.view(B, L))
-                dlb = buf("mlp_dlogits_b", (Bp, Lp), bf)
-                ops.cast_bf16(dl32, dlb, Bp * Lp)
-                # output projection: weight gradient rows >= L are never written (m_valid), its bias gradient is the
-                # column sum (the padded columns are zero and land in the slack behind the gradient buffer)
-                self._wgrad(dlb, ws["mlp_a1"], "classifier.3.weight", "classifier.3.bias", Bp, Lp, H2, B, out_rows=L)
-                da1 = buf("mlp_da1", (Bp, H2))
-                ops.gemm(dlb, P.wb("classifier.3.weight", n_elems=Lp * H2, shape=(Lp, H2)), da1, Bp, H2, Lp, Lp, H2, H2, 0, 1,
-                         ops.EPI_F32_RES, m_valid=B)
-                dn1 = buf("mlp_dn1", (Bp, H2))
-                ops.gelu_bwd(ws["mlp_n1"], da1, dn1, Bp * H2)
-                dh1b = buf("mlp_dh1b", (Bp, H2), bf)
-                ops.layernorm_bwd(ws["mlp_h1"], ws["mlp_mean"], ws["mlp_rstd"], P.w("classifier.1.weight"), B, H2,
-                                  dy_f32=dn1, dx_bf16=dh1b, dgamma=P.gr("classifier.1.weight"),
-                                  dbeta=P.gr("classifier.1.bias"), dbias=P.gr("classifier.0.bias"))
-                self._wgrad(dh1b, ws["pooled_b"], "classifier.0.weight", None, Bp, H2, H, B)
-                dpl = buf("mlp_dpooled", (Bp, H))
-                ops.gemm(dh1b, P.wb("classifier.0.weight", shape=(H2, H)), dpl, Bp, H, H2, H2, H, H, 0, 1, ops.EPI_F32_RES,
-                         m_valid=B)
-                ops.tanh_bwd(ws["pooled"], dpl, dpre, B * H)
+                ops.tanh_bwd(ws["pooled"], self._mlp_backward(ws, dlogits, B), dpre, B * H)
             elif spec.n_classes > 0 and dpooled is None:
                 hd = self._drop(self.classifier_dropout, 9001, True)
                 gs = (1.0 / B) if grad_scale is None else grad_scale
@@ -748,11 +790,11 @@ class VaultEngine:
         gpos = P.gr("embeddings.position_embeddings", shape=(v.num_patches + 1, H))
         gmt = P.gr("embeddings.token_type_embeddings.weight")
         if ws["ragged"]:
-            ops.image_sel_bwd(dx0, gpos, gmt[1], P.gr("embeddings.cls_token", shape=(H,)),
+            ops.image_sel_bwd(dx0, gpos, gmt[ws.get("img_type", 1)], P.gr("embeddings.cls_token", shape=(H,)),
                               P.gr("embeddings.patch_embeddings.projection.bias"), dyp, ws["sel"], ws["hw"], B, NP, S, T, H,
                               ws["gw"], v.image_size // v.patch_size)
         else:
-            ops.image_rows_bwd(dx0, gpos, gmt[1], P.gr("embeddings.cls_token", shape=(H,)),
+            ops.image_rows_bwd(dx0, gpos, gmt[ws.get("img_type", 1)], P.gr("embeddings.cls_token", shape=(H,)),
                                P.gr("embeddings.patch_embeddings.projection.bias"), dyp, NP, H, B, S, T)
         self._wgrad(dyp, ws["apatch"], "embeddings.patch_embeddings.projection.weight", None, Mpp, H, Kp, B * NP)
         dvs = buf("d_vt_sum", (Mlp, H))

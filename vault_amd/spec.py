@@ -84,6 +84,15 @@ class VaultSpec:
     n_classes: int = 0                 # 0 => VaultModel (no classifier head)
     head: str = "linear"               # "linear": Dropout-Linear on the pooled output (TMSC, retrieval rank head);
                                        # "mlp": Linear(H,2H)-LayerNorm-GELU-Linear(2H,n_classes) (HF VQA head)
+    num_images: int = 1                # > 1: HF ViltForImagesAndTextClassification - one encoder pass per image, the MLP
+                                       # head (Linear(nH,nH)-LayerNorm-GELU-Linear(nH,n_classes)) on the concatenated
+                                       # pooled outputs
+
+    @property
+    def mlp_dims(self) -> Tuple[int, int]:
+        """(input width, hidden width) of the MLP head."""
+        H = self.vilt.hidden_size
+        return (H, 2 * H) if self.num_images == 1 else (self.num_images * H, self.num_images * H)
     use_vilt_position_embeddings: bool = False
     add_pooling_layer: bool = True
 
@@ -181,9 +190,10 @@ def param_entries(spec: VaultSpec) -> List[ParamEntry]:
         for i in range(lm.num_hidden_layers):
             e += _layer_entries(f"bert.encoder.layer.{i}", HL, lm.intermediate_size, "bert")
     if spec.n_classes > 0 and spec.head == "mlp":
-        e += [("classifier.0.weight", (2 * H, H), "normal"), ("classifier.0.bias", (2 * H,), "normal"),
-              ("classifier.1.weight", (2 * H,), "ln_w"), ("classifier.1.bias", (2 * H,), "normal"),
-              ("classifier.3.weight", (spec.n_classes, 2 * H), "normal"), ("classifier.3.bias", (spec.n_classes,), "normal")]
+        hin, hmid = spec.mlp_dims
+        e += [("classifier.0.weight", (hmid, hin), "normal"), ("classifier.0.bias", (hmid,), "normal"),
+              ("classifier.1.weight", (hmid,), "ln_w"), ("classifier.1.bias", (hmid,), "normal"),
+              ("classifier.3.weight", (spec.n_classes, hmid), "normal"), ("classifier.3.bias", (spec.n_classes,), "normal")]
     elif spec.n_classes > 0:
         e += [("classifier.1.weight", (spec.n_classes, H), "normal"),
               ("classifier.1.bias", (spec.n_classes,), "normal")]
