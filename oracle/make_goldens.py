@@ -334,6 +334,63 @@ def run_reference_vqa(ref, name, outdir):
           f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
+def run_reference_nlvr2(ref, name, outdir):
+    """VaultForImagesAndTextClassification (ref: model.py:408-465 on HF ViltForImagesAndTextClassification): two images
+    per sample, one encoder pass each with modality type i + 1 (table resized to 3 rows), MLP head on the
+    concatenated pooled outputs, CE loss."""
+    spec = VaultSpec.tiny(2, "roberta")
+    spec.head, spec.num_images = "mlp", 2
+    spec.vilt.modality_type_vocab_size = 3
+    vc, lc = hf_configs(spec)
+    vc.num_images = 2
+    vc.num_labels = 2
+    vc.modality_type_vocab_size = 2      # the reference resizes the table itself (resize_token_type_embeddings)
+    model = ref.VaultForImagesAndTextClassification(vc, bert_config=lc).eval()
+    state = build_state(spec, 0)
+    sd = model.state_dict()
+    ext = lambda n: n if n.startswith(("bert.", "classifier.")) else "vilt." + n   # noqa: E731
+    with torch.no_grad():
+        for k, v in state.items():
+            assert tuple(sd[ext(k)].shape) == tuple(v.shape), (k, sd[ext(k)].shape, v.shape)
+            sd[ext(k)].copy_(torch.from_numpy(v))
+        model.vilt.embeddings.text_embeddings.position_embeddings.weight.zero_()   # D1
+    unexpected = [k for k in sd if k not in {ext(n) for n in state} and "position_ids" not in k and "token_type_ids" not in k]
+    assert not unexpected, unexpected[:5]
+    B, dseed = 3, 61
+    batch = synthetic_batch(spec, B, seed=dseed, n_classes=2)
+    rng = np.random.Generator(np.random.PCG64(dseed + 1))
+    img = spec.vilt.image_size
+    pix2 = np.clip(rng.standard_normal((B, 2, spec.vilt.num_channels, img, img), dtype=np.float32), -1.0, 1.0)
+    kw = {k: torch.from_numpy(batch[k]) for k in ("input_ids", "attention_mask")}
+    torch.manual_seed(0)
+    out = model(**kw, pixel_values=torch.from_numpy(pix2), labels=torch.from_numpy(batch["labels"]))
+    out.loss.backward()
+    res = {"logits": out.logits.detach().numpy(), "loss": np.float32(out.loss.item()),
+           "meta_batch": np.int64(B), "meta_data_seed": np.int64(dseed)}
+    names, norms = [], []
+    for k, p in model.named_parameters():
+        if p.grad is None or k == "vilt.embeddings.text_embeddings.position_embeddings.weight":
+            continue
+        names.append(k)
+        norms.append(float(p.grad.double().norm()))
+        if (k.startswith("classifier.") and k != "classifier.0.weight") or k in ("vilt.embeddings.token_type_embeddings.weight",
+                                                                               "vilt.pooler.dense.bias"):
+            res["grad::" + k] = p.grad.detach().numpy().copy()
+    res["grad_names"] = np.array(names)
+    res["grad_norms"] = np.array(norms, np.float64)
+    path = os.path.join(outdir, f"{name}.npz")
+    np.savez_compressed(path, **res)
+    print(name, "loss", res["loss"], "logits", res["logits"].ravel(), "n grads", len(names), "->", path,
+          f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
+def nlvr2_pixels(spec, B, dseed):
+    """The two-image pixel tensor of the NLVR2 case (shared with the tests)."""
+    rng = np.random.Generator(np.random.PCG64(dseed + 1))
+    img = spec.vilt.image_size
+    return np.clip(rng.standard_normal((B, 2, spec.vilt.num_channels, img, img), dtype=np.float32), -1.0, 1.0)
+
+
 def main():
     ref = import_reference()
     outdir = os.path.join(ROOT, "tests", "golden")
@@ -353,6 +410,8 @@ def main():
         np.savez_compressed(path, **out)
         print(name, "loss", out["loss"], "logits", out["logits"].ravel()[:6], "->", path,
               f"{os.path.getsize(path)/1024:.0f} KiB")
+    if not only or "tiny_roberta_nlvr2" in only:
+        run_reference_nlvr2(ref, "tiny_roberta_nlvr2", outdir)
     if not only or "tiny_roberta_vqa" in only:
         run_reference_vqa(ref, "tiny_roberta_vqa", outdir)
     if not only or "tiny_roberta_itr" in only:

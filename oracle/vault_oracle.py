@@ -140,7 +140,8 @@ def lm_forward(P, spec, input_ids, attention_mask, token_type_ids=None, taps: Op
     return x
 
 
-def vilt_embed(P, spec, text_in, attention_mask, token_type_ids, pixel_values, taps=None, pixel_mask=None):
+def vilt_embed(P, spec, text_in, attention_mask, token_type_ids, pixel_values, taps=None, pixel_mask=None,
+               image_type_idx: int = 1):
     """text_in: LM output [B,T,H] (inputs_embeds) or int64 ids [B,T] when no LM is used."""
     v = spec.vilt
     B = pixel_values.shape[0]
@@ -189,7 +190,7 @@ def vilt_embed(P, spec, text_in, attention_mask, token_type_ids, pixel_values, t
         img = torch.cat([cls, patches], dim=1)
         img_mask = torch.cat([torch.ones((B, 1), dtype=attention_mask.dtype),
                               torch.from_numpy(valid.astype(np.int64)).to(attention_mask.dtype)], dim=1)
-    img = img + mt[1]
+    img = img + mt[image_type_idx]
     x = torch.cat([text, img], dim=1)
     if taps is not None:
         taps["vilt_embed"] = x
@@ -228,6 +229,22 @@ def vault_forward(P, spec, batch: Dict[str, torch.Tensor], taps: Optional[dict] 
         text_in = lm_forward(P, spec, ids, am, tt, taps)
     else:
         text_in = ids
+    if getattr(spec, "num_images", 1) > 1:
+        # HF ViltForImagesAndTextClassification.forward (modeling_vilt.py): one encoder pass per image with modality
+        # type i + 1, pooled outputs concatenated, MLP classifier; the text goes through the LM once (ref
+        # VaultMixin.lm_preprocess, model.py:151-202)
+        pooled = []
+        pm = batch.get("pixel_mask")
+        for i in range(spec.num_images):
+            x, mask = vilt_embed(P, spec, text_in, am, tt, pix[:, i], None, pixel_mask=None if pm is None else pm[:, i],
+                                 image_type_idx=i + 1)
+            x = vilt_encoder(P, spec, x, mask, None)
+            x = _ln(x, P["layernorm.weight"], P["layernorm.bias"], spec.vilt.layer_norm_eps)
+            pooled.append(torch.tanh(_lin(x[:, 0], P["pooler.dense.weight"], P["pooler.dense.bias"])))
+        z = torch.cat(pooled, dim=-1)
+        h = _lin(z, P["classifier.0.weight"], P["classifier.0.bias"])
+        h = _ln(h, P["classifier.1.weight"], P["classifier.1.bias"], 1e-5)
+        return {"pooler_output": z, "logits": _lin(F.gelu(_r(h)), P["classifier.3.weight"], P["classifier.3.bias"])}
     x, mask = vilt_embed(P, spec, text_in, am, tt, pix, taps, pixel_mask=batch.get("pixel_mask"))
     x = vilt_encoder(P, spec, x, mask, taps)
     x = _ln(x, P["layernorm.weight"], P["layernorm.bias"], spec.vilt.layer_norm_eps)

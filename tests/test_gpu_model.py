@@ -233,6 +233,61 @@ def test_vqa_head_model_class_vs_reference_golden():
             assert np.linalg.norm(mine - g[k]) <= 6e-2 * np.linalg.norm(g[k]) + 1e-6, k
 
 
+def test_nlvr2_head_model_class_vs_reference_golden():
+    """VaultForImagesAndTextClassification: two encoder passes (own activation workspaces, modality types 1 / 2), the
+    MLP head on the concatenated pooled outputs, CE loss - loss and gradients against the reference's own run."""
+    from oracle.make_goldens import nlvr2_pixels
+    from vault_amd.models.vault import VaultForImagesAndTextClassification
+    g = np.load(os.path.join(GOLD, "tiny_roberta_nlvr2.npz"))
+    spec = _nodrop(VaultSpec.tiny(2, "roberta"))
+    B, dseed = int(g["meta_batch"]), int(g["meta_data_seed"])
+    bn = synthetic_batch(spec, B, seed=dseed, n_classes=2)
+    m = VaultForImagesAndTextClassification(spec.vilt, bert_config=spec.lm).to("cuda").train()
+    assert tuple(m.state_dict()["vilt.embeddings.token_type_embeddings.weight"].shape) == (3, spec.vilt.hidden_size)
+    out = m(input_ids=torch.from_numpy(bn["input_ids"]).cuda(), attention_mask=torch.from_numpy(bn["attention_mask"]).cuda(),
+            pixel_values=torch.from_numpy(nlvr2_pixels(spec, B, dseed)).cuda(), labels=torch.from_numpy(bn["labels"]).cuda())
+    out.loss.backward()
+    torch.cuda.synchronize()
+    assert np.abs(out.logits.detach().cpu().numpy() - g["logits"]).max() < 5e-3
+    assert abs(float(out.loss.detach()) - float(g["loss"])) < 3e-3
+    sd = dict(m.named_parameters())
+    num = den = 0.0
+    for k, ref_norm in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        assert sd[k].grad is not None, k
+        mine = float(sd[k].grad.double().norm())
+        num += (mine - ref_norm) ** 2; den += ref_norm ** 2
+    assert (num / den) ** 0.5 < 3e-2
+    for k in g.files:
+        if k.startswith("grad::"):
+            mine = sd[k[6:]].grad.cpu().numpy().reshape(g[k].shape)
+            assert np.linalg.norm(mine - g[k]) <= 8e-2 * np.linalg.norm(g[k]) + 1e-6, k
+    with pytest.raises(ValueError):
+        m(input_ids=torch.from_numpy(bn["input_ids"]).cuda(), pixel_values=torch.zeros(B, 3, 3, 192, 192, device="cuda"))
+
+
+def test_gradients_accumulate_across_backward_passes():
+    """Two forward/backward passes without zeroing in between leave the SUM of the two gradients in every
+    parameter (gradient accumulation; also what multi-image heads rely on)."""
+    spec = _nodrop(VaultSpec.tiny(3, "bert"))
+    state = build_state(spec, 0)
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    b1, b2 = _dev(synthetic_batch(spec, 3, seed=21, n_classes=3)), _dev(synthetic_batch(spec, 3, seed=22, n_classes=3))
+    grads = []
+    for b in (b1, b2):
+        eng.forward(b, train=True, labels=b["labels"], need_hidden=False)
+        eng.zero_grad()
+        eng.backward()
+        grads.append(eng.params.g[: eng.params.n_train].clone())
+    eng.zero_grad()
+    for b in (b1, b2):
+        eng.forward(b, train=True, labels=b["labels"], need_hidden=False)
+        eng.backward()
+    torch.cuda.synchronize()
+    both = eng.params.g[: eng.params.n_train]
+    want = grads[0] + grads[1]
+    assert float((both - want).norm() / want.norm()) < 1e-5       # float-atomic summation order only
+
+
 def test_full_size_against_reference_golden():
     """12+12 layers, hidden 768, B=2 (one padded caption): compare with numbers produced by the
     reference (HuggingFace ViltModel + RobertaModel under ref VaultForTMSC) in the build container."""

@@ -190,6 +190,35 @@ def test_oracle_matches_reference_golden_vqa_head():
             np.testing.assert_allclose(P[internal(k[6:])].grad.numpy().reshape(g[k].shape), g[k], atol=2e-6, rtol=1e-3)
 
 
+def test_oracle_matches_reference_golden_nlvr2_head():
+    """VaultForImagesAndTextClassification: two images per sample, modality types 1 / 2, MLP head on the concatenated
+    pooled outputs, CE loss - as run by the reference."""
+    from oracle.make_goldens import nlvr2_pixels
+    g = np.load(os.path.join(GOLD, "tiny_roberta_nlvr2.npz"))
+    spec = VaultSpec.tiny(2, "roberta")
+    spec.head, spec.num_images = "mlp", 2
+    spec.vilt.modality_type_vocab_size = 3
+    torch.set_num_threads(8)
+    B, dseed = int(g["meta_batch"]), int(g["meta_data_seed"])
+    bn = synthetic_batch(spec, B, seed=dseed, n_classes=2)
+    bn["pixel_values"] = nlvr2_pixels(spec, B, dseed)
+    del bn["pixel_mask"]
+    P = O.to_torch_state(build_state(spec, 0), requires_grad=True)
+    out = O.vault_forward(P, spec, O.torch_batch(bn))
+    loss = torch.nn.functional.cross_entropy(out["logits"], torch.from_numpy(bn["labels"]))
+    loss.backward()
+    np.testing.assert_allclose(out["logits"].detach().numpy(), g["logits"], atol=2e-5, rtol=0)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5
+    internal = lambda k: k[5:] if k.startswith("vilt.") else k   # noqa: E731
+    for k, ref_norm in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        n = internal(k)
+        assert P[n].grad is not None, n
+        assert abs(float(P[n].grad.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 2e-8, n
+    for k in g.files:
+        if k.startswith("grad::"):
+            np.testing.assert_allclose(P[internal(k[6:])].grad.numpy().reshape(g[k].shape), g[k], atol=2e-6, rtol=1e-3)
+
+
 def test_select_patches_edge_cases():
     # all-valid square canvas: identity order, nothing masked
     sel, valid, hw, grid, L = select_patches(np.ones((2, 64, 64), np.int64), 16)

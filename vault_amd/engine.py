@@ -798,11 +798,15 @@ class VaultEngine:
                                P.gr("embeddings.patch_embeddings.projection.bias"), dyp, NP, H, B, S, T)
         self._wgrad(dyp, ws["apatch"], "embeddings.patch_embeddings.projection.weight", None, Mpp, H, Kp, B * NP)
         dvs = buf("d_vt_sum", (Mlp, H))
-        gbeta = P.gr("embeddings.text_embeddings.LayerNorm.bias")
+        # text rows: out = LN(.) + mtype[0]  =>  d mtype[0] = sum dy = THIS backward's d beta: taken through a scratch
+        # vector (the gradient buffers accumulate across backward passes: multi-image heads, gradient accumulation)
+        dbeta_now = buf("d_vt_beta", (H,))
+        ops.pycall(dbeta_now.zero_)
         ops.layernorm_bwd(ws["vt_sum"], ws["vt_mean"], ws["vt_rstd"], P.w("embeddings.text_embeddings.LayerNorm.weight"),
                           Ml, H, dy_f32=dx0, dymap=(T, S, 0), dx_f32=dvs,
-                          dgamma=P.gr("embeddings.text_embeddings.LayerNorm.weight"), dbeta=gbeta)
-        ops.axpy(gmt[0], gbeta, 1.0, H)   # text rows: out = LN(.) + mtype[0]  =>  d mtype[0] = sum dy = dbeta
+                          dgamma=P.gr("embeddings.text_embeddings.LayerNorm.weight"), dbeta=dbeta_now)
+        ops.axpy(P.gr("embeddings.text_embeddings.LayerNorm.bias"), dbeta_now, 1.0, H)
+        ops.axpy(gmt[0], dbeta_now, 1.0, H)
         tt = ws["tt"]
         gt = [(P.gr("embeddings.text_embeddings.token_type_embeddings.weight"), tt if tt is not None else 0)]
         if spec.lm is None:

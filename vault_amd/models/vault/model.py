@@ -29,6 +29,8 @@ HIP library is missing.
 """
 from __future__ import annotations
 
+import dataclasses
+
 import json
 import logging
 import os
@@ -112,9 +114,12 @@ class _VaultFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, batch, want_logits, train, *params):
         eng = model._engine
+        extra = batch.pop("__pass__", None)     # (ws_tag, image_token_type_idx, advance_seed) of multi-image heads
+        kw = {} if extra is None else dict(ws_tag=extra[0], image_token_type_idx=extra[1], advance_seed=extra[2])
         out = eng.forward(batch, train=train, need_hidden=not want_logits or model._always_hidden,
-                          precise=bool(model.precise) and not train)
+                          precise=bool(model.precise) and not train, **kw)
         ctx.model, ctx.train, ctx.want_logits = model, train, want_logits
+        ctx.ws = eng.last
         if want_logits:
             return out["logits"].clone()
         pooled = out.get("pooler_output")
@@ -132,13 +137,32 @@ class _VaultFunction(torch.autograd.Function):
         model._prepare_grads()
         if ctx.want_logits:
             g = grads[0].contiguous().float()
-            eng.backward(dlogits=g.view(g.shape[0], -1))
+            eng.backward(dlogits=g.view(g.shape[0], -1), ws=ctx.ws)
         else:
             dh = grads[0]
             dp = grads[1] if len(grads) > 1 else None
-            eng.backward(dhidden=None if dh is None else dh.float(), dpooled=None if dp is None else dp.float())
+            eng.backward(dhidden=None if dh is None else dh.float(), dpooled=None if dp is None else dp.float(),
+                         ws=ctx.ws)
         model._publish_grads()
         return (None, None, None, None) + tuple(None for _ in range(len(ctx.needs_input_grad) - 4))
+
+
+class _MlpHeadFunction(torch.autograd.Function):
+    """The MLP task head on an external input (concatenated pooled outputs of several encoder passes): forward and
+    backward in the HIP engine, parameter gradients into the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        ctx.model = model
+        return model._engine.mlp_head_forward(x.detach().float()).clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        model._prepare_grads()
+        dx = model._engine.mlp_head_backward(dlogits).clone()
+        model._publish_grads()
+        return (None, dx) + tuple(None for _ in range(len(ctx.needs_input_grad) - 2))
 
 
 class VaultMixin(nn.Module):
@@ -162,14 +186,18 @@ class VaultMixin(nn.Module):
 
     def __init__(self, vilt_config, bert_config=None, freeze_lm: bool = False, vilt_dropout_prob: float = 0.0,
                  use_vilt_position_embeddings: bool = False, add_pooling_layer: bool = True, *, _n_classes: int = 0,
-                 _seed: int = 0, _state: Optional[Dict[str, np.ndarray]] = None, _head: str = "linear"):
+                 _seed: int = 0, _state: Optional[Dict[str, np.ndarray]] = None, _head: str = "linear",
+                 _num_images: int = 1):
         super().__init__()
         self.config = vilt_config
         self.freeze_lm = freeze_lm
         self.vilt_dropout_prob = vilt_dropout_prob
         self.spec = VaultSpec(vilt=vilt_spec_from_config(vilt_config), lm=lm_spec_from_config(bert_config),
                               n_classes=_n_classes, use_vilt_position_embeddings=use_vilt_position_embeddings,
-                              add_pooling_layer=add_pooling_layer, head=_head)
+                              add_pooling_layer=add_pooling_layer, head=_head, num_images=_num_images)
+        if _num_images > 1:
+            # ref VaultForImagesAndTextClassification.resize_token_type_embeddings: one modality type per image + text
+            self.spec.vilt = dataclasses.replace(self.spec.vilt, modality_type_vocab_size=_num_images + 1)
         self._engine: Optional[VaultEngine] = None
         if self.spec.lm is None:
             self.bert = None       # ref model.py:83-87: no LM -> plain ViLT text embeddings
@@ -479,6 +507,81 @@ class VaultForQuestionAnswering(VaultMixin):
         if labels is not None:
             labels = labels.to(logits.device, logits.dtype)
             loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, labels) * labels.shape[1]
+        if kwargs.get("return_dict", True) is False:
+            return (logits,) if loss is None else (loss, logits)
+        return _SequenceClassifierOutput(loss=loss, logits=logits)
+
+
+class VaultForImagesAndTextClassification(VaultMixin):
+    """VAuLT for classification over several images and one text, e.g. NLVR2 (ref model.py:408-465 on HF
+    ``ViltForImagesAndTextClassification``): ``pixel_values`` [B, num_images, C, H, W]; one encoder pass per image with
+    modality type i + 1 (the modality-type table has num_images + 1 rows; loading a base checkpoint copies its image
+    row to all of them), pooled outputs concatenated, classifier = Linear(nH, nH) - LayerNorm - GELU - Linear(nH,
+    num_labels); ``loss`` = cross-entropy when ``labels`` are given.  The reference sends the text through the LM once;
+    here each pass recomputes it (same dropout masks), which is the same function and the same gradient."""
+
+    _head_dropout = False
+
+    @staticmethod
+    def _ext_name(n: str) -> str:
+        return n if n.startswith(("bert.", "classifier.")) else "vilt." + n
+
+    def __init__(self, config, bert_config=None, freeze_lm: bool = False, vilt_dropout_prob: float = 0.0,
+                 use_vilt_position_embeddings: bool = False, num_images: Optional[int] = None, **kw):
+        kw.pop("__from_pretrained__", None)
+        if num_images is None:
+            num_images = _get(config, "num_images", -1)
+            if num_images is None or num_images == -1:
+                num_images = 2                      # nlvr2 (ref model.py:418-425)
+        self.num_images = int(num_images)
+        num_labels = _get(config, "num_labels", None)
+        if num_labels is None:
+            id2label = _get(config, "id2label", None)
+            num_labels = len(id2label) if id2label else 2
+        self._n_classes = int(num_labels)
+        super().__init__(config, bert_config=bert_config, freeze_lm=freeze_lm, vilt_dropout_prob=vilt_dropout_prob,
+                         use_vilt_position_embeddings=use_vilt_position_embeddings, add_pooling_layer=True,
+                         _n_classes=self._n_classes, _head="mlp", _num_images=self.num_images, **kw)
+
+    def _adopt_checkpoint_heads(self, ckpt_sd, new, own):
+        # a base / single-image checkpoint has 2 modality types: text row -> row 0, image row -> rows 1..n
+        key = "vilt.embeddings.token_type_embeddings.weight"
+        if key not in new:
+            src = ckpt_sd.get(key, ckpt_sd.get(key[5:]))
+            if src is not None and src.shape[0] == 2:
+                t = own[key].clone()
+                t[0], t[1:] = src[0], src[1]
+                new[key] = t
+
+    def forward(self, *args, labels=None, **kwargs):
+        pix = kwargs.get("pixel_values")
+        if pix is None and len(args) > 3:
+            raise TypeError("pass pixel_values by keyword")
+        if pix is None:
+            raise ValueError("You have to specify either pixel_values or image_embeds")
+        if pix.dim() == 4:
+            pix = pix.unsqueeze(1)
+        if pix.shape[1] != self.num_images:
+            raise ValueError("Make sure to match the number of images in the model with the number of images in the input.")
+        pm = kwargs.get("pixel_mask")
+        pooled = []
+        for i in range(self.num_images):
+            kw = dict(kwargs)
+            kw["pixel_values"] = pix[:, i]
+            if pm is not None:
+                kw["pixel_mask"] = pm[:, i]
+            batch = self._collect_batch(list(args), kw)
+            batch["__pass__"] = (i, i + 1, i == 0)
+            params = [p for p in self._params_by_name.values() if p.requires_grad]
+            train = self.training and torch.is_grad_enabled()
+            out = _VaultFunction.apply(self, batch, False, train, *params)
+            pooled.append(out[1])
+        z = torch.cat(pooled, dim=-1)
+        params = [p for p in self._params_by_name.values() if p.requires_grad]
+        logits = _MlpHeadFunction.apply(self, z, *params)
+        loss = None
+        if labels is not None:
+            loss = torch.nn.functional.cross_entropy(logits.view(-1, self._n_classes), labels.to(logits.device).view(-1))
         if kwargs.get("return_dict", True) is False:
             return (logits,) if loss is None else (loss, logits)
         return _SequenceClassifierOutput(loss=loss, logits=logits)
