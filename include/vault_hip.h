@@ -175,6 +175,7 @@ int vault_tanh_bwd(const float* pooled, const float* dpooled, void* dpre_bf16, l
  * LayerNorm - GELU - Linear on the pooled output; reached through ref: vault/models/vault/model.py:472-509):
  * y_bf16 = gelu(x) ; dx = dy * gelu'(x) */
 int vault_gelu_fwd(const float* x, void* y_bf16, long long n, void* stream);
+int vault_gelu_fwd_f32(const float* x, float* y_f32, long long n, void* stream);   /* MLM head: dense - GELU - LayerNorm */
 int vault_gelu_bwd(const float* x, const float* dy, float* dx, long long n, void* stream);
 
 /* ---- optimizer ------------------------------------------------------------------------------

@@ -384,6 +384,58 @@ def run_reference_nlvr2(ref, name, outdir):
           f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
+def run_reference_mlm(ref, name, outdir):
+    """VaultForMaskedLM (ref: model.py:467-469 on HF ViltForMaskedLM): ViltMLMHead on the text rows of the fused
+    sequence, decoder tied to ViLT's word embeddings, CE over ViLT's vocabulary with ignore_index -100."""
+    spec = VaultSpec.tiny(0, "roberta")
+    spec.head = "mlm"
+    vc, lc = hf_configs(spec)
+    model = ref.VaultForMaskedLM(vc, bert_config=lc).eval()
+    state = build_state(spec, 0)
+    sd = model.state_dict()
+    def ext(n):   # (transformers 5.15 keeps the vocabulary bias as mlm_score.decoder.bias; 4.48 also as mlm_score.bias)
+        if n == "mlm_score.bias":
+            return "mlm_score.decoder.bias"
+        return n if n.startswith(("bert.", "mlm_score.")) else "vilt." + n
+
+    with torch.no_grad():
+        for k, v in state.items():
+            assert tuple(sd[ext(k)].shape) == tuple(v.shape), (k, sd[ext(k)].shape, v.shape)
+            sd[ext(k)].copy_(torch.from_numpy(v))
+        model.vilt.embeddings.text_embeddings.position_embeddings.weight.zero_()   # D1
+    # the decoder must be tied to the (just overwritten) word embeddings and to mlm_score.bias
+    assert model.mlm_score.decoder.weight.data_ptr() == model.vilt.embeddings.text_embeddings.word_embeddings.weight.data_ptr()
+    B, dseed = 3, 71
+    batch = synthetic_batch(spec, B, seed=dseed, n_classes=1)
+    rng = np.random.Generator(np.random.PCG64(dseed + 1))
+    T = batch["input_ids"].shape[1]
+    labels = rng.integers(0, spec.vilt.vocab_size, size=(B, T), dtype=np.int64)
+    labels[rng.random((B, T)) > 0.3] = -100
+    labels[batch["attention_mask"] == 0] = -100
+    kw = {k: torch.from_numpy(batch[k]) for k in ("input_ids", "attention_mask", "pixel_values", "pixel_mask")}
+    torch.manual_seed(0)
+    out = model(**kw, labels=torch.from_numpy(labels))
+    out.loss.backward()
+    res = {"logits_slice": out.logits.detach().numpy()[:, :4], "logits_norm": np.float64(out.logits.detach().double().norm()),
+           "loss": np.float32(out.loss.item()), "labels": labels, "meta_batch": np.int64(B), "meta_data_seed": np.int64(dseed)}
+    names, norms = [], []
+    seen = set()
+    for k, p in model.named_parameters():
+        if p.grad is None or k == "vilt.embeddings.text_embeddings.position_embeddings.weight" or id(p) in seen:
+            continue
+        seen.add(id(p))
+        names.append(k)
+        norms.append(float(p.grad.double().norm()))
+        if k.startswith("mlm_score.") and p.grad.numel() <= 4096:
+            res["grad::" + k] = p.grad.detach().numpy().copy()
+    res["grad_names"] = np.array(names)
+    res["grad_norms"] = np.array(norms, np.float64)
+    path = os.path.join(outdir, f"{name}.npz")
+    np.savez_compressed(path, **res)
+    print(name, "loss", res["loss"], "n grads", len(names), [n for n in names if "mlm" in n or "word_emb" in n], "->", path,
+          f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
 def nlvr2_pixels(spec, B, dseed):
     """The two-image pixel tensor of the NLVR2 case (shared with the tests)."""
     rng = np.random.Generator(np.random.PCG64(dseed + 1))
@@ -410,6 +462,8 @@ def main():
         np.savez_compressed(path, **out)
         print(name, "loss", out["loss"], "logits", out["logits"].ravel()[:6], "->", path,
               f"{os.path.getsize(path)/1024:.0f} KiB")
+    if not only or "tiny_roberta_mlm" in only:
+        run_reference_mlm(ref, "tiny_roberta_mlm", outdir)
     if not only or "tiny_roberta_nlvr2" in only:
         run_reference_nlvr2(ref, "tiny_roberta_nlvr2", outdir)
     if not only or "tiny_roberta_vqa" in only:

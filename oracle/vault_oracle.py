@@ -252,7 +252,14 @@ def vault_forward(P, spec, batch: Dict[str, torch.Tensor], taps: Optional[dict] 
     if spec.add_pooling_layer:
         pooled = torch.tanh(_lin(x[:, 0], P["pooler.dense.weight"], P["pooler.dense.bias"]))
         out["pooler_output"] = pooled
-        if spec.n_classes > 0 and getattr(spec, "head", "linear") == "mlp":
+        if getattr(spec, "head", "linear") == "mlm":
+            # HF ViltMLMHead on the text rows: dense - GELU - LayerNorm - decoder (tied to ViLT's word embeddings) + bias
+            T = ids.shape[1]
+            t = F.gelu(_r(_lin(x[:, :T], P["mlm_score.transform.dense.weight"], P["mlm_score.transform.dense.bias"])))
+            t = _ln(t, P["mlm_score.transform.LayerNorm.weight"], P["mlm_score.transform.LayerNorm.bias"],
+                    spec.vilt.layer_norm_eps)
+            out["logits"] = _lin(t, P["embeddings.text_embeddings.word_embeddings.weight"], P["mlm_score.bias"])
+        elif spec.n_classes > 0 and getattr(spec, "head", "linear") == "mlp":
             # HF ViltForQuestionAnswering.classifier (modeling_vilt.py): Linear(H, 2H) - LayerNorm(2H) - GELU - Linear
             h = _lin(pooled, P["classifier.0.weight"], P["classifier.0.bias"])
             h = _ln(h, P["classifier.1.weight"], P["classifier.1.bias"], 1e-5)

@@ -265,6 +265,39 @@ def test_nlvr2_head_model_class_vs_reference_golden():
         m(input_ids=torch.from_numpy(bn["input_ids"]).cuda(), pixel_values=torch.zeros(B, 3, 3, 192, 192, device="cuda"))
 
 
+def test_mlm_head_model_class_vs_reference_golden():
+    """VaultForMaskedLM: ViltMLMHead on the text rows through the HIP engine (decoder = ViLT's word embeddings read as a
+    256-padded GEMM operand; their gradient comes from the head alone), CE with ignore_index, against the reference."""
+    from vault_amd.models.vault import VaultForMaskedLM
+    g = np.load(os.path.join(GOLD, "tiny_roberta_mlm.npz"))
+    spec = _nodrop(VaultSpec.tiny(0, "roberta"))
+    B = int(g["meta_batch"])
+    bn = synthetic_batch(spec, B, seed=int(g["meta_data_seed"]), n_classes=1)
+    m = VaultForMaskedLM(spec.vilt, bert_config=spec.lm).to("cuda").train()
+    assert {"mlm_score.decoder.bias", "mlm_score.transform.dense.weight", "vilt.embeddings.cls_token"} <= set(m.state_dict())
+    kw = {k: torch.from_numpy(bn[k]).cuda() for k in ("input_ids", "attention_mask", "pixel_values", "pixel_mask")}
+    out = m(**kw, labels=torch.from_numpy(g["labels"]).cuda())
+    out.loss.backward()
+    torch.cuda.synchronize()
+    T, V = bn["input_ids"].shape[1], spec.vilt.vocab_size
+    assert tuple(out.logits.shape) == (B, T, V)
+    lg = out.logits.detach().cpu().numpy()
+    assert np.abs(lg[:, :4] - g["logits_slice"]).max() < 1e-2 * np.abs(g["logits_slice"]).max()
+    assert abs(float(out.loss.detach()) - float(g["loss"])) < 5e-3
+    sd = dict(m.named_parameters())
+    internal = {"mlm_score.decoder.bias": "mlm_score.decoder.bias"}
+    num = den = 0.0
+    for k, ref_norm in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        assert sd[k].grad is not None, k
+        mine = float(sd[k].grad.double().norm())
+        num += (mine - ref_norm) ** 2; den += ref_norm ** 2
+    assert (num / den) ** 0.5 < 3e-2
+    for k in g.files:
+        if k.startswith("grad::"):
+            mine = sd[k[6:]].grad.cpu().numpy().reshape(g[k].shape)
+            assert np.linalg.norm(mine - g[k]) <= 8e-2 * np.linalg.norm(g[k]) + 1e-6, k
+
+
 def test_gradients_accumulate_across_backward_passes():
     """Two forward/backward passes without zeroing in between leave the SUM of the two gradients in every
     parameter (gradient accumulation; also what multi-image heads rely on)."""

@@ -219,6 +219,36 @@ def test_oracle_matches_reference_golden_nlvr2_head():
             np.testing.assert_allclose(P[internal(k[6:])].grad.numpy().reshape(g[k].shape), g[k], atol=2e-6, rtol=1e-3)
 
 
+def _mlm_internal(k):
+    if k == "mlm_score.decoder.bias":
+        return "mlm_score.bias"
+    return k[5:] if k.startswith("vilt.") else k
+
+
+def test_oracle_matches_reference_golden_mlm_head():
+    """VaultForMaskedLM: ViltMLMHead on the text rows, decoder tied to ViLT's word embeddings, CE with ignore_index."""
+    g = np.load(os.path.join(GOLD, "tiny_roberta_mlm.npz"))
+    spec = VaultSpec.tiny(0, "roberta")
+    spec.head = "mlm"
+    torch.set_num_threads(8)
+    bn = synthetic_batch(spec, int(g["meta_batch"]), seed=int(g["meta_data_seed"]), n_classes=1)
+    P = O.to_torch_state(build_state(spec, 0), requires_grad=True)
+    out = O.vault_forward(P, spec, O.torch_batch(bn))
+    V = spec.vilt.vocab_size
+    loss = torch.nn.functional.cross_entropy(out["logits"].reshape(-1, V), torch.from_numpy(g["labels"]).reshape(-1))
+    loss.backward()
+    np.testing.assert_allclose(out["logits"].detach().numpy()[:, :4], g["logits_slice"], atol=3e-5, rtol=0)
+    assert abs(float(out["logits"].detach().double().norm()) - float(g["logits_norm"])) < 1e-4 * float(g["logits_norm"])
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5
+    for k, ref_norm in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        n = _mlm_internal(k)
+        assert P[n].grad is not None, n
+        assert abs(float(P[n].grad.double().norm()) - ref_norm) <= 2e-4 * ref_norm + 2e-8, n
+    for k in g.files:
+        if k.startswith("grad::"):
+            np.testing.assert_allclose(P[_mlm_internal(k[6:])].grad.numpy().reshape(g[k].shape), g[k], atol=2e-6, rtol=1e-3)
+
+
 def test_select_patches_edge_cases():
     # all-valid square canvas: identity order, nothing masked
     sel, valid, hw, grid, L = select_patches(np.ones((2, 64, 64), np.int64), 16)

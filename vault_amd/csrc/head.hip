@@ -117,6 +117,9 @@ __global__ void tanh_bwd_kernel(const float* __restrict__ pooled, const float* _
 __global__ void gelu_fwd_kernel(const float* __restrict__ x, bf16* __restrict__ y, long long n) {
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256ll) y[i] = (bf16)gelu_f(x[i]);
 }
+__global__ void gelu_fwd_f32_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256ll) y[i] = gelu_f(x[i]);
+}
 __global__ void gelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
                                 long long n) {
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256ll)
@@ -130,6 +133,13 @@ extern "C" int vault_gelu_fwd(const float* x, void* y_bf16, long long n, void* s
   const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
   hipLaunchKernelGGL(gelu_fwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
                      reinterpret_cast<bf16*>(y_bf16), n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int vault_gelu_fwd_f32(const float* x, float* y, long long n, void* stream) {
+  if (!x || !y || n <= 0) return VAULT_EINVAL;
+  const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(gelu_fwd_f32_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, n);
   return (int)hipGetLastError();
 }
 

@@ -55,7 +55,8 @@ class ParamStore:
         self.frozen = rest
         # the MLP head's output projection is used as a GEMM operand padded to a multiple of 256 rows: readable (zero)
         # slack behind the buffers, never part of [0, n_train) that the optimizer and the all-reduce walk
-        self.slack = 256 * spec.mlp_dims[1] + 1024 if (spec.n_classes > 0 and spec.head == "mlp") else 0
+        self.slack = (256 * spec.mlp_dims[1] + 1024 if (spec.n_classes > 0 and spec.head == "mlp") else
+                      (256 * spec.vilt.hidden_size + 1024 if spec.head == "mlm" else 0))
         host = np.zeros(self.n_total + self.slack, np.float32)
         if state is None:
             state = build_state(spec, seed)
@@ -74,7 +75,8 @@ class ParamStore:
     def no_grad_names(spec: VaultSpec, freeze_lm: bool) -> List[str]:
         out = []
         if spec.lm is not None:
-            out.append("embeddings.text_embeddings.word_embeddings.weight")
+            if spec.head != "mlm":     # (the MLM decoder is tied to ViLT's word embeddings: used and trained there)
+                out.append("embeddings.text_embeddings.word_embeddings.weight")
             if not spec.use_vilt_position_embeddings:
                 out.append("embeddings.text_embeddings.position_embeddings.weight")
             if freeze_lm:
@@ -119,7 +121,11 @@ class ParamStore:
         o += ["layernorm.weight", "layernorm.bias"]
         if spec.add_pooling_layer:
             o += ["pooler.dense.weight", "pooler.dense.bias"]
-        if spec.n_classes > 0 and spec.head == "mlp":
+        if spec.head == "mlm":
+            # the vocabulary-sized bias last: it is read as a 256-padded GEMM operand (slack behind the buffers)
+            o += ["mlm_score.transform.dense.weight", "mlm_score.transform.dense.bias",
+                  "mlm_score.transform.LayerNorm.weight", "mlm_score.transform.LayerNorm.bias", "mlm_score.bias"]
+        elif spec.n_classes > 0 and spec.head == "mlp":
             # the output projection last: its [n_classes, 2H] matrix is read (never written) as 256-row padded
             o += ["classifier.0.weight", "classifier.0.bias", "classifier.1.weight", "classifier.1.bias",
                   "classifier.3.weight", "classifier.3.bias"]
@@ -665,6 +671,69 @@ class VaultEngine:
         ops.gemm(dh1b, P.wb("classifier.0.weight", shape=(Hm, Hin)), dx, Bp, Hin, Hm, Hm, Hin, Hin, 0, 1, ops.EPI_F32_RES,
                  m_valid=B)
         return dx
+
+    # ---- MLM head (HF ViltMLMHead): dense(H, H) - GELU - LayerNorm - decoder tied to ViLT's word embeddings + bias --------
+    def mlm_head_forward(self, x_f32: torch.Tensor) -> torch.Tensor:
+        """x [R, H] f32 (text rows of last_hidden_state) -> logits [R, V]."""
+        with torch.cuda.device(self.device):
+            spec, P = self.spec, self.params
+            v = spec.vilt
+            H, V = v.hidden_size, v.vocab_size
+            R = x_f32.shape[0]
+            Rp, Vp = _pad(R), _pad(V)
+            ws = self._ws.setdefault(("mlm_head", R), {})
+            bf = torch.bfloat16
+            buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
+            xin = buf("x", (Rp, H))
+            xin[:R].copy_(x_f32)
+            xb = buf("xb", (Rp, H), bf)
+            ops.cast_bf16(xin, xb, Rp * H)
+            h1 = buf("h1", (Rp, H))
+            self._linear(xb, "mlm_score.transform.dense.weight", h1, Rp, H, H, ops.EPI_F32_RES, R,
+                         bias=P.w("mlm_score.transform.dense.bias"))
+            a = buf("a", (Rp, H))
+            ops.gelu_fwd_f32(h1, a, Rp * H)
+            nb = buf("nb", (Rp, H), bf)
+            ops.layernorm_fwd(a, P.w("mlm_score.transform.LayerNorm.weight"), P.w("mlm_score.transform.LayerNorm.bias"),
+                              v.layer_norm_eps, R, H, y_bf16=nb, mean=buf("mean", (Rp,)), rstd=buf("rstd", (Rp,)))
+            lg = buf("logits", (Rp, Vp))
+            wn = "embeddings.text_embeddings.word_embeddings.weight"
+            ops.gemm(nb, P.wb(wn, n_elems=Vp * H, shape=(Vp, H)), lg, Rp, Vp, H, H, H, Vp, 0, 0, ops.EPI_F32_RES, m_valid=R,
+                     bias=P.w("mlm_score.bias", n_elems=Vp, shape=(Vp,)))
+            return lg[:R, :V]
+
+    def mlm_head_backward(self, dlogits: torch.Tensor) -> torch.Tensor:
+        with torch.cuda.device(self.device):
+            spec, P = self.spec, self.params
+            v = spec.vilt
+            H, V = v.hidden_size, v.vocab_size
+            R = dlogits.shape[0]
+            Rp, Vp = _pad(R), _pad(V)
+            ws = self._ws[("mlm_head", R)]
+            bf = torch.bfloat16
+            buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
+            dl32 = buf("dlogits", (Rp, Vp))
+            dl32.zero_()
+            dl32[:R, :V].copy_(dlogits.reshape(R, V))
+            dlb = buf("dlogits_b", (Rp, Vp), bf)
+            ops.cast_bf16(dl32, dlb, Rp * Vp)
+            wn = "embeddings.text_embeddings.word_embeddings.weight"
+            self._wgrad(dlb, ws["nb"], wn, "mlm_score.bias", Rp, Vp, H, R, out_rows=V)
+            dn = buf("dn", (Rp, H))
+            ops.gemm(dlb, P.wb(wn, n_elems=Vp * H, shape=(Vp, H)), dn, Rp, H, Vp, Vp, H, H, 0, 1, ops.EPI_F32_RES, m_valid=R)
+            da = buf("da", (Rp, H))
+            ops.layernorm_bwd(ws["a"], ws["mean"], ws["rstd"], P.w("mlm_score.transform.LayerNorm.weight"), R, H, dy_f32=dn,
+                              dx_f32=da, dgamma=P.gr("mlm_score.transform.LayerNorm.weight"),
+                              dbeta=P.gr("mlm_score.transform.LayerNorm.bias"))
+            dh1 = buf("dh1", (Rp, H))
+            ops.gelu_bwd(ws["h1"], da, dh1, Rp * H)
+            dh1b = buf("dh1b", (Rp, H), bf)
+            ops.cast_bf16(dh1, dh1b, Rp * H)
+            self._wgrad(dh1b, ws["xb"], "mlm_score.transform.dense.weight", "mlm_score.transform.dense.bias", Rp, H, H, R)
+            dx = buf("dx", (Rp, H))
+            ops.gemm(dh1b, P.wb("mlm_score.transform.dense.weight", shape=(H, H)), dx, Rp, H, H, H, H, H, 0, 1,
+                     ops.EPI_F32_RES, m_valid=R)
+            return dx[:R]
 
     def mlp_head_forward(self, x_f32: torch.Tensor, train: bool = True) -> torch.Tensor:
         """The MLP head on an external input [B, H_in] (concatenated pooled outputs of several encoder passes)."""

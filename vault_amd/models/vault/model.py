@@ -62,6 +62,12 @@ except Exception:  # pragma: no cover
             self.loss, self.logits = loss, logits
 
 
+try:
+    from transformers.modeling_outputs import MaskedLMOutput as _MaskedLMOutput
+except Exception:  # pragma: no cover
+    _MaskedLMOutput = _SequenceClassifierOutput
+
+
 def _get(cfg: Any, name: str, default=None):
     return getattr(cfg, name, default)
 
@@ -161,6 +167,24 @@ class _MlpHeadFunction(torch.autograd.Function):
         model = ctx.model
         model._prepare_grads()
         dx = model._engine.mlp_head_backward(dlogits).clone()
+        model._publish_grads()
+        return (None, dx) + tuple(None for _ in range(len(ctx.needs_input_grad) - 2))
+
+
+class _MlmHeadFunction(torch.autograd.Function):
+    """HF ``ViltMLMHead`` on the text rows of ``last_hidden_state`` in the HIP engine (decoder tied to ViLT's word
+    embeddings, whose gradient it feeds)."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        ctx.model = model
+        return model._engine.mlm_head_forward(x.detach().float()).clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        model._prepare_grads()
+        dx = model._engine.mlm_head_backward(dlogits.contiguous().float()).clone()
         model._publish_grads()
         return (None, dx) + tuple(None for _ in range(len(ctx.needs_input_grad) - 2))
 
@@ -585,3 +609,46 @@ class VaultForImagesAndTextClassification(VaultMixin):
         if kwargs.get("return_dict", True) is False:
             return (logits,) if loss is None else (loss, logits)
         return _SequenceClassifierOutput(loss=loss, logits=logits)
+
+
+class VaultForMaskedLM(VaultMixin):
+    """VAuLT for masked language modelling (ref model.py:467-469 on HF ``ViltForMaskedLM``): ``ViltMLMHead`` (dense -
+    GELU - LayerNorm - decoder tied to ViLT's word embeddings + vocabulary bias) on the text rows of the fused sequence;
+    ``loss`` = cross-entropy over ViLT's vocabulary (``ignore_index`` -100) when ``labels`` are given.  ``state_dict``
+    keys ``vilt.*`` / ``bert.*`` / ``mlm_score.*`` (the bias as ``mlm_score.decoder.bias``; ``mlm_score.bias`` of older
+    checkpoints and the tied ``mlm_score.decoder.weight`` are accepted on load)."""
+
+    _always_hidden = True
+
+    @staticmethod
+    def _ext_name(n: str) -> str:
+        if n == "mlm_score.bias":
+            return "mlm_score.decoder.bias"
+        return n if n.startswith(("bert.", "mlm_score.")) else "vilt." + n
+
+    def __init__(self, config, bert_config=None, freeze_lm: bool = False, vilt_dropout_prob: float = 0.0,
+                 use_vilt_position_embeddings: bool = False, **kw):
+        super().__init__(config, bert_config=bert_config, freeze_lm=freeze_lm, vilt_dropout_prob=vilt_dropout_prob,
+                         use_vilt_position_embeddings=use_vilt_position_embeddings, add_pooling_layer=True,
+                         _n_classes=0, _head="mlm", **kw)
+
+    def _adopt_checkpoint_heads(self, ckpt_sd, new, own):
+        if "mlm_score.decoder.bias" not in new and "mlm_score.bias" in ckpt_sd:
+            new["mlm_score.decoder.bias"] = ckpt_sd["mlm_score.bias"]
+
+    def forward(self, *args, labels=None, **kwargs):
+        out = self._run(args, kwargs, want_logits=False)
+        hid = out[0] if isinstance(out, tuple) else out
+        ids = kwargs.get("input_ids", args[0] if args else None)
+        B, T = ids.shape
+        H = hid.shape[-1]
+        params = [p for p in self._params_by_name.values() if p.requires_grad]
+        logits = _MlmHeadFunction.apply(self, hid[:, :T].reshape(B * T, H), *params)
+        V = logits.shape[-1]
+        logits = logits.view(B, T, V)
+        loss = None
+        if labels is not None:
+            loss = torch.nn.functional.cross_entropy(logits.view(-1, V), labels.to(logits.device).view(-1))
+        if kwargs.get("return_dict", True) is False:
+            return (logits,) if loss is None else (loss, logits)
+        return _MaskedLMOutput(loss=loss, logits=logits)

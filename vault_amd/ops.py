@@ -322,6 +322,10 @@ def gelu_fwd(x, y_bf16, n):
     _invoke("vault_gelu_fwd", C.c_void_p(_p(x)), C.c_void_p(_p(y_bf16)), C.c_longlong(n), _stream())
 
 
+def gelu_fwd_f32(x, y, n):
+    _invoke("vault_gelu_fwd_f32", C.c_void_p(_p(x)), C.c_void_p(_p(y)), C.c_longlong(n), _stream())
+
+
 def gelu_bwd(x, dy, dx, n):
     _invoke("vault_gelu_bwd", C.c_void_p(_p(x)), C.c_void_p(_p(dy)), C.c_void_p(_p(dx)), C.c_longlong(n), _stream())
 

@@ -84,6 +84,8 @@ class VaultSpec:
     n_classes: int = 0                 # 0 => VaultModel (no classifier head)
     head: str = "linear"               # "linear": Dropout-Linear on the pooled output (TMSC, retrieval rank head);
                                        # "mlp": Linear(H,2H)-LayerNorm-GELU-Linear(2H,n_classes) (HF VQA head)
+                                       # "mlm": HF ViltMLMHead on the text rows (dense-GELU-LayerNorm, decoder tied to
+                                       #        ViLT's word embeddings, n_classes = ViLT vocab size)
     num_images: int = 1                # > 1: HF ViltForImagesAndTextClassification - one encoder pass per image, the MLP
                                        # head (Linear(nH,nH)-LayerNorm-GELU-Linear(nH,n_classes)) on the concatenated
                                        # pooled outputs
@@ -189,7 +191,11 @@ def param_entries(spec: VaultSpec) -> List[ParamEntry]:
         ]
         for i in range(lm.num_hidden_layers):
             e += _layer_entries(f"bert.encoder.layer.{i}", HL, lm.intermediate_size, "bert")
-    if spec.n_classes > 0 and spec.head == "mlp":
+    if spec.head == "mlm":
+        e += [("mlm_score.transform.dense.weight", (H, H), "normal"), ("mlm_score.transform.dense.bias", (H,), "normal"),
+              ("mlm_score.transform.LayerNorm.weight", (H,), "ln_w"), ("mlm_score.transform.LayerNorm.bias", (H,), "normal"),
+              ("mlm_score.bias", (v.vocab_size,), "normal")]
+    elif spec.n_classes > 0 and spec.head == "mlp":
         hin, hmid = spec.mlp_dims
         e += [("classifier.0.weight", (hmid, hin), "normal"), ("classifier.0.bias", (hmid,), "normal"),
               ("classifier.1.weight", (hmid,), "ln_w"), ("classifier.1.bias", (hmid,), "normal"),
