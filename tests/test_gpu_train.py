@@ -216,3 +216,28 @@ def test_data_parallel_two_ranks_equal_one_rank_on_the_global_batch(tmp_path, us
     d = (r0["p"] - eng.params.p.cpu()).abs()
     # same tolerance as tape-vs-eager: float-atomic summation order + sign-like AdamW steps on ~0 gradients
     assert float(d.mean()) < 2e-6 and float((d > 1e-5).float().mean()) < 0.03
+
+
+
+def test_evaluate_pass_matches_oracle_predictions():
+    """The reference's evaluation pass (eval-mode forward, mean CE, argmax, accuracy, macro-F1) on the HIP engine vs
+    the same quantities from the CPU oracle."""
+    from vault_amd.train import evaluate, evaluation_metrics
+    spec = VaultSpec.tiny(3, "roberta")
+    state = build_state(spec, 0)
+    eng = VaultEngine(spec, "cuda:0", state=state, with_grads=False)
+    batches, ref_pred, ref_true, ref_loss, n = [], [], [], 0.0, 0
+    P = O.to_torch_state(state)
+    for i, B in enumerate((5, 3, 4)):
+        bn = synthetic_batch(spec, B, seed=200 + i, n_classes=3)
+        db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
+        batches.append((db, torch.from_numpy(bn["labels"]).cuda()))
+        loss, out = O.vault_loss(P, spec, O.torch_batch(bn))
+        ref_pred += out["logits"].argmax(-1).tolist(); ref_true += bn["labels"].tolist()
+        ref_loss += float(loss) * B; n += B
+    res = evaluate(eng, batches)
+    want = evaluation_metrics(ref_true, ref_pred)
+    assert abs(res["eval_loss"] - ref_loss / n) < 2e-3
+    # random-init logits are close to each other: allow one flipped argmax out of 12
+    assert abs(res["eval_accuracy"] - want["eval_accuracy"]) <= 1.0 / n + 1e-9
+    assert 0.0 <= res["macro_f1_score"] <= 1.0

@@ -134,6 +134,21 @@ def test_itr_head_class_keys_and_itm_checkpoint_adoption(tmp_path):
     assert torch.equal(got["vilt.pooler.dense.weight"], sd["vilt.pooler.dense.weight"])
 
 
+def test_evaluation_metrics_match_sklearn():
+    from sklearn.metrics import precision_recall_fscore_support
+    from vault_amd.train import evaluation_metrics
+    rng = np.random.default_rng(0)
+    for ncls in (2, 3, 6):
+        t = rng.integers(0, ncls, size=200)
+        p = np.where(rng.random(200) < 0.6, t, rng.integers(0, ncls, size=200))
+        if ncls == 6:
+            p[p == 5] = 0          # a class that is never predicted, and one (4) that never occurs in the truth
+            t[t == 4] = 1
+        m = evaluation_metrics(t.tolist(), p.tolist())
+        _, _, f1, _ = precision_recall_fscore_support(t, p, average="macro", zero_division=0)
+        assert abs(m["macro_f1_score"] - f1) < 1e-12 and abs(m["eval_accuracy"] - float(np.mean(t == p))) < 1e-12
+
+
 # ---- data parallel: bucketed all-reduce over gloo, world_size 2 ---------------------------------
 def _dp_worker(rank, world, port, q):
     import torch.distributed as dist

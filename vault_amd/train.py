@@ -22,6 +22,7 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import ops
@@ -231,3 +232,39 @@ class TrainStep:
         if advance:
             P._pb3_fresh = False   # the split-bf16 (precise inference) shadow is stale now
             self.step_idx += 1
+
+
+def evaluation_metrics(eval_true, eval_preds) -> Dict[str, float]:
+    """``eval_accuracy`` and ``macro_f1_score`` as the reference computes them (ref: vault/tmsc_utils/trainer.py:513-549:
+    sklearn ``precision_recall_fscore_support(average="macro", zero_division=0)`` over the union of the labels that
+    occur in truth or predictions, and the plain match rate)."""
+    t = np.asarray(list(eval_true)).reshape(-1)
+    p = np.asarray(list(eval_preds)).reshape(-1)
+    f1s = []
+    for c in np.union1d(t, p):
+        tp = float(np.sum((p == c) & (t == c)))
+        fp = float(np.sum((p == c) & (t != c)))
+        fn = float(np.sum((p != c) & (t == c)))
+        prec = tp / (tp + fp) if tp + fp > 0 else 0.0
+        rec = tp / (tp + fn) if tp + fn > 0 else 0.0
+        f1s.append(2 * prec * rec / (prec + rec) if prec + rec > 0 else 0.0)
+    return dict(eval_accuracy=float(np.mean(p == t)) if t.size else 0.0,
+                macro_f1_score=float(np.mean(f1s)) if f1s else 0.0)
+
+
+def evaluate(engine: VaultEngine, batches) -> Dict[str, float]:
+    """The reference's evaluation pass (ref: vault/tmsc_utils/trainer.py:429-484): eval-mode forward per batch (all
+    dropouts off), mean cross-entropy weighted by batch size, argmax predictions, accuracy and macro-F1.
+    ``batches`` yields ``(batch_dict_on_device, labels_on_device)``."""
+    preds, true = [], []
+    loss_sum, n = 0.0, 0
+    for batch, labels in batches:
+        out = engine.forward(batch, train=False, labels=labels, need_hidden=False)
+        B = int(labels.shape[0])
+        loss_sum += float(out["loss"].item()) * B
+        n += B
+        preds.extend(out["logits"].view(B, -1).argmax(dim=-1).tolist())
+        true.extend(labels.view(-1).tolist())
+    res = evaluation_metrics(true, preds)
+    res["eval_loss"] = loss_sum / max(n, 1)
+    return res
