@@ -134,6 +134,46 @@ def test_itr_head_class_keys_and_itm_checkpoint_adoption(tmp_path):
     assert torch.equal(got["vilt.pooler.dense.weight"], sd["vilt.pooler.dense.weight"])
 
 
+def test_from_pretrained_reads_hf_checkpoints_and_exports_key_for_key(tmp_path):
+    """checkpoints written by HuggingFace's own ``save_pretrained`` (ViltModel + RobertaModel, safetensors)
+    load into the flat / fused parameter layout, and the exported ``state_dict`` loads back into the HF classes key for
+    key (ref: vault/models/vault/model.py:92-128)."""
+    from transformers import RobertaConfig, RobertaModel, ViltConfig, ViltModel
+    from vault_amd.models.vault import VaultForTMSC
+    spec = VaultSpec.tiny(3, "roberta")
+    v, lm = spec.vilt, spec.lm
+    vc = ViltConfig(vocab_size=v.vocab_size, hidden_size=v.hidden_size, num_hidden_layers=v.num_hidden_layers,
+                    num_attention_heads=v.num_attention_heads, intermediate_size=v.intermediate_size,
+                    image_size=v.image_size, patch_size=v.patch_size, max_position_embeddings=v.max_position_embeddings)
+    rc = RobertaConfig(vocab_size=lm.vocab_size, max_position_embeddings=lm.max_position_embeddings, type_vocab_size=1,
+                       hidden_size=lm.hidden_size, num_hidden_layers=lm.num_hidden_layers,
+                       num_attention_heads=lm.num_attention_heads, intermediate_size=lm.intermediate_size,
+                       layer_norm_eps=lm.layer_norm_eps, pad_token_id=1)
+    torch.manual_seed(0)
+    hv, hb = ViltModel(vc), RobertaModel(rc, add_pooling_layer=False)
+    hv.save_pretrained(str(tmp_path / "vilt")); hb.save_pretrained(str(tmp_path / "bert"))
+    m = VaultForTMSC.from_pretrained(str(tmp_path / "vilt"), str(tmp_path / "bert"), n_classes=3)
+    ours = m.state_dict()
+    skip = lambda k: k.endswith("position_ids") or k.endswith("embeddings.token_type_ids")   # noqa: E731
+    n = 0
+    for k, t in hv.state_dict().items():
+        if not skip(k):
+            assert torch.equal(ours[k], t), k
+            n += 1
+    for k, t in hb.state_dict().items():
+        if not skip(k):
+            assert torch.equal(ours["bert." + k], t), k
+            n += 1
+    assert n == len(ours) - 2                                    # everything but the fresh TMSC classifier
+    # export: back into fresh HF modules, nothing missing but buffers, nothing unexpected
+    hv2, hb2 = ViltModel(vc), RobertaModel(rc, add_pooling_layer=False)
+    r = hv2.load_state_dict({k: t for k, t in ours.items() if not k.startswith(("bert.", "classifier."))}, strict=False)
+    assert not r.unexpected_keys and all(skip(k) for k in r.missing_keys)
+    r = hb2.load_state_dict({k[5:]: t for k, t in ours.items() if k.startswith("bert.")}, strict=False)
+    assert not r.unexpected_keys and all(skip(k) for k in r.missing_keys)
+    assert torch.equal(hv2.state_dict()["encoder.layer.1.output.dense.weight"], hv.state_dict()["encoder.layer.1.output.dense.weight"])
+
+
 def test_evaluation_metrics_match_sklearn():
     from sklearn.metrics import precision_recall_fscore_support
     from vault_amd.train import evaluation_metrics
