@@ -216,12 +216,6 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   // MFMAs are issued through inline asm with the accumulator tied in place in the AGPR half of the
   // register file ("+a"): hipcc otherwise allocates out-of-place destinations for this many live
   // accumulators and spills.  `volatile` keeps every cluster inside its phase.
-  // four MFMAs (one A fragment x four B fragments) - the unit the phase body interleaves loads with
-#define MMA4(KS, MT, MB, NB, RA, RB)                                                       \
-  _Pragma("unroll") for (int nt_ = 0; nt_ < NTQ; ++nt_)                                    \
-      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                               \
-                   : "+a"(acc[(MB) + (MT)][(NB) + nt_])                                    \
-                   : "v"(RA[MT][KS]), "v"(RB[nt_][KS]));
 
   bf16x8 RA0[4][2], RA1[4][2], RB0[4][2], RB1[4][2];
 
@@ -250,35 +244,75 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   //     (a duplicate of the last tile lands in a slot nobody reads), so the counted waits never change;
   //   * FIRST (first iteration behind an overlapped epilogue) selects the store-tolerant wait of phases 1-5
   //     by a uniform branch.
-#define PHASE(WAITN, WAITF, LOADU, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB) \
+#define LOAD_TR_H(DST, ADDR, BUF, H, KS)                                                                 \
+  {                                                                                                      \
+    const uint32_t ad_ = (ADDR) + (BUF) * BUFB;                                                          \
+    DST[KS] = cat_tr(tr16_asm<(H) * HT + (KS) * 8192>(ad_), tr16_asm<(H) * HT + (KS) * 8192 + 1024>(ad_)); \
+  }
+#define LOADA_UH(RA, BUF, H, U, KS)                                                                      \
+  {                                                                                                      \
+    if constexpr (A_MODE == 0) {                                                                         \
+      const char* base_ = smem + (BUF) * BUFB + (H) * HT;                                                \
+      RA[U][KS] = *LDS_PTR(const bf16x8, base_ + ((KS) ? a_o1 : a_o0) + (U) * 2048);                     \
+    } else {                                                                                             \
+      LOAD_TR_H(RA[U], a_tr[U], BUF, H, KS)                                                              \
+    }                                                                                                    \
+  }
+#define LOADB_UH(RB, BUF, H, U, KS)                                                                      \
+  if constexpr ((U) < NTQ) {                                                                             \
+    if constexpr (B_MODE == 0) {                                                                         \
+      const char* base_ = smem + (BUF) * BUFB + 2 * HT + (H) * HT;                                       \
+      RB[U][KS] = *LDS_PTR(const bf16x8, base_ + ((KS) ? b_o1 : b_o0) + (U) * 2048);                     \
+    } else {                                                                                             \
+      LOAD_TR_H(RB[U], b_tr[U], BUF, H, KS)                                                              \
+    }                                                                                                    \
+  }
+  // one MFMA; GA(MT, KS) = the group of NTQ MFMAs of one A fragment, with two insertion points (after the
+  // first and after the third MFMA) for one staging piece or one fragment read each: never more than one
+  // memory instruction (+ its address arithmetic) between two MFMAs
+#define MMA1(KS, MT, NT, MB, NB, RA, RB)                                                   \
+  if constexpr ((NT) < NTQ)                                                                \
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                 \
+                 : "+a"(acc[(MB) + (MT)][(NB) + (NT)])                                     \
+                 : "v"(RA[MT][KS]), "v"(RB[NT][KS]));
+#define GA(KS, MT, MB, NB, RA, RB, INS_A, INS_B)                                           \
+    MMA1(KS, MT, 0, MB, NB, RA, RB) INS_A;                                                 \
+    MMA1(KS, MT, 1, MB, NB, RA, RB) MMA1(KS, MT, 2, MB, NB, RA, RB) INS_B;                 \
+    MMA1(KS, MT, 3, MB, NB, RA, RB)
+#define PHASE(WAITN, WAITF, LOADUH, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB) \
   {                                                                            \
     __builtin_amdgcn_s_setprio(1);                                             \
     asm volatile("s_nop 1");                                                   \
-    MMA4(0, 0, MB, NB, RA, RB) PIECE(IH, IBUF, IT, 0);                         \
-    MMA4(0, 1, MB, NB, RA, RB) PIECE(IH, IBUF, IT, 1);                         \
-    LOADU(RN, LBUF, LH, 0)                                                     \
-    MMA4(0, 2, MB, NB, RA, RB) PIECE(IH, IBUF, IT, 2);                         \
-    LOADU(RN, LBUF, LH, 1)                                                     \
-    MMA4(0, 3, MB, NB, RA, RB) PIECE(IH, IBUF, IT, 3);                         \
-    LOADU(RN, LBUF, LH, 2)                                                     \
-    MMA4(1, 0, MB, NB, RA, RB)                                                 \
-    LOADU(RN, LBUF, LH, 3)                                                     \
-    MMA4(1, 1, MB, NB, RA, RB)                                                 \
-    MMA4(1, 2, MB, NB, RA, RB)                                                 \
-    MMA4(1, 3, MB, NB, RA, RB)                                                 \
+    GA(0, 0, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 0), LOADUH(RN, LBUF, LH, 0, 0)) \
+    GA(0, 1, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 1), LOADUH(RN, LBUF, LH, 1, 0)) \
+    GA(0, 2, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 2), LOADUH(RN, LBUF, LH, 2, 0)) \
+    GA(0, 3, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 3), LOADUH(RN, LBUF, LH, 3, 0)) \
+    GA(1, 0, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 0, 1), LOADUH(RN, LBUF, LH, 1, 1)) \
+    GA(1, 1, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 2, 1), LOADUH(RN, LBUF, LH, 3, 1)) \
+    GA(1, 2, MB, NB, RA, RB, , )                                               \
+    GA(1, 3, MB, NB, RA, RB, , )                                               \
     __builtin_amdgcn_s_setprio(0);                                             \
     if constexpr ((WAITF) != (WAITN)) { WAITBAR2(first, WAITF, WAITN); } else { WAITBAR(WAITN); } \
   }
 #define HALF_A                                                                                       \
-    PHASE(W32, CAPW(W32, 5), LOADB_U, RB1, 0, 1, pieceA, 0, 0, t2, 0, 0, RA0, RB0)                   \
-    PHASE(W23, CAPW(W23, 4), LOADA_U, RA1, 0, 1, pieceB, 0, 0, t2, 0, NTQ, RA0, RB1)                 \
-    PHASE(W23, CAPW(W23, 3), LOADA_U, RA0, 1, 0, pieceB, 1, 0, t2, 4, NTQ, RA1, RB1)                 \
-    PHASE(W32, CAPW(W32, 2), LOADB_U, RB1, 1, 1, pieceA, 1, 0, t2, 4, 0, RA1, RB0)
+    PHASE(W32, CAPW(W32, 5), LOADB_UH, RB1, 0, 1, pieceA, 0, 0, t2, 0, 0, RA0, RB0)                   \
+    PHASE(W23, CAPW(W23, 4), LOADA_UH, RA1, 0, 1, pieceB, 0, 0, t2, 0, NTQ, RA0, RB1)                 \
+    PHASE(W23, CAPW(W23, 3), LOADA_UH, RA0, 1, 0, pieceB, 1, 0, t2, 4, NTQ, RA1, RB1)                 \
+    PHASE(W32, CAPW(W32, 2), LOADB_UH, RB1, 1, 1, pieceA, 1, 0, t2, 4, 0, RA1, RB0)
+  // the same for the last (odd) K tile: no fragments are read ahead in its last two phases.  (Not only to save
+  // the reads: their results would be dead, and hipcc - which cannot know that these asm outputs arrive
+  // asynchronously - would reuse the destination registers for staging addresses while the data is on its way.)
+#define NOLOAD_UH(R, BUF, H, U, KS)
+#define HALF_A_LAST                                                                                  \
+    PHASE(W32, CAPW(W32, 5), LOADB_UH, RB1, 0, 1, pieceA, 0, 0, t2, 0, 0, RA0, RB0)                   \
+    PHASE(W23, CAPW(W23, 4), LOADA_UH, RA1, 0, 1, pieceB, 0, 0, t2, 0, NTQ, RA0, RB1)                 \
+    PHASE(W23, CAPW(W23, 3), NOLOAD_UH, RA0, 1, 0, pieceB, 1, 0, t2, 4, NTQ, RA1, RB1)                \
+    PHASE(W32, CAPW(W32, 2), NOLOAD_UH, RB1, 1, 1, pieceA, 1, 0, t2, 4, 0, RA1, RB0)
 #define HALF_B                                                                                       \
-    PHASE(W32, CAPW(W32, 1), LOADB_U, RB0, 1, 0, pieceA, 0, 1, t3, 0, NTQ, RA0, RB1)                 \
-    PHASE(W23, W23, LOADA_U, RA1, 1, 1, pieceB, 1, 1, t3, 0, 0, RA0, RB0)                            \
-    PHASE(W23, W23, LOADA_U, RA0, 0, 0, pieceB, 0, 1, t3, 4, 0, RA1, RB0)                            \
-    PHASE(W32, W32, LOADB_U, RB0, 0, 0, pieceA, 1, 1, t3, 4, NTQ, RA1, RB1)
+    PHASE(W32, CAPW(W32, 1), LOADB_UH, RB0, 1, 0, pieceA, 0, 1, t3, 0, NTQ, RA0, RB1)                 \
+    PHASE(W23, W23, LOADA_UH, RA1, 1, 1, pieceB, 1, 1, t3, 0, 0, RA0, RB0)                            \
+    PHASE(W23, W23, LOADA_UH, RA0, 0, 0, pieceB, 0, 1, t3, 4, 0, RA1, RB0)                            \
+    PHASE(W32, W32, LOADB_UH, RB0, 0, 0, pieceA, 1, 1, t3, 4, NTQ, RA1, RB1)
   bool behind_stores = false;   // the staged half-tiles were issued between the steps of a fully valid tile's epilogue
   while (true) {
     // ---- fragment read offsets: recomputed per work item from an opaque copy of the lane id, so that they
@@ -319,10 +353,10 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     // ---- retire K tile 0's first half-tiles, preload the first quadrant's fragments ("ovl": the staged
     //      half-tiles were issued between the steps of a fully valid tile's epilogue, whose stores sit behind them)
     const bool ovl = behind_stores;
-    if (ovl) { WAITBAR(CAPW(3 * 4 + 3 * PB, 7)); } else { WAITBAR(3 * 4 + 3 * PB); }
+    WAITBAR2(ovl, CAPW(3 * 4 + 3 * PB, 7), 3 * 4 + 3 * PB);
     LOADA(RA0, 0, 0)
     LOADB(RB0, 0, 0)
-    if (ovl) { WAITBAR(CAPW(W32, 6)); } else { WAITBAR(W32); }
+    WAITBAR2(ovl, CAPW(W32, 6), W32);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -339,7 +373,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     if (t < nk) {                  // odd contraction length: one more K tile
       const bool first = ovl && (t == 0);
       const int t2 = nk - 1;
-      HALF_A
+      HALF_A_LAST
     }
     WAITBAR(0);   // every wave has read its last fragments: the ring may be refilled
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> accumulator reads (hazard is invisible inside asm)
@@ -405,6 +439,8 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     w = wnext;
   }
 #undef HALF_A
+#undef HALF_A_LAST
+#undef NOLOAD_UH
 #undef HALF_B
 #undef PHASE
 #undef LOADA
@@ -412,7 +448,11 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
 #undef LOADA_U
 #undef LOADB_U
 #undef LOAD_TR
-#undef MMA4
+#undef LOAD_TR_H
+#undef LOADA_UH
+#undef LOADB_UH
+#undef MMA1
+#undef GA
 #undef CAPW
 }
 
