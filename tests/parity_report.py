@@ -1,4 +1,4 @@
-"""Dev tool: HIP engine vs CPU oracle on the golden batches; prints error magnitudes."""
+"""Test-side report (not collected by pytest; run by hand): HIP engine vs CPU oracle on the golden batches; prints error magnitudes."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
