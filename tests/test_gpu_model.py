@@ -359,6 +359,26 @@ def test_full_size_against_reference_golden():
             assert rel < 8e-2, (k, rel)
 
 
+def test_single_image_and_caption_through_vaultmodel_full_size():
+    """BASELINE configs[0]: one image + one caption through the headless VaultModel (ViLT-B32 + bertweet-base shapes)
+    in eval mode; sample 0 of the full-size reference golden, run alone (B = 1: every buffer padded to one tile)."""
+    from vault_amd.models.vault import VaultModel
+    g = np.load(os.path.join(GOLD, "full_bertweet_b2.npz"))
+    spec = _nodrop(VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3))
+    bn = synthetic_batch(spec, int(g["meta_batch"]), seed=int(g["meta_data_seed"]), n_classes=3)
+    kw = {k: torch.from_numpy(v[:1]).cuda() for k, v in bn.items() if k != "labels"}
+    enc = VaultModel(spec.vilt, bert_config=spec.lm, vilt_dropout_prob=0.0).to("cuda").eval()
+    with torch.no_grad():
+        o = enc(**kw)
+    T = bn["input_ids"].shape[1]
+    assert o.last_hidden_state.shape == (1, T + 1 + 144, 768) and o.pooler_output.shape == (1, 768)
+    assert np.abs(o.pooler_output.cpu().numpy() - g["pooler_output"][:1]).max() < 2e-2
+    h = o.last_hidden_state[:, : T + 1].cpu().numpy()
+    assert np.abs(h - g["hidden_text_cls"][:1]).max() < 1.5e-2 * np.abs(g["hidden_text_cls"]).max()
+    pn = np.sort(np.linalg.norm(o.last_hidden_state[:, T + 1:].cpu().numpy(), axis=-1), axis=1)
+    np.testing.assert_allclose(pn, g["hidden_patch_sorted_norms"][:1], rtol=5e-3)
+
+
 def test_eval_determinism_and_no_lm():
     spec = VaultSpec.tiny(3, "roberta")
     spec_nolm = VaultSpec(vilt=spec.vilt, lm=None, n_classes=0)
