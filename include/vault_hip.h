@@ -49,6 +49,17 @@ typedef struct vault_gemm_args {
 } vault_gemm_args;
 int vault_gemm(const vault_gemm_args* args, void* stream);
 
+/* ---- MXFP8 forward GEMM (BASELINE config "fp8 MFMA forward, bf16 backward") -------------------------------------
+ * OCP microscaling format: e4m3 elements [rows][K] (K contiguous) + one E8M0 scale byte per 32 consecutive k,
+ * [rows][K/32].  vault_quant_mxfp8 converts a bf16 operand (activations of the forward pass, bf16 weight shadow):
+ * scale exponent = floor(log2(max |x| of the block)) - 8, elements rounded to nearest even, saturating at +-448.
+ * vault_gemm_mxfp8: out = epilogue(A . B^T) with A = [M][K], B = [N][K] in that format (args->A / args->B point to
+ * the element bytes, lda = ldb = K, a_mode = b_mode = 0, splits <= 1), fp32 accumulation in
+ * v_mfma_scale_f32_16x16x128_f8f6f4, epilogues EPI_BF16, EPI_BF16_GELU, EPI_F32_RES as vault_gemm.
+ * M % 256 == 0, N % 256 == 0, K % 128 == 0.  Same Linear layers as vault_gemm (forward only). */
+int vault_quant_mxfp8(const void* src_bf16, long long rows, int K, int ld_src, void* dst_q, void* dst_scale, void* stream);
+int vault_gemm_mxfp8(const vault_gemm_args* args, const void* a_scale, const void* b_scale, void* stream);
+
 
 /* ---- LayerNorm ----------------------------------------------------------------------------
  * fp32 statistics, one wave per row, H in {256, 512, 768, 1024, 1536}.  Replaces nn.LayerNorm at

@@ -1,0 +1,138 @@
+"""MXFP8 forward GEMM and its quantiser (BASELINE config "fp8 MFMA forward, bf16 backward") through the C ABI.
+
+Parity is defined on the format itself: the quantiser against the OCP MX rule restated with torch's CPU
+float8_e4m3fn cast (bit-exact), the GEMM against an fp32 matmul of the DEQUANTISED operands (what the matrix pipe
+computes, up to fp32 summation order) and, with integer data, exactly."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+EPI_BF16, EPI_GELU, EPI_RES = 0, 1, 3
+
+
+def _quant_ref(x_bf16: torch.Tensor):
+    """OCP MX restated on the CPU: per 32 k, scale exponent floor(log2 amax) - 8; e4m3 RNE, saturating."""
+    x = x_bf16.float().cpu()
+    rows, K = x.shape
+    b = x.view(rows, K // 32, 32)
+    amax = b.abs().amax(-1)
+    ex = torch.where(amax > 0, torch.floor(torch.log2(amax.double())).to(torch.int32) + 127 - 8, torch.zeros_like(amax, dtype=torch.int32))
+    e8 = ex.clamp(0, 254)
+    inv = torch.pow(torch.tensor(2.0, dtype=torch.float64), (127 - e8).double()).float()
+    y = (b * inv[..., None]).clamp(-448.0, 448.0)
+    q = y.to(torch.float8_e4m3fn).view(torch.uint8).view(rows, K)
+    return q, e8.to(torch.uint8)
+
+
+def _dequant(q_u8: torch.Tensor, s_u8: torch.Tensor):
+    rows, K = q_u8.shape
+    v = q_u8.cpu().view(torch.float8_e4m3fn).float().view(rows, K // 32, 32)
+    sc = torch.pow(torch.tensor(2.0, dtype=torch.float64), s_u8.cpu().double() - 127.0).float()
+    return (v * sc[..., None]).view(rows, K)
+
+
+def _quant_gpu(x_bf16):
+    from vault_amd import ops
+    rows, K = x_bf16.shape
+    q = torch.empty(rows, K, dtype=torch.uint8, device="cuda")
+    s = torch.empty(rows, K // 32, dtype=torch.uint8, device="cuda")
+    ops.quant_mxfp8(x_bf16, rows, K, K, q, s)
+    torch.cuda.synchronize()
+    return q, s
+
+
+@pytest.mark.parametrize("rows,K,scale", [(64, 128, 1.0), (300, 768, 0.02), (256, 3072, 30.0)])
+def test_quantiser_bit_exact_against_the_ocp_rule(rows, K, scale):
+    g = torch.Generator().manual_seed(rows + K)
+    x = (torch.randn(rows, K, generator=g) * scale * torch.exp(2.0 * torch.randn(rows, 1, generator=g))).bfloat16()
+    x[0, :32] = 0                        # an all-zero block
+    x[1, 5] = 1e30                       # a huge outlier
+    x[2, 40:44] = torch.tensor([448.0, -448.0, 500.0, 2.0 ** -20]).bfloat16()
+    q, s = _quant_gpu(x.cuda())
+    qr, sr = _quant_ref(x)
+    assert torch.equal(s.cpu(), sr)
+    assert torch.equal(q.cpu(), qr)
+
+
+def _run_gemm(q_a, s_a, q_w, s_w, M, N, K, epi, **kw):
+    from vault_amd import ops
+    f32 = epi == EPI_RES
+    out = torch.zeros(M, N, dtype=torch.float32 if f32 else torch.bfloat16, device="cuda")
+    ops.gemm_mxfp8(q_a, s_a, q_w, s_w, out, M, N, K, N, epi, **kw)
+    torch.cuda.synchronize()
+    return out
+
+
+def test_gemm_exact_on_integer_data_with_power_of_two_block_scales():
+    """Checks the operand map of v_mfma_scale_f32_16x16x128_f8f6f4 as the kernel uses it: every product is an
+    integer times a power of two, so any misplaced element, k block or scale byte changes the result."""
+    M, N, K = 512, 256, 384
+    g = torch.Generator().manual_seed(5)
+    ia = torch.randint(-3, 4, (M, K), generator=g).float()
+    iw = torch.randint(-3, 4, (N, K), generator=g).float()
+    q_a = ia.to(torch.float8_e4m3fn).view(torch.uint8).cuda()
+    q_w = iw.to(torch.float8_e4m3fn).view(torch.uint8).cuda()
+    s_a = torch.randint(125, 130, (M, K // 32), generator=g).to(torch.uint8).cuda()
+    s_w = torch.randint(126, 129, (N, K // 32), generator=g).to(torch.uint8).cuda()
+    ref = _dequant(q_a, s_a).double() @ _dequant(q_w, s_w).double().t()
+    res = torch.zeros(M, N, device="cuda")
+    out = _run_gemm(q_a, s_a, q_w, s_w, M, N, K, EPI_RES, res=res)
+    assert torch.equal(out.cpu().double(), ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (768, 2304, 768), (512, 768, 3072)])
+def test_gemm_against_fp32_matmul_of_the_dequantised_operands(M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    q_a, s_a = _quant_gpu(x)
+    q_w, s_w = _quant_gpu(w)
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    m_valid = M - 19
+    ref = (_dequant(q_a, s_a).double() @ _dequant(q_w, s_w).double().t()).float() + bias.cpu()
+    out = _run_gemm(q_a, s_a, q_w, s_w, M, N, K, EPI_RES, bias=bias, res=res, m_valid=m_valid)
+    err = (out.cpu()[:m_valid] - (ref + res.cpu())[:m_valid]).abs().max().item()
+    # (the matrix pipe aligns the 128 products of a step before adding them: ~3e-5 of the largest output, more
+    #  than an fp32 sum of the same products would lose)
+    assert err <= 2e-4 * ref.abs().max().item() + 1e-5, err
+    assert out[m_valid:].abs().max().item() == 0.0
+    # and how far the format itself is from the bf16 operands (information, loose bound: e4m3 has 3 mantissa bits)
+    exact = x.float().cpu().double() @ w.float().cpu().double().t()
+    rel = ((ref - bias.cpu()).double() - exact).norm() / exact.norm()
+    assert rel < 0.06, rel
+
+
+def test_gemm_gelu_and_bf16_epilogues():
+    M, N, K = 512, 768, 768
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(M, K, generator=g).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    q_a, s_a = _quant_gpu(x)
+    q_w, s_w = _quant_gpu(w)
+    bias = torch.randn(N, generator=g).cuda()
+    pre = (_dequant(q_a, s_a).double() @ _dequant(q_w, s_w).double().t()).float() + bias.cpu()
+    out = _run_gemm(q_a, s_a, q_w, s_w, M, N, K, EPI_BF16, bias=bias)
+    assert (out.float().cpu() - pre).abs().max().item() <= pre.abs().max().item() * 2 ** -7
+    out2 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    y = _run_gemm(q_a, s_a, q_w, s_w, M, N, K, EPI_GELU, bias=bias, out2=out2)
+    want = torch.nn.functional.gelu(pre)
+    assert (y.float().cpu() - want).abs().max().item() <= want.abs().max().item() * 2 ** -7 + 2e-3
+    xs = pre.clone().requires_grad_(True)
+    torch.nn.functional.gelu(xs).sum().backward()
+    assert (out2.float().cpu() - xs.grad).abs().max().item() <= 1e-2
+
+
+def test_rejects_what_the_kernel_cannot_do():
+    from vault_amd import lib as L, ops
+    q = torch.zeros(256, 128, dtype=torch.uint8, device="cuda")
+    s = torch.zeros(256, 4, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(256, 256, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.gemm_mxfp8(q, s, q, s, out, 256, 256, 96, 256, EPI_BF16)       # K % 128
+    with pytest.raises(RuntimeError):
+        ops.gemm_mxfp8(q, s, q, s, out, 256, 256, 128, 256, 5)             # split-K atomics: backward stays bf16
+    with pytest.raises(RuntimeError):
+        ops.quant_mxfp8(out, 256, 100, 256, q, s)                          # K % 32

@@ -3,8 +3,9 @@
 #include "gemm.h"
 #include "../../include/vault_hip.h"
 
-extern "C" int vault_gemm(const vault_gemm_args* a, void* stream) {
-  if (a == nullptr) return VAULT_EINVAL;
+int vault_gemm_mx8_launch(const GemmParams& p, const void* a_scale, const void* b_scale, int epi, hipStream_t st);
+
+static GemmParams params_of(const vault_gemm_args* a) {
   GemmParams p{};
   p.A = reinterpret_cast<const __bf16*>(a->A);
   p.B = reinterpret_cast<const __bf16*>(a->B);
@@ -20,7 +21,17 @@ extern "C" int vault_gemm(const vault_gemm_args* a, void* stream) {
   p.drop_scale = a->drop_scale;
   p.gn = a->gn;
   p.persist = a->persist;
-  return vault_gemm_launch(p, a->a_mode, a->b_mode, a->epi, a->cfg, reinterpret_cast<hipStream_t>(stream));
+  return p;
+}
+
+extern "C" int vault_gemm(const vault_gemm_args* a, void* stream) {
+  if (a == nullptr) return VAULT_EINVAL;
+  return vault_gemm_launch(params_of(a), a->a_mode, a->b_mode, a->epi, a->cfg, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int vault_gemm_mxfp8(const vault_gemm_args* a, const void* a_scale, const void* b_scale, void* stream) {
+  if (a == nullptr || a->a_mode != 0 || a->b_mode != 0 || a->splits > 1) return VAULT_EINVAL;
+  return vault_gemm_mx8_launch(params_of(a), a_scale, b_scale, a->epi, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int vault_abi_version(void) { return 1; }

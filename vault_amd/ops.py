@@ -142,6 +142,25 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_va
     _invoke("vault_gemm", C.byref(a), _stream(), struct=a, drop=drop)
 
 
+def quant_mxfp8(src_bf16, rows, K, ld, dst_q, dst_scale):
+    """bf16 [rows][ld >= K] -> MXFP8: e4m3 bytes [rows][K] + E8M0 block scales [rows][K/32] (include/vault_hip.h)."""
+    _invoke("vault_quant_mxfp8", C.c_void_p(_p(src_bf16)), C.c_longlong(rows), C.c_int(K), C.c_int(ld),
+            C.c_void_p(_p(dst_q)), C.c_void_p(_p(dst_scale)), _stream())
+
+
+def gemm_mxfp8(Aq, As, Bq, Bs, out, M, N, K, ldo, epi, *, m_valid=0, bias=None, res=None, out2=None,
+               drop: Drop = NO_DROP):
+    """out = epilogue(A . B^T) on MXFP8 operands (forward Linear layers of the fp8-forward configuration)."""
+    a = L.GemmArgs()
+    a.A, a.B, a.out, a.out2 = _p(Aq), _p(Bq), _p(out), _p(out2)
+    a.bias, a.res = _p(bias), _p(res)
+    a.M, a.N, a.K, a.lda, a.ldb, a.ldo, a.m_valid = M, N, K, K, K, ldo, m_valid
+    a.a_mode, a.b_mode, a.epi, a.cfg, a.splits, a.accumulate = 0, 0, epi, -1, 1, 0
+    a.persist = GEMM_SCHED
+    a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
+    _invoke("vault_gemm_mxfp8", C.byref(a), C.c_void_p(_p(As)), C.c_void_p(_p(Bs)), _stream(), struct=a, drop=drop)
+
+
 def layernorm_fwd(x, gamma, beta, eps, rows, H, *, y_bf16=None, y_f32=None, mean=None, rstd=None, post_add=None,
                   xmap=(0, 0, 0), ymap=(0, 0, 0), drop: Drop = NO_DROP, y_split3=None):
     a = LnFwdArgs()
