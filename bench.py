@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--freeze-lm", action="store_true")
+    ap.add_argument("--fp8-forward", action="store_true",
+                    help="BASELINE config 5: MXFP8 forward Linear GEMMs (block-scaled fp8 MFMA), bf16 backward")
     ap.add_argument("--lm", default="bertweet", choices=["bertweet", "bert-base-uncased"])
     args = ap.parse_args()
 
@@ -115,7 +117,7 @@ def main():
 
     lm = LMSpec.bertweet_base() if args.lm == "bertweet" else LMSpec.bert_base_uncased()
     spec = VaultSpec(vilt=ViltSpec(), lm=lm, n_classes=3)
-    eng = VaultEngine(spec, dev, seed=0, freeze_lm=args.freeze_lm, classifier_dropout=0.1)
+    eng = VaultEngine(spec, dev, seed=0, freeze_lm=args.freeze_lm, classifier_dropout=0.1, fp8_forward=args.fp8_forward)
     total = args.steps + args.warmup
     stepper = TrainStep(eng, learning_rate=2e-5, warmup_ratio=0.1, total_steps=max(total, 10), process_group=pg,
                        assume_full_pixel_mask=True)   # synthetic 384x384 images, all-ones masks: no per-step mask check
@@ -198,10 +200,12 @@ def main():
             "metric": "train samples/sec (img+text pairs) ViLT-B32+BERTweet, bs256, 1/2/4/8 MI355X",
             "value": round(sps, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "mxfp8 forward GEMMs / bf16 backward" if args.fp8_forward else "bf16",
+            "data": "synthetic",
             "config": {"workload": f"ViLT-B32 + {args.lm} fine-tune step (fwd+bwd+AdamW), per-GPU batch {B}, "
                                    f"40 text tokens + 384x384 image (185-token fused sequence), "
-                                   f"{'frozen LM' if args.freeze_lm else 'all weights trained'}",
+                                   f"{'frozen LM' if args.freeze_lm else 'all weights trained'}"
+                                   f"{', MXFP8 forward Linears' if args.fp8_forward else ''}",
                        "global_batch": B * world, "seq_len": 185, "parallelism": f"dp{world}"},
             "roofline": r_wgrad, "roofline_ffn1": r_ffn1,
             "step_mfma_frac": round(sps / world * flop_per_sample / PEAK_BF16, 4),

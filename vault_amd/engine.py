@@ -211,8 +211,14 @@ class VaultEngine:
     WGRAD_TARGET_WGS = 768
 
     def __init__(self, spec: VaultSpec, device="cuda:0", state=None, seed: int = 0, freeze_lm: bool = False,
-                 with_grads: bool = True, classifier_dropout: float = 0.1):
+                 with_grads: bool = True, classifier_dropout: float = 0.1, fp8_forward: bool = False):
         self.spec, self.device = spec, torch.device(device)
+        # BASELINE config "fp8 MFMA forward, bf16 backward": the forward Linear layers of both encoder stacks run on
+        # MXFP8 operands (QKV and FFN-in: activations quantised in front of the GEMM, weights from the bf16 shadow once
+        # per forward);
+        # everything saved for backward, and backward itself, stay bf16 (straight-through)
+        self.fp8_forward = fp8_forward
+        self._w8: Dict[str, tuple] = {}
         self.freeze_lm = freeze_lm and spec.lm is not None
         self.classifier_dropout = classifier_dropout
         if spec.vilt.hidden_size % 256 or (spec.lm and spec.lm.hidden_size != spec.vilt.hidden_size):
@@ -270,6 +276,34 @@ class VaultEngine:
         return self._ws[key]
 
     # ---- helpers ----------------------------------------------------------------------------
+    def _fp8_scratch(self, M, K):
+        """MXFP8 image of the A operand of the GEMM about to run (consumed at once: one buffer per shape)."""
+        key = ("fp8_a", M, K)
+        if key not in self._ws:
+            self._ws[key] = (torch.empty(M * K, dtype=torch.uint8, device=self.device),
+                             torch.empty(M * (K // 32), dtype=torch.uint8, device=self.device))
+        return self._ws[key]
+
+    def _fp8_refresh_weights(self):
+        """MXFP8 shadow of the encoder Linear weights, re-quantised from the bf16 shadow (a launch per weight: on
+        the tape of a train step, so every step sees the weights the optimizer just wrote)."""
+        P = self.params
+        for ln in self.ll + self.vl:
+            # the two Linears fed by a LayerNorm (K = H): measured at M = 47360 (tools/mx8_bench.py), quantise + MXFP8
+            # GEMM 133 / 246 us against 192 / 336 us in bf16; attention-out is bound by its fp32 epilogue either way and
+            # FFN-out would pay 85 us to quantise its [M, 4H] operand (until the GELU epilogue emits MXFP8 itself)
+            for wname in (ln.qw, ln.iw):
+                o, shp = P.offsets[wname]
+                N = 3 * shp[0] if wname == ln.qw else shp[0]     # fused QKV: three [H, H] blocks stored back to back
+                K = shp[1]
+                if N % 256 or K % 128:
+                    continue
+                if wname not in self._w8:
+                    self._w8[wname] = (torch.empty(N * K, dtype=torch.uint8, device=self.device),
+                                       torch.empty(N * (K // 32), dtype=torch.uint8, device=self.device))
+                wq, wsc = self._w8[wname]
+                ops.quant_mxfp8(P.wb(wname, n_elems=N * K, shape=(N, K)), N, K, K, wq, wsc)
+
     def _linear(self, a_bf16, wname, out, M, N, K, epi, m_valid, bias=None, precise=False, ldo=None, **kw):
         """out = epilogue(A . W^T).  ``precise``: A is a [M, 3K] = [hi | lo | hi] split-bf16 operand and the
         weight its [N, 3K] = [hi | hi | lo] counterpart: the same kernel over a 3x longer contraction."""
@@ -277,6 +311,12 @@ class VaultEngine:
         if precise:
             ops.gemm(a_bf16, P.wb3(wname, N, K), out, M, N, 3 * K, 3 * K, 3 * K, N if ldo is None else ldo, 0, 0, epi,
                      m_valid=m_valid, bias=bias, **kw)
+        elif self.fp8_forward and wname in self._w8 and M % 256 == 0:
+            wq, wsc = self._w8[wname]
+            aq, asc = self._fp8_scratch(M, K)
+            ops.quant_mxfp8(a_bf16, M, K, K, aq, asc)
+            kw.pop("split3", None)   # (only set in precise mode)
+            ops.gemm_mxfp8(aq, asc, wq, wsc, out, M, N, K, N, epi, m_valid=m_valid, bias=bias, **kw)
         else:
             ops.gemm(a_bf16, P.wb(wname, n_elems=N * K, shape=(N, K)), out, M, N, K, K, K, N if ldo is None else ldo,
                      0, 0, epi, m_valid=m_valid, bias=bias, **kw)
@@ -450,6 +490,8 @@ class VaultEngine:
         ws["drop_seed"] = self.drop_seed
         pr = precise
         W3 = 3 if pr else 1   # operand width multiplier of the split-bf16 path
+        if self.fp8_forward and not pr:
+            self._fp8_refresh_weights()
 
         # ------------------------------ language model ------------------------------
         if spec.lm is not None:
