@@ -75,6 +75,8 @@ typedef struct vault_ln_fwd_args {
   int x_rpg, x_gstride, x_goff, y_rpg, y_gstride, y_goff;
   uint32_t drop_thresh, drop_seed, drop_stream; float drop_scale;
   void* y_split3;   /* optional bf16 [rows][3H] = [hi | lo | hi]: A operand of a split-bf16 (precise) GEMM */
+  void* y_q; void* y_scale;   /* optional (ABI 2): MXFP8 image of y_bf16, e4m3 [rows][H] + E8M0 [rows][H/32] - the bytes
+                                 vault_quant_mxfp8 gives for y_bf16: A operand of vault_gemm_mxfp8 */
 } vault_ln_fwd_args;
 int vault_layernorm_fwd(const vault_ln_fwd_args* args, void* stream);
 

@@ -214,3 +214,17 @@ def test_train_step_with_fp8_forward_learns_a_fixed_batch():
     labels = torch.from_numpy(bn["labels"]).cuda()
     losses = [float(step(db, labels)) for _ in range(40)]
     assert max(losses[-5:]) < 0.6 * losses[0], losses[::6]
+
+
+def test_layernorm_emits_the_mxfp8_image_of_its_bf16_output():
+    """vault_layernorm_fwd(y_q, y_scale): byte for byte what vault_quant_mxfp8 gives for y_bf16."""
+    from vault_amd import ops
+    rows, H = 777, 768
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(rows, H, generator=g) * torch.exp(torch.randn(rows, 1, generator=g))).cuda()
+    gamma = (1.0 + 0.1 * torch.randn(H, generator=g)).cuda(); beta = (0.1 * torch.randn(H, generator=g)).cuda()
+    yb = torch.zeros(rows, H, dtype=torch.bfloat16, device="cuda")
+    q = torch.zeros(rows, H, dtype=torch.uint8, device="cuda"); s = torch.zeros(rows, H // 32, dtype=torch.uint8, device="cuda")
+    ops.layernorm_fwd(x, gamma, beta, 1e-12, rows, H, y_bf16=yb, y_q=q, y_scale=s)
+    q2, s2 = _quant_gpu(yb)
+    assert torch.equal(s, s2) and torch.equal(q, q2)

@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ post_add,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
                                                      uint32_t drop_thresh, uint32_t drop_seed, uint32_t drop_stream,
-                                                     float drop_scale, bf16* __restrict__ y_split3) {
+                                                     float drop_scale, bf16* __restrict__ y_split3,
+                                                     uint8_t* __restrict__ y_q, uint8_t* __restrict__ y_scale) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -75,6 +76,30 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (y_bf16) {
       uint2 w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
       *reinterpret_cast<uint2*>(y_bf16 + orow * H + c) = w;
+    }
+    if (y_q) {
+      // MXFP8 image of the bf16 output (the bytes vault_quant_mxfp8 would produce from y_bf16): a block of 32
+      // consecutive columns is held by 8 consecutive lanes
+      float b[4];
+      float amax = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { b[e] = (float)(bf16)o[e]; amax = fmaxf(amax, fabsf(b[e])); }
+      amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+      amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+      amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+      int e8 = 0;
+      if (amax > 0.f) {
+        e8 = (int)((__builtin_bit_cast(uint32_t, amax) >> 23) & 0xff) - 8;
+        e8 = e8 < 0 ? 0 : e8;
+      }
+      const float inv = __builtin_bit_cast(float, (uint32_t)(254 - e8) << 23);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b[e] = fminf(fmaxf(b[e] * inv, -448.f), 448.f);
+      int w8 = 0;
+      w8 = __builtin_amdgcn_cvt_pk_fp8_f32(b[0], b[1], w8, false);
+      w8 = __builtin_amdgcn_cvt_pk_fp8_f32(b[2], b[3], w8, true);
+      *reinterpret_cast<int*>(y_q + orow * H + c) = w8;
+      if ((lane & 7) == 0) y_scale[orow * (H / 32) + (c >> 5)] = (uint8_t)e8;
     }
     if (y_split3) {   // [hi | lo | hi] A-operand layout of the split-bf16 (precise) GEMM path
       bf16 hi[4], lo[4];
@@ -222,7 +247,8 @@ extern "C" int vault_layernorm_fwd(const vault_ln_fwd_args* a, void* stream) {
 #define LN_FWD(V)                                                                                          \
   hipLaunchKernelGGL(ln_fwd_kernel<V>, grid, block, 0, st, a->x, xm, a->gamma, a->beta, a->eps, a->rows,   \
                      a->H, reinterpret_cast<bf16*>(a->y_bf16), a->y_f32, ym, a->post_add, a->mean, a->rstd, \
-                     a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale, reinterpret_cast<bf16*>(a->y_split3))
+                     a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale, reinterpret_cast<bf16*>(a->y_split3), \
+                     reinterpret_cast<uint8_t*>(a->y_q), reinterpret_cast<uint8_t*>(a->y_scale))
   switch (a->H / 256) {
     case 1: LN_FWD(1); break;
     case 2: LN_FWD(2); break;

@@ -304,7 +304,8 @@ class VaultEngine:
                 wq, wsc = self._w8[wname]
                 ops.quant_mxfp8(P.wb(wname, n_elems=N * K, shape=(N, K)), N, K, K, wq, wsc)
 
-    def _linear(self, a_bf16, wname, out, M, N, K, epi, m_valid, bias=None, precise=False, ldo=None, **kw):
+    def _linear(self, a_bf16, wname, out, M, N, K, epi, m_valid, bias=None, precise=False, ldo=None, prequant=False,
+                **kw):
         """out = epilogue(A . W^T).  ``precise``: A is a [M, 3K] = [hi | lo | hi] split-bf16 operand and the
         weight its [N, 3K] = [hi | hi | lo] counterpart: the same kernel over a 3x longer contraction."""
         P = self.params
@@ -314,7 +315,8 @@ class VaultEngine:
         elif self.fp8_forward and wname in self._w8 and M % 256 == 0:
             wq, wsc = self._w8[wname]
             aq, asc = self._fp8_scratch(M, K)
-            ops.quant_mxfp8(a_bf16, M, K, K, aq, asc)
+            if not prequant:          # (the LayerNorm in front wrote the MXFP8 image of its bf16 output itself)
+                ops.quant_mxfp8(a_bf16, M, K, K, aq, asc)
             kw.pop("split3", None)   # (only set in precise mode)
             ops.gemm_mxfp8(aq, asc, wq, wsc, out, M, N, K, N, epi, m_valid=m_valid, bias=bias, **kw)
         else:
@@ -513,10 +515,12 @@ class VaultEngine:
                   for i in range(nl + 1)]
             lm_train = train   # dropout stays active in a frozen LM too (ref: model.py:189 only disables grad)
             pdh, pda = lm.hidden_dropout_prob, lm.attention_probs_dropout_prob
+            q8l = self._fp8_scratch(Mlp, H) if (self.fp8_forward and not pr and Mlp % 256 == 0) else (None, None)
             ops.layernorm_fwd(esum, P.w("bert.embeddings.LayerNorm.weight"), P.w("bert.embeddings.LayerNorm.bias"),
                               lm.layer_norm_eps, Ml, H, y_f32=y[0], y_bf16=None if pr else yb[0],
                               y_split3=yb[0] if pr else None, mean=buf("lm_emean", (Mlp,)),
-                              rstd=buf("lm_erstd", (Mlp,)), drop=self._drop(pdh, 1, lm_train))
+                              rstd=buf("lm_erstd", (Mlp,)), drop=self._drop(pdh, 1, lm_train),
+                              y_q=q8l[0], y_scale=q8l[1])
             for i, ln in enumerate(self.ll):
                 sfx = f"{i}" if keep else ""
                 qkv = buf(f"lm_qkv{sfx}", (Mlp, 3 * H), bf)
@@ -529,24 +533,26 @@ class VaultEngine:
                 act = buf(f"lm_act{sfx}{p3}", (Mlp, W3 * FF), bf)
                 h2 = buf(f"lm_h2{sfx}", (Mlp, H))
                 self._linear(yb[i], ln.qw, qkv, Mlp, 3 * H, H, ops.EPI_BF16, Ml,
-                             bias=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)), precise=pr)
+                             bias=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)), precise=pr, prequant=q8l[0] is not None)
                 ops.attention_fwd(qkv, amf, None if pr else ctx, lse, B, T, H, heads,
                                   drop=self._drop(pda, 16 * i + 2, lm_train), ctx_split3=ctx if pr else None)
                 self._linear(ctx, ln.ow, h1, Mlp, H, H, ops.EPI_F32_RES, Ml, bias=P.w(ln.ob), res=y[i],
                              drop=self._drop(pdh, 16 * i + 3, lm_train), precise=pr)
                 ops.layernorm_fwd(h1, P.w(ln.ln1w), P.w(ln.ln1b), lm.layer_norm_eps, Ml, H, y_f32=y1,
                                   y_bf16=None if pr else y1b, y_split3=y1b if pr else None,
-                                  mean=buf(f"lm_m1{sfx}", (Mlp,)), rstd=buf(f"lm_r1{sfx}", (Mlp,)))
+                                  mean=buf(f"lm_m1{sfx}", (Mlp,)), rstd=buf(f"lm_r1{sfx}", (Mlp,)),
+                                  y_q=q8l[0], y_scale=q8l[1])
                 ops.pycall(lambda: self._prof_begin("ffn1"))
                 self._linear(y1b, ln.iw, act, Mlp, FF, H, ops.EPI_BF16_GELU, Ml, bias=P.w(ln.ib), out2=u, precise=pr,
-                             split3=pr, ldo=W3 * FF)
+                             split3=pr, ldo=W3 * FF, prequant=q8l[0] is not None)
                 fl_l = 2.0 * Ml * FF * H * W3
                 ops.pycall(lambda: self._prof_end("ffn1", fl_l))
                 self._linear(act, ln.fw, h2, Mlp, H, FF, ops.EPI_F32_RES, Ml, bias=P.w(ln.fb), res=y1,
                              drop=self._drop(pdh, 16 * i + 4, lm_train), precise=pr)
                 ops.layernorm_fwd(h2, P.w(ln.ln2w), P.w(ln.ln2b), lm.layer_norm_eps, Ml, H, y_f32=y[i + 1],
                                   y_bf16=None if pr else yb[i + 1], y_split3=yb[i + 1] if pr else None,
-                                  mean=buf(f"lm_m2{sfx}", (Mlp,)), rstd=buf(f"lm_r2{sfx}", (Mlp,)))
+                                  mean=buf(f"lm_m2{sfx}", (Mlp,)), rstd=buf(f"lm_r2{sfx}", (Mlp,)),
+                                  y_q=q8l[0], y_scale=q8l[1])
             text_src = y[nl]
             use_pos = spec.use_vilt_position_embeddings
             tables = [(P.w("embeddings.text_embeddings.token_type_embeddings.weight"), tt if tt is not None else 0)]
@@ -600,17 +606,20 @@ class VaultEngine:
             xm = buf(f"xm{sfx}", (Mp, H)); n2 = buf(f"n2{sfx}{p3}", (Mp, W3 * H), bf)
             u = buf(f"u{sfx}", (Mp, FF), bf) if train else None
             act = buf(f"act{sfx}{p3}", (Mp, W3 * FF), bf)
+            q8 = self._fp8_scratch(Mp, H) if (self.fp8_forward and not pr and Mp % 256 == 0) else (None, None)
             ops.layernorm_fwd(x[i], P.w(ln.ln1w), P.w(ln.ln1b), v.layer_norm_eps, M, H, y_bf16=None if pr else n1,
-                              y_split3=n1 if pr else None, mean=buf(f"m1{sfx}", (Mp,)), rstd=buf(f"r1{sfx}", (Mp,)))
+                              y_split3=n1 if pr else None, mean=buf(f"m1{sfx}", (Mp,)), rstd=buf(f"r1{sfx}", (Mp,)),
+                              y_q=q8[0], y_scale=q8[1])
             self._linear(n1, ln.qw, qkv, Mp, 3 * H, H, ops.EPI_BF16, M, bias=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)),
-                         precise=pr)
+                         precise=pr, prequant=q8[0] is not None)
             ops.attention_fwd(qkv, km, None if pr else ctx, lse, B, S, H, heads, ctx_split3=ctx if pr else None)
             self._linear(ctx, ln.ow, xm, Mp, H, H, ops.EPI_F32_RES, M, bias=P.w(ln.ob), res=x[i], precise=pr)
             ops.layernorm_fwd(xm, P.w(ln.ln2w), P.w(ln.ln2b), v.layer_norm_eps, M, H, y_bf16=None if pr else n2,
-                              y_split3=n2 if pr else None, mean=buf(f"m2{sfx}", (Mp,)), rstd=buf(f"r2{sfx}", (Mp,)))
+                              y_split3=n2 if pr else None, mean=buf(f"m2{sfx}", (Mp,)), rstd=buf(f"r2{sfx}", (Mp,)),
+                              y_q=q8[0], y_scale=q8[1])
             ops.pycall(lambda: self._prof_begin("ffn1"))
             self._linear(n2, ln.iw, act, Mp, FF, H, ops.EPI_BF16_GELU, M, bias=P.w(ln.ib), out2=u, precise=pr,
-                         split3=pr, ldo=W3 * FF)
+                         split3=pr, ldo=W3 * FF, prequant=q8[0] is not None)
             fl_v = 2.0 * M * FF * H * W3
             ops.pycall(lambda: self._prof_end("ffn1", fl_v))
             self._linear(act, ln.fw, x[i + 1], Mp, H, FF, ops.EPI_F32_RES, M, bias=P.w(ln.fb), res=xm, precise=pr)

@@ -21,7 +21,7 @@ class LnFwdArgs(C.Structure):
                 ("x_rpg", C.c_int), ("x_gstride", C.c_int), ("x_goff", C.c_int),
                 ("y_rpg", C.c_int), ("y_gstride", C.c_int), ("y_goff", C.c_int),
                 ("drop_thresh", C.c_uint32), ("drop_seed", C.c_uint32), ("drop_stream", C.c_uint32),
-                ("drop_scale", C.c_float), ("y_split3", C.c_void_p)]
+                ("drop_scale", C.c_float), ("y_split3", C.c_void_p), ("y_q", C.c_void_p), ("y_scale", C.c_void_p)]
 
 
 class LnBwdArgs(C.Structure):
@@ -162,7 +162,7 @@ def gemm_mxfp8(Aq, As, Bq, Bs, out, M, N, K, ldo, epi, *, m_valid=0, bias=None, 
 
 
 def layernorm_fwd(x, gamma, beta, eps, rows, H, *, y_bf16=None, y_f32=None, mean=None, rstd=None, post_add=None,
-                  xmap=(0, 0, 0), ymap=(0, 0, 0), drop: Drop = NO_DROP, y_split3=None):
+                  xmap=(0, 0, 0), ymap=(0, 0, 0), drop: Drop = NO_DROP, y_split3=None, y_q=None, y_scale=None):
     a = LnFwdArgs()
     a.x, a.gamma, a.beta, a.post_add = _p(x), _p(gamma), _p(beta), _p(post_add)
     a.y_bf16, a.y_f32, a.mean, a.rstd = _p(y_bf16), _p(y_f32), _p(mean), _p(rstd)
@@ -171,6 +171,7 @@ def layernorm_fwd(x, gamma, beta, eps, rows, H, *, y_bf16=None, y_f32=None, mean
     a.y_rpg, a.y_gstride, a.y_goff = ymap
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
     a.y_split3 = _p(y_split3)
+    a.y_q, a.y_scale = _p(y_q), _p(y_scale)
     _invoke("vault_layernorm_fwd", C.byref(a), _stream(), struct=a, drop=drop)
 
 
