@@ -216,6 +216,14 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(spec)
             except Exception as e:  # pragma: no cover
                 out["cpu_baseline"] = {"error": repr(e)}
+        # librccl prints its version banner through C stdio, which a redirected stdout only flushes at exit - after
+        # this line.  Flush it first: the JSON line must be the last thing on stdout.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # pragma: no cover
+            pass
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()
