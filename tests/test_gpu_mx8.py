@@ -228,3 +228,21 @@ def test_layernorm_emits_the_mxfp8_image_of_its_bf16_output():
     ops.layernorm_fwd(x, gamma, beta, 1e-12, rows, H, y_bf16=yb, y_q=q, y_scale=s)
     q2, s2 = _quant_gpu(yb)
     assert torch.equal(s, s2) and torch.equal(q, q2)
+
+
+def test_model_class_switch():
+    """`model.fp8_forward = True` on the reference-shaped classes selects the MXFP8 forward."""
+    from vault_amd.models.vault import VaultForTMSC
+    from vault_amd.spec import VaultSpec, synthetic_batch
+    spec = VaultSpec.tiny(3, "roberta")
+    bn = synthetic_batch(spec, 3, seed=11, n_classes=3)
+    model = VaultForTMSC(spec.vilt, n_classes=3, vilt_dropout_prob=0.0, bert_config=spec.lm).to("cuda").eval()
+    kw = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
+    with torch.no_grad():
+        a = model(**kw).clone()
+        model.fp8_forward = True
+        b = model(**kw).clone()
+        model.fp8_forward = False
+        c = model(**kw).clone()
+    assert model._engine._w8 and torch.equal(a, c)
+    assert 0 < (a - b).abs().max().item() < 0.05 * a.abs().max().item() + 2e-2

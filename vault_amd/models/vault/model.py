@@ -120,6 +120,7 @@ class _VaultFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, batch, want_logits, train, *params):
         eng = model._engine
+        eng.fp8_forward = bool(model.fp8_forward)
         extra = batch.pop("__pass__", None)     # (ws_tag, image_token_type_idx, advance_seed) of multi-image heads
         kw = {} if extra is None else dict(ws_tag=extra[0], image_token_type_idx=extra[1], advance_seed=extra[2])
         out = eng.forward(batch, train=train, need_hidden=not want_logits or model._always_hidden,
@@ -207,6 +208,9 @@ class VaultMixin(nn.Module):
     #: inference only: run every Linear as a split-bf16 ("bf16x3") GEMM - fp32-class products on the bf16
     #: MFMA path, ~3x the GEMM time - to meet the 1e-3 logits parity bar against the fp32 reference
     precise = False
+    #: forward Linear layers fed by a LayerNorm (QKV, FFN-in) on MXFP8 operands, backward in bf16 (BASELINE config
+    #: "fp8 MFMA forward, bf16 backward"): faster, outside the 1e-3 parity bar
+    fp8_forward = False
 
     def __init__(self, vilt_config, bert_config=None, freeze_lm: bool = False, vilt_dropout_prob: float = 0.0,
                  use_vilt_position_embeddings: bool = False, add_pooling_layer: bool = True, *, _n_classes: int = 0,
