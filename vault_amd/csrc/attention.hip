@@ -69,7 +69,7 @@ struct AttnDrop {
   float scale;
 };
 
-template <int NKT, int NWV, int WPE>
+template <int NKT, int NWV, int WPE, bool DROP = true>
 __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
                                                        bf16* __restrict__ ctx, float* __restrict__ lse, int S, int H,
                                                        int heads, float scale, AttnDrop dr, bf16* __restrict__ ctx3) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __r
         for (int r = 0; r < 4; ++r) {
           float pv = __builtin_amdgcn_exp2f(a[r] * sl2 - mxs);
           sum += pv;
-          if (dr.thresh != 0u) {
+          if (DROP && dr.thresh != 0u) {
             const uint32_t idx = (bh * (uint32_t)S + (uint32_t)q_l) * (uint32_t)S + (uint32_t)(kt * 16 + 4 * g + r);
             pv = dropout_keep(dr.seed, dr.stream, idx, dr.thresh) ? pv * dr.scale : 0.f;
           }
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __r
 // Backward.  Phase A (wave = query tile): dQ.  Phase B (wave = key tile): dK, dV.  P is recomputed
 // from Q, K and the forward's log-sum-exp; both phases recompute the score tile in the orientation
 // whose accumulator is directly the next MFMA's A operand.
-template <int NKT, int NWV, int WPE>
+template <int NKT, int NWV, int WPE, bool DROP = true>
 __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
                                                        const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
                                                        const float* __restrict__ lse, bf16* __restrict__ dqkv, int S,
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __r
         for (int r = 0; r < 4; ++r) {
           const float pv = __builtin_amdgcn_exp2f((a[r] + m4[r]) * sl2 + nl);
           float dpv = dp[r];
-          if (dr.thresh != 0u) {
+          if (DROP && dr.thresh != 0u) {
             const uint32_t idx = (bh * (uint32_t)S + (uint32_t)q_l) * (uint32_t)S + (uint32_t)(kt * 16 + 4 * g + r);
             dpv = dropout_keep(dr.seed, dr.stream, idx, dr.thresh) ? dpv * dr.scale : 0.f;
           }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __r
         for (int r = 0; r < 4; ++r) {
           float pv = __builtin_amdgcn_exp2f((a[r] + mk) * sl2 + nl4[r]);
           float dpv = dp[r];
-          if (dr.thresh != 0u) {
+          if (DROP && dr.thresh != 0u) {
             const uint32_t idx = (bh * (uint32_t)S + (uint32_t)(qt * 16 + 4 * g + r)) * (uint32_t)S + (uint32_t)k_l;
             const bool keep = dropout_keep(dr.seed, dr.stream, idx, dr.thresh);
             dpv = keep ? dpv * dr.scale : 0.f;
@@ -352,6 +352,260 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __r
   }
 }
 
+// Backward, resident form (64 < S <= 192): Q, K, V and dO of a (batch, head) are ALL held in LDS (4 x 24 KiB), so every
+// operand is read from HBM exactly once (the two-phase kernel above reads Q, K, V twice and dO three times: 662 MB
+// per launch measured against 364 MB algorithmic at B = 256), and nothing is re-staged between the dQ and the
+// dK / dV passes (no barrier between them).  One workgroup of NWV waves per CU (a wave owns 2 NKT / NWV 16-row tiles
+// in both passes and works on them together, sharing every fragment read) walks the (batch, head) items
+// persistently; the operands of the NEXT item are fetched into registers (two 16-byte chunks per thread and matrix
+// at 12 waves) before the current item's passes and written to LDS after them, so the loads of item i + 1 are in
+// flight under the arithmetic of item i.  delta = rowsum(dO * O) comes from the same registers.  The item barriers
+// wait for LDS only (`s_waitcnt lgkmcnt(0)`; `__syncthreads()` would also wait for the stores just issued).
+// Measured at B = 256, S = 185 (tools/attn_bench.py, same box): 233 us against 296 us for the two-phase kernel;
+// four waves x three tiles (512 registers per lane, a third of the LDS reads) 287 us: the loop is bound by the LDS
+// round trips in front of the transposed-fragment MFMAs, which the compiler neither hoists (register cap 168 at
+// three waves per SIMD) nor overlaps within one wave.
+template <int NKT, int NWV, bool DROP = true>
+__global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
+                                                         const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
+                                                         const float* __restrict__ lse, bf16* __restrict__ dqkv, int S,
+                                                         int H, int heads, int items, float scale, AttnDrop dr) {
+  constexpr int SK = NKT * 32;
+  constexpr int NT = NWV * 64;
+  constexpr int NC = (SK * 8) / NT;   // 16-byte chunks per thread and matrix
+  constexpr int TPW = (2 * NKT) / NWV;   // 16-row tiles per wave, processed together
+  static_assert((2 * NKT) % NWV == 0, "tiles must divide evenly over the waves");
+  static_assert((SK * 8) % NT == 0 && NT % 8 == 0 && SK <= NT, "chunk / row bookkeeping");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* Ks = smem + SK * 128;
+  char* Vs = smem + 2 * SK * 128;
+  char* Ds = smem + 3 * SK * 128;   // dO
+  float* mb = reinterpret_cast<float*>(smem + 4 * SK * 128);
+  float* lse_s = mb + SK;          // -lse * log2e ; -inf for q >= S
+  float* dl_s = lse_s + SK;        // delta[q]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int ld = 3 * H;
+  const float sl2 = scale * LOG2E;
+
+  u32x4 rq[NC], rk[NC], rv[NC], rd[NC], ro[NC];
+  float rl = 0.f, rm = 0.f;
+  auto fetch = [&](int item) {
+    const int b = item / heads, h = item - b * heads;
+    const size_t row0 = (size_t)b * S;
+    const bf16* qb = qkv + row0 * ld + h * 64;
+    const bf16* ob = ctx + row0 * H + h * 64;
+    const bf16* db = dctx + row0 * H + h * 64;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = tid + i * NT, row = c >> 3, pos = c & 7;
+      rq[i] = rk[i] = rv[i] = rd[i] = ro[i] = u32x4{0u, 0u, 0u, 0u};
+      if (row < S) {
+        const bf16* r = qb + (size_t)row * ld + pos * 8;
+        rq[i] = *reinterpret_cast<const u32x4*>(r);
+        rk[i] = *reinterpret_cast<const u32x4*>(r + H);
+        rv[i] = *reinterpret_cast<const u32x4*>(r + 2 * H);
+        rd[i] = *reinterpret_cast<const u32x4*>(db + (size_t)row * H + pos * 8);
+        ro[i] = *reinterpret_cast<const u32x4*>(ob + (size_t)row * H + pos * 8);
+      }
+    }
+    if (tid < SK) {
+      rl = (tid < S) ? lse[(size_t)item * S + tid] : INFINITY;
+      rm = (tid < S && keymask != nullptr) ? keymask[(size_t)b * S + tid] : 1.f;
+    }
+  };
+
+  int item = blockIdx.x;
+  if (item < items) fetch(item);
+  for (; item < items; item += gridDim.x) {
+    // ---- registers -> LDS images, delta, key bias, -lse ----
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = tid + i * NT, row = c >> 3, pos = c & 7;
+      const int off = row * 128 + ((pos ^ (swz_row(row) << 1)) << 4);
+      *reinterpret_cast<u32x4*>(Qs + off) = rq[i];
+      *reinterpret_cast<u32x4*>(Ks + off) = rk[i];
+      *reinterpret_cast<u32x4*>(Vs + off) = rv[i];
+      *reinterpret_cast<u32x4*>(Ds + off) = rd[i];
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float2 a = unpack_bf16x2(ro[i][w]), d = unpack_bf16x2(rd[i][w]);
+        s += a.x * d.x + a.y * d.y;
+      }
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      if (pos == 0) dl_s[row] = s;   // rows >= S hold zeros: delta = 0
+    }
+    if (tid < SK) {
+      mb[tid] = (tid < S && rm != 0.f) ? 0.f : -INFINITY;
+      lse_s[tid] = -rl * LOG2E;      // -inf for rows >= S
+    }
+    const int b = item / heads, h = item - b * heads;
+    const uint32_t bh = (uint32_t)item;
+    bf16* dqbase = dqkv + (size_t)b * S * ld + h * 64;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (no vmcnt wait: the previous item's stores stay in flight)
+    if (item + (int)gridDim.x < items) fetch(item + gridDim.x);
+
+    // ---------------- dQ: wave = TPW query tiles at once (they share every K / V fragment read) ----------------
+    {
+      bf16x8 qf[TPW][2], df[TPW][2];
+      float nl[TPW], dl[TPW];
+      f32x4 o[TPW][4];
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const int qt = wave * TPW + j;
+        qf[j][0] = frag_rows(Qs, qt, 0, g, l15); qf[j][1] = frag_rows(Qs, qt, 1, g, l15);
+        df[j][0] = frag_rows(Ds, qt, 0, g, l15); df[j][1] = frag_rows(Ds, qt, 1, g, l15);
+        nl[j] = lse_s[qt * 16 + l15]; dl[j] = dl_s[qt * 16 + l15];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll 1
+      for (int T = 0; T < NKT; ++T) {
+        f32x4 ds2[TPW][2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int kt = 2 * T + hh;
+          const bf16x8 k0 = frag_rows(Ks, kt, 0, g, l15), k1 = frag_rows(Ks, kt, 1, g, l15);
+          const bf16x8 v0 = frag_rows(Vs, kt, 0, g, l15), v1 = frag_rows(Vs, kt, 1, g, l15);
+          const f32x4 m4 = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[j][0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[j][1], a, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, df[j][0], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, df[j][1], dp, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pv = __builtin_amdgcn_exp2f((a[r] + m4[r]) * sl2 + nl[j]);
+              float dpv = dp[r];
+              if (DROP && dr.thresh != 0u) {
+                const uint32_t q_l = (uint32_t)((wave * TPW + j) * 16 + l15);
+                const uint32_t idx = (bh * (uint32_t)S + q_l) * (uint32_t)S + (uint32_t)(kt * 16 + 4 * g + r);
+                dpv = dropout_keep(dr.seed, dr.stream, idx, dr.thresh) ? dpv * dr.scale : 0.f;
+              }
+              ds2[j][hh][r] = pv * (dpv - dl[j]) * scale;
+            }
+          }
+        }
+        bf16x8 dsf[TPW];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) dsf[j] = pack_frag(ds2[j][0], ds2[j][1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x8 kt_ = frag_tr(Ks, T, dt, g, l15);
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) o[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsf[j], o[j][dt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const int q_l = (wave * TPW + j) * 16 + l15;
+        if (q_l < S) {
+          bf16* dst = dqbase + (size_t)q_l * ld + 4 * g;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const uint2 w = {pack_bf16x2(o[j][dt][0], o[j][dt][1]), pack_bf16x2(o[j][dt][2], o[j][dt][3])};
+            *reinterpret_cast<uint2*>(dst + dt * 16) = w;
+          }
+        }
+      }
+    }
+    // ---------------- dK, dV: wave = TPW key tiles at once (they share every Q / dO fragment read) ----------------
+    {
+      bf16x8 kf[TPW][2], vf[TPW][2];
+      float mk[TPW];
+      f32x4 dk[TPW][4], dv[TPW][4];
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const int kt = wave * TPW + j;
+        kf[j][0] = frag_rows(Ks, kt, 0, g, l15); kf[j][1] = frag_rows(Ks, kt, 1, g, l15);
+        vf[j][0] = frag_rows(Vs, kt, 0, g, l15); vf[j][1] = frag_rows(Vs, kt, 1, g, l15);
+        mk[j] = mb[kt * 16 + l15];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dk[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dv[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll 1
+      for (int T = 0; T < NKT; ++T) {
+        f32x4 p2[TPW][2], ds2[TPW][2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int qt = 2 * T + hh;
+          const bf16x8 q0 = frag_rows(Qs, qt, 0, g, l15), q1 = frag_rows(Qs, qt, 1, g, l15);
+          const bf16x8 d0 = frag_rows(Ds, qt, 0, g, l15), d1 = frag_rows(Ds, qt, 1, g, l15);
+          const f32x4 nl4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * g);
+          const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dl_s + qt * 16 + 4 * g);
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, kf[j][0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, kf[j][1], a, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf[j][0], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf[j][1], dp, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float pv = __builtin_amdgcn_exp2f((a[r] + mk[j]) * sl2 + nl4[r]);
+              float dpv = dp[r];
+              if (DROP && dr.thresh != 0u) {
+                const uint32_t k_l = (uint32_t)((wave * TPW + j) * 16 + l15);
+                const uint32_t idx = (bh * (uint32_t)S + (uint32_t)(qt * 16 + 4 * g + r)) * (uint32_t)S + k_l;
+                const bool keep = dropout_keep(dr.seed, dr.stream, idx, dr.thresh);
+                dpv = keep ? dpv * dr.scale : 0.f;
+                ds2[j][hh][r] = pv * (dpv - dl4[r]) * scale;
+                pv = keep ? pv * dr.scale : 0.f;
+              } else {
+                ds2[j][hh][r] = pv * (dpv - dl4[r]) * scale;
+              }
+              p2[j][hh][r] = pv;
+            }
+          }
+        }
+        bf16x8 pf[TPW], dsf[TPW];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          pf[j] = pack_frag(p2[j][0], p2[j][1]);
+          dsf[j] = pack_frag(ds2[j][0], ds2[j][1]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x8 dt_ = frag_tr(Ds, T, dt, g, l15), qt_ = frag_tr(Qs, T, dt, g, l15);
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) {
+            dv[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt_, pf[j], dv[j][dt], 0, 0, 0);
+            dk[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsf[j], dk[j][dt], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const int k_l = (wave * TPW + j) * 16 + l15;
+        if (k_l < S) {
+          bf16* dstk = dqbase + H + (size_t)k_l * ld + 4 * g;
+          bf16* dstv = dqbase + 2 * H + (size_t)k_l * ld + 4 * g;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const uint2 wk = {pack_bf16x2(dk[j][dt][0], dk[j][dt][1]), pack_bf16x2(dk[j][dt][2], dk[j][dt][3])};
+            const uint2 wv = {pack_bf16x2(dv[j][dt][0], dv[j][dt][1]), pack_bf16x2(dv[j][dt][2], dv[j][dt][3])};
+            *reinterpret_cast<uint2*>(dstk + dt * 16) = wk;
+            *reinterpret_cast<uint2*>(dstv + dt * 16) = wv;
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the images before the next item overwrites them
+  }
+}
+
+template <int NKT>
+constexpr int attn_res_lds_bytes() { return NKT * 32 * 128 * 4 + NKT * 32 * 4 * 3; }
+
 template <int NKT>
 constexpr int attn_lds_bytes() { return NKT * 32 * 128 * 2 + NKT * 32 * 4 * 3; }
 
@@ -365,14 +619,17 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
   const AttnDrop dr{a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale};
   dim3 grid(a->heads, a->B), block(256);
   const float scale = 0.125f;  // 1/sqrt(64)
+#define FWD_V(NK, NW, WP, DR)                                                                                          \
+    hipLaunchKernelGGL((attn_fwd_kernel<NK, NW, WP, DR>), grid, dim3(NW * 64), attn_lds_bytes<NK>(), st,                \
+                       reinterpret_cast<const bf16*>(a->qkv), a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, \
+                       a->H, a->heads, scale, dr, reinterpret_cast<bf16*>(a->ctx_split3))
+  // (dropout is a template switch: a per-element run-time test splits the loop body into basic blocks that the
+  //  instruction scheduler cannot move MFMAs and LDS reads across)
+  const bool drop = a->drop_thresh != 0u;
   if (a->S <= 64) {
-    hipLaunchKernelGGL((attn_fwd_kernel<2, 4, 3>), grid, dim3(256), attn_lds_bytes<2>(), st, reinterpret_cast<const bf16*>(a->qkv),
-                       a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
-                       reinterpret_cast<bf16*>(a->ctx_split3));
+    if (drop) FWD_V(2, 4, 3, true); else FWD_V(2, 4, 3, false);
   } else if (a->S <= 192) {
-    hipLaunchKernelGGL((attn_fwd_kernel<6, 12, 6>), grid, dim3(768), attn_lds_bytes<6>(), st, reinterpret_cast<const bf16*>(a->qkv),
-                       a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
-                       reinterpret_cast<bf16*>(a->ctx_split3));
+    if (drop) FWD_V(6, 12, 6, true); else FWD_V(6, 12, 6, false);
   } else {   // long sequences of padded, larger images: K/V image 80 KiB -> one block per CU
     auto kern = attn_fwd_kernel<10, 4, 1>;
     static bool attr_done = false;
@@ -386,6 +643,7 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
                        a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
                        reinterpret_cast<bf16*>(a->ctx_split3));
   }
+#undef FWD_V
   return (int)hipGetLastError();
 }
 
@@ -398,14 +656,31 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
   const AttnDrop dr{a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale};
   dim3 grid(a->heads, a->B), block(256);
   const float scale = 0.125f;
+  const bool drop = a->drop_thresh != 0u;
+#define OLD_V(NK, DR)                                                                                                         \
+    hipLaunchKernelGGL((attn_bwd_kernel<NK, 4, 3, DR>), grid, dim3(256), attn_lds_bytes<NK>(), st, reinterpret_cast<const bf16*>(a->qkv), \
+                       a->keymask, reinterpret_cast<const bf16*>(a->ctx), reinterpret_cast<const bf16*>(a->dctx), a->lse,     \
+                       reinterpret_cast<bf16*>(a->dqkv), a->S, a->H, a->heads, scale, dr)
+#define RES_V(DR)                                                                                                             \
+    {                                                                                                                         \
+      auto kern = attn_bwd_res_kernel<6, 12, DR>;   /* 98.3 KiB of LDS: one 12-wave workgroup per CU, persistent */           \
+      static bool attr_done = false;                                                                                          \
+      if (!attr_done) {                                                                                                       \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                           attn_res_lds_bytes<6>());                                                          \
+        if (e != hipSuccess) return (int)e;                                                                                   \
+        attr_done = true;                                                                                                     \
+      }                                                                                                                       \
+      hipLaunchKernelGGL(kern, dim3(items < 256 ? items : 256), dim3(768), attn_res_lds_bytes<6>(), st,                       \
+                         reinterpret_cast<const bf16*>(a->qkv), a->keymask, reinterpret_cast<const bf16*>(a->ctx),            \
+                         reinterpret_cast<const bf16*>(a->dctx), a->lse, reinterpret_cast<bf16*>(a->dqkv), a->S, a->H,        \
+                         a->heads, items, scale, dr);                                                                         \
+    }
   if (a->S <= 64) {
-    hipLaunchKernelGGL((attn_bwd_kernel<2, 4, 3>), grid, dim3(256), attn_lds_bytes<2>(), st, reinterpret_cast<const bf16*>(a->qkv),
-                       a->keymask, reinterpret_cast<const bf16*>(a->ctx), reinterpret_cast<const bf16*>(a->dctx), a->lse,
-                       reinterpret_cast<bf16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
+    if (drop) OLD_V(2, true); else OLD_V(2, false);
   } else if (a->S <= 192) {
-    hipLaunchKernelGGL((attn_bwd_kernel<6, 4, 3>), grid, dim3(256), attn_lds_bytes<6>(), st, reinterpret_cast<const bf16*>(a->qkv),
-                       a->keymask, reinterpret_cast<const bf16*>(a->ctx), reinterpret_cast<const bf16*>(a->dctx), a->lse,
-                       reinterpret_cast<bf16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
+    const int items = a->B * a->heads;
+    if (drop) RES_V(true) else RES_V(false)
   } else {
     auto kern = attn_bwd_kernel<10, 4, 1>;
     static bool attr_done = false;
@@ -419,5 +694,7 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
                        a->keymask, reinterpret_cast<const bf16*>(a->ctx), reinterpret_cast<const bf16*>(a->dctx), a->lse,
                        reinterpret_cast<bf16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
   }
+#undef OLD_V
+#undef RES_V
   return (int)hipGetLastError();
 }
