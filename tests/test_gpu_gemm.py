@@ -15,7 +15,8 @@ EPI_BF16, EPI_GELU, EPI_DGELU, EPI_RES, EPI_PATCH, EPI_ATOMIC = range(6)
 
 
 def _gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, cfg=-1, m_valid=0, splits=1, bias=None,
-          res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, accumulate=0, colsum=None, persist=0):
+          res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, accumulate=0, colsum=None, persist=0, batch=0,
+          batch_a=0, batch_b=0, batch_o=0):
     lib = L.load()
     a = L.GemmArgs()
     a.A, a.B, a.out = A.data_ptr(), B.data_ptr(), out.data_ptr()
@@ -29,6 +30,7 @@ def _gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, cfg=-1, m_vali
     a.a_mode, a.b_mode, a.epi, a.cfg, a.splits, a.accumulate = a_mode, b_mode, epi, cfg, splits, accumulate
     a.rpg, a.gstride, a.goff = rpg, gstride, goff
     a.persist = persist
+    a.batch, a.batch_a, a.batch_b, a.batch_o = batch, batch_a, batch_b, batch_o
     st = torch.cuda.current_stream().cuda_stream
     L.check(lib.vault_gemm(C.byref(a), C.c_void_p(st)), "vault_gemm")
 
@@ -114,6 +116,30 @@ def test_wgrad_tn_splitk(cfg, splits):
     _gemm(dY, X, dW, Nout, Kin, Mtok, Nout, Kin, Kin, 1, 1, EPI_ATOMIC, cfg=cfg, splits=splits, accumulate=1)
     torch.cuda.synchronize()
     assert (dW - 2 * ref).abs().max().item() <= 4e-4 * ref.abs().max().item() + 2e-3
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_wgrad_batched_layers(cfg, splits):
+    """`batch` weight gradients of one shape in one launch (ABI 3): problem b reads slice b of the stacked dY / X
+    tensors and accumulates into out + b * batch_o (the layers of a stack in the flat gradient buffer, with other
+    tensors in between); the ring kernel refuses batches."""
+    L_, Mtok, Nout, Kin = 3, 768, 512, 256
+    dY = _rand(L_, Mtok, Nout, seed=21).bfloat16()
+    X = _rand(L_, Mtok, Kin, seed=22).bfloat16()
+    stride_o = Nout * Kin + 4096                      # gap between the layers' dW (other parameters of a layer)
+    flat = torch.ones(L_ * stride_o, device="cuda")
+    _gemm(dY, X, flat, Nout, Kin, Mtok, Nout, Kin, Kin, 1, 1, EPI_ATOMIC, cfg=cfg, splits=splits, accumulate=1,
+          batch=L_, batch_a=Mtok * Nout, batch_b=Mtok * Kin, batch_o=stride_o)
+    torch.cuda.synchronize()
+    for b in range(L_):
+        ref = 1.0 + dY[b].float().t() @ X[b].float()
+        got = flat[b * stride_o:b * stride_o + Nout * Kin].view(Nout, Kin)
+        assert (got - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-3, b
+        assert torch.equal(flat[b * stride_o + Nout * Kin:(b + 1) * stride_o], torch.ones(4096, device="cuda"))
+    with pytest.raises(RuntimeError):
+        _gemm(dY, X, flat, Nout, Kin, Mtok, Nout, Kin, Kin, 1, 1, EPI_ATOMIC, cfg=3, splits=1, accumulate=1,
+              batch=L_, batch_a=Mtok * Nout, batch_b=Mtok * Kin, batch_o=stride_o)
 
 
 def test_patch_epilogue_rowmap():

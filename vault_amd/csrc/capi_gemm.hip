@@ -21,6 +21,7 @@ static GemmParams params_of(const vault_gemm_args* a) {
   p.drop_scale = a->drop_scale;
   p.gn = a->gn;
   p.persist = a->persist;
+  p.batch = a->batch; p.batch_a = a->batch_a; p.batch_b = a->batch_b; p.batch_o = a->batch_o;
   return p;
 }
 
@@ -34,4 +35,4 @@ extern "C" int vault_gemm_mxfp8(const vault_gemm_args* a, const void* a_scale, c
   return vault_gemm_mx8_launch(params_of(a), a_scale, b_scale, a->epi, reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" int vault_abi_version(void) { return 2; }
+extern "C" int vault_abi_version(void) { return 3; }

@@ -32,7 +32,18 @@ constexpr int BK = 64;
 template <int EPI> struct EpiTraits;
 
 template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, int EPI>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p_in) {
+  GemmParams p = p_in;
+  int split_z = blockIdx.z;
+  if constexpr (EPI == EPI_F32_ATOMIC) {
+    if (p.batch > 1) {   // batched weight gradients: z = problem * splits + split
+      const int bz = blockIdx.z / p.splits;
+      split_z = blockIdx.z - bz * p.splits;
+      p.A += (size_t)bz * p.batch_a;
+      p.B += (size_t)bz * p.batch_b;
+      p.out = reinterpret_cast<float*>(p.out) + (size_t)bz * p.batch_o;
+    }
+  }
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM / 16;
   constexpr int TN = BN / WN / 16;
@@ -63,7 +74,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
   // ---- split-K range
   const int nk_total = p.K / BK;
   const int per = (nk_total + p.splits - 1) / p.splits;
-  const int kt0 = blockIdx.z * per;
+  const int kt0 = split_z * per;
   const int kt1 = min(nk_total, kt0 + per);
   const int nk = kt1 - kt0;
 
@@ -214,7 +225,8 @@ int launch_cfg(const GemmParams& p, hipStream_t st) {
   // resident blocks: 256 CUs x (blocks that fit: LDS-limited, 160 KiB per CU)
   const int resident = 256 * std::max(1, (160 * 1024) / LDS);
   const int total = (p.M / BM) * (p.N / BN);
-  dim3 grid((p.persist & 2) == 0 ? std::min(total, resident) : total, 1, p.splits);   // persistent unless (persist & 2)
+  const int nbatch = (EPI == EPI_F32_ATOMIC && p.batch > 1) ? p.batch : 1;
+  dim3 grid((p.persist & 2) == 0 ? std::min(total, resident) : total, 1, p.splits * nbatch);   // persistent unless (persist & 2)
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), LDS, st, q);
   return (int)hipGetLastError();
 }
@@ -239,6 +251,13 @@ int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, i
   if (p.A == nullptr || p.B == nullptr || p.out == nullptr) return VAULT_EINVAL;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return VAULT_EINVAL;
   if ((p.lda & 7) || (p.ldb & 7) || (p.ldo & 7)) return VAULT_EINVAL;
+  if (p.batch > 1) {   // batched weight gradients: double-buffered kernel, atomic epilogue only
+    if (epi != EPI_F32_ATOMIC || cfg == 3 || cfg == 4 || (p.batch_a & 7) || (p.batch_b & 7) || (p.batch_o & 3) ||
+        (long long)p.batch * p.splits > 65535)
+      return VAULT_EINVAL;
+    if (cfg < 0) cfg = (p.M % 128 == 0 && p.N % 128 == 0) ? 0 : -1;
+    if (cfg < 0) return VAULT_EINVAL;
+  }
   if (cfg < 0) {
     // default kernel/tile choice (measured on MI355X at M = 47360, tools/gemm_bench.py + tools/k_sweep.py):
     //   256x256 persistent ring kernel from K = 512 up and for all wgrads (A stored [K][M]): its epilogue

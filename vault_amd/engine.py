@@ -18,6 +18,8 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -209,6 +211,13 @@ class VaultEngine:
     """Forward / backward of VaultModel / VaultForTMSC over one batch resident in HBM."""
 
     WGRAD_TARGET_WGS = 768
+    # Weight gradients of the LM layers (40-token sequences: 10240 rows at B = 256) are deferred and contracted
+    # `LM_WGRAD_GROUP` layers per launch (vault_gemm batch, ABI 3): one layer alone fills the GPU only with split-K
+    # partial sums through float atomics and 50-80 k-step blocks; 12 layers together give 432-1728 tiles of the full
+    # contraction.  0 = all layers in one group at the end of the LM backward (a data-parallel step uses smaller
+    # groups, so that the all-reduce of the upper layers still starts under the backward of the lower ones).
+    LM_WGRAD_BATCHED = True
+    LM_WGRAD_GROUP = 0
 
     def __init__(self, spec: VaultSpec, device="cuda:0", state=None, seed: int = 0, freeze_lm: bool = False,
                  with_grads: bool = True, classifier_dropout: float = 0.1, fp8_forward: bool = False):
@@ -227,6 +236,8 @@ class VaultEngine:
             raise ValueError("head dimension must be 64")
         with torch.cuda.device(self.device):
             self.params = ParamStore(spec, self.device, state, seed, self.freeze_lm, with_grads)
+        if os.environ.get("VAULT_LM_WGRAD_BATCHED") == "0":   # development override (same-box A/B)
+            self.LM_WGRAD_BATCHED = False
         self.vl = [_LayerNames(f"encoder.layer.{i}", "vilt") for i in range(spec.vilt.num_hidden_layers)]
         self.ll = ([_LayerNames(f"bert.encoder.layer.{i}", "bert") for i in range(spec.lm.num_hidden_layers)]
                    if spec.lm else [])
@@ -258,6 +269,18 @@ class VaultEngine:
         if t is None:
             t = torch.zeros(shape, dtype=dtype, device=self.device)
             ws[name] = t
+        return t
+
+    def _stack(self, ws, base, n, shape, dtype):
+        """`n` equally shaped buffers `base0 .. base{n-1}` as slices of ONE tensor (`base_all`): uniform stride between
+        the layers of a stack, as the batched weight-gradient GEMM addresses them."""
+        key = base + "_all"
+        t = ws.get(key)
+        if t is None:
+            t = torch.zeros((n,) + tuple(shape), dtype=dtype, device=self.device)
+            ws[key] = t
+            for i in range(n):
+                ws[f"{base}{i}"] = t[i]
         return t
 
     MAX_RAGGED_WORKSPACES = 2   # padded-image geometries kept alive (each owns every activation buffer of a step)
@@ -361,6 +384,23 @@ class VaultEngine:
             ops.pycall(lambda: self._prof_end("wgrad", fl))
         if bname is not None:
             ops.colsum(dy_bf16, Nout, m_valid, Nout, P.gr(bname, n_elems=Nout, shape=(Nout,)))
+
+    def _wgrad_batched(self, dY_all, X_all, wnames, i0, Mtok_pad, Nout, Kin):
+        """dW_l[Nout,Kin] += dY_l[Mtok,Nout]^T . X_l[Mtok,Kin] for the consecutive layers l = i0 .. i0 + len(wnames) - 1 of a
+        stack in ONE launch (vault_gemm `batch`): dY_l / X_l are slices of the stacked operand tensors, the dW_l lie
+        at a uniform stride in the flat gradient buffer (identical layer layouts)."""
+        P = self.params
+        G = len(wnames)
+        offs = [P.offsets[w][0] for w in wnames]
+        stride_o = (offs[1] - offs[0]) if G > 1 else 0
+        if any(offs[k + 1] - offs[k] != stride_o for k in range(G - 1)) or Nout % 128 or Kin % 128:
+            raise RuntimeError("batched weight gradients need identically laid out layers and 128-multiples")
+        gw = P.gr(wnames[0], n_elems=Nout * Kin, shape=(Nout, Kin))
+        tiles = (Nout // 128) * (Kin // 128) * G
+        splits = max(1, min(8, Mtok_pad // 512, int(round(512.0 / tiles))))   # ~two resident 128x128 blocks per CU
+        ops.gemm(dY_all[i0], X_all[i0], gw, Nout, Kin, Mtok_pad, Nout, Kin, Kin, 1, 1, ops.EPI_F32_ATOMIC, cfg=0,
+                 splits=splits, accumulate=1, batch=G, batch_a=dY_all.stride(0), batch_b=X_all.stride(0),
+                 batch_o=stride_o)
 
     def _drop(self, p: float, stream: int, train: bool) -> Drop:
         return Drop(p, self.drop_seed, stream) if (train and p > 0.0) else NO_DROP
@@ -510,6 +550,11 @@ class VaultEngine:
                                         (P.w("bert.embeddings.token_type_embeddings.weight"), lm_tt)], Ml, H)
             keep = train and not self.freeze_lm
             nl = lm.num_hidden_layers
+            if keep and not pr and self.LM_WGRAD_BATCHED and H % 128 == 0 and FF % 128 == 0:
+                # X operands of the deferred, batched weight gradients: one tensor per kind, a layer per slice
+                self._stack(ws, "lm_yb", nl + 1, (Mlp, H), bf)
+                for base, width in (("lm_ctx", H), ("lm_y1b", H), ("lm_act", FF)):
+                    self._stack(ws, base, nl, (Mlp, width), bf)
             y = [buf(f"lm_y{i}" if keep else f"lm_y{i % 2}", (Mlp, H)) for i in range(nl + 1)]
             yb = [buf((f"lm_yb{i}" if keep else f"lm_yb{i % 2}") + ("_3" if pr else ""), (Mlp, W3 * H), bf)
                   for i in range(nl + 1)]
@@ -944,35 +989,61 @@ class VaultEngine:
         y, yb = ws["lm_y"], ws["lm_yb"]
         amf = ws["amf"]
         pdh, pda = lm.hidden_dropout_prob, lm.attention_probs_dropout_prob
-        dh = buf("lm_dh", (Mlp, H)); dhb = buf("lm_dhb", (Mlp, H), bf)
-        dh1 = buf("lm_dh1", (Mlp, H)); dh1b = buf("lm_dh1b", (Mlp, H), bf)
-        ldU = buf("lm_dU", (Mlp, FF), bf); ldN = buf("lm_dN", (Mlp, H), bf)
-        ldctx = buf("lm_dctx", (Mlp, H), bf); ldqkv = buf("lm_dqkv", (Mlp, 3 * H), bf)
+        dh = buf("lm_dh", (Mlp, H)); dh1 = buf("lm_dh1", (Mlp, H))
+        batched = self.LM_WGRAD_BATCHED and "lm_act_all" in ws and P.gr(self.ll[0].fw) is not None
+        if batched:
+            # dY operands of every layer stay alive until their group's batched weight-gradient launches
+            dhb_all = self._stack(ws, "lm_dhb", nl, (Mlp, H), bf); dh1b_all = self._stack(ws, "lm_dh1b", nl, (Mlp, H), bf)
+            ldU_all = self._stack(ws, "lm_dU", nl, (Mlp, FF), bf); ldqkv_all = self._stack(ws, "lm_dqkv", nl, (Mlp, 3 * H), bf)
+            group = self.LM_WGRAD_GROUP if self.LM_WGRAD_GROUP > 0 else nl
+        else:
+            dhb = buf("lm_dhb", (Mlp, H), bf); dh1b = buf("lm_dh1b", (Mlp, H), bf)
+            ldU = buf("lm_dU", (Mlp, FF), bf); ldqkv = buf("lm_dqkv", (Mlp, 3 * H), bf)
+        ldN = buf("lm_dN", (Mlp, H), bf); ldctx = buf("lm_dctx", (Mlp, H), bf)
         dyb = None          # bf16 part of d y2 (from the next layer's QKV dgrad)
         dyf = dvs           # f32 part of d y2
         for i in reversed(range(nl)):
             ln = self.ll[i]
             g = lambda k: ws[f"lm_{k}{i}"]  # noqa: E731
+            if batched:
+                dhb, dh1b, ldU, ldqkv = dhb_all[i], dh1b_all[i], ldU_all[i], ldqkv_all[i]
             # y2 = LN2(h2)
             ops.layernorm_bwd(g("h2"), g("m2"), g("r2"), P.w(ln.ln2w), Ml, H, dy_bf16=dyb, dy_f32=dyf, dx_f32=dh,
                               dx_bf16=dhb, dgamma=P.gr(ln.ln2w), dbeta=P.gr(ln.ln2b),
                               drop=self._drop(pdh, 16 * i + 4, True), dbias=P.gr(ln.fb))
             self._dgrad(dhb, ln.fw, ldU, Mlp, FF, H, ops.EPI_BF16_DGELU, Ml, aux=g("u"), colsum=P.gr(ln.ib))
-            self._wgrad(dhb, g("act"), ln.fw, None, Mlp, H, FF, Ml)
+            if not batched:
+                self._wgrad(dhb, g("act"), ln.fw, None, Mlp, H, FF, Ml)
             self._dgrad(ldU, ln.iw, ldN, Mlp, H, FF, ops.EPI_BF16, Ml)
-            self._wgrad(ldU, g("y1b"), ln.iw, None, Mlp, FF, H, Ml)
+            if not batched:
+                self._wgrad(ldU, g("y1b"), ln.iw, None, Mlp, FF, H, Ml)
             # y1 = LN1(h1) ; d y1 = dgrad(bf16) + dh (residual)
             ops.layernorm_bwd(g("h1"), g("m1"), g("r1"), P.w(ln.ln1w), Ml, H, dy_bf16=ldN, dy_f32=dh, dx_f32=dh1,
                               dx_bf16=dh1b, dgamma=P.gr(ln.ln1w), dbeta=P.gr(ln.ln1b),
                               drop=self._drop(pdh, 16 * i + 3, True), dbias=P.gr(ln.ob))
             self._dgrad(dh1b, ln.ow, ldctx, Mlp, H, H, ops.EPI_BF16, Ml)
-            self._wgrad(dh1b, g("ctx"), ln.ow, None, Mlp, H, H, Ml)
+            if not batched:
+                self._wgrad(dh1b, g("ctx"), ln.ow, None, Mlp, H, H, Ml)
             ops.attention_bwd(g("qkv"), amf, g("ctx"), g("lse"), ldctx, ldqkv, B, T, H, heads,
                               drop=self._drop(pda, 16 * i + 2, True))
             self._dgrad(ldqkv, ln.qw, ldN, Mlp, H, 3 * H, ops.EPI_BF16, Ml)
-            self._wgrad(ldqkv, yb[i], ln.qw, ln.qb, Mlp, 3 * H, H, Ml)
+            if not batched:
+                self._wgrad(ldqkv, yb[i], ln.qw, ln.qb, Mlp, 3 * H, H, Ml)
+            else:
+                ops.colsum(ldqkv, 3 * H, Ml, 3 * H, P.gr(ln.qb, n_elems=3 * H, shape=(3 * H,)))
             dyb, dyf = ldN, dh1   # consumed by the next iteration's LN2 backward before being overwritten
-            note(f"lm{i}")
+            if not batched:
+                note(f"lm{i}")
+            elif i % group == 0:
+                # the weight gradients of layers i .. hi - 1, one launch per kind (dY, X: slices i.. of the stacks)
+                hi = min(nl, i + group)
+                for dY_all, X_all, wsel, Nout, Kin in ((dhb_all, ws["lm_act_all"], "fw", H, FF),
+                                                       (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
+                                                       (dh1b_all, ws["lm_ctx_all"], "ow", H, H),
+                                                       (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H)):
+                    self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.ll[i:hi]], i, Mlp, Nout, Kin)
+                for j in reversed(range(i, hi)):
+                    note(f"lm{j}")
         # embeddings: y0 = dropout(LN(esum))
         desum = buf("lm_desum", (Mlp, H))
         ops.layernorm_bwd(ws["lm_esum"], ws["lm_emean"], ws["lm_erstd"], P.w("bert.embeddings.LayerNorm.weight"), Ml, H,

@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VAULT_HIP_LIB: development override (A/B of two builds of the SAME HIP library on one box); still no fallback
 LIB_PATH = os.environ.get("VAULT_HIP_LIB") or os.path.join(_HERE, "libvault_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 
@@ -23,6 +23,7 @@ class GemmArgs(C.Structure):
         ("rpg", C.c_int), ("gstride", C.c_int), ("goff", C.c_int),
         ("drop_thresh", C.c_uint32), ("drop_seed", C.c_uint32), ("drop_stream", C.c_uint32),
         ("drop_scale", C.c_float), ("gn", C.c_int), ("persist", C.c_int),
+        ("batch", C.c_int), ("batch_a", C.c_longlong), ("batch_b", C.c_longlong), ("batch_o", C.c_longlong),
     ]
 
 

@@ -128,7 +128,7 @@ GEMM_SCHED = int(__import__("os").environ.get("VAULT_GEMM_SCHED", "0"))   # env:
 
 def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_valid=0, splits=1, accumulate=0,
          bias=None, res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, drop: Drop = NO_DROP,
-         colsum=None, split3=False):
+         colsum=None, split3=False, batch=0, batch_a=0, batch_b=0, batch_o=0):
     a = L.GemmArgs()
     a.A, a.B, a.out, a.out2 = _p(A), _p(B), _p(out), _p(out2)
     a.bias, a.res, a.aux, a.addtab = _p(bias), _p(res), _p(aux), _p(addtab)
@@ -138,6 +138,7 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_va
     a.a_mode, a.b_mode, a.epi, a.cfg, a.splits, a.accumulate = a_mode, b_mode, epi, cfg, splits, accumulate
     a.rpg, a.gstride, a.goff = rpg, gstride, goff
     a.persist = GEMM_SCHED
+    a.batch, a.batch_a, a.batch_b, a.batch_o = batch, batch_a, batch_b, batch_o   # batched weight gradients (ABI 3)
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
     _invoke("vault_gemm", C.byref(a), _stream(), struct=a, drop=drop)
 
