@@ -218,6 +218,7 @@ class VaultEngine:
     # groups, so that the all-reduce of the upper layers still starts under the backward of the lower ones).
     LM_WGRAD_BATCHED = True
     LM_WGRAD_GROUP = 0
+    WGRAD_BATCH_MAX_ROWS = 16384   # the ViLT layers take the same route up to this many (padded) token rows (B <= 88)
 
     def __init__(self, spec: VaultSpec, device="cuda:0", state=None, seed: int = 0, freeze_lm: bool = False,
                  with_grads: bool = True, classifier_dropout: float = 0.1, fp8_forward: bool = False):
@@ -643,6 +644,11 @@ class VaultEngine:
                                   ws["gw"], v.image_size // v.patch_size)
 
         # ------------------------------ ViLT encoder ------------------------------
+        if (train and not pr and self.LM_WGRAD_BATCHED and Mp <= self.WGRAD_BATCH_MAX_ROWS and H % 128 == 0
+                and FF % 128 == 0):
+            # small per-GPU batches: the ViLT layers' weight gradients are deferred and batched like the LM's
+            for base, width in (("n1", H), ("ctx", H), ("n2", H), ("act", FF)):
+                self._stack(ws, base, nv, (Mp, width), bf)
         for i, ln in enumerate(self.vl):
             sfx = f"{i}" if train else ""
             p3 = "_3" if pr else ""
@@ -883,8 +889,16 @@ class VaultEngine:
 
         dx = [buf("dx_a", (Mp, H)), buf("dx_b", (Mp, H))]
         dxb = [buf("dxb_a", (Mp, H), bf), buf("dxb_b", (Mp, H), bf)]
+        vbatch = self.LM_WGRAD_BATCHED and "act_all" in ws and P.gr(self.vl[0].fw) is not None
+        if vbatch:
+            # dY operands of every ViLT layer stay alive until their group's batched weight-gradient launches:
+            # A = gradient at the layer output (FFN-out's dY), B = gradient behind the attention block (attn-out's dY)
+            dxbA_all = self._stack(ws, "v_dxbA", nv, (Mp, H), bf); dxbB_all = self._stack(ws, "v_dxbB", nv, (Mp, H), bf)
+            dU_all = self._stack(ws, "v_dU", nv, (Mp, FF), bf); dqkv_all = self._stack(ws, "v_dqkv", nv, (Mp, 3 * H), bf)
+            vgroup = self.LM_WGRAD_GROUP if self.LM_WGRAD_GROUP > 0 else nv
+        dxb_top = dxbA_all[nv - 1] if vbatch else dxb[0]
         ops.pycall(dx[0].zero_)
-        ops.pycall(dxb[0].zero_)
+        ops.pycall(dxb_top.zero_)
         # ------------------------------ tail ------------------------------
         if spec.add_pooling_layer and (spec.n_classes > 0 or dpooled is not None):
             Bp = ws["Bp"]
@@ -905,48 +919,70 @@ class VaultEngine:
             dh0 = buf("dh0", (Bp, H), bf)
             self._dgrad(dpre, "pooler.dense.weight", dh0, Bp, H, H, ops.EPI_BF16, B)
             ops.layernorm_bwd(x[nv], ws["f_mean"], ws["f_rstd"], P.w("layernorm.weight"), B, H, dy_bf16=dh0,
-                              dx_f32=dx[0], dx_bf16=dxb[0], dgamma=P.gr("layernorm.weight"),
+                              dx_f32=dx[0], dx_bf16=dxb_top, dgamma=P.gr("layernorm.weight"),
                               dbeta=P.gr("layernorm.bias"), xmap=(1, S, 0), dxmap=(1, S, 0),
                               dbias=None if dhidden is not None else P.gr(self.vl[nv - 1].fb))
         if dhidden is not None:
             # gradient w.r.t. last_hidden_state (all rows): LN backward over all rows, added on top
             ops.layernorm_bwd(x[nv], ws["f_mean_all"], ws["f_rstd_all"], P.w("layernorm.weight"), M, H,
-                              dy_f32=dhidden.contiguous().view(M, H), dres=dx[0], dx_f32=dx[0], dx_bf16=dxb[0],
+                              dy_f32=dhidden.contiguous().view(M, H), dres=dx[0], dx_f32=dx[0], dx_bf16=dxb_top,
                               dgamma=P.gr("layernorm.weight"), dbeta=P.gr("layernorm.bias"),
                               dbias=P.gr(self.vl[nv - 1].fb))
         note("head")
 
         # ------------------------------ ViLT encoder ------------------------------
-        dU = buf("dU", (Mp, FF), bf); dN = buf("dN", (Mp, H), bf)
-        dctx = buf("dctx", (Mp, H), bf); dqkv = buf("dqkv", (Mp, 3 * H), bf)
+        dN = buf("dN", (Mp, H), bf); dctx = buf("dctx", (Mp, H), bf)
+        if not vbatch:
+            dU = buf("dU", (Mp, FF), bf); dqkv = buf("dqkv", (Mp, 3 * H), bf)
         km = ws["keymask"]
         cur = 0
         for i in reversed(range(nv)):
             ln = self.vl[i]
             g = lambda k: ws[f"{k}{i}"]  # noqa: E731
+            if vbatch:
+                dyA, dyB, dU, dqkv = dxbA_all[i], dxbB_all[i], dU_all[i], dqkv_all[i]
+                dyN = dxbA_all[i - 1] if i > 0 else dxb[0]
+            else:
+                dyA, dyB, dyN = dxb[cur], dxb[cur ^ 1], dxb[cur]
             # FFN
             # (bias gradients are column sums of dY: fused into the kernel that PRODUCES dY - the LayerNorm
             #  backward for the residual-stream gradient, the GEMM epilogue for dU)
-            self._dgrad(dxb[cur], ln.fw, dU, Mp, FF, H, ops.EPI_BF16_DGELU, M, aux=g("u"), colsum=P.gr(ln.ib))
-            self._wgrad(dxb[cur], g("act"), ln.fw, None, Mp, H, FF, M)
+            self._dgrad(dyA, ln.fw, dU, Mp, FF, H, ops.EPI_BF16_DGELU, M, aux=g("u"), colsum=P.gr(ln.ib))
+            if not vbatch:
+                self._wgrad(dyA, g("act"), ln.fw, None, Mp, H, FF, M)
             self._dgrad(dU, ln.iw, dN, Mp, H, FF, ops.EPI_BF16, M)
-            self._wgrad(dU, g("n2"), ln.iw, None, Mp, FF, H, M)
+            if not vbatch:
+                self._wgrad(dU, g("n2"), ln.iw, None, Mp, FF, H, M)
             nxt = cur ^ 1
             ops.layernorm_bwd(g("xm"), g("m2"), g("r2"), P.w(ln.ln2w), M, H, dy_bf16=dN, dres=dx[cur], dx_f32=dx[nxt],
-                              dx_bf16=dxb[nxt], dgamma=P.gr(ln.ln2w), dbeta=P.gr(ln.ln2b), dbias=P.gr(ln.ob))
+                              dx_bf16=dyB, dgamma=P.gr(ln.ln2w), dbeta=P.gr(ln.ln2b), dbias=P.gr(ln.ob))
             cur = nxt
             # attention
-            self._dgrad(dxb[cur], ln.ow, dctx, Mp, H, H, ops.EPI_BF16, M)
-            self._wgrad(dxb[cur], g("ctx"), ln.ow, None, Mp, H, H, M)
+            self._dgrad(dyB, ln.ow, dctx, Mp, H, H, ops.EPI_BF16, M)
+            if not vbatch:
+                self._wgrad(dyB, g("ctx"), ln.ow, None, Mp, H, H, M)
             ops.attention_bwd(g("qkv"), km, g("ctx"), g("lse"), dctx, dqkv, B, S, H, heads)
             self._dgrad(dqkv, ln.qw, dN, Mp, H, 3 * H, ops.EPI_BF16, M)
-            self._wgrad(dqkv, g("n1"), ln.qw, ln.qb, Mp, 3 * H, H, M)
+            if not vbatch:
+                self._wgrad(dqkv, g("n1"), ln.qw, ln.qb, Mp, 3 * H, H, M)
+            else:
+                ops.colsum(dqkv, 3 * H, M, 3 * H, P.gr(ln.qb, n_elems=3 * H, shape=(3 * H,)))
             nxt = cur ^ 1
             ops.layernorm_bwd(x[i], g("m1"), g("r1"), P.w(ln.ln1w), M, H, dy_bf16=dN, dres=dx[cur], dx_f32=dx[nxt],
-                              dx_bf16=dxb[nxt], dgamma=P.gr(ln.ln1w), dbeta=P.gr(ln.ln1b),
+                              dx_bf16=dyN, dgamma=P.gr(ln.ln1w), dbeta=P.gr(ln.ln1b),
                               dbias=P.gr(self.vl[i - 1].fb) if i > 0 else None)
             cur = nxt
-            note(f"vilt{i}")
+            if not vbatch:
+                note(f"vilt{i}")
+            elif i % vgroup == 0:
+                hi = min(nv, i + vgroup)
+                for dY_all, X_all, wsel, Nout, Kin in ((dxbA_all, ws["act_all"], "fw", H, FF),
+                                                       (dU_all, ws["n2_all"], "iw", FF, H),
+                                                       (dxbB_all, ws["ctx_all"], "ow", H, H),
+                                                       (dqkv_all, ws["n1_all"], "qw", 3 * H, H)):
+                    self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.vl[i:hi]], i, Mp, Nout, Kin)
+                for j in reversed(range(i, hi)):
+                    note(f"vilt{j}")
 
         # ------------------------------ ViLT embeddings ------------------------------
         dx0 = dx[cur]
