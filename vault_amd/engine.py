@@ -239,6 +239,8 @@ class VaultEngine:
             self.params = ParamStore(spec, self.device, state, seed, self.freeze_lm, with_grads)
         if os.environ.get("VAULT_LM_WGRAD_BATCHED") == "0":   # development override (same-box A/B)
             self.LM_WGRAD_BATCHED = False
+        if os.environ.get("VAULT_WGRAD_GROUP"):   # layers per batched weight-gradient launch (tuning knob for DP runs)
+            self.LM_WGRAD_GROUP = int(os.environ["VAULT_WGRAD_GROUP"])
         self.vl = [_LayerNames(f"encoder.layer.{i}", "vilt") for i in range(spec.vilt.num_hidden_layers)]
         self.ll = ([_LayerNames(f"bert.encoder.layer.{i}", "bert") for i in range(spec.lm.num_hidden_layers)]
                    if spec.lm else [])
