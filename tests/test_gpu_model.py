@@ -321,6 +321,30 @@ def test_gradients_accumulate_across_backward_passes():
     assert float((both - want).norm() / want.norm()) < 1e-5       # float-atomic summation order only
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("group", [0, 1])
+def test_batched_weight_gradients_equal_the_per_layer_ones(group):
+    """Deferred, batched weight gradients (vault_gemm batch: all layers of a stack per launch, or - `group` = 1 - one
+    launch per layer at every group boundary, the data-parallel form) leave the gradients of the per-layer launches."""
+    spec = _nodrop(VaultSpec.tiny(3, "roberta"))
+    state = build_state(spec, 0)
+    b = _dev(synthetic_batch(spec, 5, seed=31, n_classes=3))
+    grads, tags = [], []
+    for batched in (False, True):
+        eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+        eng.LM_WGRAD_BATCHED, eng.LM_WGRAD_GROUP = batched, group
+        eng.forward(b, train=True, labels=b["labels"], need_hidden=False)
+        eng.zero_grad()
+        seen = []
+        eng.backward(after_layer=seen.append)
+        torch.cuda.synchronize()
+        assert ("lm_act_all" in eng.last) == batched and ("act_all" in eng.last) == batched
+        grads.append(eng.params.g[: eng.params.n_train].clone())
+        tags.append(seen)
+    assert tags[0] == tags[1]        # stages are still reported in descending address order, each exactly once
+    assert float((grads[0] - grads[1]).norm() / grads[0].norm()) < 1e-5   # float-atomic summation order only
+
+
 def test_full_size_against_reference_golden():
     """12+12 layers, hidden 768, B=2 (one padded caption): compare with numbers produced by the
     reference (HuggingFace ViltModel + RobertaModel under ref VaultForTMSC) in the build container."""
