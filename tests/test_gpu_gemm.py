@@ -118,12 +118,12 @@ def test_wgrad_tn_splitk(cfg, splits):
     assert (dW - 2 * ref).abs().max().item() <= 4e-4 * ref.abs().max().item() + 2e-3
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
 @pytest.mark.parametrize("splits", [1, 3])
 def test_wgrad_batched_layers(cfg, splits):
     """`batch` weight gradients of one shape in one launch (ABI 3): problem b reads slice b of the stacked dY / X
     tensors and accumulates into out + b * batch_o (the layers of a stack in the flat gradient buffer, with other
-    tensors in between); the ring kernel refuses batches."""
+    tensors in between); the 192-wide ring form and the non-atomic epilogues refuse batches."""
     L_, Mtok, Nout, Kin = 3, 768, 512, 256
     dY = _rand(L_, Mtok, Nout, seed=21).bfloat16()
     X = _rand(L_, Mtok, Kin, seed=22).bfloat16()
@@ -138,8 +138,28 @@ def test_wgrad_batched_layers(cfg, splits):
         assert (got - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-3, b
         assert torch.equal(flat[b * stride_o + Nout * Kin:(b + 1) * stride_o], torch.ones(4096, device="cuda"))
     with pytest.raises(RuntimeError):
-        _gemm(dY, X, flat, Nout, Kin, Mtok, Nout, Kin, Kin, 1, 1, EPI_ATOMIC, cfg=3, splits=1, accumulate=1,
+        _gemm(dY, X, flat, Nout, Kin, Mtok, Nout, Kin, Kin, 1, 1, EPI_ATOMIC, cfg=4, splits=1, accumulate=1,
               batch=L_, batch_a=Mtok * Nout, batch_b=Mtok * Kin, batch_o=stride_o)
+
+
+@pytest.mark.parametrize("persist", [0, 1])
+def test_wgrad_batched_ring_many_items(persist):
+    """Ring kernel with more work items than blocks (12 problems x 9 tiles x 3 splits = 324 > 256): every block walks
+    several (problem, split, tile) items, statically or through the ticket scheduler."""
+    L_, Mtok, Nout, Kin = 12, 1024, 768, 768
+    dY = _rand(L_, Mtok, Nout, seed=23).bfloat16()
+    X = _rand(L_, Mtok, Kin, seed=24).bfloat16()
+    stride_o = Nout * Kin + 768
+    flat = torch.zeros(L_ * stride_o, device="cuda")
+    for _ in range(2):   # (two launches: the dynamic scheduler's double-buffered ticket counters)
+        _gemm(dY, X, flat, Nout, Kin, Mtok, Nout, Kin, Kin, 1, 1, EPI_ATOMIC, cfg=3, splits=3, accumulate=1,
+              batch=L_, batch_a=Mtok * Nout, batch_b=Mtok * Kin, batch_o=stride_o, persist=persist)
+    torch.cuda.synchronize()
+    for b in range(L_):
+        ref = 2.0 * (dY[b].float().t() @ X[b].float())
+        got = flat[b * stride_o:b * stride_o + Nout * Kin].view(Nout, Kin)
+        assert (got - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 2e-3, b
+        assert float(flat[b * stride_o + Nout * Kin:(b + 1) * stride_o].abs().max()) == 0.0
 
 
 def test_patch_epilogue_rowmap():

@@ -252,10 +252,10 @@ int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, i
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return VAULT_EINVAL;
   if ((p.lda & 7) || (p.ldb & 7) || (p.ldo & 7)) return VAULT_EINVAL;
   if (p.batch > 1) {   // batched weight gradients: double-buffered kernel, atomic epilogue only
-    if (epi != EPI_F32_ATOMIC || cfg == 3 || cfg == 4 || (p.batch_a & 7) || (p.batch_b & 7) || (p.batch_o & 3) ||
+    if (epi != EPI_F32_ATOMIC || cfg == 4 || (p.batch_a & 7) || (p.batch_b & 7) || (p.batch_o & 3) ||
         (long long)p.batch * p.splits > 65535)
       return VAULT_EINVAL;
-    if (cfg < 0) cfg = (p.M % 128 == 0 && p.N % 128 == 0) ? 0 : -1;
+    if (cfg < 0) cfg = (p.M % 256 == 0 && p.N % 256 == 0) ? 3 : ((p.M % 128 == 0 && p.N % 128 == 0) ? 0 : -1);
     if (cfg < 0) return VAULT_EINVAL;
   }
   if (cfg < 0) {

@@ -89,13 +89,17 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
 
   // ---- work items: (split z, tile) pairs, z-major; every split owns >= 1 K tile (launcher)
   const int tiles_m = p.M >> 8, tiles_n = p.N / BNT, ntiles = tiles_m * tiles_n;
-  const int nwork = ntiles * p.splits;
+  // (batched weight gradients, EPI_F32_ATOMIC: `batch` problems of one shape, problem-major in the work list - the
+  //  XCD-contiguous renumbering then gives an XCD whole problems, so a problem's panels fill ONE L2)
+  const int nbatch = (EPI == EPI_F32_ATOMIC && p.batch > 1) ? p.batch : 1;
+  const int nwork = ntiles * p.splits * nbatch;
   const int nk_total = p.K >> 6;
   const int per = (nk_total + p.splits - 1) / p.splits;
 
   // ---- staging sources: uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset, two 1-KiB pieces
   //      per wave per half-tile
   int m0, n0, nk;
+  float* out_cur = reinterpret_cast<float*>(p.out);   // EPI_F32_ATOMIC: this work item's problem (batched launches)
   const char* a_base;
   const char* b_base;
   uint32_t a_off[4], b_off[4];
@@ -108,17 +112,28 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     // the XCD-contiguous renumbering runs over the WHOLE work list (z-major): with split-K an XCD then works on
     // one or two K ranges only, so the A / B panels of a range are fetched into one or two L2s instead of all
     // eight (weight gradients, 36 tiles x 7 splits: L2 fill 970 -> ~460 MB per launch by this count)
-    const int lin = gemm_xcd_contiguous(nwork, w);
+    int lin = gemm_xcd_contiguous(nwork, w);
+    const __bf16* pA = p.A;
+    const __bf16* pB = p.B;
+    if constexpr (EPI == EPI_F32_ATOMIC) {
+      if (nbatch > 1) {
+        const int per_problem = ntiles * p.splits;
+        const int bz = lin / per_problem;
+        lin -= bz * per_problem;
+        pA += (size_t)bz * p.batch_a; pB += (size_t)bz * p.batch_b;
+        out_cur = reinterpret_cast<float*>(p.out) + (size_t)bz * p.batch_o;
+      }
+    }
     const int z = lin / ntiles, tl = lin - z * ntiles;
     int tile_m, tile_n;
     gemm_raster(tl, tiles_m, tiles_n, p.gn, tile_m, tile_n);
     m0 = tile_m << 8; n0 = tile_n * BNT;
     const int kt0 = z * per;
     nk = min(nk_total, kt0 + per) - kt0;
-    if constexpr (A_MODE == 0) a_base = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda + (size_t)kt0 * 64);
-    else a_base = reinterpret_cast<const char*>(p.A + (size_t)kt0 * 64 * p.lda + m0);
-    if constexpr (B_MODE == 0) b_base = reinterpret_cast<const char*>(p.B + (size_t)n0 * p.ldb + (size_t)kt0 * 64);
-    else b_base = reinterpret_cast<const char*>(p.B + (size_t)kt0 * 64 * p.ldb + n0);
+    if constexpr (A_MODE == 0) a_base = reinterpret_cast<const char*>(pA + (size_t)m0 * p.lda + (size_t)kt0 * 64);
+    else a_base = reinterpret_cast<const char*>(pA + (size_t)kt0 * 64 * p.lda + m0);
+    if constexpr (B_MODE == 0) b_base = reinterpret_cast<const char*>(pB + (size_t)n0 * p.ldb + (size_t)kt0 * 64);
+    else b_base = reinterpret_cast<const char*>(pB + (size_t)kt0 * 64 * p.ldb + n0);
   };
   int w = blockIdx.x;
   setup(w);
@@ -379,6 +394,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> accumulator reads (hazard is invisible inside asm)
 
     const int em0 = m0, en0 = n0;
+    float* const eout = out_cur;
     // ---- next work item: own XCD's ticket, else steal; broadcast through LDS
     int* sched_lds = reinterpret_cast<int*>(smem + 2 * BUFB + SCRATCH_BYTES);
     if (!dyn) {
@@ -432,8 +448,15 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     const int wnext = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(sched_lds));
     const bool more = wnext >= 0;
     if (more) setup(wnext);
-    gemm_epilogue<8, TN, EPI, 2, 2, true>(acc, p, smem + 2 * BUFB, em0, en0, wr * 128, wc * (NTQ * 32), wave, lane,
-                                          [&](int step) { if (more) stage_first(step); }, more ? 4 : 0);
+    if constexpr (EPI == EPI_F32_ATOMIC) {
+      GemmParams pe = p;
+      pe.out = eout;   // (the tile being written belongs to the previous work item's problem)
+      gemm_epilogue<8, TN, EPI, 2, 2, true>(acc, pe, smem + 2 * BUFB, em0, en0, wr * 128, wc * (NTQ * 32), wave, lane,
+                                            [&](int step) { if (more) stage_first(step); }, more ? 4 : 0);
+    } else {
+      gemm_epilogue<8, TN, EPI, 2, 2, true>(acc, p, smem + 2 * BUFB, em0, en0, wr * 128, wc * (NTQ * 32), wave, lane,
+                                            [&](int step) { if (more) stage_first(step); }, more ? 4 : 0);
+    }
     if (!more) break;
     behind_stores = (em0 + 256 <= p.m_valid);
     w = wnext;
@@ -479,7 +502,7 @@ int launch256(const GemmParams& p, hipStream_t st) {
   const int nk_total = p.K >> 6;
   const int per = (nk_total + p.splits - 1) / p.splits;
   q.splits = (nk_total + per - 1) / per;                        // every split owns at least one K tile
-  const int nwork = (p.M >> 8) * (p.N / BNT) * q.splits;
+  const int nwork = (p.M >> 8) * (p.N / BNT) * q.splits * ((EPI == EPI_F32_ATOMIC && p.batch > 1) ? p.batch : 1);
   dim3 grid(std::min(nwork, 256), 1, 1);
   q.persist = (p.persist & 0xff) | (((p.persist & 1) ? next_parity() : 0) << 8);   // the sequence counts dynamic launches only
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, q);

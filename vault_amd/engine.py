@@ -218,6 +218,7 @@ class VaultEngine:
     # groups, so that the all-reduce of the upper layers still starts under the backward of the lower ones).
     LM_WGRAD_BATCHED = True
     LM_WGRAD_GROUP = 0
+    WGRAD_BATCH_RING = True        # batched launches on the 256x256 ring kernel where the shapes allow (else 128x128)
     WGRAD_BATCH_MAX_ROWS = 16384   # the ViLT layers take the same route up to this many (padded) token rows (B <= 88)
 
     def __init__(self, spec: VaultSpec, device="cuda:0", state=None, seed: int = 0, freeze_lm: bool = False,
@@ -239,6 +240,8 @@ class VaultEngine:
             self.params = ParamStore(spec, self.device, state, seed, self.freeze_lm, with_grads)
         if os.environ.get("VAULT_LM_WGRAD_BATCHED") == "0":   # development override (same-box A/B)
             self.LM_WGRAD_BATCHED = False
+        if os.environ.get("VAULT_WGRAD_BATCH_RING") == "0":   # development override (same-box A/B)
+            self.WGRAD_BATCH_RING = False
         if os.environ.get("VAULT_WGRAD_GROUP"):   # layers per batched weight-gradient launch (tuning knob for DP runs)
             self.LM_WGRAD_GROUP = int(os.environ["VAULT_WGRAD_GROUP"])
         self.vl = [_LayerNames(f"encoder.layer.{i}", "vilt") for i in range(spec.vilt.num_hidden_layers)]
@@ -399,9 +402,17 @@ class VaultEngine:
         if any(offs[k + 1] - offs[k] != stride_o for k in range(G - 1)) or Nout % 128 or Kin % 128:
             raise RuntimeError("batched weight gradients need identically laid out layers and 128-multiples")
         gw = P.gr(wnames[0], n_elems=Nout * Kin, shape=(Nout, Kin))
-        tiles = (Nout // 128) * (Kin // 128) * G
-        splits = max(1, min(8, Mtok_pad // 512, int(round(512.0 / tiles))))   # ~two resident 128x128 blocks per CU
-        ops.gemm(dY_all[i0], X_all[i0], gw, Nout, Kin, Mtok_pad, Nout, Kin, Kin, 1, 1, ops.EPI_F32_ATOMIC, cfg=0,
+        nk = Mtok_pad // 64
+        if Nout % 256 == 0 and Kin % 256 == 0 and self.WGRAD_BATCH_RING:
+            # ring kernel, persistent over (layer, split, tile) items, layer-major: an XCD works on whole layers.  Split
+            # count by a cost model of the launch: rounds of 256 blocks x (k-steps at 1.67 us + ~40 us fixed per item)
+            cfg, tiles = 3, (Nout // 256) * (Kin // 256) * G
+            cost = lambda sp: -(-tiles * sp // 256) * (1.67 * -(-nk // sp) + 40.0)   # noqa: E731
+            splits = min((sp for sp in range(1, 9) if nk // sp >= 2), key=cost)
+        else:
+            cfg, tiles = 0, (Nout // 128) * (Kin // 128) * G
+            splits = max(1, min(8, Mtok_pad // 512, int(round(512.0 / tiles))))   # ~two resident 128x128 blocks per CU
+        ops.gemm(dY_all[i0], X_all[i0], gw, Nout, Kin, Mtok_pad, Nout, Kin, Kin, 1, 1, ops.EPI_F32_ATOMIC, cfg=cfg,
                  splits=splits, accumulate=1, batch=G, batch_a=dY_all.stride(0), batch_b=X_all.stride(0),
                  batch_o=stride_o)
 
