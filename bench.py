@@ -189,9 +189,9 @@ def main():
                     "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
                     "traffic": traffic, "launches_timed": len(ms), "avg_launch_ms": round(float(np.mean(ms)), 4)}
 
-        r_wgrad = roof("wgrad", "gemm256_kernel<1,1,5,4> (A[K][M]^T B[K][N], EPI_F32_ATOMIC, split-K): the weight-gradient GEMMs "
-                                f"of the ViLT layers and the patch projection, dW[N x K] += dY[{M} tokens][N]^T X[tokens][K] "
-                                "(the LM's 40-token contractions take the 128x128 double-buffered kernel)",
+        r_wgrad = roof("wgrad", "gemm256_kernel<1,1,5,4> (A[K][M]^T B[K][N], EPI_F32_ATOMIC): the weight-gradient GEMMs, "
+                                f"dW[N x K] += dY[tokens][N]^T X[tokens][K] - batched launches of 6 layers each ({M} ViLT tokens / "
+                                f"{B * 40} LM tokens per layer; FFN-out, FFN-in, attention-out, QKV) and the patch projection",
                        "r01_pmc_gemm_wgrad.json")
         r_ffn1 = roof("ffn1", "gemm256_kernel<0,0,1,4> (EPI_BF16_GELU): FFN-in forward, ViLT "
                               f"[{M}x{v.intermediate_size}x{v.hidden_size}] + LM [{B * 40}x{v.intermediate_size}x{v.hidden_size}]",

@@ -211,15 +211,17 @@ class VaultEngine:
     """Forward / backward of VaultModel / VaultForTMSC over one batch resident in HBM."""
 
     WGRAD_TARGET_WGS = 768
-    # Weight gradients of the LM layers (40-token sequences: 10240 rows at B = 256) are deferred and contracted
-    # `LM_WGRAD_GROUP` layers per launch (vault_gemm batch, ABI 3): one layer alone fills the GPU only with split-K
-    # partial sums through float atomics and 50-80 k-step blocks; 12 layers together give 432-1728 tiles of the full
-    # contraction.  0 = all layers in one group at the end of the LM backward (a data-parallel step uses smaller
-    # groups, so that the all-reduce of the upper layers still starts under the backward of the lower ones).
+    # Weight gradients of the encoder layers are deferred and contracted `LM_WGRAD_GROUP` layers per launch (vault_gemm
+    # batch, ABI 3): one layer alone fills the GPU only with split-K partial sums through float atomics (and, for the
+    # LM's 40-token sequences or small batches, 25-50 k-step blocks); a group of layers gives 100-400 tiles of the full
+    # contraction.  Groups of 6 of the 12 layers measured best or equal at every batch size (B = 256: 42.7 ms/step,
+    # one group of 12: 43.1, groups of 4: 43.6, per-layer launches: 45.6) and let a data-parallel step all-reduce the
+    # upper group's gradients under the backward of the lower layers.  0 = all layers of a stack in one group.
     LM_WGRAD_BATCHED = True
-    LM_WGRAD_GROUP = 0
+    LM_WGRAD_GROUP = 6
     WGRAD_BATCH_RING = True        # batched launches on the 256x256 ring kernel where the shapes allow (else 128x128)
-    WGRAD_BATCH_MAX_ROWS = 16384   # the ViLT layers take the same route up to this many (padded) token rows (B <= 88)
+    WGRAD_BATCH_MAX_ROWS = 131072  # the ViLT layers take the same route up to this many (padded) token rows (B <= 708:
+                                   # 22 GB of per-layer dY operands at that size; 7.9 GB at B = 256)
 
     def __init__(self, spec: VaultSpec, device="cuda:0", state=None, seed: int = 0, freeze_lm: bool = False,
                  with_grads: bool = True, classifier_dropout: float = 0.1, fp8_forward: bool = False):
@@ -242,6 +244,8 @@ class VaultEngine:
             self.LM_WGRAD_BATCHED = False
         if os.environ.get("VAULT_WGRAD_BATCH_RING") == "0":   # development override (same-box A/B)
             self.WGRAD_BATCH_RING = False
+        if os.environ.get("VAULT_WGRAD_BATCH_MAX_ROWS"):
+            self.WGRAD_BATCH_MAX_ROWS = int(os.environ["VAULT_WGRAD_BATCH_MAX_ROWS"])
         if os.environ.get("VAULT_WGRAD_GROUP"):   # layers per batched weight-gradient launch (tuning knob for DP runs)
             self.LM_WGRAD_GROUP = int(os.environ["VAULT_WGRAD_GROUP"])
         self.vl = [_LayerNames(f"encoder.layer.{i}", "vilt") for i in range(spec.vilt.num_hidden_layers)]
@@ -391,7 +395,7 @@ class VaultEngine:
         if bname is not None:
             ops.colsum(dy_bf16, Nout, m_valid, Nout, P.gr(bname, n_elems=Nout, shape=(Nout,)))
 
-    def _wgrad_batched(self, dY_all, X_all, wnames, i0, Mtok_pad, Nout, Kin):
+    def _wgrad_batched(self, dY_all, X_all, wnames, i0, Mtok_pad, Nout, Kin, m_valid):
         """dW_l[Nout,Kin] += dY_l[Mtok,Nout]^T . X_l[Mtok,Kin] for the consecutive layers l = i0 .. i0 + len(wnames) - 1 of a
         stack in ONE launch (vault_gemm `batch`): dY_l / X_l are slices of the stacked operand tensors, the dW_l lie
         at a uniform stride in the flat gradient buffer (identical layer layouts)."""
@@ -412,9 +416,14 @@ class VaultEngine:
         else:
             cfg, tiles = 0, (Nout // 128) * (Kin // 128) * G
             splits = max(1, min(8, Mtok_pad // 512, int(round(512.0 / tiles))))   # ~two resident 128x128 blocks per CU
+        if cfg == 3:
+            ops.pycall(lambda: self._prof_begin("wgrad"))
         ops.gemm(dY_all[i0], X_all[i0], gw, Nout, Kin, Mtok_pad, Nout, Kin, Kin, 1, 1, ops.EPI_F32_ATOMIC, cfg=cfg,
                  splits=splits, accumulate=1, batch=G, batch_a=dY_all.stride(0), batch_b=X_all.stride(0),
                  batch_o=stride_o)
+        if cfg == 3:
+            fl = 2.0 * m_valid * Nout * Kin * G
+            ops.pycall(lambda: self._prof_end("wgrad", fl))
 
     def _drop(self, p: float, stream: int, train: bool) -> Drop:
         return Drop(p, self.drop_seed, stream) if (train and p > 0.0) else NO_DROP
@@ -659,7 +668,7 @@ class VaultEngine:
         # ------------------------------ ViLT encoder ------------------------------
         if (train and not pr and self.LM_WGRAD_BATCHED and Mp <= self.WGRAD_BATCH_MAX_ROWS and H % 128 == 0
                 and FF % 128 == 0):
-            # small per-GPU batches: the ViLT layers' weight gradients are deferred and batched like the LM's
+            # the ViLT layers' weight gradients are deferred and batched like the LM's
             for base, width in (("n1", H), ("ctx", H), ("n2", H), ("act", FF)):
                 self._stack(ws, base, nv, (Mp, width), bf)
         for i, ln in enumerate(self.vl):
@@ -993,7 +1002,7 @@ class VaultEngine:
                                                        (dU_all, ws["n2_all"], "iw", FF, H),
                                                        (dxbB_all, ws["ctx_all"], "ow", H, H),
                                                        (dqkv_all, ws["n1_all"], "qw", 3 * H, H)):
-                    self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.vl[i:hi]], i, Mp, Nout, Kin)
+                    self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.vl[i:hi]], i, Mp, Nout, Kin, M)
                 for j in reversed(range(i, hi)):
                     note(f"vilt{j}")
 
@@ -1090,7 +1099,7 @@ class VaultEngine:
                                                        (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
                                                        (dh1b_all, ws["lm_ctx_all"], "ow", H, H),
                                                        (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H)):
-                    self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.ll[i:hi]], i, Mlp, Nout, Kin)
+                    self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.ll[i:hi]], i, Mlp, Nout, Kin, Ml)
                 for j in reversed(range(i, hi)):
                     note(f"lm{j}")
         # embeddings: y0 = dropout(LN(esum))

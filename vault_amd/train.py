@@ -164,12 +164,8 @@ class TrainStep:
             # GEMM tiles out dynamically so that a CU held by the collective does not stall a static tile walk.
             # (The tape records the argument structs: this must be set before the first step is recorded.)
             ops.GEMM_SCHED = 3
-            # deferred weight gradients in two groups of 6 layers (not all 12 at the end): the all-reduce of the upper
-            # group's gradient range starts under the backward of the layers below it.  Single-GPU cost of the grouping
-            # at B = 256: 0.18 ms/step for groups of 6, 0.86 ms for groups of 4 (a group's 576 tiles need two rounds of
-            # the 512 resident blocks)
-            if engine.LM_WGRAD_GROUP == 0:
-                engine.LM_WGRAD_GROUP = 6
+            # (the deferred, batched weight gradients already come in groups of 6 layers - engine.LM_WGRAD_GROUP - so the
+            # upper group's gradient range is all-reduced under the backward of the layers below it)
         if self.world > 1 or (os.environ.get("VAULT_FORCE_DP") == "1" and dist.is_available() and dist.is_initialized()):
             b = GradBuckets(engine, bucket_mb)
             self.reducer = BucketReducer(engine.params.g[:engine.params.n_train], b.stage_lo, b.last_tag, b.bucket_elems, dist, process_group,
