@@ -46,11 +46,12 @@ typedef struct vault_gemm_args {
   int persist; /* scheduling: bit 0 = ring kernel hands tiles out dynamically (per-XCD ticket counters), bit 1 = the
                   double-buffered kernel launches one block per tile instead of its persistent grid; 3 when the GEMMs
                   share the GPU with another kernel (RCCL collectives of a data-parallel step), 0 otherwise */
-  int batch;   /* ABI 3, EPI_F32_ATOMIC on the double-buffered kernel (cfg 0..2) only: `batch` > 1 weight gradients of
-                  one shape in one launch, problem b at A + b * batch_a, B + b * batch_b (bf16 elements) and
-                  out + b * batch_o (floats).  The layers of an encoder stack share their shapes: contracted in one
-                  launch they fill the GPU without split-K partial sums (short token contractions: the LM's 40-token
-                  sequences, small per-GPU batches).  0 / 1 = a single GEMM */
+  int batch;   /* ABI 3, EPI_F32_ATOMIC only (cfg 0..3; default: the 256x256 ring kernel when M and N are multiples of 256,
+                  else 128x128): `batch` > 1 weight gradients of one shape in one launch, problem b at A + b * batch_a,
+                  B + b * batch_b (bf16 elements) and out + b * batch_o (floats).  The layers of an encoder stack share
+                  their shapes: contracted in one launch they fill the GPU with few or no split-K partial sums, and
+                  the ring kernel's layer-major work list keeps a layer's operand panels in one XCD's L2.
+                  0 / 1 = a single GEMM */
   long long batch_a, batch_b, batch_o;
 } vault_gemm_args;
 int vault_gemm(const vault_gemm_args* args, void* stream);

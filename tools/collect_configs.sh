@@ -13,6 +13,6 @@ python bench.py --fp8-forward --no-cpu-baseline > $O/bench_fp8.json 2> $O/bench_
 python bench.py --no-cpu-baseline > $O/bench_bf16_same_box.json 2> $O/bench_bf16.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fp8 -o run -- python3 bench.py --fp8-forward --steps 8 --warmup 3 --no-cpu-baseline > $O/fp8_rocprof.log 2>&1
 python tools/prof_summary.py $O/fp8 > $O/fp8_kernel_stats.txt; rm -rf $O/fp8
-VAULT_GEMM_SCHED=3 VAULT_WGRAD_GROUP=6 python bench.py --no-cpu-baseline > $O/bench_dp_mode_one_gpu.json 2> $O/bench_dp.err
+VAULT_GEMM_SCHED=3 python bench.py --no-cpu-baseline > $O/bench_dp_mode_one_gpu.json 2> $O/bench_dp.err
 python tools/ragged_bench.py > $O/ragged.txt 2>&1
 ls -la $O

@@ -39,10 +39,9 @@ struct GemmParams {
                     // kernel launches one block per tile instead of its persistent grid.  3 = both: for GEMMs that share
                     // the GPU with another kernel (RCCL collectives of a data-parallel step)
   int gn;           // n-tiles per raster group (set by the launcher: B panel of a group stays L2-resident)
-  // batched weight gradients (EPI_F32_ATOMIC, double-buffered kernel only): `batch` independent GEMMs of one shape in
-  // one launch, problem b at A + b * batch_a, B + b * batch_b (bf16 elements), out + b * batch_o (floats); grid.z =
-  // batch * splits.  The layers of a stack share shapes: their weight gradients run without (or with few) split-K
-  // partial sums once all of them are contracted in one launch.  batch <= 1: a single GEMM.
+  // batched weight gradients (EPI_F32_ATOMIC): `batch` independent GEMMs of one shape in one launch, problem b at
+  // A + b * batch_a, B + b * batch_b (bf16 elements), out + b * batch_o (floats).  Double-buffered kernel: grid.z =
+  // batch * splits; ring kernel: (problem, split, tile) work items, problem-major.  batch <= 1: a single GEMM.
   int batch;
   long long batch_a, batch_b, batch_o;
 };
