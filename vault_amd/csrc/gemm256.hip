@@ -141,8 +141,10 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   const int xcd = blockIdx.x & 7;
   auto items_of = [&](int x) { return x < nwork ? (nwork - x + 7) >> 3 : 0; };          // j < items_of(x)
   auto static_of = [&](int x) { return x < (int)gridDim.x ? ((int)gridDim.x - x + 7) >> 3 : 0; };
-  // a ticket stands for TICKET_ITEMS consecutive items of an XCD's list: one returning atomic per that many tiles
-  constexpr int TICKET_ITEMS = 2;
+  // a ticket stands for TICKET_ITEMS consecutive items of an XCD's list: one returning atomic per that many tiles.
+  // Work lists of at most two items per block (batched weight gradients: 486 items on 256 blocks) take single-item
+  // tickets: pairs would give half of the blocks three items and the rest one - three rounds instead of two.
+  const int TICKET_ITEMS = (nwork <= 2 * (int)gridDim.x) ? 1 : 2;
   int pend_w = -1;           // thread 0: second item of the current ticket, not yet started
   int last_tk = 0;           // thread 0: last ticket drawn from the own list
   const bool dyn = (p.persist & 1) != 0;   // dynamic hand-out of work items (else: block b walks b, b + grid, ...)
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
           const int j = static_of(x) + TICKET_ITEMS * (int)tk;
           if (j < items_of(x)) {
             wn = x + 8 * j;
-            if (j + 1 < items_of(x)) pend_w = x + 8 * (j + 1);
+            if (TICKET_ITEMS == 2 && j + 1 < items_of(x)) pend_w = x + 8 * (j + 1);
           }
         };
         // Far from the end of this XCD's list (judged by the last ticket this block drew): draw directly.
