@@ -64,6 +64,36 @@ def test_library_exports_every_declared_symbol():
     assert lib.vault_abi_version() == 3
 
 
+def test_ctypes_structures_match_the_c_header(tmp_path):
+    """The ctypes mirrors of the argument structs (vault_amd/lib.py, ops.py) have the size and the field offsets gcc
+    gives the structs of include/vault_hip.h: the FFI boundary cannot drift silently."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from vault_amd import lib as L, ops
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    pairs = {"vault_gemm_args": L.GemmArgs, "vault_ln_fwd_args": ops.LnFwdArgs, "vault_ln_bwd_args": ops.LnBwdArgs,
+             "vault_attn_args": ops.AttnArgs, "vault_gather_args": ops.GatherArgs, "vault_head_args": ops.HeadArgs}
+    hdr = os.path.join(ROOT, "include", "vault_hip.h")
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{hdr}"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-o", str(exe), str(src)], check=True)   # (unknown field names fail to compile)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = dict(l.rsplit(" ", 1) for l in out if l)
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
 def test_product_does_not_import_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "vault_amd")):
         for f in files:
