@@ -376,3 +376,75 @@ def test_ring_kernel_dynamic_scheduler_wgrad_splits():
         _gemm(A, B, out, M, N, K, M, N, N, 1, 1, EPI_ATOMIC, cfg=3, splits=splits, persist=1)
         torch.cuda.synchronize()
         assert (out - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+# ---- 8-wave kernel with register-direct epilogue (cfg 5: 256-wide tiles, cfg 6: 192-wide; gemm8w.hip): forward-form
+#      operands (A [M][K], B [N][K]), swapped-operand MFMA with permuted weight rows, loads running ahead across tiles
+def _gprime(z):
+    return 0.5 * (1 + torch.erf(z / math.sqrt(2))) + z * torch.exp(-0.5 * z * z) / math.sqrt(2 * math.pi)
+
+
+@pytest.mark.parametrize("cfg", [5, 6])
+@pytest.mark.parametrize("shape", [(256, 768, 128), (512, 768, 768), (256, 2304, 192), (768, 768, 3072), (1280, 1536, 320),
+                                   (256 * 43, 3072, 832), (256 * 150, 768, 768)])
+@pytest.mark.parametrize("epi", ["bf16", "gelu", "gelu_inf", "res", "dgelu"])
+def test_8wave_kernel_every_epilogue(cfg, shape, epi):
+    """One tile row, fewer tiles than the 256 resident blocks, several tiles per block, odd and even K tile counts,
+    partial and fully masked row blocks; three runs each (a racy wait shows as run-to-run differences)."""
+    M, N, K = shape
+    A = _rand(M, K, seed=81).bfloat16()
+    W = _rand(N, K, scale=0.05, seed=82).bfloat16()
+    bias = _rand(N, seed=83)
+    m_valid = M - 150 if M > 256 else M - 37
+    z = A.float() @ W.float().t() + bias
+    first = None
+    for rep in range(3):
+        if epi == "bf16":
+            out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            cs = torch.full((N,), 1.0, device="cuda")
+            _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_BF16, cfg=cfg, bias=bias, m_valid=m_valid, colsum=cs)
+            ref, tol = z, z.abs().max().item() * 2 ** -7
+            torch.cuda.synchronize()
+            want = 1.0 + out[:m_valid].float().sum(0)
+            assert (cs - want).abs().max().item() <= 2e-3 * want.abs().max().item() + 1e-2
+        elif epi in ("gelu", "gelu_inf"):
+            out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            pre = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda") if epi == "gelu" else None
+            _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_GELU, cfg=cfg, bias=bias, out2=pre, m_valid=m_valid)
+            ref = torch.nn.functional.gelu(z); tol = ref.abs().max().item() * 2 ** -7
+            if pre is not None:
+                torch.cuda.synchronize()
+                assert (pre[:m_valid].float() - _gprime(z)[:m_valid]).abs().max().item() <= 2 ** -7
+                assert pre[m_valid:].abs().max().item() == 0.0
+        elif epi == "res":
+            res = _rand(M, N, seed=84)
+            out = torch.zeros(M, N, device="cuda")
+            _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_RES, cfg=cfg, bias=bias, res=res, m_valid=m_valid)
+            ref, tol = z + res, 2e-4 * z.abs().max().item() + 1e-5
+        else:
+            aux = _rand(M, N, seed=85).bfloat16()
+            out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            cs = torch.zeros(N, device="cuda")
+            _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_DGELU, cfg=cfg, aux=aux, colsum=cs, m_valid=m_valid)
+            ref = (z - bias) * aux.float(); tol = ref.abs().max().item() * 2 ** -7
+            torch.cuda.synchronize()
+            want = out[:m_valid].float().sum(0)
+            assert (cs - want).abs().max().item() <= 2e-3 * want.abs().max().item() + 1e-2
+        torch.cuda.synchronize()
+        assert (out[:m_valid].float() - ref[:m_valid]).abs().max().item() <= tol
+        assert out[m_valid:].abs().max().item() == 0.0          # masked rows untouched
+        if first is None:
+            first = out.clone()
+        else:
+            assert torch.equal(out, first)
+
+
+def test_8wave_kernel_refuses_what_it_does_not_take():
+    A = torch.zeros(256, 256, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(256, 256, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError):      # k-strided weights (dgrad form): the engine feeds it the transposed shadow
+        _gemm(A, A, out, 256, 256, 128, 256, 256, 256, 0, 1, EPI_BF16, cfg=5)
+    with pytest.raises(RuntimeError):      # a single K tile
+        _gemm(A, A, out, 256, 256, 64, 256, 256, 256, 0, 0, EPI_BF16, cfg=5)
+    with pytest.raises(RuntimeError):      # N not a multiple of 192
+        _gemm(A, A, out, 256, 256, 128, 256, 256, 256, 0, 0, EPI_BF16, cfg=6)

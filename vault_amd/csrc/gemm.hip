@@ -244,6 +244,8 @@ int launch_modes(const GemmParams& p, int cfg, hipStream_t st) {
 }  // namespace
 
 int vault_gemm256_launch(const GemmParams& p, int a_mode, int b_mode, int epi, int ntq, hipStream_t st);
+bool vault_gemm8w_supports(const GemmParams& p, int a_mode, int b_mode, int epi, int ntw);
+int vault_gemm8w_launch(const GemmParams& p, int epi, int ntw, hipStream_t st);
 
 int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, int cfg, hipStream_t st) {
   GemmParams p = p_in;
@@ -276,6 +278,11 @@ int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, i
   }
   // the ring kernel's residual epilogue always loads its residual operand: without one use the simple kernel
   if ((cfg == 3 || cfg == 4) && epi == EPI_F32_RES && p.res == nullptr) cfg = (p.N % 256 == 0) ? 2 : 1;
+  if (cfg == 5 || cfg == 6) {   // 8-wave kernel with register-direct epilogue (gemm8w.hip), 256- / 192-wide tiles:
+    const int ntw = (cfg == 5) ? 4 : 3;   // forward-form operands only
+    if (!vault_gemm8w_supports(p, a_mode, b_mode, epi, ntw)) return VAULT_EINVAL;
+    return vault_gemm8w_launch(p, epi, ntw, st);
+  }
   if (cfg == 3) return vault_gemm256_launch(p, a_mode, b_mode, epi, 4, st);
   if (cfg == 4) return vault_gemm256_launch(p, a_mode, b_mode, epi, 3, st);
   const int key = a_mode * 2 + b_mode;
