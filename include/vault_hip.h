@@ -32,7 +32,11 @@ int vault_abi_version(void);
  * Rows >= m_valid are not stored.  cfg < 0 selects the kernel/tile automatically; explicit values: 0 / 1 / 2 =
  * double-buffered kernel with 128x128 / 256x128 / 256x256 tiles, 3 / 4 = persistent ring kernel with
  * 256x256 / 256x192 tiles (M % 256 == 0, N % 256 / 192 == 0; its residual epilogue needs `res`, without one
- * the launcher takes the double-buffered kernel). */
+ * the launcher takes the double-buffered kernel), 5 / 6 (ABI 4) = 8-wave kernel with 256x256 / 256x192 tiles whose
+ * epilogue stores the accumulators straight from registers (a_mode = b_mode = 0 only, K >= 128, no split-K, no split3,
+ * no dropout, epi 0 / 1 / 2 / 3; M x ldo x 4 B < 4 GiB): the automatic choice for the bf16-output Linears with K <= 1024.
+ * Threading: one host thread per device; the ring kernel's dynamic scheduler (persist bit 0) keeps per-device ticket
+ * counters that assume its launches are serialised on ONE stream per device. */
 typedef struct vault_gemm_args {
   const void* A; const void* B; void* out; void* out2;
   const float* bias; const float* res; const void* aux; const float* addtab;
@@ -207,6 +211,12 @@ int vault_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, long 
                      float beta2, float eps, float weight_decay, float bias_corr_factor, float grad_scale,
                      int zero_grad, void* stream);
 int vault_cast_bf16(const float* x, void* y_bf16, long long n, void* stream);
+/* ABI 4: dst[b][c][r] = src[b][r][c] for `batch` bf16 matrices of rows x cols (multiples of 64) at uniform element strides
+ * (8-aligned): the transposed weight shadow W^T [in][out] of a Linear.  The data gradient dX = dY . W (autograd of
+ * HF:models/vilt/modeling_vilt.py:355-414) then runs as a forward-form GEMM (b_mode 0) on the register-direct kernel
+ * (cfg 5 / 6), which takes no k-strided weights. */
+int vault_transpose_bf16(const void* src, void* dst, int rows, int cols, int batch, long long stride_src,
+                         long long stride_dst, void* stream);
 /* Split-bf16 operands: out[r][3K] = [hi | lo | hi] (layout 0, activations) or [hi | hi | lo] (layout 1,
  * weights), hi = bf16(x), lo = bf16(x - hi).  One bf16 GEMM over the 3K-long contraction then equals
  * A_hi B_hi + A_lo B_hi + A_hi B_lo: fp32-class products (2^-17) on the bf16 MFMA path - the precise

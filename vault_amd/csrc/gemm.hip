@@ -21,6 +21,7 @@
 // HF:models/vilt/modeling_vilt.py:303-414 and HF:models/roberta/modeling_roberta.py:222-398, the
 // Conv2d patch projection (modeling_vilt.py:290-300) and their autograd backward.
 #include <algorithm>
+#include <cstdlib>
 #include "common.h"
 #include "gemm.h"
 #include "gemm_epi.h"
@@ -260,6 +261,7 @@ int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, i
     if (cfg < 0) cfg = (p.M % 256 == 0 && p.N % 256 == 0) ? 3 : ((p.M % 128 == 0 && p.N % 128 == 0) ? 0 : -1);
     if (cfg < 0) return VAULT_EINVAL;
   }
+  const bool auto_cfg = cfg < 0;
   if (cfg < 0) {
     // default kernel/tile choice (measured on MI355X at M = 47360, tools/gemm_bench.py + tools/k_sweep.py):
     //   256x256 persistent ring kernel from K = 512 up and for all wgrads (A stored [K][M]): its epilogue
@@ -275,6 +277,22 @@ int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, i
     } else {
       cfg = (p.M % 256 == 0 && p.N % 128 == 0 && epi != EPI_F32_ATOMIC) ? 1 : 0;
     }
+  }
+  // bf16-output Linears with short contractions (forward-form operands: QKV, FFN-in (GELU), and - on the transposed
+  // weight shadow - the FFN-out (gelu' product) and attention-out data gradients): the 8-wave kernel whose epilogue
+  // stores from registers (tools/gemm_bench.py at M = 47360, same box: QKV 168 against 193-198 us, FFN-in 299 against
+  // 355-388, gelu'-product dgrad 282 against 294-317, N = K = 768 dgrad 55 against ~90).  Not the f32-residual forms
+  // (bound by their HBM bytes: the ring kernel's 192-wide form is as fast), not K = 3072 (ring: better main loop) and not
+  // with dynamic tile scheduling requested (data-parallel runs beside RCCL kernels: the ring kernel's ticket scheduler).
+  static const bool use8w = [] { const char* e = getenv("VAULT_GEMM8W"); return !(e && e[0] == '0'); }();   // development A/B switch
+  if (auto_cfg && use8w && (p.persist & 1) == 0 && a_mode == 0 && b_mode == 0 && p.K <= 1024 && p.M >= 2048 &&
+      (epi == EPI_BF16 || epi == EPI_BF16_GELU || epi == EPI_BF16_DGELU)) {
+    auto eff8 = [](long tiles) { return (double)tiles / (double)(((tiles + 255) / 256) * 256); };
+    const bool ok4 = vault_gemm8w_supports(p, a_mode, b_mode, epi, 4), ok3 = vault_gemm8w_supports(p, a_mode, b_mode, epi, 3);
+    // (256-wide tiles unless the 192-wide ones fill the last round of CUs much better: N = 768; at N = 2304 - 6.5
+    //  against 8.7 rounds - the wider tile's fewer staging bytes per FLOP still win: 168 against 188 us)
+    if (ok4 && (!ok3 || eff8((long)(p.M / 256) * (p.N / 256)) >= 0.9 * eff8((long)(p.M / 256) * (p.N / 192)))) cfg = 5;
+    else if (ok3) cfg = 6;
   }
   // the ring kernel's residual epilogue always loads its residual operand: without one use the simple kernel
   if ((cfg == 3 || cfg == 4) && epi == EPI_F32_RES && p.res == nullptr) cfg = (p.N % 256 == 0) ? 2 : 1;

@@ -95,3 +95,44 @@ extern "C" int vault_cast_bf16(const float* x, void* y_bf16, long long n, void* 
                      reinterpret_cast<bf16*>(y_bf16), n4);
   return (int)hipGetLastError();
 }
+
+// ---- transposed bf16 weight shadow: dst[b][c][r] = src[b][r][c] for `batch` matrices of rows x cols at uniform strides
+// (the layers of a stack in the flat bf16 parameter buffer).  The data-gradient GEMMs dX = dY . W then read W^T as a
+// forward-form operand ([N = in][K = out], K contiguous): the register-direct GEMM (gemm8w.hip) takes no k-strided
+// weights.  64 x 64 tiles through LDS (padded rows), 16-byte global accesses on both sides.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int rows,
+                                                             int cols, long long stride_src, long long stride_dst) {
+  __shared__ bf16 tile[64][72];
+  const int tiles_c = cols >> 6;
+  const int tr = blockIdx.x / tiles_c, tc = blockIdx.x - tr * tiles_c;
+  const bf16* s = src + (size_t)blockIdx.y * stride_src + (size_t)(tr * 64) * cols + tc * 64;
+  bf16* d = dst + (size_t)blockIdx.y * stride_dst + (size_t)(tc * 64) * rows + tr * 64;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int r = (t >> 3) + 32 * k, c8 = (t & 7) * 8;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(s + (size_t)r * cols + c8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[r][c8 + e] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = (t >> 3) + 32 * k, r8 = (t & 7) * 8;   // output row c (a source column), 8 consecutive source rows
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[r8 + e][c];
+    *reinterpret_cast<bf16x8*>(d + (size_t)c * rows + r8) = v;
+  }
+}
+
+extern "C" int vault_transpose_bf16(const void* src, void* dst, int rows, int cols, int batch, long long stride_src,
+                                    long long stride_dst, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || (rows & 63) || (cols & 63) || batch <= 0 || batch > 65535 ||
+      (stride_src & 7) || (stride_dst & 7))
+    return VAULT_EINVAL;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((rows >> 6) * (cols >> 6), batch), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16*>(src),
+                     reinterpret_cast<bf16*>(dst), rows, cols, stride_src, stride_dst);
+  return (int)hipGetLastError();
+}

@@ -67,6 +67,10 @@ class ParamStore:
         self.p = torch.from_numpy(host).to(device)
         self.pb = torch.zeros(self.n_total + self.slack, dtype=torch.bfloat16, device=device)
         ops.cast_bf16(self.p, self.pb, self.n_total)
+        # transposed bf16 shadow W^T [in][out] of the Linears whose data gradient runs as a forward-form GEMM on the
+        # register-direct kernel (attention-out and FFN-out of every trained encoder layer): {weight name: tensor}
+        self.pbT: Dict[str, torch.Tensor] = {}
+        self._pbT_groups: List[tuple] = []
         self.g = self.m = self.v = None
         if with_grads:
             self.g = torch.zeros(self.n_train + self.slack, device=device)
@@ -135,6 +139,34 @@ class ParamStore:
             o += ["classifier.1.weight", "classifier.1.bias"]
         return o
 
+    # ---- transposed weight shadow -----------------------------------------------------------
+    def enable_transposed(self, groups):
+        """``groups``: lists of weight names of identical shape lying at a uniform stride in the flat buffer (the layers
+        of a stack); one stacked [L, in, out] bf16 tensor per group, refreshed by :meth:`refresh_transposed`."""
+        for names in groups:
+            offs = [self.offsets[n][0] for n in names]
+            shp = self.offsets[names[0]][1]
+            rows, cols = int(shp[0]), int(np.prod(shp[1:]))
+            stride = (offs[1] - offs[0]) if len(offs) > 1 else 0
+            if rows % 64 or cols % 64 or stride % 8 or any(offs[k + 1] - offs[k] != stride for k in range(len(offs) - 1)):
+                continue
+            t = torch.zeros((len(names), cols, rows), dtype=torch.bfloat16, device=self.device)
+            for k, n in enumerate(names):
+                self.pbT[n] = t[k]
+            self._pbT_groups.append((offs[0], rows, cols, len(names), stride, t))
+        self.refresh_transposed()
+
+    def refresh_transposed(self):
+        """Re-derive the transposed shadow from the bf16 shadow (after every change of the parameters)."""
+        for o, rows, cols, L, stride, t in self._pbT_groups:
+            ops.transpose_bf16(self.pb[o:], t, rows, cols, L, stride, rows * cols)
+
+    def refresh_shadows(self):
+        """fp32 master -> bf16 shadow -> transposed shadow (after the master changed outside the fused optimizer)."""
+        ops.cast_bf16(self.p, self.pb, self.n_total)
+        self.refresh_transposed()
+        self._pb3_fresh = False
+
     # ---- views ------------------------------------------------------------------------------
     def _view(self, buf, name, n_elems=None, shape=None):
         o, shp = self.offsets[name]
@@ -187,8 +219,7 @@ class ParamStore:
             o, shp = self.offsets[n]
             host[o:o + int(np.prod(shp))] = np.asarray(v, np.float32).reshape(-1)
         self.p.copy_(torch.from_numpy(host))
-        ops.cast_bf16(self.p, self.pb, self.n_total)
-        self._pb3_fresh = False
+        self.refresh_shadows()
 
 
 class _LayerNames:
@@ -251,6 +282,10 @@ class VaultEngine:
         self.vl = [_LayerNames(f"encoder.layer.{i}", "vilt") for i in range(spec.vilt.num_hidden_layers)]
         self.ll = ([_LayerNames(f"bert.encoder.layer.{i}", "bert") for i in range(spec.lm.num_hidden_layers)]
                    if spec.lm else [])
+        if with_grads and os.environ.get("VAULT_DGRAD_TRANSPOSED", "1") != "0":
+            stacks = [self.vl] + ([self.ll] if (self.ll and not self.freeze_lm) else [])
+            with torch.cuda.device(self.device):
+                self.params.enable_transposed([[getattr(ln, k) for ln in st] for st in stacks for k in ("ow", "fw")])
         self._ws: Dict[tuple, dict] = {}
         self.drop_seed = 0
         self.last: Optional[dict] = None
@@ -359,6 +394,11 @@ class VaultEngine:
     def _dgrad(self, dy_bf16, wname, out, M, Kin, Nout, epi, m_valid, **kw):
         # dX[M,Kin] = dY[M,Nout] . W[Nout,Kin]
         P = self.params
+        wt = P.pbT.get(wname)
+        if wt is not None and M % 256 == 0:
+            # forward-form operands on the transposed shadow W^T [Kin][Nout]: the register-direct GEMM
+            ops.gemm(dy_bf16, wt, out, M, Kin, Nout, Nout, Nout, Kin, 0, 0, epi, m_valid=m_valid, **kw)
+            return
         ops.gemm(dy_bf16, P.wb(wname, n_elems=Nout * Kin, shape=(Nout, Kin)), out, M, Kin, Nout, Nout, Kin, Kin, 0, 1,
                  epi, m_valid=m_valid, **kw)
 

@@ -278,15 +278,11 @@ class VaultMixin(nn.Module):
     def _sync_engine_from_params(self):
         """After load_state_dict (which copies into the views in place) refresh the bf16 shadow."""
         if self._engine is not None:
-            from ... import ops
-            P = self._engine.params
-            ops.cast_bf16(P.p, P.pb, P.n_total)
+            self._engine.params.refresh_shadows()
 
     def refresh_weights(self):
         """Call after an external optimizer changed the fp32 parameters (re-derives the bf16 copies)."""
         self._sync_engine_from_params()
-        if self._engine is not None:
-            self._engine.params._pb3_fresh = False
 
     def _prepare_grads(self):
         P = self._engine.params

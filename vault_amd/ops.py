@@ -366,3 +366,9 @@ def cast_bf16(x, y_bf16, n):
 def split3_bf16(x_f32, out_bf16, rows, K, layout):
     _invoke("vault_split3_bf16", C.c_void_p(_p(x_f32)), C.c_void_p(_p(out_bf16)), C.c_longlong(rows), C.c_int(K),
             C.c_int(layout), _stream())
+
+
+def transpose_bf16(src, dst, rows, cols, batch=1, stride_src=0, stride_dst=0):
+    """dst[b][c][r] = src[b][r][c] (bf16; rows, cols multiples of 64): transposed weight shadow for the data gradients."""
+    _invoke("vault_transpose_bf16", C.c_void_p(_p(src)), C.c_void_p(_p(dst)), C.c_int(rows), C.c_int(cols), C.c_int(batch),
+            C.c_longlong(stride_src), C.c_longlong(stride_dst), _stream())

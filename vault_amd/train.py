@@ -232,6 +232,8 @@ class TrainStep:
                                self.b1, self.b2, self.eps, self.wd, bias_corr_factor=bc, grad_scale=1.0 / self.world,
                                zero_grad=True)
         if advance:
+            with torch.cuda.device(eng.device):
+                P.refresh_transposed()   # W^T shadow of the data-gradient GEMMs, from the bf16 shadow just written
             P._pb3_fresh = False   # the split-bf16 (precise inference) shadow is stale now
             self.step_idx += 1
 
