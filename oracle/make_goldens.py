@@ -172,6 +172,12 @@ CASES = {
     "tiny_bert": (lambda: VaultSpec.tiny(3, "bert"), 3, 12),
     "full_bertweet_b2": (lambda: VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3), 2, 13),
 }
+# BASELINE config 4: bert-base-uncased shapes (vocab 30522, 512 positions, 2 token types, eps 1e-12) with the LM frozen
+# the way the reference's from_pretrained(freeze_lm=True) freezes it (ref: vault/models/vault/model.py:124-126:
+# ``freeze_lm`` attribute + ``set_parameter_requires_grad(model.bert, False)``; forward then runs the LM under no_grad, :189)
+FROZEN_CASES = {
+    "full_bert_base_frozen_b2": (lambda: VaultSpec(vilt=ViltSpec(), lm=LMSpec.bert_base_uncased(), n_classes=3), 2, 14),
+}
 # padded batches of different image sizes: name -> (spec factory, valid (h, w) per sample, canvas, seed).
 # tiny: patch 16, position table 12 x 12; canvas 192 x 256 = 12 x 16 patches: one full-canvas image (192 patches: the
 # sequence is longer than the table), one small image (10 x 7 patches, 122 masked padding rows), one square image
@@ -456,6 +462,22 @@ def main():
         batch = synthetic_batch(spec, B, seed=dseed, n_classes=spec.n_classes)
         # make sure one caption is short so padding/masking is exercised
         out = run_reference(model, spec, batch)
+        out["meta_batch"] = np.int64(B)
+        out["meta_data_seed"] = np.int64(dseed)
+        path = os.path.join(outdir, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(name, "loss", out["loss"], "logits", out["logits"].ravel()[:6], "->", path,
+              f"{os.path.getsize(path)/1024:.0f} KiB")
+    for name, (mk, B, dseed) in FROZEN_CASES.items():
+        if only and name not in only:
+            continue
+        spec = mk()
+        model, _ = build_reference_model(ref, spec, seed=0)
+        model.freeze_lm = True
+        sys.modules["vault.utils"].set_parameter_requires_grad(model.bert, False)
+        batch = synthetic_batch(spec, B, seed=dseed, n_classes=spec.n_classes)
+        out = run_reference(model, spec, batch)
+        assert not any(str(n).startswith("bert.") for n in out["grad_names"]), "frozen LM received gradients"
         out["meta_batch"] = np.int64(B)
         out["meta_data_seed"] = np.int64(dseed)
         path = os.path.join(outdir, f"{name}.npz")

@@ -358,9 +358,14 @@ def test_full_size_against_reference_golden():
     eng.zero_grad()
     eng.backward()
     torch.cuda.synchronize()
-    assert np.abs(out["logits"].cpu().numpy() - g["logits"]).max() < 8e-3
-    assert abs(float(out["loss"]) - float(g["loss"])) < 2e-3
-    assert np.abs(out["pooler_output"].cpu().numpy() - g["pooler_output"]).max() < 2e-2
+    # bf16 fast mode, measured 4.3e-3 / 1.2-1.7e-3 / 1.1e-2 (the level moves with the kernels' summation
+    # order; the north star's 1e-3 is met by the precise mode, test_precise_mode_meets_the_1e3_logits_bar):
+    # bounds = largest measured + 25 %
+    dl_, dloss_ = np.abs(out["logits"].cpu().numpy() - g["logits"]).max(), abs(float(out["loss"]) - float(g["loss"]))
+    print(f"full_bertweet_b2: |dlogits| {dl_:.2e} |dloss| {dloss_:.2e}")
+    assert dl_ < 5.5e-3
+    assert dloss_ < 2.1e-3
+    assert np.abs(out["pooler_output"].cpu().numpy() - g["pooler_output"]).max() < 1.4e-2
     T = bn["input_ids"].shape[1]
     h = out["last_hidden_state"][:, : T + 1].cpu().numpy()
     assert np.abs(h - g["hidden_text_cls"]).max() < 1.5e-2 * np.abs(g["hidden_text_cls"]).max()
@@ -531,3 +536,177 @@ def test_precise_mode_tiny(kind, seed):
     assert (out["logits"].cpu() - ref["logits"]).abs().max() < 3e-4
     rh = ref["last_hidden_state"]
     assert (out["last_hidden_state"].cpu() - rh).abs().max() < 2e-3 * rh.abs().max()
+
+
+def test_frozen_bert_base_full_size_against_reference_golden():
+    """BASELINE config 4 at its real shapes: ViLT-B32 + bert-base-uncased (vocab 30522, 512 positions, 2 token types,
+    eps 1e-12) with the LM frozen like ref from_pretrained(freeze_lm=True) (model.py:124-126,189), B = 2, against numbers
+    produced by the reference itself (oracle/make_goldens.py: full_bert_base_frozen_b2)."""
+    g = np.load(os.path.join(GOLD, "full_bert_base_frozen_b2.npz"))
+    spec = _nodrop(VaultSpec(vilt=ViltSpec(), lm=LMSpec.bert_base_uncased(), n_classes=3))
+    bn = synthetic_batch(spec, int(g["meta_batch"]), seed=int(g["meta_data_seed"]), n_classes=3)
+    eng = VaultEngine(spec, "cuda:0", seed=0, classifier_dropout=0.0, freeze_lm=True)
+    assert not any(n.startswith("bert.") for n in eng.params.trainable)
+    db = _dev(bn)
+    out = eng.forward(db, train=True, labels=db["labels"], need_hidden=True)
+    eng.zero_grad()
+    eng.backward()
+    torch.cuda.synchronize()
+    # measured 3.9e-3 / 1.0e-3 / 9e-3 (bf16 operands over 24 layers, see DESIGN.md 2): bounds = measured + 25 %
+    dl_, dloss_ = np.abs(out["logits"].cpu().numpy() - g["logits"]).max(), abs(float(out["loss"]) - float(g["loss"]))
+    print(f"full_bert_base_frozen_b2: |dlogits| {dl_:.2e} |dloss| {dloss_:.2e}")
+    assert dl_ < 5.5e-3
+    assert dloss_ < 2.1e-3
+    assert np.abs(out["pooler_output"].cpu().numpy() - g["pooler_output"]).max() < 1.5e-2
+    names = [str(n) for n in g["grad_names"]]
+    assert names and not any(n.startswith("bert.") for n in names)
+    bad = []
+    for n, rn in zip(names, g["grad_norms"]):
+        if ".key.bias" in n:
+            continue
+        mine = float(eng.params.gr(n).double().norm())
+        if abs(mine - rn) > 0.08 * rn + 1e-7:
+            bad.append((n, mine, rn))
+    assert not bad, bad[:5]
+    for k in g.files:
+        if k.startswith("grad::") and ".key.bias" not in k and not k.startswith("grad::bert."):
+            mine = eng.params.gr(k[6:]).cpu().numpy().reshape(g[k].shape)
+            rel = np.linalg.norm(mine - g[k]) / (np.linalg.norm(g[k]) + 1e-12)
+            assert rel < 8e-2, (k, rel)
+
+
+def test_full_size_batch_48_forward_backward_vs_oracle():
+    """The code paths of the B = 256 bench inside a real step, against the fp32 CPU oracle computed here: B = 48 at full
+    size gives 8,880 fused tokens = 35 row tiles x 9-12 column tiles (more GEMM tiles than the 256 persistent blocks:
+    several tiles per block in the 8-wave and ring kernels), 576 (batch, head) items in the resident attention
+    backward (> 256 workgroups), batched weight gradients in groups of 6 layers with the cost-model split count,
+    LayerNorm / column sums over thousands of rows.  Compared: logits, loss, pooled output, every parameter's
+    gradient norm, cosine and relative error of the large gradients."""
+    spec = _nodrop(VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3))
+    B = 48
+    bn = synthetic_batch(spec, B, seed=77, n_classes=3)
+    state = build_state(spec, 0)
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    db = _dev(bn)
+    out = eng.forward(db, train=True, labels=db["labels"], need_hidden=False)
+    eng.zero_grad()
+    eng.backward()
+    torch.cuda.synchronize()
+    assert "act_all" in eng.last and "lm_act_all" in eng.last          # the deferred, batched weight gradients ran
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    P = O.to_torch_state(state, requires_grad=True)
+    loss, ref = O.vault_loss(P, spec, O.torch_batch(bn))
+    loss.backward()
+    dl = (out["logits"].cpu() - ref["logits"].detach()).abs().max().item()
+    dloss = abs(float(out["loss"]) - float(loss.detach()))
+    print(f"full size B=48: |dlogits| {dl:.2e} |dloss| {dloss:.2e}")
+    assert dl < 7e-3, dl                                               # (max over 48 samples; B = 2 golden: 4.3e-3)
+    assert dloss < 1.5e-3
+    assert (out["pooler_output"].cpu() - ref["pooler_output"].detach()).abs().max().item() < 1.5e-2
+    bad, tot_err, tot_ref = [], 0.0, 0.0
+    for n in eng.params.trainable:
+        gr = P[n].grad
+        if gr is None or ".key.bias" in n:
+            continue
+        mine = eng.params.gr(n).cpu().double().reshape(gr.shape)
+        rn = float(gr.double().norm())
+        err = float((mine - gr.double()).norm())
+        tot_err += err ** 2; tot_ref += rn ** 2
+        if abs(float(mine.norm()) - rn) > 0.08 * rn + 1e-7:
+            bad.append((n, float(mine.norm()), rn))
+        if gr.numel() >= 768 * 768:
+            cos = float((mine * gr.double()).sum() / (mine.norm() * gr.double().norm() + 1e-30))
+            assert cos > 0.995 and err < 6e-2 * rn, (n, cos, err / rn)
+    assert not bad, bad[:5]
+    assert (tot_err / tot_ref) ** 0.5 < 2.5e-2                         # global relative L2 (1.0 % at B = 2)
+
+
+def test_experiment_script_call_sequence(tmp_path):
+    """The model-side calls of the reference's driver (ref: experiments/clsf_vault.py:196-220): from_pretrained with the
+    script's keyword arguments -> resize_token_embeddings(len(tokenizer)) -> integrate_entities_into_model (resize, get,
+    max-pool description rows into the new rows, set: vault/entity_linking.py:115-148, restated here with a stand-in
+    tokenizer) -> .to(device) -> forward; checked against the oracle on the resulting state_dict."""
+    import json
+    from safetensors.torch import save_file
+    from vault.models.vault import VaultForTMSC
+    spec = _nodrop(VaultSpec.tiny(3, "roberta"))
+    v, lm = spec.vilt, spec.lm
+    state = build_state(spec, 0)
+    for d, cfg, keys in (("vilt", {f: getattr(v, f) for f in ("vocab_size", "max_position_embeddings", "type_vocab_size",
+                                                               "modality_type_vocab_size", "hidden_size", "num_hidden_layers",
+                                                               "num_attention_heads", "intermediate_size", "layer_norm_eps",
+                                                               "image_size", "patch_size", "num_channels")},
+                          [k for k in state if not k.startswith(("bert.", "classifier."))]),
+                         ("bert", dict(model_type="roberta", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                                       **{f: getattr(lm, f) for f in ("vocab_size", "max_position_embeddings", "type_vocab_size",
+                                                                      "hidden_size", "num_hidden_layers", "num_attention_heads",
+                                                                      "intermediate_size", "layer_norm_eps", "pad_token_id")}),
+                          [k for k in state if k.startswith("bert.")])):
+        (tmp_path / d).mkdir()
+        json.dump(cfg, open(tmp_path / d / "config.json", "w"))
+        save_file({(k[5:] if d == "bert" else k): torch.from_numpy(state[k]) for k in keys}, str(tmp_path / d / "model.safetensors"))
+    model = VaultForTMSC.from_pretrained(str(tmp_path / "vilt"), str(tmp_path / "bert"), freeze_lm=False, n_classes=3,
+                                         vilt_dropout_prob=0.0, use_vilt_position_embeddings=False)
+
+    class Tok:                       # a tokenizer two entity tokens larger than the checkpoint's vocabulary
+        def __len__(self):
+            return lm.vocab_size + 2
+
+        def encode(self, text):
+            return [0] + [5 + (ord(c) % 100) for c in text][:12] + [2]
+
+    tok, descriptions = Tok(), ["a river in spain", "football club"]
+    model.resize_token_embeddings(len(tok))
+    # integrate_entities_into_model(model, descriptions, tok):
+    model.resize_token_embeddings(len(tok))
+    ecls = model.get_input_embeddings()
+    emb = ecls.weight.clone()
+    for i, desc in enumerate(reversed(descriptions)):
+        emb[-(i + 1)] = emb[tok.encode(desc)].max(0)[0]
+    ecls.weight = torch.nn.parameter.Parameter(emb)
+    model.set_input_embeddings(ecls)
+    model = model.to("cuda").eval()
+    assert model._engine.spec.lm.vocab_size == len(tok)
+    bn = synthetic_batch(model.spec, 3, seed=55, n_classes=3)
+    bn["input_ids"][0, 3] = len(tok) - 1                              # the new entity tokens occur in the text
+    bn["input_ids"][1, 2] = len(tok) - 2
+    kw = {k: torch.from_numpy(x).cuda() for k, x in bn.items() if k != "labels"}
+    with torch.no_grad():
+        logits = model(**kw)
+    sd = {k: t.detach().cpu().numpy() for k, t in model.state_dict().items()}
+    assert np.array_equal(sd["bert.embeddings.word_embeddings.weight"], emb.detach().numpy())
+    ref = O.vault_forward(O.to_torch_state(sd), model.spec, O.torch_batch(bn))
+    assert (logits.cpu() - ref["logits"]).abs().max().item() < 3e-3
+
+
+def test_external_torch_optimizer_through_the_module():
+    """INTEGRATION.md's claim that the reference trainer's loop works unchanged: ``torch.optim.AdamW`` stepping
+    ``model.parameters()`` (views of the fp32 master buffer) - the bf16 shadows every GEMM reads must follow.  Three
+    steps against the oracle driven by the same optimizer class; without the refresh the loss would not move."""
+    from vault_amd.models.vault import VaultForTMSC
+    spec = _nodrop(VaultSpec.tiny(3, "roberta"))
+    state = build_state(spec, 0)
+    model = VaultForTMSC(spec.vilt, n_classes=3, vilt_dropout_prob=0.0, bert_config=spec.lm, _state=state).to("cuda").train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.0)
+    bn = synthetic_batch(spec, 4, seed=61, n_classes=3)
+    kw = {k: torch.from_numpy(x).cuda() for k, x in bn.items() if k != "labels"}
+    labels = torch.from_numpy(bn["labels"]).cuda()
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(model(**kw), labels)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    P = O.to_torch_state(state, requires_grad=True)
+    ropt = torch.optim.AdamW([p for p in P.values()], lr=1e-3, weight_decay=0.0)
+    ref = []
+    for _ in range(3):
+        ropt.zero_grad()
+        loss, _ = O.vault_loss(P, spec, O.torch_batch(bn))
+        loss.backward()
+        ropt.step()
+        ref.append(float(loss.detach()))
+    assert ref[2] < ref[0] - 0.05                                     # lr 1e-3: the loss moves visibly
+    for a, b in zip(losses, ref):
+        assert abs(a - b) < 0.05 * abs(ref[0] - ref[2]) + 5e-3, (losses, ref)

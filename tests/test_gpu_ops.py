@@ -155,3 +155,48 @@ def test_attention_dropout_consistency():
     lhs = (dqkv[:, 2 * H:].float() * vprime.float()).sum().item()
     rhs = (dctx.float() * ctxp.float()).sum().item()
     assert abs(lhs - rhs) < 2e-2 * max(1.0, abs(rhs)), (lhs, rhs)
+
+
+@pytest.mark.parametrize("B,S,heads", [(50, 185, 12), (64, 185, 12), (300, 40, 12)])
+def test_attention_fwd_bwd_many_items(B, S, heads):
+    """More (batch, head) items than the 256 persistent workgroups of the resident attention backward (B = 50 x 12 heads =
+    600, B = 64: 768 = three full rounds): every workgroup walks several items with the next item's operands prefetched
+    under the current one's arithmetic - the code path of the B = 256 bench (3,072 items).  Key masks on a few samples,
+    three runs (a race in the item hand-off shows as run-to-run differences)."""
+    H = heads * 64
+    M = B * S
+    Mp = ((M + 255) // 256) * 256
+    qkv = torch.zeros(Mp, 3 * H, dtype=torch.bfloat16, device="cuda")
+    qkv[:M] = (_rand(M, 3 * H, seed=20) * 1.5).bfloat16()
+    keymask = torch.ones(B, S, device="cuda")
+    g = torch.Generator().manual_seed(5)
+    for b in range(0, B, 7):
+        n = int(torch.randint(1, S // 2, (1,), generator=g))
+        keymask[b, S - n:] = 0
+    keymask[3, 5:17] = 0
+    ctx = torch.zeros(Mp, H, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, heads, S, device="cuda")
+    ops.attention_fwd(qkv, keymask, ctx, lse, B, S, H, heads)
+    qr = qkv[:M].float().clone().requires_grad_(True)
+    ref, s = _attn_ref(qr, keymask, B, S, H, heads)
+    torch.cuda.synchronize()
+    assert (ctx[:M].float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
+    assert (lse - torch.logsumexp(s, dim=-1)).abs().max().item() < 1e-3
+    dctx = torch.zeros(Mp, H, dtype=torch.bfloat16, device="cuda")
+    dctx[:M] = _rand(M, H, seed=21).bfloat16()
+    ref.backward(dctx[:M].float())
+    gref = qr.grad
+    first = None
+    for rep in range(3):
+        dqkv = torch.zeros(Mp, 3 * H, dtype=torch.bfloat16, device="cuda")
+        ops.attention_bwd(qkv, keymask, ctx, lse, dctx, dqkv, B, S, H, heads)
+        torch.cuda.synchronize()
+        d = dqkv[:M].float()
+        assert (d - gref).abs().max().item() < 3e-2 * gref.abs().max().item()
+        # per-sample relative error: one wrong item among hundreds must not hide in a global norm
+        per = ((d - gref).view(B, -1).norm(dim=1) / gref.view(B, -1).norm(dim=1)).max().item()
+        assert per < 1.5e-2, per
+        if first is None:
+            first = dqkv.clone()
+        else:
+            assert torch.equal(dqkv, first)

@@ -257,3 +257,41 @@ def test_bucket_reducer_gloo_world2():
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == res[1][2]
+
+
+def test_embedding_surgery_api_and_vault_alias_package():
+    """ref model.py:130-149 / 499-509 on the CPU-resident module: resize_token_embeddings keeps the old rows, the
+    get -> rewrite -> set sequence of ``integrate_entities_into_model`` (ref: vault/entity_linking.py:133-148) lands in
+    the state_dict, renew_classifier swaps the VQA output projection; ``vault.models.vault`` is an import alias."""
+    from vault.models.vault import VaultForQuestionAnswering as AliasVQA, VaultForTMSC, VaultProcessor  # noqa: F401
+    import vault_amd.models.vault as impl
+    assert VaultForTMSC is impl.VaultForTMSC and AliasVQA is impl.VaultForQuestionAnswering
+    spec = VaultSpec.tiny(3, "roberta")
+    m = VaultForTMSC(spec.vilt, n_classes=3, bert_config=spec.lm)
+    name = "bert.embeddings.word_embeddings.weight"
+    old = m.state_dict()[name].clone()
+    V = old.shape[0]
+    emb = m.resize_token_embeddings(V + 5)
+    assert emb is m.get_input_embeddings() and tuple(emb.weight.shape) == (V + 5, spec.vilt.hidden_size)
+    assert m.spec.lm.vocab_size == V + 5 and torch.equal(m.state_dict()[name][:V], old)
+    assert set(m.state_dict()) == {n for n, _, _ in param_entries(m.spec)}
+    # the reference's entity integration: clone the table, overwrite the last rows, re-assign, hand back
+    ecls = m.get_input_embeddings()
+    table = ecls.weight.clone()
+    table[-1] = table[[3, 4, 9]].max(0)[0]
+    ecls.weight = torch.nn.parameter.Parameter(table)
+    m.set_input_embeddings(ecls)
+    assert torch.equal(m.state_dict()[name], table.detach())
+    assert dict(m.named_parameters())[name] is m._params_by_name[name]
+    m.resize_token_embeddings(V)                                   # shrinking keeps the first rows
+    assert torch.equal(m.state_dict()[name], old)
+    q = AliasVQA(spec.vilt, bert_config=spec.lm, n_classes=7)
+    w0 = q.state_dict()["classifier.0.weight"].clone()
+    q.renew_classifier(11)
+    sd = q.state_dict()
+    assert tuple(sd["classifier.3.weight"].shape) == (11, 2 * spec.vilt.hidden_size) and float(sd["classifier.3.bias"].abs().max()) == 0.0
+    assert torch.equal(sd["classifier.0.weight"], w0)
+    # positional order of the reference's pinned ViltModel.forward: head_mask sits at index 5
+    with pytest.raises(NotImplementedError, match="head_mask"):
+        m._collect_batch([torch.zeros(1, 40, dtype=torch.long), None, None, torch.zeros(1, 3, 192, 192), None,
+                          torch.ones(2, 4)], {})

@@ -632,7 +632,7 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
     if (drop) FWD_V(6, 12, 6, true); else FWD_V(6, 12, 6, false);
   } else {   // long sequences of padded, larger images: K/V image 80 KiB -> one block per CU
     auto kern = attn_fwd_kernel<10, 4, 1>;
-    static bool attr_done = false;
+    static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];
     if (!attr_done) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          attn_lds_bytes<10>());
@@ -664,7 +664,7 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
 #define RES_V(DR)                                                                                                             \
     {                                                                                                                         \
       auto kern = attn_bwd_res_kernel<6, 12, DR>;   /* 98.3 KiB of LDS: one 12-wave workgroup per CU, persistent */           \
-      static bool attr_done = false;                                                                                          \
+      static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];                                                                                          \
       if (!attr_done) {                                                                                                       \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                            attn_res_lds_bytes<6>());                                                          \
@@ -683,7 +683,7 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
     if (drop) RES_V(true) else RES_V(false)
   } else {
     auto kern = attn_bwd_kernel<10, 4, 1>;
-    static bool attr_done = false;
+    static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];
     if (!attr_done) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          attn_lds_bytes<10>());

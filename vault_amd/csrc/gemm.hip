@@ -211,12 +211,14 @@ int launch_cfg(const GemmParams& p, hipStream_t st) {
   constexpr int STAGE = (BM + BN) * BK * 2;
   constexpr int LDS = 2 * STAGE;
   auto kern = gemm_kernel<BM, BN, WM, WN, A_MODE, B_MODE, EPI>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VAULT_EINVAL;
+  if (!attr_done[dev]) {   // (function attributes are per device)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    attr_done[dev] = true;
   }
   GemmParams q = p;
   // raster groups of 4 n-tiles for short contractions (the group's B panel, 4 x BN x K bf16 <= 1.5 MiB, stays

@@ -35,8 +35,8 @@
 
 namespace {
 
-// Dynamic tile scheduler state (one per device code object; kernels of ONE stream are serialised, which is how the
-// engine launches them): two sets of eight per-XCD ticket counters.  Launch k draws from set k & 1 and clears the
+// Dynamic tile scheduler state (a `__device__` global: one copy per device; the launcher grants dynamic hand-out to
+// ONE stream per device, whose kernels are serialised - see RingSched below): two sets of eight per-XCD ticket counters.  Launch k draws from set k & 1 and clears the
 // other set for launch k + 1 (no end-of-kernel reset, no "last block" bookkeeping).
 __device__ unsigned int g_ring_tickets[2][8];
 
@@ -481,10 +481,19 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
 #undef CAPW
 }
 
-// launch parity of the dynamic scheduler's counter sets: ONE sequence for every instantiation of the kernel
-inline int next_parity() {
-  static unsigned seq = 0;
-  return (int)(seq++ & 1u);
+// Host side of the dynamic scheduler, PER DEVICE (the counters are a `__device__` global: one copy per device): the
+// launch parity - ONE sequence for every instantiation of the kernel - and the stream the dynamic launches of that
+// device are serialised on.  Launch k clears the counter set launch k + 1 draws from, which is only sound when the
+// launches of a device run one after the other: dynamic hand-out is therefore granted to ONE stream per device (the
+// first that asks); a launch that asks for it on another stream gets the static walk (correct, no shared state).
+struct RingSched {
+  unsigned seq = 0;
+  hipStream_t stream = nullptr;
+  bool bound = false;
+};
+inline RingSched& ring_sched(int dev) {
+  static RingSched s[64];
+  return s[(dev >= 0 && dev < 64) ? dev : 0];
 }
 
 template <int A_MODE, int B_MODE, int EPI, int NTQ>
@@ -493,11 +502,13 @@ int launch256(const GemmParams& p, hipStream_t st) {
   if ((p.M & 255) || (p.N % BNT) || (p.K & 63)) return VAULT_EINVAL;
   constexpr int LDS = 2 * BUFB + 4 * 16 * ((NTQ == 4 ? 64 : 96) + 4) * 4 + 16;   // ring + epilogue scratch (gemm_epi.h: 16 x LD floats per wave) + scheduler word
   auto kern = gemm256_kernel<A_MODE, B_MODE, EPI, NTQ>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VAULT_EINVAL;
+  if (!attr_done[dev]) {   // (function attributes are per device)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    attr_done[dev] = true;
   }
   GemmParams q = p;
   q.gn = (p.gn > 0) ? std::min(p.gn, p.N / BNT) : p.N / BNT;   // default: plain m-major raster (see gemm.hip)
@@ -506,7 +517,15 @@ int launch256(const GemmParams& p, hipStream_t st) {
   q.splits = (nk_total + per - 1) / per;                        // every split owns at least one K tile
   const int nwork = (p.M >> 8) * (p.N / BNT) * q.splits * ((EPI == EPI_F32_ATOMIC && p.batch > 1) ? p.batch : 1);
   dim3 grid(std::min(nwork, 256), 1, 1);
-  q.persist = (p.persist & 0xff) | (((p.persist & 1) ? next_parity() : 0) << 8);   // the sequence counts dynamic launches only
+  int persist = p.persist & 0xff;
+  int parity = 0;
+  if (persist & 1) {
+    RingSched& rs = ring_sched(dev);
+    if (!rs.bound) { rs.bound = true; rs.stream = st; }
+    if (rs.stream == st) parity = (int)(rs.seq++ & 1u);   // the sequence counts this device's dynamic launches only
+    else persist &= ~1;                                   // another stream of this device: static walk
+  }
+  q.persist = persist | (parity << 8);
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, q);
   return (int)hipGetLastError();
 }

@@ -142,7 +142,7 @@ int launch_mx8(const GemmParams& p, const uint8_t* a_scale, const uint8_t* b_sca
   if (p.M % BM || p.N % BN || p.K % BKB) return VAULT_EINVAL;
   constexpr int LDS = 2 * ((BM + BN) * BKB + (BM + BN) * 4);
   auto kern = gemm_mx8_kernel<BM, BN, WM, WN, EPI>;
-  static bool attr_done = false;
+  static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;

@@ -75,6 +75,15 @@ def _get(cfg: Any, name: str, default=None):
 def vilt_spec_from_config(cfg) -> ViltSpec:
     if isinstance(cfg, ViltSpec):
         return cfg
+    # what the kernels compute: refuse configurations that would silently compute something else
+    if _get(cfg, "hidden_act", "gelu") != "gelu":
+        raise NotImplementedError("only the exact-erf 'gelu' activation is implemented")
+    if _get(cfg, "qkv_bias", True) is False:
+        raise NotImplementedError("ViLT without q/k/v biases (qkv_bias=False) is not implemented")
+    for k in ("hidden_dropout_prob", "attention_probs_dropout_prob"):
+        if float(_get(cfg, k, 0.0) or 0.0) != 0.0:
+            raise NotImplementedError(f"ViLT-internal dropout ({k} != 0) is not implemented (the pre-trained ViLT "
+                                      "checkpoints and the reference run with 0: SURVEY D2)")
     d = ViltSpec()
     return ViltSpec(**{f: _get(cfg, f, getattr(d, f)) for f in (
         "vocab_size", "max_position_embeddings", "type_vocab_size", "modality_type_vocab_size", "hidden_size",
@@ -96,6 +105,8 @@ def lm_spec_from_config(cfg) -> Optional[LMSpec]:
     kw["pad_token_id"] = (1 if kind == "roberta" else 0) if pad is None else pad
     if _get(cfg, "hidden_act", "gelu") != "gelu":
         raise NotImplementedError("only the exact-erf 'gelu' activation is implemented")
+    if _get(cfg, "position_embedding_type", "absolute") not in (None, "absolute"):
+        raise NotImplementedError("only absolute LM position embeddings are implemented")
     return LMSpec(kind=kind, **kw)
 
 
@@ -240,6 +251,7 @@ class VaultMixin(nn.Module):
             self._names.append(n)
         lookup = dict(self.named_parameters())
         self._params_by_name = {n: lookup[self._ext_name(n)] for n in self._names}
+        self._seen_version = -1
 
     #: classes built on a HF ``ViltFor...`` head model keep the encoder under ``vilt.`` and name their head
     #: differently: engine-internal name -> state_dict key
@@ -274,11 +286,13 @@ class VaultMixin(nn.Module):
             p.data = P.w(n)
             if P.has_grad(n):
                 p.grad = None
+        self._seen_version = self._param_version()
 
     def _sync_engine_from_params(self):
         """After load_state_dict (which copies into the views in place) refresh the bf16 shadow."""
         if self._engine is not None:
             self._engine.params.refresh_shadows()
+            self._seen_version = self._param_version()
 
     def refresh_weights(self):
         """Call after an external optimizer changed the fp32 parameters (re-derives the bf16 copies)."""
@@ -297,13 +311,83 @@ class VaultMixin(nn.Module):
                 p.grad = P.gr(n)
 
     # ---- reference API --------------------------------------------------------------------
+    # ---- (token) embedding surgery: ref model.py:130-149, used by experiments/clsf_vault.py:205-220 and
+    #      vault/entity_linking.py:115-148 (resize -> get -> rewrite rows -> set) ------------------------------
+    def _word_embedding_name(self) -> str:
+        return ("bert.embeddings.word_embeddings.weight" if self.spec.lm is not None
+                else "embeddings.text_embeddings.word_embeddings.weight")
+
+    def _replace_parameters(self, new_spec: VaultSpec, new_values: Dict[str, torch.Tensor]):
+        """Adopt ``new_spec`` (changed table / head shapes) and the given tensors: re-register the changed
+        ``nn.Parameter``s at their dotted paths and, when the model lives on a GPU, re-allocate the engine's flat
+        buffers from the current values (every parameter keeps its value, ``p.data`` become views of the new buffers,
+        optimizer state of the engine is reset like a fresh ``nn.Parameter`` has none)."""
+        dev = None if self._engine is None else self._engine.device
+        cur = {n: p.detach().float().cpu() for n, p in self._params_by_name.items()}
+        self._engine = None
+        self.spec = new_spec
+        shapes = {n: tuple(shp) for n, shp, _ in param_entries(new_spec)}
+        if set(shapes) != set(self._names):
+            raise RuntimeError("parameter inventory changed: rebuild the model")
+        for n, shp in shapes.items():
+            v = new_values.get(n, cur[n])
+            if tuple(v.shape) != shp:
+                raise ValueError(f"{n}: expected shape {shp}, got {tuple(v.shape)}")
+            old = self._params_by_name[n]
+            if n in new_values or tuple(old.shape) != shp:
+                p = nn.Parameter(v.detach().float().cpu().clone(), requires_grad=old.requires_grad)
+                _attach(self, self._ext_name(n), p)
+                self._params_by_name[n] = p
+            else:
+                old.data = cur[n]
+                old.grad = None
+        if dev is not None:
+            self._bind(dev)
+
     def get_input_embeddings(self):
-        n = ("bert.embeddings.word_embeddings.weight" if self.spec.lm is not None
-             else "embeddings.text_embeddings.word_embeddings.weight")
-        return self._params_by_name[n]
+        """The word-embedding module of the LM (of ViLT without one), ref model.py:137-142: an ``nn.Module`` with a
+        ``weight`` parameter [vocab, hidden], as ``integrate_entities_into_model`` expects."""
+        mod = self
+        for part in self._ext_name(self._word_embedding_name()).split(".")[:-1]:
+            mod = mod._modules[part]
+        return mod
+
+    def set_input_embeddings(self, value):
+        """ref model.py:144-149: adopt ``value.weight`` (an ``nn.Embedding``-like module, or the module
+        :meth:`get_input_embeddings` returned after its ``weight`` was re-assigned) as the word-embedding table; a
+        different row count resizes the vocabulary."""
+        w = value.weight if hasattr(value, "weight") else value
+        w = w.detach().float().cpu()
+        name = self._word_embedding_name()
+        if w.dim() != 2 or w.shape[1] != self.spec.vilt.hidden_size:
+            raise ValueError("embedding table must be [vocab, hidden]")
+        spec = self._spec_with_vocab(int(w.shape[0]))
+        self._replace_parameters(spec, {name: w})
+
+    def _spec_with_vocab(self, n: int) -> VaultSpec:
+        if self.spec.lm is not None:
+            return dataclasses.replace(self.spec, lm=dataclasses.replace(self.spec.lm, vocab_size=n))
+        if self.spec.head == "mlm":
+            raise NotImplementedError("resizing ViLT's vocabulary under the tied masked-LM head is not implemented")
+        return dataclasses.replace(self.spec, vilt=dataclasses.replace(self.spec.vilt, vocab_size=n))
 
     def resize_token_embeddings(self, tokenizer_length):
-        raise NotImplementedError("resize_token_embeddings: rebuild the model with the new vocab_size")
+        """ref model.py:130-135 -> HF ``resize_token_embeddings``: the first min(old, new) rows are kept, new rows are
+        drawn like a fresh HF embedding (normal, std = initializer_range 0.02).  Returns the embedding module."""
+        name = self._word_embedding_name()
+        old = self._params_by_name[name].detach().float().cpu()
+        n = int(tokenizer_length)
+        if n != old.shape[0]:
+            new = torch.empty(n, old.shape[1]).normal_(mean=0.0, std=0.02)
+            k = min(n, old.shape[0])
+            new[:k] = old[:k]
+            self._replace_parameters(self._spec_with_vocab(n), {name: new})
+        if hasattr(self.config, "vocab_size") and self.spec.lm is None:
+            try:
+                self.config.vocab_size = n
+            except Exception:
+                pass
+        return self.get_input_embeddings()
 
     @classmethod
     def from_pretrained(cls, pretrained_vilt: str, pretrained_bert: Optional[str] = None, freeze_lm: bool = False,
@@ -351,13 +435,18 @@ class VaultMixin(nn.Module):
         raise NotImplementedError("lm_preprocess is fused into forward in this build")
 
     def _collect_batch(self, args, kwargs) -> Dict[str, torch.Tensor]:
-        names = ["input_ids", "attention_mask", "token_type_ids", "pixel_values", "pixel_mask", "inputs_embeds",
-                 "image_embeds", "image_token_type_idx", "output_attentions", "output_hidden_states", "return_dict"]
+        # positional order of ViltModel.forward under the reference's pinned transformers 4.48 (``head_mask`` at index 5:
+        # ref lm_preprocess reads inputs_embeds from args[6], model.py:170-172)
+        names = ["input_ids", "attention_mask", "token_type_ids", "pixel_values", "pixel_mask", "head_mask",
+                 "inputs_embeds", "image_embeds", "image_token_type_idx", "output_attentions", "output_hidden_states",
+                 "return_dict"]
         kw = dict(zip(names, args))
         dup = set(kw) & set(kwargs)
         if dup:
             raise TypeError(f"got multiple values for {sorted(dup)}")
         kw.update(kwargs)
+        if kw.get("head_mask") is not None:
+            raise NotImplementedError("head_mask is not implemented in this build")
         ids, emb = kw.get("input_ids"), kw.get("inputs_embeds")
         if ids is not None and emb is not None:
             raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
@@ -385,8 +474,23 @@ class VaultMixin(nn.Module):
                 batch[k] = kw[k].to(dev)
         return batch
 
+    def _param_version(self) -> int:
+        return sum(p._version for p in self._params_by_name.values())
+
+    def _refresh_if_params_changed(self):
+        """An external optimizer (``torch.optim`` on ``model.parameters()``, the reference trainer's loop) writes the
+        fp32 master buffer in place; every GEMM reads the bf16 shadows: re-derive them when any parameter's version
+        counter moved since the last forward."""
+        if self._engine is None:
+            return
+        v = self._param_version()
+        if v != self._seen_version:
+            self._engine.params.refresh_shadows()
+            self._seen_version = self._param_version()
+
     def _run(self, args, kwargs, want_logits: bool):
         batch = self._collect_batch(list(args), kwargs)
+        self._refresh_if_params_changed()
         params = [p for p in self._params_by_name.values() if p.requires_grad]
         train = self.training and torch.is_grad_enabled()   # autograd disables grad inside Function.forward
         return _VaultFunction.apply(self, batch, want_logits, train, *params)
@@ -522,8 +626,14 @@ class VaultForQuestionAnswering(VaultMixin):
         return model
 
     def renew_classifier(self, num_labels: int):
-        raise NotImplementedError("renew_classifier: build the model with n_classes=<num_labels> "
-                                  "(the head lives in the engine's flat parameter buffer)")
+        """ref model.py:499-509: a freshly initialised output projection ``classifier[-1]`` for ``num_labels`` answers
+        (normal std 0.02 weight, zero bias); the rest of the model keeps its values."""
+        num_labels = int(num_labels)
+        Hm = self.spec.mlp_dims[1]
+        spec = dataclasses.replace(self.spec, n_classes=num_labels)
+        self._n_classes = num_labels
+        self._replace_parameters(spec, {"classifier.3.weight": torch.empty(num_labels, Hm).normal_(mean=0.0, std=0.02),
+                                        "classifier.3.bias": torch.zeros(num_labels)})
 
     def forward(self, *args, labels=None, **kwargs):
         logits = self._run(args, kwargs, want_logits=True)

@@ -160,6 +160,9 @@ class TrainStep:
         import os
         # VAULT_FORCE_DP=1 exercises the bucketed all-reduce path even with a single rank (debug/testing)
         if self.world > 1:
+            # every rank draws its own dropout masks: the keep/drop hash takes (seed, stream, LOCAL element index), so
+            # equal seeds would give sample j of every rank the same pattern
+            engine.drop_seed = (engine.drop_seed + dist.get_rank(process_group) * 0x9E3779B1) & 0xFFFFFFFF
             # the gradient all-reduce (RCCL kernels on a side stream) shares the CUs with the backward GEMMs: hand the
             # GEMM tiles out dynamically so that a CU held by the collective does not stall a static tile walk.
             # (The tape records the argument structs: this must be set before the first step is recorded.)
@@ -185,7 +188,10 @@ class TrainStep:
             # staging decides the image geometry (square all-valid canvas, or a padded batch of differently sized
             # images: host-side patch selection); every geometry has its own workspace, hence its own tape
             ws = eng.stage_inputs(batch, True, labels, validate=not self.assume_full_pixel_mask)
-            key = ws["key"]
+            # what the recorded launches bake in besides the buffers of the (B, T, geometry) workspace: whether token
+            # types were given, the launch stream, the GEMM scheduling mode and the forward number format
+            key = ws["key"] + (ws["tt"] is None, torch.cuda.current_stream().cuda_stream, ops.GEMM_SCHED,
+                               bool(eng.fp8_forward))
             if self.use_tape and self._tape is not None and self._tape_key == key and self._tape_ws is ws:
                 eng.drop_seed = (eng.drop_seed + 1) & 0xFFFFFFFF
                 self._tape.replay(seed=eng.drop_seed)
