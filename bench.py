@@ -11,8 +11,8 @@ RCCL all-reduce of gradients).
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").  `roofline` is the dominant kernel of the
 step by GPU time (rocprofv3 --stats, profiles/): the weight-gradient instantiation of the bf16 MFMA ring
 GEMM, gemm256_kernel<1,1,EPI_F32_ATOMIC,4>, timed live with events on the launch stream around all of its
-launches (ViLT layers + patch projection) in every 4th timed step; `roofline_ffn1` is the same for the FFN-in forward instantiation (the
-largest single GEMM call site); `step_mfma_frac` is the whole step against the 2.5 PFLOP/s dense bf16 peak
+launches (ViLT layers + patch projection) in every 4th timed step; `roofline_ffn1` is the same for the FFN-in forward GEMM (the
+largest single GEMM call site; 8-wave kernel gemm8w_kernel<EPI_BF16_GELU,4>); `step_mfma_frac` is the whole step against the 2.5 PFLOP/s dense bf16 peak
 with BASELINE.md's 120.67 GFLOP/sample.  `cpu_baseline` times the CPU oracle (plain fp32 torch
 restatement of the reference path) on the host cores, on a bounded sample.
 """
@@ -38,53 +38,87 @@ FLOP_PER_SAMPLE_TRAIN = 120.67e9      # BASELINE.md §2 (fwd 40.22 GF x 3)
 PEAK_BF16 = 2.5e15                    # MI355X dense bf16 MFMA, MI355X_MICROARCH.md
 
 
-def cpu_baseline(spec, seconds_budget: float = 30.0, batch: int = 8):
+def _physical_cores() -> int:
+    try:
+        import psutil
+        return int(psutil.cpu_count(logical=False) or os.cpu_count() or 1)
+    except Exception:
+        return int(os.cpu_count() or 1)
+
+
+def cpu_baseline(spec, seconds_budget: float = 36.0):
     """Oracle (fp32 torch restatement of the reference path) fwd + bwd + HF-AdamW on the host cores.
 
-    Bounded sample: at most `seconds_budget` of timed CPU work at batch 8 (one un-timed step first:
-    allocator / thread-pool warm-up).  32 threads at most: eager torch CPU ops on this model stop scaling
-    (and collapse from oversubscription) far below the 256 hardware threads of the GPU box."""
+    Bounded samples: batch 8 at 32 threads, batch 8 at every physical core, batch 32 at 32 threads - a
+    third of `seconds_budget` each (one un-timed step first: allocator / thread-pool warm-up).  Eager torch CPU ops on
+    this model stop scaling far below the core count of the GPU box, so `value` / `cores` are the FASTEST point; every
+    point is listed in `runs`."""
     from oracle import vault_oracle as O
-    cores = max(1, min(32, os.cpu_count() or 1))
-    torch.set_num_threads(cores)
     state = build_state(spec, 0)
-    P = O.to_torch_state(state, requires_grad=True)
-    names = [k for k in P]
-    m = {k: torch.zeros_like(v) for k, v in P.items()}
-    v2 = {k: torch.zeros_like(v) for k, v in P.items()}
-    bn = synthetic_batch(spec, batch, seed=99, n_classes=3)
-    tb = O.torch_batch(bn)
+    phys = _physical_cores()
+    points = [(min(32, phys), 8), (phys, 8), (min(32, phys), 32)]
+    runs = []
+    for cores, batch in points:
+        if any(r["cores"] == cores and r["batch"] == batch for r in runs):
+            continue
+        torch.set_num_threads(cores)
+        P = O.to_torch_state(state, requires_grad=True)
+        names = [k for k in P]
+        m = {k: torch.zeros_like(v) for k, v in P.items()}
+        v2 = {k: torch.zeros_like(v) for k, v in P.items()}
+        tb = O.torch_batch(synthetic_batch(spec, batch, seed=99, n_classes=3))
 
-    def step(t):
-        for p in P.values():
-            p.grad = None
-        loss, _ = O.vault_loss(P, spec, tb)
-        loss.backward()
-        with torch.no_grad():
-            for k in names:
-                g = P[k].grad
-                if g is None:
-                    continue
-                O.hf_adamw_step(P[k], g, m[k], v2[k], 2e-5, t)
-        return float(loss.detach())
+        def step(t):
+            for p in P.values():
+                p.grad = None
+            loss, _ = O.vault_loss(P, spec, tb)
+            loss.backward()
+            with torch.no_grad():
+                for k in names:
+                    g = P[k].grad
+                    if g is not None:
+                        O.hf_adamw_step(P[k], g, m[k], v2[k], 2e-5, t)
 
-    t0 = time.time()
-    step(1)  # warm-up (allocator, thread pools), also a guard: a pathological host aborts the baseline
-    warm = time.time() - t0
-    if warm > 4 * seconds_budget:
-        return {"value": round(batch / warm, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-                "sample": f"warm-up step only (fwd+bwd+AdamW fp32, batch {batch}): {warm:.1f} s - host too slow to time more"}
-    t0 = time.time()
-    n = 0
-    while True:
-        step(n + 2)
-        n += 1
-        if time.time() - t0 > seconds_budget * 0.5 or n >= 16:
-            break
-    dt = time.time() - t0
-    return {"value": round(batch * n / dt, 3), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{n} full fine-tune steps (fwd+bwd+AdamW, fp32) of the CPU oracle at batch {batch}, "
-                      f"same model shape and synthetic inputs; {dt:.1f} s on {cores} threads"}
+        t0 = time.time()
+        step(1)
+        warm = time.time() - t0
+        if warm > seconds_budget:   # a pathological host: keep the warm-up step as the sample
+            runs.append({"cores": cores, "batch": batch, "value": round(batch / warm, 3), "steps": 1, "seconds": round(warm, 1)})
+            continue
+        t0 = time.time()
+        n = 0
+        while True:
+            step(n + 2)
+            n += 1
+            if time.time() - t0 > seconds_budget / 3.0 or n >= 16:
+                break
+        dt = time.time() - t0
+        runs.append({"cores": cores, "batch": batch, "value": round(batch * n / dt, 3), "steps": n, "seconds": round(dt, 1)})
+        del P, m, v2
+    best = max(runs, key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "samples/s", "cores": best["cores"], "kind": "port",
+            "sample": f"{best['steps']} full fine-tune steps (fwd+bwd+AdamW, fp32) of the CPU oracle at batch {best['batch']}, same "
+                      f"model shape and synthetic inputs; {best['seconds']} s on {best['cores']} threads "
+                      f"({phys} physical cores on the box; the optimizer part is formula-pinned only: no reference AdamW "
+                      f"under transformers 5.15)",
+            "runs": runs}
+
+
+def measure_parity(eng, spec, args, dev):
+    """Logits / loss of the eval-mode forward on the reference-generated golden batch (tests/golden/, B = 2, the same
+    deterministic weights the bench engine holds: seed 0) - in the number format the timed steps use, and in the
+    precise (split-bf16) inference mode with its throughput at the bench batch."""
+    name = "full_bert_base_frozen_b2" if args.lm == "bert-base-uncased" else "full_bertweet_b2"
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    bn = synthetic_batch(spec, int(g["meta_batch"]), seed=int(g["meta_data_seed"]), n_classes=3)
+    db = {k: torch.from_numpy(v).to(dev) for k, v in bn.items()}
+    out = {}
+    for mode, precise in (("fast", False), ("precise", True)):
+        o = eng.forward(db, train=False, labels=db["labels"], need_hidden=False, precise=precise)
+        torch.cuda.synchronize(dev)
+        out[mode] = {"max_abs_dlogits": float(np.abs(o["logits"].cpu().numpy() - g["logits"]).max()),
+                     "dloss": abs(float(o["loss"]) - float(g["loss"]))}
+    return name, out
 
 
 def main():
@@ -98,6 +132,8 @@ def main():
     ap.add_argument("--fp8-forward", action="store_true",
                     help="BASELINE config 5: MXFP8 forward Linear GEMMs (block-scaled fp8 MFMA), bf16 backward")
     ap.add_argument("--lm", default="bertweet", choices=["bertweet", "bert-base-uncased"])
+    ap.add_argument("--no-parity", action="store_true", help="skip the golden-batch parity measurement and the precise-mode timing")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the second timed loop with pipelined host->device input copies")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -123,6 +159,16 @@ def main():
                        assume_full_pixel_mask=True)   # synthetic 384x384 images, all-ones masks: no per-step mask check
 
     B = args.batch
+    parity = None
+    if rank == 0 and not args.no_parity:
+        gname, par = measure_parity(eng, spec, args, dev)
+        parity = {"golden": f"tests/golden/{gname}.npz (reference-generated, B = 2, eval mode)",
+                  "mode": ("mxfp8 forward GEMMs" if args.fp8_forward else "bf16 MFMA operands, fp32 accumulate (the timed mode)"),
+                  "max_abs_dlogits": round(par["fast"]["max_abs_dlogits"], 6), "dloss": round(par["fast"]["dloss"], 6),
+                  "north_star_tolerance": 1e-3,
+                  "precise_mode": {"what": "inference-only split-bf16 (bf16x3) GEMMs: fp32-class products on the bf16 MFMA path",
+                                   "max_abs_dlogits": round(par["precise"]["max_abs_dlogits"], 6),
+                                   "dloss": round(par["precise"]["dloss"], 6)}}
     bn = synthetic_batch(spec, B, seed=1234 + rank, n_classes=3)
     batch = {k: torch.from_numpy(v).to(dev) for k, v in bn.items() if k != "labels"}
     labels = torch.from_numpy(bn["labels"]).to(dev)
@@ -162,6 +208,73 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- second loop: the same K steps with the input copies inside the loop (ref: tmsc_utils/trainer.py:183-202,353
+    #      batch_to_device): a fresh host batch per step from pinned memory, copied on a side stream into one of two
+    #      device buffers while the previous step computes (the engine's staging then takes a device-to-device copy)
+    h2d = None
+    if not args.no_h2d:
+        nb = 2
+        host = []
+        for i in range(nb):
+            hb = synthetic_batch(spec, B, seed=4321 + 7 * rank + i, n_classes=3)
+            host.append({k: torch.from_numpy(v).pin_memory() for k, v in hb.items() if k in ("input_ids", "attention_mask", "pixel_values", "pixel_mask", "labels")})
+        devb = [{k: torch.empty_like(v, device=dev) for k, v in host[0].items()} for _ in range(nb)]
+        copy_stream = torch.cuda.Stream(device=dev)
+        ready = [torch.cuda.Event() for _ in range(nb)]
+        consumed = [torch.cuda.Event() for _ in range(nb)]
+
+        def prefetch(k):
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(consumed[k % nb])
+                for name, t_ in host[k % nb].items():
+                    devb[k % nb][name].copy_(t_, non_blocking=True)
+                ready[k % nb].record(copy_stream)
+
+        for i in range(nb):
+            consumed[i].record(torch.cuda.current_stream(dev))
+        prefetch(0)
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            if k + 1 < args.steps:
+                prefetch(k + 1)
+            torch.cuda.current_stream(dev).wait_event(ready[k % nb])
+            d = devb[k % nb]
+            stepper({n_: d[n_] for n_ in ("input_ids", "attention_mask", "pixel_values", "pixel_mask")}, d["labels"])
+            consumed[k % nb].record(torch.cuda.current_stream(dev))
+        sync_all()
+        dt2 = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt2 = float(t.item())
+        h2d = {"value": round(B * world * args.steps / dt2, 2), "ms_per_step": round(dt2 / args.steps * 1e3, 3),
+               "what": "the same steps with a fresh pinned host batch per step copied host->device on a side stream "
+                       "(double-buffered, overlapped with the previous step) + one device-to-device copy into the staging buffers"}
+
+    precise_fwd = None
+    if rank == 0 and not args.no_parity and not args.fp8_forward:
+        # throughput of the mode that meets the north star's 1e-3: eval forward, split-bf16 GEMMs, at the bench batch
+        ev = {k: v for k, v in batch.items()}
+        for _ in range(2):
+            eng.forward(ev, train=False, need_hidden=False, precise=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            eng.forward(ev, train=False, need_hidden=False, precise=True)
+        torch.cuda.synchronize(dev)
+        tp = (time.perf_counter() - t0) / 5
+        for _ in range(2):
+            eng.forward(ev, train=False, need_hidden=False)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            eng.forward(ev, train=False, need_hidden=False)
+        torch.cuda.synchronize(dev)
+        tf = (time.perf_counter() - t0) / 5
+        precise_fwd = {"precise_forward_samples_per_s": round(B / tp, 1), "fast_forward_samples_per_s": round(B / tf, 1),
+                       "batch": B}
+
     if rank == 0:
         sps = B * world * args.steps / dt
         v = spec.vilt
@@ -179,23 +292,26 @@ def main():
             # HBM/fabric bytes of that kernel from PMC counters (separate rocprofv3 --pmc passes, committed under
             # profiles/: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE), average per launch; only for the profiled batch
             traffic = None
+            traffic_src = None
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 if pm.get("batch") == B and pm.get("lm") == args.lm and not args.freeze_lm:
                     traffic = pm["traffic_bytes_per_launch_avg"]
+                    traffic_src = f"profiles/{pmc_file} (separate rocprofv3 --pmc passes of this workload; not measured in this run)"
             except Exception:
                 traffic = None
             return {"bound": "mfma", "kernel": kernel, "flop_per_launch_avg": round(float(np.mean(fl)) / 1e9, 2),
                     "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
-                    "traffic": traffic, "launches_timed": len(ms), "avg_launch_ms": round(float(np.mean(ms)), 4)}
+                    "traffic": traffic, "traffic_source": traffic_src, "launches_timed": len(ms),
+                    "avg_launch_ms": round(float(np.mean(ms)), 4)}
 
         r_wgrad = roof("wgrad", "gemm256_kernel<1,1,5,4> (A[K][M]^T B[K][N], EPI_F32_ATOMIC): the weight-gradient GEMMs, "
                                 f"dW[N x K] += dY[tokens][N]^T X[tokens][K] - batched launches of 6 layers each ({M} ViLT tokens / "
                                 f"{B * 40} LM tokens per layer; FFN-out, FFN-in, attention-out, QKV) and the patch projection",
-                       "r01_pmc_gemm_wgrad.json")
-        r_ffn1 = roof("ffn1", "gemm256_kernel<0,0,1,4> (EPI_BF16_GELU): FFN-in forward, ViLT "
+                       "r02_pmc_gemm_wgrad.json")
+        r_ffn1 = roof("ffn1", "gemm8w_kernel<1,4> (EPI_BF16_GELU, 256-wide tiles, register-direct epilogue): FFN-in forward, ViLT "
                               f"[{M}x{v.intermediate_size}x{v.hidden_size}] + LM [{B * 40}x{v.intermediate_size}x{v.hidden_size}]",
-                      "r01_pmc_gemm_ffn1.json")
+                      "r02_pmc_gemm_ffn1.json")
         out = {
             "metric": "train samples/sec (img+text pairs) ViLT-B32+BERTweet, bs256, 1/2/4/8 MI355X",
             "value": round(sps, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -211,6 +327,12 @@ def main():
             "step_mfma_frac": round(sps / world * flop_per_sample / PEAK_BF16, 4),
             "final_loss": round(loss, 5),
         }
+        if parity is not None:
+            if precise_fwd is not None:
+                parity["precise_mode"].update(precise_fwd)
+            out["parity"] = parity
+        if h2d is not None:
+            out["with_h2d_input_copies"] = h2d
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(spec)

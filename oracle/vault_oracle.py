@@ -140,6 +140,36 @@ def lm_forward(P, spec, input_ids, attention_mask, token_type_ids=None, taps: Op
     return x
 
 
+def _select_patches(pixel_mask: torch.Tensor, gh: int, gw: int):
+    """The oracle's OWN restatement of the patch bookkeeping of ``ViltEmbeddings.visual_embed``
+    (HF:models/vilt/modeling_vilt.py:96-101 mask interpolation, :130-160 valid / non-valid indices and the padding
+    draw) - independent of the product's ``vault_amd.spec.select_patches``.  Where the reference samples
+    (``torch.multinomial`` over valid patches for the order, over non-valid ones for the padding), the deterministic
+    member of its outcome set is taken: valid patches in ``nonzero`` (row-major) order, padding = the non-valid patches
+    repeated in order.  Returns numpy sel [B, L] (slot on the gh x gw grid), valid [B, L], hw [B, 2] and L."""
+    x_mask = F.interpolate(pixel_mask[:, None, :, :].float(), size=(gh, gw)).long()     # nearest, like HF :97
+    x_h = x_mask[:, 0].sum(dim=1)[:, 0]
+    x_w = x_mask[:, 0].sum(dim=2)[:, 0]
+    eff = x_h * x_w
+    L = int(eff.max())
+    flat = x_mask.flatten(1)                                                            # [B, gh*gw]
+    sel_rows, valid_rows = [], []
+    for b in range(flat.shape[0]):
+        v_idx = flat[b].nonzero(as_tuple=False)[:, 0]
+        nv_idx = (1 - flat[b]).nonzero(as_tuple=False)[:, 0]
+        pad = L - int(v_idx.numel())
+        if pad <= 0:
+            sel_rows.append(v_idx[:L]); valid_rows.append(torch.ones(L, dtype=torch.long))
+        else:
+            reps = nv_idx.repeat((pad + nv_idx.numel() - 1) // nv_idx.numel())[:pad]
+            sel_rows.append(torch.cat([v_idx, reps]))
+            valid_rows.append(torch.cat([torch.ones(v_idx.numel(), dtype=torch.long), torch.zeros(pad, dtype=torch.long)]))
+    sel = torch.stack(sel_rows).numpy().astype(np.int32)
+    valid = torch.stack(valid_rows).numpy().astype(np.int32)
+    hw = torch.stack([x_h, x_w], dim=1).numpy().astype(np.int32)
+    return sel, valid, hw, L
+
+
 def vilt_embed(P, spec, text_in, attention_mask, token_type_ids, pixel_values, taps=None, pixel_mask=None,
                image_type_idx: int = 1):
     """text_in: LM output [B,T,H] (inputs_embeds) or int64 ids [B,T] when no LM is used."""
@@ -174,9 +204,8 @@ def vilt_embed(P, spec, text_in, attention_mask, token_type_ids, pixel_values, t
     else:
         # padded / non-square images (HF:models/vilt/modeling_vilt.py:92-178): per-image bilinear resize of the
         # g x g position table to the image's own h x w patch grid (align_corners=True, zero outside), patch
-        # selection by vault_amd.spec.select_patches (deterministic stand-in for the reference's multinomial)
-        from vault_amd.spec import select_patches
-        sel, valid, hw, _, L = select_patches(pixel_mask.numpy(), v.patch_size, -1)
+        # selection by _select_patches above (the deterministic member of the reference's random outcomes)
+        sel, valid, hw, L = _select_patches(pixel_mask, gh, gw)
         spatial = pos[:, 1:, :].transpose(1, 2).reshape(1, -1, g, g)
         rows = []
         for b in range(B):
