@@ -180,6 +180,14 @@ int vault_image_pos_sel_fwd(float* x, const float* pos_emb, const int* sel, cons
 int vault_image_sel_bwd(const float* dx, float* dpos, float* dmtype1, float* dcls, float* dconv_bias, void* dyp_bf16,
                         const int* sel, const int* hw, int B, int L, int S, int T, int H, int gw, int G, void* stream);
 int vault_axpy_f32(float* dst, const float* src, float a, long long n, void* stream);
+/* ABI 4: externally supplied image embeddings (HF ViltEmbeddings.forward with `image_embeds`, modeling_vilt.py:190-207;
+ * reached from the reference through TomViltForTMSC, ref: vault/models/tomvilt/model.py:281-287): only the modality type
+ * is added.  out[map(r)] = src[r] + vec with map(r) = (r / rpg) * gstride + goff + r % rpg (the image rows of the fused
+ * sequence); backward: dsrc[r] = dx[map(r)], dvec (optional) += their column sums. */
+int vault_rows_add_f32(const float* src, const float* vec, float* out, int rows, int H, int rpg, int gstride, int goff,
+                       void* stream);
+int vault_rows_gather_bwd_f32(const float* dx, float* dsrc, float* dvec, int rows, int H, int rpg, int gstride, int goff,
+                              void* stream);
 
 /* ---- head + loss ----------------------------------------------------------------------------
  * pooled = tanh(pre) ; logits = dropout(pooled) Wc^T + bc ; loss_sum += loss_scale * sum_b CE_b

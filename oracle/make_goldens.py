@@ -442,6 +442,38 @@ def run_reference_mlm(ref, name, outdir):
           f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
+def run_reference_embeds(ref, name, outdir):
+    """``inputs_embeds`` + ``image_embeds`` through the reference classes (ref model.py:170-200 hands inputs_embeds to the
+    LM; HF ViltEmbeddings.forward takes image_embeds as they are, modeling_vilt.py:190-207; the path TomViltForTMSC uses,
+    ref: vault/models/tomvilt/model.py:281-287): logits, pooled output, hidden states and the gradients of both inputs."""
+    spec = VaultSpec.tiny(3, "bert")
+    model, _ = build_reference_model(ref, spec, seed=0)
+    B, T, L, H = 3, 40, 37, spec.vilt.hidden_size
+    rng = np.random.default_rng(31)
+    te = torch.from_numpy((rng.standard_normal((B, T, H)) * 0.5).astype(np.float32)).requires_grad_(True)
+    ie = torch.from_numpy((rng.standard_normal((B, L, H)) * 0.5).astype(np.float32)).requires_grad_(True)
+    am = np.ones((B, T), np.int64); am[1, 29:] = 0
+    pm = np.ones((B, L), np.int64); pm[2, 30:] = 0
+    tt = np.zeros((B, T), np.int64); tt[:, 20:] = 1
+    labels = np.array([0, 2, 1], np.int64)
+    model.zero_grad(set_to_none=True)
+    enc = super(type(model), model).forward(inputs_embeds=te, image_embeds=ie, attention_mask=torch.from_numpy(am),
+                                            pixel_mask=torch.from_numpy(pm), token_type_ids=torch.from_numpy(tt))
+    logits = model.classifier(enc.pooler_output).squeeze(-1)
+    loss = torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(labels))
+    loss.backward()
+    out = dict(inputs_embeds=te.detach().numpy(), image_embeds=ie.detach().numpy(), attention_mask=am, pixel_mask=pm,
+               token_type_ids=tt, labels=labels, logits=logits.detach().numpy(),
+               pooler_output=enc.pooler_output.detach().numpy(), last_hidden_state=enc.last_hidden_state.detach().numpy(),
+               loss=np.float32(loss.item()), d_inputs_embeds=te.grad.numpy(), d_image_embeds=ie.grad.numpy(),
+               grad_norm_word_embeddings=np.float64(0.0 if model.bert.embeddings.word_embeddings.weight.grad is None else
+                                                    float(model.bert.embeddings.word_embeddings.weight.grad.norm())),
+               grad_modality_type=model.embeddings.token_type_embeddings.weight.grad.numpy())
+    path = os.path.join(outdir, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, "loss", out["loss"], "logits", out["logits"].ravel()[:6], "->", path, f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
 def nlvr2_pixels(spec, B, dseed):
     """The two-image pixel tensor of the NLVR2 case (shared with the tests)."""
     rng = np.random.Generator(np.random.PCG64(dseed + 1))
@@ -484,6 +516,8 @@ def main():
         np.savez_compressed(path, **out)
         print(name, "loss", out["loss"], "logits", out["logits"].ravel()[:6], "->", path,
               f"{os.path.getsize(path)/1024:.0f} KiB")
+    if not only or "tiny_bert_embeds_inputs" in only:
+        run_reference_embeds(ref, "tiny_bert_embeds_inputs", outdir)
     if not only or "tiny_roberta_mlm" in only:
         run_reference_mlm(ref, "tiny_roberta_mlm", outdir)
     if not only or "tiny_roberta_nlvr2" in only:

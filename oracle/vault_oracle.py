@@ -114,12 +114,25 @@ def lm_position_ids(input_ids: torch.Tensor, lm) -> torch.Tensor:
     return torch.arange(input_ids.shape[1]).unsqueeze(0).expand_as(input_ids)
 
 
-def lm_forward(P, spec, input_ids, attention_mask, token_type_ids=None, taps: Optional[dict] = None):
+def lm_forward(P, spec, input_ids, attention_mask, token_type_ids=None, taps: Optional[dict] = None,
+               inputs_embeds: Optional[torch.Tensor] = None):
+    """``inputs_embeds`` [B,T,H] instead of ids (ref model.py:170-190 passes them on to the LM): the word-embedding
+    lookup is skipped and the position ids count every position (HF:models/roberta/modeling_roberta.py
+    ``create_position_ids_from_inputs_embeds``: pad + 1 .. pad + T; BERT: arange)."""
     lm = spec.lm
-    pos = lm_position_ids(input_ids, lm)
+    if inputs_embeds is not None:
+        B_, T_ = inputs_embeds.shape[:2]
+        base = lm.pad_token_id + 1 if lm.kind == "roberta" else 0
+        pos = (torch.arange(T_) + base).unsqueeze(0).expand(B_, T_)
+        words = inputs_embeds
+        like = torch.zeros((B_, T_), dtype=torch.long)
+    else:
+        pos = lm_position_ids(input_ids, lm)
+        words = P["bert.embeddings.word_embeddings.weight"][input_ids]
+        like = input_ids
     if token_type_ids is None or lm.type_vocab_size < 2:
-        token_type_ids = torch.zeros_like(input_ids)   # ref: model.py:174-180
-    x = (P["bert.embeddings.word_embeddings.weight"][input_ids]
+        token_type_ids = torch.zeros_like(like)   # ref: model.py:174-180
+    x = (words
          + P["bert.embeddings.token_type_embeddings.weight"][token_type_ids]
          + P["bert.embeddings.position_embeddings.weight"][pos])
     x = _ln(x, P["bert.embeddings.LayerNorm.weight"], P["bert.embeddings.LayerNorm.bias"], lm.layer_norm_eps)
@@ -171,10 +184,10 @@ def _select_patches(pixel_mask: torch.Tensor, gh: int, gw: int):
 
 
 def vilt_embed(P, spec, text_in, attention_mask, token_type_ids, pixel_values, taps=None, pixel_mask=None,
-               image_type_idx: int = 1):
+               image_type_idx: int = 1, image_embeds: Optional[torch.Tensor] = None):
     """text_in: LM output [B,T,H] (inputs_embeds) or int64 ids [B,T] when no LM is used."""
     v = spec.vilt
-    B = pixel_values.shape[0]
+    B = attention_mask.shape[0]
     T = attention_mask.shape[1]
     if token_type_ids is None:
         token_type_ids = torch.zeros((B, T), dtype=torch.long)
@@ -191,6 +204,11 @@ def vilt_embed(P, spec, text_in, attention_mask, token_type_ids, pixel_values, t
             v.layer_norm_eps)
     mt = P["embeddings.token_type_embeddings.weight"]
     text = e + mt[0]
+    if image_embeds is not None:
+        img = image_embeds + mt[image_type_idx]
+        img_mask = (torch.ones(img.shape[:2], dtype=attention_mask.dtype) if pixel_mask is None
+                    else pixel_mask.flatten(1).to(attention_mask.dtype))
+        return torch.cat([text, img], dim=1), torch.cat([attention_mask, img_mask], dim=1)
     pe = F.conv2d(_r(pixel_values), _r(P["embeddings.patch_embeddings.projection.weight"]),
                   P["embeddings.patch_embeddings.projection.bias"], stride=v.patch_size)
     gh, gw = pe.shape[2], pe.shape[3]
@@ -250,14 +268,28 @@ def vault_forward(P, spec, batch: Dict[str, torch.Tensor], taps: Optional[dict] 
     """Returns dict(last_hidden_state, pooler_output[, logits]).  Eval-mode arithmetic
     (all dropouts off) unless ``classifier_keep_mask`` is given (train-mode head dropout
     with an explicit mask so a GPU run with the same mask can be compared)."""
-    ids = batch["input_ids"]
+    ids = batch.get("input_ids")
     am = batch["attention_mask"]
     tt = batch.get("token_type_ids")
-    pix = batch["pixel_values"]
+    pix = batch.get("pixel_values")
+    temb = batch.get("inputs_embeds")
     if spec.lm is not None:
-        text_in = lm_forward(P, spec, ids, am, tt, taps)
+        text_in = lm_forward(P, spec, ids, am, tt, taps, inputs_embeds=temb)
     else:
-        text_in = ids
+        text_in = ids if temb is None else temb
+    if batch.get("image_embeds") is not None:
+        # HF ViltEmbeddings.forward with image_embeds (modeling_vilt.py:190-207): no patch projection / CLS / position
+        # table; image_masks = pixel_mask.flatten(1); only the modality type is added
+        x, mask = vilt_embed(P, spec, text_in, am, tt, None, taps, pixel_mask=batch.get("pixel_mask"),
+                             image_embeds=batch["image_embeds"])
+        x = vilt_encoder(P, spec, x, mask, taps)
+        x = _ln(x, P["layernorm.weight"], P["layernorm.bias"], spec.vilt.layer_norm_eps)
+        out = {"last_hidden_state": x}
+        if spec.add_pooling_layer:
+            out["pooler_output"] = torch.tanh(_lin(x[:, 0], P["pooler.dense.weight"], P["pooler.dense.bias"]))
+            if spec.n_classes > 0 and getattr(spec, "head", "linear") == "linear":
+                out["logits"] = F.linear(out["pooler_output"], P["classifier.1.weight"], P["classifier.1.bias"]).squeeze(-1)
+        return out
     if getattr(spec, "num_images", 1) > 1:
         # HF ViltForImagesAndTextClassification.forward (modeling_vilt.py): one encoder pass per image with modality
         # type i + 1, pooled outputs concatenated, MLP classifier; the text goes through the LM once (ref

@@ -710,3 +710,45 @@ def test_external_torch_optimizer_through_the_module():
     assert ref[2] < ref[0] - 0.05                                     # lr 1e-3: the loss moves visibly
     for a, b in zip(losses, ref):
         assert abs(a - b) < 0.05 * abs(ref[0] - ref[2]) + 5e-3, (losses, ref)
+
+
+def test_inputs_embeds_and_image_embeds_vs_reference_golden():
+    """``inputs_embeds`` (text embeddings handed to the LM in place of ids, ref model.py:170-200) and ``image_embeds`` +
+    ``pixel_mask`` [B, L] (HF modeling_vilt.py:190-207; the path of ref TomViltForTMSC, tomvilt/model.py:281-287) through
+    the module API against numbers produced by the reference classes: outputs, and the gradients that flow back to both
+    inputs through the autograd bridge."""
+    from vault_amd.models.vault import VaultForTMSC, VaultModel
+    g = np.load(os.path.join(GOLD, "tiny_bert_embeds_inputs.npz"))
+    spec = _nodrop(VaultSpec.tiny(3, "bert"))
+    state = build_state(spec, 0)
+    model = VaultForTMSC(spec.vilt, n_classes=3, vilt_dropout_prob=0.0, bert_config=spec.lm, _state=state).to("cuda").train()
+    te = torch.from_numpy(g["inputs_embeds"]).cuda().requires_grad_(True)
+    ie = torch.from_numpy(g["image_embeds"]).cuda().requires_grad_(True)
+    kw = dict(inputs_embeds=te, image_embeds=ie, attention_mask=torch.from_numpy(g["attention_mask"]).cuda(),
+              pixel_mask=torch.from_numpy(g["pixel_mask"]).cuda(), token_type_ids=torch.from_numpy(g["token_type_ids"]).cuda())
+    logits = model(**kw)
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(g["labels"]).cuda())
+    loss.backward()
+    assert np.abs(logits.detach().cpu().numpy() - g["logits"]).max() < 3e-3
+    assert abs(float(loss) - float(g["loss"])) < 2e-3
+    for mine, ref in ((te.grad, g["d_inputs_embeds"]), (ie.grad, g["d_image_embeds"])):
+        mine = mine.cpu().numpy()
+        assert np.linalg.norm(mine - ref) < 5e-2 * np.linalg.norm(ref)
+    assert float(model._engine.params.gr("bert.embeddings.word_embeddings.weight").abs().max()) == 0.0   # no lookup, no gradient
+    gm = model._engine.params.gr("embeddings.token_type_embeddings.weight").cpu().numpy()
+    assert np.linalg.norm(gm - g["grad_modality_type"]) < 5e-2 * np.linalg.norm(g["grad_modality_type"])
+    # headless encoder, eval mode: hidden states of every valid row
+    enc = VaultModel(spec.vilt, bert_config=spec.lm, _state={k: v for k, v in state.items() if not k.startswith("classifier.")}).to("cuda").eval()
+    with torch.no_grad():
+        o = enc(**{k: (v.detach() if torch.is_tensor(v) else v) for k, v in kw.items()})
+    T = g["attention_mask"].shape[1]
+    valid = np.concatenate([g["attention_mask"], g["pixel_mask"]], axis=1).astype(bool)
+    h, hr = o.last_hidden_state.cpu().numpy(), g["last_hidden_state"]
+    assert h.shape == hr.shape == (3, T + g["image_embeds"].shape[1], spec.vilt.hidden_size)
+    assert np.abs(h[valid] - hr[valid]).max() < 1.5e-2 * np.abs(hr).max()
+    assert np.abs(o.pooler_output.cpu().numpy() - g["pooler_output"]).max() < 1e-2
+    # HF's errors for inconsistent inputs
+    with pytest.raises(ValueError):
+        enc(input_ids=torch.zeros(3, T, dtype=torch.long), inputs_embeds=te.detach(), image_embeds=ie.detach())
+    with pytest.raises(ValueError):
+        enc(inputs_embeds=te.detach())

@@ -291,3 +291,25 @@ def test_linear_schedule():
     assert O.linear_schedule_lr(1.0, 10, 10, 100) == 1.0
     assert abs(O.linear_schedule_lr(1.0, 55, 10, 100) - 0.5) < 1e-12
     assert O.linear_schedule_lr(1.0, 100, 10, 100) == 0.0
+
+
+def test_embeds_inputs_vs_reference_golden():
+    """``inputs_embeds`` (through the LM) and ``image_embeds`` (+ ``pixel_mask`` [B, L]) as the reference classes take
+    them (ref model.py:170-200, HF modeling_vilt.py:190-207): outputs and the gradients of both inputs."""
+    g = np.load(os.path.join(GOLD, "tiny_bert_embeds_inputs.npz"))
+    spec = VaultSpec.tiny(3, "bert")
+    P = O.to_torch_state(build_state(spec, 0), requires_grad=True)
+    te = torch.from_numpy(g["inputs_embeds"]).requires_grad_(True)
+    ie = torch.from_numpy(g["image_embeds"]).requires_grad_(True)
+    batch = dict(inputs_embeds=te, image_embeds=ie, attention_mask=torch.from_numpy(g["attention_mask"]),
+                 pixel_mask=torch.from_numpy(g["pixel_mask"]), token_type_ids=torch.from_numpy(g["token_type_ids"]),
+                 labels=torch.from_numpy(g["labels"]))
+    loss, out = O.vault_loss(P, spec, batch)
+    loss.backward()
+    np.testing.assert_allclose(out["logits"].detach().numpy(), g["logits"], atol=2e-5)
+    np.testing.assert_allclose(out["pooler_output"].detach().numpy(), g["pooler_output"], atol=2e-5)
+    np.testing.assert_allclose(out["last_hidden_state"].detach().numpy(), g["last_hidden_state"], atol=2e-4)
+    np.testing.assert_allclose(te.grad.numpy(), g["d_inputs_embeds"], atol=2e-6, rtol=1e-3)
+    np.testing.assert_allclose(ie.grad.numpy(), g["d_image_embeds"], atol=2e-6, rtol=1e-3)
+    assert float(g["grad_norm_word_embeddings"]) == 0.0 and P["bert.embeddings.word_embeddings.weight"].grad is None
+    np.testing.assert_allclose(P["embeddings.token_type_embeddings.weight"].grad.numpy(), g["grad_modality_type"], atol=2e-6, rtol=1e-3)

@@ -257,3 +257,58 @@ extern "C" int vault_axpy_f32(float* dst, const float* src, float a, long long n
   hipLaunchKernelGGL(axpy_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dst, src, a, n);
   return (int)hipGetLastError();
 }
+
+// ---- externally supplied image embeddings (HF ViltEmbeddings.forward with `image_embeds`, modeling_vilt.py:190-207:
+// no patch projection, no CLS token, no position table - only the modality type is added; reached from the reference
+// through TomViltForTMSC, ref: vault/models/tomvilt/model.py:281-287).
+// fwd: out[map(r)] = src[r] + vec   ; map(r) = (r / rpg) * gstride + goff + r % rpg  (rows of the fused sequence)
+// bwd: dsrc[r] = dx[map(r)] ; dvec += column sums of those rows
+__global__ __launch_bounds__(256) void rows_add_kernel(const float* __restrict__ src, const float* __restrict__ vec,
+                                                       float* __restrict__ out, int rows, int H, int rpg, int gstride, int goff) {
+  const int h4 = H >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (long long)rows * h4; i += (long long)gridDim.x * 256) {
+    const int r = (int)(i / h4), c = (int)(i - (long long)r * h4) * 4;
+    const size_t orow = (size_t)(r / rpg) * gstride + goff + (r % rpg);
+    const f32x4 s = *reinterpret_cast<const f32x4*>(src + (size_t)r * H + c);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(vec + c);
+    *reinterpret_cast<f32x4*>(out + orow * H + c) = s + v;
+  }
+}
+
+__global__ __launch_bounds__(256) void rows_gather_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dsrc,
+                                                              float* __restrict__ dvec, int rows, int H, int rpg, int gstride,
+                                                              int goff) {
+  // block = 64 rows x all columns (thread t: 4 columns at (t % (H/4)) ... strided over H/4 column groups)
+  const int h4 = H >> 2;
+  const int r0 = blockIdx.x * 64;
+  for (int cg = threadIdx.x; cg < h4; cg += 256) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < min(rows, r0 + 64); ++r) {
+      const size_t xrow = (size_t)(r / rpg) * gstride + goff + (r % rpg);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(dx + xrow * H + cg * 4);
+      *reinterpret_cast<f32x4*>(dsrc + (size_t)r * H + cg * 4) = v;
+      acc += v;
+    }
+    if (dvec != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(dvec + cg * 4 + e, acc[e]);
+    }
+  }
+}
+
+extern "C" int vault_rows_add_f32(const float* src, const float* vec, float* out, int rows, int H, int rpg, int gstride,
+                                  int goff, void* stream) {
+  if (!src || !vec || !out || rows <= 0 || H <= 0 || (H & 3) || rpg <= 0) return VAULT_EINVAL;
+  const long long n = (long long)rows * (H >> 2);
+  hipLaunchKernelGGL(rows_add_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), src, vec, out, rows, H, rpg, gstride, goff);
+  return (int)hipGetLastError();
+}
+
+extern "C" int vault_rows_gather_bwd_f32(const float* dx, float* dsrc, float* dvec, int rows, int H, int rpg, int gstride,
+                                         int goff, void* stream) {
+  if (!dx || !dsrc || rows <= 0 || H <= 0 || (H & 3) || rpg <= 0) return VAULT_EINVAL;
+  hipLaunchKernelGGL(rows_gather_bwd_kernel, dim3((rows + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dx,
+                     dsrc, dvec, rows, H, rpg, gstride, goff);
+  return (int)hipGetLastError();
+}

@@ -39,6 +39,9 @@
 #include "common.h"
 #include "gemm.h"
 
+#ifndef W8_ABLATE
+#define W8_ABLATE 0
+#endif
 #ifndef W8_STORE_MOD
 #define W8_STORE_MOD ""   // development: cache policy of the bf16 output stores (" nt", " sc1", ...)
 #endif
@@ -314,7 +317,11 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
       for (int e = 0; e < (HAS_CSUM ? 16 : 1); ++e) csum[e] = 0.f;
       // addresses: uniform 64-bit base (SGPR pair) + ONE 32-bit byte offset per lane, stepped by 16 rows per mt
       // (the launcher keeps M x ldo x 4 B below 4 GiB)
+#if W8_ABLATE == 2   // development: every tile writes the same 256 rows (the stores stay in L2)
+      const uint32_t off0 = (uint32_t)(((size_t)(wr * 128 + el15) * p.ldo + nc) * 2);
+#else
       const uint32_t off0 = (uint32_t)(((size_t)(mw + el15) * p.ldo + nc) * 2);
+#endif
       const uint32_t step = (uint32_t)p.ldo * 32u;
       const char* outp = reinterpret_cast<const char*>(p.out);
       const char* out2p = reinterpret_cast<const char*>(p.out2);
@@ -411,7 +418,11 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
           }
           const u32x4 wv = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
                             pack_bf16x2(v[6], v[7])};
+#if W8_ABLATE == 1   // development: half of the stores
+          if ((FULL || m < p.m_valid) && j == 0) {
+#else
           if (FULL || m < p.m_valid) {
+#endif
             const uint32_t o = off0 + (uint32_t)mt * step + (j ? c1 : 0u);
             if (nv == 8) {
               if constexpr (EPI == EPI_BF16_GELU)

@@ -488,9 +488,17 @@ class VaultEngine:
         (B, T, train) workspace, so that every kernel argument of a step is pointer-stable (required for
         tape replay).  ``validate=False`` skips the pixel-mask check (it synchronises the device)."""
         spec, v = self.spec, self.spec.vilt
-        ids = batch["input_ids"]
-        B, T = ids.shape
+        ids = batch.get("input_ids")
+        temb = batch.get("inputs_embeds")          # [B, T, H] f32 instead of token ids (ref model.py:170-200)
+        if ids is None and temb is None:
+            raise ValueError("You have to specify either input_ids or inputs_embeds")
+        B, T = (ids.shape if ids is not None else temb.shape[:2])
         H, FF, heads = v.hidden_size, v.intermediate_size, v.num_attention_heads
+        if temb is not None and tuple(temb.shape) != (B, T, H):
+            raise ValueError(f"inputs_embeds must be [B, T, {H}]")
+        iemb = batch.get("image_embeds")           # [B, L, H] f32 instead of pixels (HF modeling_vilt.py:190-207)
+        if iemb is not None:
+            return self._stage_image_embeds(batch, train, labels, ws_tag, ids, temb, iemb, B, T)
         pix = batch["pixel_values"]
         if pix.dim() != 4 or pix.shape[1] != v.num_channels or pix.shape[2] % v.patch_size or pix.shape[3] % v.patch_size:
             raise ValueError(f"pixel_values must be [B,{v.num_channels},HP,WP] with HP, WP multiples of the patch size "
@@ -534,8 +542,9 @@ class VaultEngine:
         ws.update(S=S, M=B * S, Mp=_pad(B * S), H=H, FF=FF, heads=heads, NP=NP, train=train,
                   Ml=B * T, Mlp=_pad(B * T), ragged=ragged, HP=HP, WP=WP)
         buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
-        buf("in_ids", (B, T), torch.int64).copy_(ids)
+        self._stage_text(ws, ids, temb, B, T, H)
         buf("in_pix", tuple(pix.shape)).copy_(pix)
+        ws["img_embeds"] = None
         km = buf("keymask", (B, S))
         am = batch.get("attention_mask")
         if am is None:
@@ -552,6 +561,49 @@ class VaultEngine:
         buf("in_amf", (B, T)).copy_(km[:, :T])
         tt = batch.get("token_type_ids")
         ws["ids"], ws["pix"], ws["amf"] = ws["in_ids"], ws["in_pix"], ws["in_amf"]
+        ws["tt"] = None if tt is None else buf("in_tt", (B, T), torch.int64).copy_(tt)
+        ws["labels"] = None if labels is None else buf("in_labels", (B,), torch.int64).copy_(labels)
+        return ws
+
+    def _stage_text(self, ws, ids, temb, B, T, H):
+        """Token ids, or text embeddings in their place (``inputs_embeds``: the word-embedding lookup is skipped; position
+        ids then count every position like HF ``create_position_ids_from_inputs_embeds``: ids that are never the pad id)."""
+        idb = self._buf(ws, "in_ids", (B, T), torch.int64)
+        if temb is None:
+            idb.copy_(ids)
+            ws["txt_embeds"] = None
+        else:
+            pad = self.spec.lm.pad_token_id if self.spec.lm is not None else 0
+            idb.fill_(pad + 1)
+            ws["txt_embeds"] = self._buf(ws, "in_temb", (_pad(B * T), H), torch.float32)
+            ws["txt_embeds"][:B * T].copy_(temb.reshape(B * T, H))
+
+    def _stage_image_embeds(self, batch, train, labels, ws_tag, ids, temb, iemb, B, T):
+        """Staging for externally supplied image embeddings: the image part of the fused sequence is ``image_embeds`` +
+        modality type, ``pixel_mask`` [B, L] is its key mask (HF: ``image_masks = pixel_mask.flatten(1)``)."""
+        v = self.spec.vilt
+        H, FF, heads = v.hidden_size, v.intermediate_size, v.num_attention_heads
+        if iemb.dim() != 3 or iemb.shape[0] != B or iemb.shape[2] != H:
+            raise ValueError(f"image_embeds must be [B, L, {H}]")
+        L = int(iemb.shape[1])
+        S = T + L
+        if S > 320:
+            raise ValueError(f"fused sequence {S} exceeds the attention kernels' 320 keys")
+        ws = self.workspace(B, T, train, (L, -1, -1), ws_tag)
+        ws.update(S=S, M=B * S, Mp=_pad(B * S), H=H, FF=FF, heads=heads, NP=L, train=train, Ml=B * T, Mlp=_pad(B * T),
+                  ragged=False, HP=0, WP=0)
+        buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
+        self._stage_text(ws, ids, temb, B, T, H)
+        ws["img_embeds"] = buf("in_iemb", (_pad(B * L), H))
+        ws["img_embeds"][:B * L].copy_(iemb.reshape(B * L, H))
+        km = buf("keymask", (B, S))
+        am = batch.get("attention_mask")
+        km[:, :T] = 1.0 if am is None else am
+        pm = batch.get("pixel_mask")
+        km[:, T:] = 1.0 if pm is None else pm.reshape(B, L)
+        buf("in_amf", (B, T)).copy_(km[:, :T])
+        tt = batch.get("token_type_ids")
+        ws["ids"], ws["pix"], ws["amf"] = ws["in_ids"], None, ws["in_amf"]
         ws["tt"] = None if tt is None else buf("in_tt", (B, T), torch.int64).copy_(tt)
         ws["labels"] = None if labels is None else buf("in_labels", (B,), torch.int64).copy_(labels)
         return ws
@@ -608,9 +660,10 @@ class VaultEngine:
             pos = buf("lm_pos", (B, T), torch.int32)
             ops.position_ids(ids, pos, B, T, 1 if lm.kind == "roberta" else 0, lm.pad_token_id)
             esum = buf("lm_esum", (Mlp, H))
-            ops.gather_sum(None, esum, [(P.w("bert.embeddings.word_embeddings.weight"), ids),
-                                        (P.w("bert.embeddings.position_embeddings.weight"), pos),
-                                        (P.w("bert.embeddings.token_type_embeddings.weight"), lm_tt)], Ml, H)
+            te = ws.get("txt_embeds")
+            ops.gather_sum(te, esum, [None if te is not None else (P.w("bert.embeddings.word_embeddings.weight"), ids),
+                                      (P.w("bert.embeddings.position_embeddings.weight"), pos),
+                                      (P.w("bert.embeddings.token_type_embeddings.weight"), lm_tt)], Ml, H)
             keep = train and not self.freeze_lm
             nl = lm.num_hidden_layers
             if keep and not pr and self.LM_WGRAD_BATCHED and H % 128 == 0 and FF % 128 == 0:
@@ -667,10 +720,10 @@ class VaultEngine:
         else:
             Ml, Mlp = B * T, _pad(B * T)
             ws.update(Ml=Ml, Mlp=Mlp)
-            text_src = None
+            text_src = ws.get("txt_embeds")        # inputs_embeds replace ViLT's own word-embedding lookup
             use_pos = True
             tables = [(P.w("embeddings.text_embeddings.token_type_embeddings.weight"), tt if tt is not None else 0),
-                      (P.w("embeddings.text_embeddings.word_embeddings.weight"), ids)]
+                      None if text_src is not None else (P.w("embeddings.text_embeddings.word_embeddings.weight"), ids)]
         if use_pos:
             tables.append((P.w("embeddings.text_embeddings.position_embeddings.weight"), "mod"))
         ws["use_pos"] = use_pos
@@ -687,6 +740,18 @@ class VaultEngine:
         Kp = v.num_channels * v.patch_size * v.patch_size
         Mpp = _pad(B * NP)
         ws.update(Kp=Kp, Mpp=Mpp)
+        if ws.get("img_embeds") is not None:
+            # externally supplied image embeddings: + modality type, straight into the image rows of the fused sequence
+            ops.rows_add(ws["img_embeds"], mt[ws.get("img_type", 1)], x[0], B * NP, H, NP, S, T)
+        else:
+            self._patch_embed_forward(ws, x, mt, pix, pr, W3, Kp, Mpp, buf, bf)
+        ws["lm_y"], ws["lm_yb"] = (y if spec.lm is not None else None), (yb if spec.lm is not None else None)
+        return self._forward_encoder(ws, x, need_hidden, loss_scale, pr, W3, labels, km, train, buf, bf)
+
+    def _patch_embed_forward(self, ws, x, mt, pix, pr, W3, Kp, Mpp, buf, bf):
+        spec, P = self.spec, self.params
+        v = spec.vilt
+        B, T, S, H, NP = (ws[k] for k in ("B", "T", "S", "H", "NP"))
         apatch = buf("apatch_3" if pr else "apatch", (Mpp, W3 * Kp), bf)
         addtab = buf("addtab", (NP, H))
         wpn = "embeddings.patch_embeddings.projection.weight"
@@ -705,6 +770,11 @@ class VaultEngine:
             ops.image_pos_sel_fwd(x[0], P.w("embeddings.position_embeddings"), ws["sel"], ws["hw"], B, NP, S, T, H,
                                   ws["gw"], v.image_size // v.patch_size)
 
+    def _forward_encoder(self, ws, x, need_hidden, loss_scale, pr, W3, labels, km, train, buf, bf):
+        spec, P = self.spec, self.params
+        v = spec.vilt
+        B, T, S, M, Mp, H, FF, heads, NP = (ws[k] for k in ("B", "T", "S", "M", "Mp", "H", "FF", "heads", "NP"))
+        nv = v.num_hidden_layers
         # ------------------------------ ViLT encoder ------------------------------
         if (train and not pr and self.LM_WGRAD_BATCHED and Mp <= self.WGRAD_BATCH_MAX_ROWS and H % 128 == 0
                 and FF % 128 == 0):
@@ -776,7 +846,7 @@ class VaultEngine:
             else:
                 ops.head_fwd(pre, None, None, None, pooled, None, None, B, H, 0, 0.0)   # VaultModel: tanh only
             out["pooler_output"] = pooled[:B]
-        ws["x"], ws["lm_y"], ws["lm_yb"] = x, (y if spec.lm is not None else None), (yb if spec.lm is not None else None)
+        ws["x"] = x
         self.last = ws
         return out
 
@@ -1052,14 +1122,20 @@ class VaultEngine:
         dyp = buf("dyp", (Mpp, H), bf)
         gpos = P.gr("embeddings.position_embeddings", shape=(v.num_patches + 1, H))
         gmt = P.gr("embeddings.token_type_embeddings.weight")
-        if ws["ragged"]:
+        if ws.get("img_embeds") is not None:
+            # externally supplied image embeddings: their gradient (for the caller's autograd) and the modality type's
+            die = buf("d_iemb", (_pad(B * NP), H))
+            ops.rows_gather_bwd(dx0, die, gmt[ws.get("img_type", 1)], B * NP, H, NP, S, T)
+            ws["d_image_embeds"] = die[:B * NP].view(B, NP, H)
+        elif ws["ragged"]:
             ops.image_sel_bwd(dx0, gpos, gmt[ws.get("img_type", 1)], P.gr("embeddings.cls_token", shape=(H,)),
                               P.gr("embeddings.patch_embeddings.projection.bias"), dyp, ws["sel"], ws["hw"], B, NP, S, T, H,
                               ws["gw"], v.image_size // v.patch_size)
         else:
             ops.image_rows_bwd(dx0, gpos, gmt[ws.get("img_type", 1)], P.gr("embeddings.cls_token", shape=(H,)),
                                P.gr("embeddings.patch_embeddings.projection.bias"), dyp, NP, H, B, S, T)
-        self._wgrad(dyp, ws["apatch"], "embeddings.patch_embeddings.projection.weight", None, Mpp, H, Kp, B * NP)
+        if ws.get("img_embeds") is None:
+            self._wgrad(dyp, ws["apatch"], "embeddings.patch_embeddings.projection.weight", None, Mpp, H, Kp, B * NP)
         dvs = buf("d_vt_sum", (Mlp, H))
         # text rows: out = LN(.) + mtype[0]  =>  d mtype[0] = sum dy = THIS backward's d beta: taken through a scratch
         # vector (the gradient buffers accumulate across backward passes: multi-image heads, gradient accumulation)
@@ -1073,7 +1149,10 @@ class VaultEngine:
         tt = ws["tt"]
         gt = [(P.gr("embeddings.text_embeddings.token_type_embeddings.weight"), tt if tt is not None else 0)]
         if spec.lm is None:
-            gt.append((P.gr("embeddings.text_embeddings.word_embeddings.weight"), ws["ids"]))
+            if ws.get("txt_embeds") is not None:
+                ws["d_inputs_embeds"] = dvs[:Ml].view(B, T, H)     # inputs_embeds stood in for the word embeddings
+            else:
+                gt.append((P.gr("embeddings.text_embeddings.word_embeddings.weight"), ws["ids"]))
         if ws["use_pos"]:
             gt.append((P.gr("embeddings.text_embeddings.position_embeddings.weight"), "mod"))
         ops.scatter_add(dvs, gt, Ml, H, period=T)
@@ -1147,7 +1226,10 @@ class VaultEngine:
         ops.layernorm_bwd(ws["lm_esum"], ws["lm_emean"], ws["lm_erstd"], P.w("bert.embeddings.LayerNorm.weight"), Ml, H,
                           dy_bf16=dyb, dy_f32=dyf, dx_f32=desum, dgamma=P.gr("bert.embeddings.LayerNorm.weight"),
                           dbeta=P.gr("bert.embeddings.LayerNorm.bias"), drop=self._drop(pdh, 1, True), drop_on_dy=True)
-        ops.scatter_add(desum, [(P.gr("bert.embeddings.word_embeddings.weight"), ws["ids"]),
+        if ws.get("txt_embeds") is not None:
+            ws["d_inputs_embeds"] = desum[:Ml].view(B, T, H)
+        ops.scatter_add(desum, [None if ws.get("txt_embeds") is not None else
+                                (P.gr("bert.embeddings.word_embeddings.weight"), ws["ids"]),
                                 (P.gr("bert.embeddings.position_embeddings.weight"), ws["lm_pos"]),
                                 (P.gr("bert.embeddings.token_type_embeddings.weight"), ws["lm_tt"])], Ml, H,
                         rowmask=amf)   # padded positions are masked keys everywhere: their gradient is exactly 0

@@ -21,8 +21,10 @@ Padded batches of differently sized images (``pixel_mask`` with zeros, canvases 
 pre-training one, up to 320 fused tokens) take the general image path of the engine: the order of the patch
 rows in ``last_hidden_state`` is row-major (the reference's is random), padding rows are masked.
 
-Not implemented in this build (raise): ``inputs_embeds`` / ``image_embeds`` inputs,
-``output_attentions`` / ``output_hidden_states``.
+``inputs_embeds`` (text embeddings in place of token ids: fed to the LM, or to ViLT's text embeddings without one) and
+``image_embeds`` (image-token embeddings in place of pixels, ``pixel_mask`` [B, L] as their key mask: only the modality
+type is added, as in HF ``ViltEmbeddings.forward``) are taken, and their gradients flow back to the caller.
+Not implemented in this build (raise): ``head_mask``, ``output_attentions`` / ``output_hidden_states``.
 
 There is no CPU or eager-PyTorch compute path: forward raises if the model is not on a GPU or the
 HIP library is missing.
@@ -129,8 +131,12 @@ class _VaultFunction(torch.autograd.Function):
     straight into the flat gradient buffer (``p.grad`` are views of it)."""
 
     @staticmethod
-    def forward(ctx, model, batch, want_logits, train, *params):
+    def forward(ctx, model, batch, want_logits, train, inputs_embeds, image_embeds, *params):
         eng = model._engine
+        if inputs_embeds is not None:
+            batch["inputs_embeds"] = inputs_embeds.detach().to(eng.device, torch.float32)
+        if image_embeds is not None:
+            batch["image_embeds"] = image_embeds.detach().to(eng.device, torch.float32)
         eng.fp8_forward = bool(model.fp8_forward)
         extra = batch.pop("__pass__", None)     # (ws_tag, image_token_type_idx, advance_seed) of multi-image heads
         kw = {} if extra is None else dict(ws_tag=extra[0], image_token_type_idx=extra[1], advance_seed=extra[2])
@@ -162,7 +168,10 @@ class _VaultFunction(torch.autograd.Function):
             eng.backward(dhidden=None if dh is None else dh.float(), dpooled=None if dp is None else dp.float(),
                          ws=ctx.ws)
         model._publish_grads()
-        return (None, None, None, None) + tuple(None for _ in range(len(ctx.needs_input_grad) - 4))
+        d_te = ctx.ws.get("d_inputs_embeds") if ctx.needs_input_grad[4] else None
+        d_ie = ctx.ws.get("d_image_embeds") if ctx.needs_input_grad[5] else None
+        return (None, None, None, None, None if d_te is None else d_te.clone(), None if d_ie is None else d_ie.clone()) + \
+            tuple(None for _ in range(len(ctx.needs_input_grad) - 6))
 
 
 class _MlpHeadFunction(torch.autograd.Function):
@@ -432,7 +441,19 @@ class VaultMixin(nn.Module):
         """Hook: map head tensors of a pre-training checkpoint onto this class's head (see the ITR class)."""
 
     def lm_preprocess(self, *args, **kwargs):
-        raise NotImplementedError("lm_preprocess is fused into forward in this build")
+        """ref model.py:151-202 runs the LM here and hands ``inputs_embeds`` to ``vilt_forward``; in this build the LM runs
+        inside the engine's forward (one launch sequence, no round trip through Python), so this only applies the
+        reference's argument normalisation: token types zeroed for single-type LMs (model.py:174-180)."""
+        args = list(args)
+        if self.spec.lm is not None and self.spec.lm.type_vocab_size < 2:
+            tt = kwargs.get("token_type_ids", args[2] if len(args) > 2 else None)
+            if tt is not None:
+                z = torch.zeros_like(tt)
+                if len(args) > 2:
+                    args[2] = z
+                else:
+                    kwargs["token_type_ids"] = z
+        return args, kwargs
 
     def _collect_batch(self, args, kwargs) -> Dict[str, torch.Tensor]:
         # positional order of ViltModel.forward under the reference's pinned transformers 4.48 (``head_mask`` at index 5:
@@ -452,26 +473,31 @@ class VaultMixin(nn.Module):
             raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
         if ids is None and emb is None:
             raise ValueError("You have to specify either input_ids or inputs_embeds")
-        if emb is not None:
-            raise NotImplementedError("inputs_embeds is not implemented in this build")
         pix, iemb = kw.get("pixel_values"), kw.get("image_embeds")
         if pix is not None and iemb is not None:
             raise ValueError("You cannot specify both pixel_values and image_embeds at the same time")
         if pix is None and iemb is None:
             raise ValueError("You have to specify either pixel_values or image_embeds")
-        if iemb is not None:
-            raise NotImplementedError("image_embeds is not implemented in this build")
-        if pix.shape[0] != ids.shape[0]:
+        if (pix if pix is not None else iemb).shape[0] != (ids if ids is not None else emb).shape[0]:
             raise ValueError("The text inputs and image inputs need to have the same batch size")
         if kw.get("output_attentions") or kw.get("output_hidden_states"):
             raise NotImplementedError("output_attentions / output_hidden_states are not implemented in this build")
         if self._engine is None:
             raise RuntimeError("VaultModel has no CPU path: move the model to a GPU (model.to('cuda')) first")
         dev = self._engine.device
-        batch = {"input_ids": ids.to(dev, torch.int64), "pixel_values": pix.to(dev, torch.float32)}
+        batch = {}
+        if ids is not None:
+            batch["input_ids"] = ids.to(dev, torch.int64)
+        if pix is not None:
+            batch["pixel_values"] = pix.to(dev, torch.float32)
         for k in ("attention_mask", "token_type_ids", "pixel_mask"):
             if kw.get(k) is not None:
                 batch[k] = kw[k].to(dev)
+        # (the embeddings travel as autograd inputs of the bridge: their gradients flow back to the caller, e.g. the
+        #  TomBERT front-end of ref: vault/models/tomvilt/model.py:281-287)
+        self._embeds = (emb, iemb)
+        if kw.get("image_token_type_idx") is not None and not isinstance(self, VaultForImagesAndTextClassification):
+            batch["__pass__"] = (0, int(kw["image_token_type_idx"]), True)
         return batch
 
     def _param_version(self) -> int:
@@ -493,7 +519,8 @@ class VaultMixin(nn.Module):
         self._refresh_if_params_changed()
         params = [p for p in self._params_by_name.values() if p.requires_grad]
         train = self.training and torch.is_grad_enabled()   # autograd disables grad inside Function.forward
-        return _VaultFunction.apply(self, batch, want_logits, train, *params)
+        emb, iemb = self._embeds
+        return _VaultFunction.apply(self, batch, want_logits, train, emb, iemb, *params)
 
     def vilt_forward(self, *args, **kwargs):
         return self.forward(*args, **kwargs)
@@ -708,7 +735,7 @@ class VaultForImagesAndTextClassification(VaultMixin):
             batch["__pass__"] = (i, i + 1, i == 0)
             params = [p for p in self._params_by_name.values() if p.requires_grad]
             train = self.training and torch.is_grad_enabled()
-            out = _VaultFunction.apply(self, batch, False, train, *params)
+            out = _VaultFunction.apply(self, batch, False, train, None, None, *params)
             pooled.append(out[1])
         z = torch.cat(pooled, dim=-1)
         params = [p for p in self._params_by_name.values() if p.requires_grad]

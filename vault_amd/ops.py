@@ -372,3 +372,13 @@ def transpose_bf16(src, dst, rows, cols, batch=1, stride_src=0, stride_dst=0):
     """dst[b][c][r] = src[b][r][c] (bf16; rows, cols multiples of 64): transposed weight shadow for the data gradients."""
     _invoke("vault_transpose_bf16", C.c_void_p(_p(src)), C.c_void_p(_p(dst)), C.c_int(rows), C.c_int(cols), C.c_int(batch),
             C.c_longlong(stride_src), C.c_longlong(stride_dst), _stream())
+
+
+def rows_add(src, vec, out, rows, H, rpg, gstride, goff):
+    _invoke("vault_rows_add_f32", C.c_void_p(_p(src)), C.c_void_p(_p(vec)), C.c_void_p(_p(out)), C.c_int(rows), C.c_int(H),
+            C.c_int(rpg), C.c_int(gstride), C.c_int(goff), _stream())
+
+
+def rows_gather_bwd(dx, dsrc, dvec, rows, H, rpg, gstride, goff):
+    _invoke("vault_rows_gather_bwd_f32", C.c_void_p(_p(dx)), C.c_void_p(_p(dsrc)), C.c_void_p(_p(dvec)), C.c_int(rows),
+            C.c_int(H), C.c_int(rpg), C.c_int(gstride), C.c_int(goff), _stream())
