@@ -231,6 +231,47 @@ int vault_transpose_bf16(const void* src, void* dst, int rows, int cols, int bat
  * inference mode used to meet the 1e-3 logits parity bar. */
 int vault_split3_bf16(const float* x, void* out_bf16, long long rows, int K, int layout, void* stream);
 
+/* ---- stage-level entries (ABI 4): one encoder layer forward / backward per call ---------------------------------
+ * For hosts that do not want to re-implement the kernel order.  The caller owns every buffer
+ * (vault_layer_workspace_bytes tells how much a layer saves for backward); the calls only enqueue on `stream`.
+ *   vault_vilt_layer_fwd/bwd  HF ViltLayer.forward, modeling_vilt.py:430-451 (+ autograd): pre-LN
+ *   vault_lm_layer_fwd/bwd    HF RobertaLayer / BertLayer.forward, modeling_roberta.py:421-463: post-LN, dropouts
+ * Buffers are token-major [rows_pad][width], rows_pad = rows rounded up to 256 with zero rows behind the valid ones.
+ * ViLT uses: x_in (f32) -> n1, qkv, ctx, lse, xm (= x + attention block, f32), n2, act, u (gelu', training) -> x_out.
+ * LM uses:   x_in (f32) + x_in_bf16 -> qkv, ctx, lse, xm (= h1, f32), y1 (f32) + n2 (= y1 in bf16), act, u, h2 (f32)
+ *            -> x_out (f32) + x_out_bf16.   m1/r1, m2/r2: mean / rstd of the two LayerNorms.
+ * wo_t / wf_t: optional transposed bf16 shadows (vault_transpose_bf16) of the attention-out / FFN-out weights: their
+ * data gradients then run as forward-form GEMMs on the register-direct kernel. */
+typedef struct vault_layer_args {
+  int B, S, H, FF, heads, rows, rows_pad; float eps;
+  const void *wqkv, *wo, *wi, *wf, *wo_t, *wf_t;                       /* bf16 [3H,H] [H,H] [FF,H] [H,FF] ([H,H]^T [FF,H]^T...) */
+  const float *bqkv, *bo, *bi, *bf, *ln1w, *ln1b, *ln2w, *ln2b;        /* f32 */
+  const float* x_in; const void* x_in_bf16; float* x_out; void* x_out_bf16; const float* keymask;
+  void *n1, *qkv, *ctx; float* lse; float* xm; float* y1; void* n2; void* act; void* u; float* h2;
+  float *m1, *r1, *m2, *r2;
+  uint32_t attn_drop_thresh, hid_drop_thresh, drop_seed, drop_stream_base; float attn_drop_scale, hid_drop_scale;
+  int persist;                                                          /* GEMM scheduling, as vault_gemm_args.persist */
+} vault_layer_args;
+/* backward: dy = gradient at the layer output (ViLT: dy_f32 = residual-stream gradient + dy_bf16 = its bf16 copy, the
+ * FFN-out dY; LM: dy_bf16 (optional) + dy_f32, summed).  Outputs: dx_f32 / dx_bf16 at the layer input (LM: the two parts
+ * of d y, summed by the consumer: dx_bf16 = dqkv . Wqkv, dx_f32 = d h1).  Scratch: dU [rows_pad][FF] bf16, dN / dctx /
+ * dmid_bf16 (LM also dh1_bf16) [rows_pad][H] bf16, dqkv [rows_pad][3H] bf16, dmid_f32 [rows_pad][H] f32.  Parameter gradients are ACCUMULATED (+=)
+ * into the g_* f32 pointers; NULL skips one; do_wgrad = 0 leaves the four weight gradients to the caller (the engine
+ * batches them over layers).  g_bf_below (ViLT): bias gradient of the layer below's FFN-out (= column sums of dx). */
+typedef struct vault_layer_bwd_args {
+  const vault_layer_args* fwd;
+  const void* dy_bf16; const float* dy_f32;
+  float* dx_f32; void* dx_bf16;
+  void *dU, *dN, *dctx, *dqkv, *dmid_bf16, *dh1_bf16; float* dmid_f32;
+  float *g_wqkv, *g_bqkv, *g_wo, *g_bo, *g_wi, *g_bi, *g_wf, *g_bf, *g_ln1w, *g_ln1b, *g_ln2w, *g_ln2b, *g_bf_below;
+  int do_wgrad;
+} vault_layer_bwd_args;
+long long vault_layer_workspace_bytes(int B, int S, int H, int FF, int heads, int train, long long* rows_pad_out);
+int vault_vilt_layer_fwd(const vault_layer_args* args, void* stream);
+int vault_vilt_layer_bwd(const vault_layer_bwd_args* args, void* stream);
+int vault_lm_layer_fwd(const vault_layer_args* args, void* stream);
+int vault_lm_layer_bwd(const vault_layer_bwd_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,7 +74,8 @@ def test_ctypes_structures_match_the_c_header(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("gcc not available")
     pairs = {"vault_gemm_args": L.GemmArgs, "vault_ln_fwd_args": ops.LnFwdArgs, "vault_ln_bwd_args": ops.LnBwdArgs,
-             "vault_attn_args": ops.AttnArgs, "vault_gather_args": ops.GatherArgs, "vault_head_args": ops.HeadArgs}
+             "vault_attn_args": ops.AttnArgs, "vault_gather_args": ops.GatherArgs, "vault_head_args": ops.HeadArgs,
+             "vault_layer_args": ops.LayerArgs, "vault_layer_bwd_args": ops.LayerBwdArgs}
     hdr = os.path.join(ROOT, "include", "vault_hip.h")
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{hdr}"', 'int main(void) {']
     for cname, cls in pairs.items():

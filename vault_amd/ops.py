@@ -382,3 +382,50 @@ def rows_add(src, vec, out, rows, H, rpg, gstride, goff):
 def rows_gather_bwd(dx, dsrc, dvec, rows, H, rpg, gstride, goff):
     _invoke("vault_rows_gather_bwd_f32", C.c_void_p(_p(dx)), C.c_void_p(_p(dsrc)), C.c_void_p(_p(dvec)), C.c_int(rows),
             C.c_int(H), C.c_int(rpg), C.c_int(gstride), C.c_int(goff), _stream())
+
+
+class LayerArgs(C.Structure):
+    """vault_layer_args (include/vault_hip.h): one encoder layer's weights, activations and dropout description."""
+    _fields_ = ([(n, C.c_int) for n in ("B", "S", "H", "FF", "heads", "rows", "rows_pad")] + [("eps", C.c_float)] +
+                [(n, C.c_void_p) for n in ("wqkv", "wo", "wi", "wf", "wo_t", "wf_t", "bqkv", "bo", "bi", "bf", "ln1w", "ln1b",
+                                           "ln2w", "ln2b", "x_in", "x_in_bf16", "x_out", "x_out_bf16", "keymask", "n1", "qkv",
+                                           "ctx", "lse", "xm", "y1", "n2", "act", "u", "h2", "m1", "r1", "m2", "r2")] +
+                [(n, C.c_uint32) for n in ("attn_drop_thresh", "hid_drop_thresh", "drop_seed", "drop_stream_base")] +
+                [("attn_drop_scale", C.c_float), ("hid_drop_scale", C.c_float), ("persist", C.c_int)])
+
+
+class LayerBwdArgs(C.Structure):
+    _fields_ = ([("fwd", C.POINTER(LayerArgs))] +
+                [(n, C.c_void_p) for n in ("dy_bf16", "dy_f32", "dx_f32", "dx_bf16", "dU", "dN", "dctx", "dqkv", "dmid_bf16",
+                                           "dh1_bf16", "dmid_f32", "g_wqkv", "g_bqkv", "g_wo", "g_bo", "g_wi", "g_bi", "g_wf",
+                                           "g_bf", "g_ln1w", "g_ln1b", "g_ln2w", "g_ln2b", "g_bf_below")] +
+                [("do_wgrad", C.c_int)])
+
+
+def layer_args(**kw) -> LayerArgs:
+    a = LayerArgs()
+    for k, v in kw.items():
+        setattr(a, k, _p(v) if isinstance(v, torch.Tensor) else v)
+    a.persist = GEMM_SCHED
+    return a
+
+
+def layer_bwd_args(fwd: LayerArgs, **kw) -> LayerBwdArgs:
+    g = LayerBwdArgs()
+    g.fwd = C.pointer(fwd)
+    for k, v in kw.items():
+        setattr(g, k, _p(v) if isinstance(v, torch.Tensor) else v)
+    g._fwd_keep = fwd     # (the struct holds a raw pointer: keep the Python object alive with it)
+    return g
+
+
+def layer_call(name: str, args, seeded: bool = False):
+    """vault_{vilt,lm}_layer_{fwd,bwd}: one layer per C call.  ``seeded``: the struct carries a dropout seed the tape
+    re-keys between replays (for the backward form: its forward struct)."""
+    fn = getattr(L.load(), name)
+    call = (C.byref(args), _stream())
+    if _TAPE is not None:
+        _TAPE.calls.append((fn, call))
+        if seeded:
+            _TAPE.seeded.append(args if isinstance(args, LayerArgs) else args._fwd_keep)
+    L.check(fn(*call), name)
