@@ -251,6 +251,11 @@ class VaultEngine:
     LM_WGRAD_BATCHED = True
     LM_WGRAD_GROUP = 6
     WGRAD_BATCH_RING = True        # batched launches on the 256x256 ring kernel where the shapes allow (else 128x128)
+    # Encoder layers through the stage-level C ABI (vault_{vilt,lm}_layer_{fwd,bwd}: one C call per layer and direction,
+    # the kernel order lives in csrc/stage.hip) when the step is host-launch-bound: up to this many (padded) fused token
+    # rows; larger batches keep the per-kernel calls below (same kernels, same order) so that bench.py can bracket single
+    # GEMM call sites with events.  VAULT_STAGE_ABI=0 / 1 forces either.
+    STAGE_MAX_ROWS = 8192
     WGRAD_BATCH_MAX_ROWS = 131072  # the ViLT layers take the same route up to this many (padded) token rows (B <= 708:
                                    # 22 GB of per-layer dY operands at that size; 7.9 GB at B = 256)
 
@@ -464,6 +469,34 @@ class VaultEngine:
         if cfg == 3:
             fl = 2.0 * m_valid * Nout * Kin * G
             ops.pycall(lambda: self._prof_end("wgrad", fl))
+
+    def _use_stage(self, rows_pad: int, pr: bool) -> bool:
+        e = os.environ.get("VAULT_STAGE_ABI")
+        if pr or self.fp8_forward:
+            return False
+        if e in ("0", "1"):
+            return e == "1"
+        return rows_pad <= self.STAGE_MAX_ROWS
+
+    def _stage_layer_args(self, ws, ln, style, i, rows, rows_pad, S, keymask, x_in, x_out, bufs, drops=None,
+                          x_in_bf16=None, x_out_bf16=None):
+        """vault_layer_args of one encoder layer (kept in the workspace: backward refers to it)."""
+        P = self.params
+        H, FF, heads, B = ws["H"], ws["FF"], ws["heads"], ws["B"]
+        eps = self.spec.vilt.layer_norm_eps if style == "vilt" else self.spec.lm.layer_norm_eps
+        kw = dict(B=B, S=S, H=H, FF=FF, heads=heads, rows=rows, rows_pad=rows_pad, eps=eps,
+                  wqkv=P.wb(ln.qw, n_elems=3 * H * H, shape=(3 * H, H)), wo=P.wb(ln.ow), wi=P.wb(ln.iw), wf=P.wb(ln.fw),
+                  wo_t=P.pbT.get(ln.ow), wf_t=P.pbT.get(ln.fw),
+                  bqkv=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)), bo=P.w(ln.ob), bi=P.w(ln.ib), bf=P.w(ln.fb),
+                  ln1w=P.w(ln.ln1w), ln1b=P.w(ln.ln1b), ln2w=P.w(ln.ln2w), ln2b=P.w(ln.ln2b),
+                  x_in=x_in, x_out=x_out, x_in_bf16=x_in_bf16, x_out_bf16=x_out_bf16, keymask=keymask, **bufs)
+        if drops is not None:
+            da, dh = drops
+            kw.update(attn_drop_thresh=da.thresh, attn_drop_scale=da.scale, hid_drop_thresh=dh.thresh, hid_drop_scale=dh.scale,
+                      drop_seed=self.drop_seed & 0xFFFFFFFF, drop_stream_base=16 * i)
+        a = ops.layer_args(**{k: v for k, v in kw.items() if v is not None})
+        ws[f"stage_{style}{i}"] = a
+        return a
 
     def _drop(self, p: float, stream: int, train: bool) -> Drop:
         return Drop(p, self.drop_seed, stream) if (train and p > 0.0) else NO_DROP
@@ -682,6 +715,8 @@ class VaultEngine:
                               y_split3=yb[0] if pr else None, mean=buf("lm_emean", (Mlp,)),
                               rstd=buf("lm_erstd", (Mlp,)), drop=self._drop(pdh, 1, lm_train),
                               y_q=q8l[0], y_scale=q8l[1])
+            lm_stage = self._use_stage(Mlp, pr)
+            ws["lm_stage"] = lm_stage
             for i, ln in enumerate(self.ll):
                 sfx = f"{i}" if keep else ""
                 qkv = buf(f"lm_qkv{sfx}", (Mlp, 3 * H), bf)
@@ -693,6 +728,16 @@ class VaultEngine:
                 u = buf(f"lm_u{sfx}", (Mlp, FF), bf) if keep else None
                 act = buf(f"lm_act{sfx}{p3}", (Mlp, W3 * FF), bf)
                 h2 = buf(f"lm_h2{sfx}", (Mlp, H))
+                if lm_stage:
+                    da, dh = self._drop(pda, 16 * i + 2, lm_train), self._drop(pdh, 16 * i + 3, lm_train)
+                    a = self._stage_layer_args(
+                        ws, ln, "lm", i, Ml, Mlp, T, amf, y[i], y[i + 1],
+                        dict(qkv=qkv, ctx=ctx, lse=lse, xm=h1, y1=y1, n2=y1b, act=act, u=u, h2=h2,
+                             m1=buf(f"lm_m1{sfx}", (Mlp,)), r1=buf(f"lm_r1{sfx}", (Mlp,)),
+                             m2=buf(f"lm_m2{sfx}", (Mlp,)), r2=buf(f"lm_r2{sfx}", (Mlp,))),
+                        drops=(da, dh), x_in_bf16=yb[i], x_out_bf16=yb[i + 1])
+                    ops.layer_call("vault_lm_layer_fwd", a, seeded=bool(da.thresh or dh.thresh))
+                    continue
                 self._linear(yb[i], ln.qw, qkv, Mlp, 3 * H, H, ops.EPI_BF16, Ml,
                              bias=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)), precise=pr, prequant=q8l[0] is not None)
                 ops.attention_fwd(qkv, amf, None if pr else ctx, lse, B, T, H, heads,
@@ -789,6 +834,15 @@ class VaultEngine:
             xm = buf(f"xm{sfx}", (Mp, H)); n2 = buf(f"n2{sfx}{p3}", (Mp, W3 * H), bf)
             u = buf(f"u{sfx}", (Mp, FF), bf) if train else None
             act = buf(f"act{sfx}{p3}", (Mp, W3 * FF), bf)
+            if self._use_stage(Mp, pr):
+                ws["vilt_stage"] = True
+                a = self._stage_layer_args(
+                    ws, ln, "vilt", i, M, Mp, S, km, x[i], x[i + 1],
+                    dict(n1=n1, qkv=qkv, ctx=ctx, lse=lse, xm=xm, n2=n2, act=act, u=u, m1=buf(f"m1{sfx}", (Mp,)),
+                         r1=buf(f"r1{sfx}", (Mp,)), m2=buf(f"m2{sfx}", (Mp,)), r2=buf(f"r2{sfx}", (Mp,))))
+                ops.layer_call("vault_vilt_layer_fwd", a)
+                continue
+            ws["vilt_stage"] = False
             q8 = self._fp8_scratch(Mp, H) if (self.fp8_forward and not pr and Mp % 256 == 0) else (None, None)
             ops.layernorm_fwd(x[i], P.w(ln.ln1w), P.w(ln.ln1b), v.layer_norm_eps, M, H, y_bf16=None if pr else n1,
                               y_split3=n1 if pr else None, mean=buf(f"m1{sfx}", (Mp,)), rstd=buf(f"r1{sfx}", (Mp,)),
@@ -1076,6 +1130,30 @@ class VaultEngine:
                 dyN = dxbA_all[i - 1] if i > 0 else dxb[0]
             else:
                 dyA, dyB, dyN = dxb[cur], dxb[cur ^ 1], dxb[cur]
+            if ws.get("vilt_stage"):
+                # the whole layer backward in one C call (csrc/stage.hip: the same kernels in the same order as below)
+                nxt = cur ^ 1
+                gb = ops.layer_bwd_args(
+                    ws[f"stage_vilt{i}"], dy_bf16=dyA, dy_f32=dx[cur], dx_f32=dx[cur], dx_bf16=dyN, dU=dU, dN=dN, dctx=dctx,
+                    dqkv=dqkv, dmid_bf16=dyB, dmid_f32=dx[nxt], do_wgrad=0 if vbatch else 1,
+                    g_wqkv=P.gr(ln.qw, n_elems=3 * H * H, shape=(3 * H, H)), g_bqkv=P.gr(ln.qb, n_elems=3 * H, shape=(3 * H,)),
+                    g_wo=P.gr(ln.ow), g_bo=P.gr(ln.ob), g_wi=P.gr(ln.iw), g_bi=P.gr(ln.ib), g_wf=P.gr(ln.fw),
+                    g_ln1w=P.gr(ln.ln1w), g_ln1b=P.gr(ln.ln1b), g_ln2w=P.gr(ln.ln2w), g_ln2b=P.gr(ln.ln2b),
+                    g_bf_below=P.gr(self.vl[i - 1].fb) if i > 0 else None)
+                ws[f"stage_vilt_bwd{i}"] = gb
+                ops.layer_call("vault_vilt_layer_bwd", gb)
+                if not vbatch:
+                    note(f"vilt{i}")
+                elif i % vgroup == 0:
+                    hi = min(nv, i + vgroup)
+                    for dY_all, X_all, wsel, Nout, Kin in ((dxbA_all, ws["act_all"], "fw", H, FF),
+                                                           (dU_all, ws["n2_all"], "iw", FF, H),
+                                                           (dxbB_all, ws["ctx_all"], "ow", H, H),
+                                                           (dqkv_all, ws["n1_all"], "qw", 3 * H, H)):
+                        self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.vl[i:hi]], i, Mp, Nout, Kin, M)
+                    for j in reversed(range(i, hi)):
+                        note(f"vilt{j}")
+                continue
             # FFN
             # (bias gradients are column sums of dY: fused into the kernel that PRODUCES dY - the LayerNorm
             #  backward for the residual-stream gradient, the GEMM epilogue for dU)
@@ -1184,6 +1262,30 @@ class VaultEngine:
             g = lambda k: ws[f"lm_{k}{i}"]  # noqa: E731
             if batched:
                 dhb, dh1b, ldU, ldqkv = dhb_all[i], dh1b_all[i], ldU_all[i], ldqkv_all[i]
+            if ws.get("lm_stage"):
+                a = ws[f"stage_lm{i}"]
+                a.drop_seed = self.drop_seed & 0xFFFFFFFF
+                gb = ops.layer_bwd_args(
+                    a, dy_bf16=dyb, dy_f32=dyf, dx_f32=dh1, dx_bf16=ldN, dU=ldU, dN=ldN, dctx=ldctx, dqkv=ldqkv,
+                    dmid_bf16=dhb, dh1_bf16=dh1b, dmid_f32=dh, do_wgrad=0 if batched else 1,
+                    g_wqkv=P.gr(ln.qw, n_elems=3 * H * H, shape=(3 * H, H)), g_bqkv=P.gr(ln.qb, n_elems=3 * H, shape=(3 * H,)),
+                    g_wo=P.gr(ln.ow), g_bo=P.gr(ln.ob), g_wi=P.gr(ln.iw), g_bi=P.gr(ln.ib), g_wf=P.gr(ln.fw), g_bf=P.gr(ln.fb),
+                    g_ln1w=P.gr(ln.ln1w), g_ln1b=P.gr(ln.ln1b), g_ln2w=P.gr(ln.ln2w), g_ln2b=P.gr(ln.ln2b))
+                ws[f"stage_lm_bwd{i}"] = gb
+                ops.layer_call("vault_lm_layer_bwd", gb, seeded=bool(a.attn_drop_thresh or a.hid_drop_thresh))
+                dyb, dyf = ldN, dh1
+                if not batched:
+                    note(f"lm{i}")
+                elif i % group == 0:
+                    hi = min(nl, i + group)
+                    for dY_all, X_all, wsel, Nout, Kin in ((dhb_all, ws["lm_act_all"], "fw", H, FF),
+                                                           (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
+                                                           (dh1b_all, ws["lm_ctx_all"], "ow", H, H),
+                                                           (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H)):
+                        self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.ll[i:hi]], i, Mlp, Nout, Kin, Ml)
+                    for j in reversed(range(i, hi)):
+                        note(f"lm{j}")
+                continue
             # y2 = LN2(h2)
             ops.layernorm_bwd(g("h2"), g("m2"), g("r2"), P.w(ln.ln2w), Ml, H, dy_bf16=dyb, dy_f32=dyf, dx_f32=dh,
                               dx_bf16=dhb, dgamma=P.gr(ln.ln2w), dbeta=P.gr(ln.ln2b),
