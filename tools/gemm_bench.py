@@ -38,6 +38,7 @@ o_f = torch.empty(M, FF, dtype=torch.bfloat16, device="cuda"); o_f2 = torch.empt
 o_h = torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
 dW = torch.zeros(FF, H, device="cuda")
 
+o_dqkv = rb(M, 3 * H)
 cases = []
 for cfg in [c for c in CFGS if c not in (5, 6)]:
     cases += [
@@ -47,10 +48,12 @@ for cfg in [c for c in CFGS if c not in (5, 6)]:
         (f"fwd ffn2  cfg{cfg}", 2 * M * FF * H, lambda cfg=cfg: _gemm(Xf, W2, o_h32, M, H, FF, FF, FF, H, 0, 0, EPI_RES, cfg=cfg, bias=bias_h, res=res)),
         (f"dgrad ffn2 cfg{cfg}", 2 * M * FF * H, lambda cfg=cfg: _gemm(X, W2, o_f, M, FF, H, H, FF, FF, 0, 1, EPI_DGELU, cfg=cfg, aux=o_f2)),
         (f"dgrad ffn1 cfg{cfg}", 2 * M * FF * H, lambda cfg=cfg: _gemm(Xf, W1, o_h, M, H, FF, FF, H, H, 0, 1, EPI_BF16, cfg=cfg)),
+        (f"dgrad proj cfg{cfg}", 2 * M * H * H, lambda cfg=cfg: _gemm(X, Wo, o_h, M, H, H, H, H, H, 0, 1, EPI_BF16, cfg=cfg)),
+        (f"dgrad qkv  cfg{cfg}", 2 * M * 3 * H * H, lambda cfg=cfg: _gemm(o_dqkv, Wqkv, o_h, M, H, 3 * H, 3 * H, H, H, 0, 1, EPI_BF16, cfg=cfg)),
     ]
 # 8-wave register-direct kernel (cfg 5 / 6): forward-form operands only - the data gradients run on the transposed weight shadow
 W2t = W2.t().contiguous(); W1t = W1.t().contiguous(); Wot = Wo.t().contiguous(); Wqkvt = Wqkv.t().contiguous()
-o_dqkv = rb(M, 3 * H); csum_f = torch.zeros(FF, device="cuda")
+csum_f = torch.zeros(FF, device="cuda")
 for c8 in [c for c in CFGS if c in (5, 6)]:
     for persist in (0,):
         tag = f"cfg{c8}"

@@ -286,8 +286,19 @@ int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, i
   // 355-388, gelu'-product dgrad 282 against 294-317, N = K = 768 dgrad 55 against ~90).  Not the f32-residual forms
   // (bound by their HBM bytes: the ring kernel's 192-wide form is as fast), not K = 3072 (ring: better main loop) and not
   // with dynamic tile scheduling requested (data-parallel runs beside RCCL kernels: the ring kernel's ticket scheduler).
+  // Few row tiles (LM stack at batch <= 128, both stacks at batch 8): the 256-row kernels leave most CUs idle and a
+  // block's K loop runs alone on its CU - 128x128 tiles spread the same work over 4x the blocks (tools/gemm_bench.py,
+  // M = 2560: attention-out 13.4 against 21.0 us, FFN-out 36.3 against 53.3, FFN-in 23.4 against 26.6, gelu'-product
+  // dgrad 20.5 against 31; M = 5120: FFN-in 41.2 against 45.8, FFN-out 40.5 against 56.3; from M = 10240 the big tiles win)
+  static const bool use_small = [] { const char* e = getenv("VAULT_GEMM_SMALL"); return !(e && e[0] == '0'); }();   // development A/B switch
+  bool small = false;
+  if (auto_cfg && use_small && p.batch <= 1 && epi != EPI_F32_ATOMIC && a_mode == 0 && p.M % 256 == 0 && p.N % 128 == 0) {
+    const long c192 = (long)(p.M / 256) * ((p.N + 191) / 192), c256 = (long)(p.M / 256) * ((p.N + 255) / 256);
+    small = c192 < 128 || (p.N >= 3072 && c256 <= 256);
+    if (small) cfg = 0;
+  }
   static const bool use8w = [] { const char* e = getenv("VAULT_GEMM8W"); return !(e && e[0] == '0'); }();   // development A/B switch
-  if (auto_cfg && use8w && (p.persist & 1) == 0 && a_mode == 0 && b_mode == 0 && p.K <= 1024 && p.M >= 2048 &&
+  if (auto_cfg && !small && use8w && (p.persist & 1) == 0 && a_mode == 0 && b_mode == 0 && p.K <= 1024 && p.M >= 2048 &&
       (epi == EPI_BF16 || epi == EPI_BF16_GELU || epi == EPI_BF16_DGELU)) {
     auto eff8 = [](long tiles) { return (double)tiles / (double)(((tiles + 255) / 256) * 256); };
     const bool ok4 = vault_gemm8w_supports(p, a_mode, b_mode, epi, 4), ok3 = vault_gemm8w_supports(p, a_mode, b_mode, epi, 3);

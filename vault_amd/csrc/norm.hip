@@ -3,6 +3,7 @@
 //
 // Replaces nn.LayerNorm at HF:models/vilt/modeling_vilt.py:431-447,637 (pre-LN, eps 1e-12) and
 // HF:models/roberta/modeling_roberta.py:339,397 (post-LN, eps 1e-5) and their backward.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/vault_hip.h"
 
@@ -118,8 +119,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ; dy = dy_bf16 + dy_f32 (either may be
 // null).  Outputs dx_f32 = dx + dres (optional) and a bf16 copy (optionally dropout-masked for the
 // branch that sits behind a dropout in forward).  dgamma / dbeta: per-block partials + float atomics.
-template <int VPT>
-__global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__ dy_bf16, const float* __restrict__ dy_f32,
+template <int VPT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void ln_bwd_kernel(const bf16* __restrict__ dy_bf16, const float* __restrict__ dy_f32,
                                                      RowMap dymap, const float* __restrict__ x, RowMap xmap,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, int rows, int H,
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__
   }
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
-  for (int row = r0 + wave; row < r1; row += 4) {
+  for (int row = r0 + wave; row < r1; row += WAVES) {
     const size_t xr = xmap(row) * H, dr = dymap(row) * H;
     const float mu = mean[row], rs = rstd[row];
     f32x4 xh[VPT], gy[VPT];
@@ -200,19 +201,30 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const bf16* __restrict__
     }
   }
   if (dgamma == nullptr && dbias == nullptr) return;
-  // cross-wave reduction, one quantity at a time through a [4][H] buffer (12 KiB at H = 768: keeps
-  // the LDS footprint - and with it the occupancy of this HBM-bound kernel - low)
+  // cross-wave reduction, one quantity at a time through a [4][H] buffer (12 KiB at H = 768) that the waves add
+  // into four at a time (LDS float atomics run ~a lane per clock here: 30 us for this - plain read-add-write
+  // rounds instead), then one global atomic per column and block.  The global atomics of all blocks land on the
+  // same H addresses at the end of the kernel and serialise in the L2: with 1024 blocks that tail cost 14-22 us
+  // per launch whatever the row count (tools/ln_bench.py), hence 16-wave blocks, one per CU (<= 256 blocks)
 #pragma unroll
   for (int qn = 0; qn < 3; ++qn) {
     float* dst = qn == 0 ? dgamma : (qn == 1 ? dbeta : dbias);
     if (dst == nullptr) continue;     // uniform
+    for (int r = 0; r < WAVES / 4; ++r) {
+      if ((wave >> 2) == r) {
+        float* rw = red[wave & 3];
 #pragma unroll
-    for (int j = 0; j < VPT; ++j)
+        for (int j = 0; j < VPT; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        red[wave][(lane + 64 * j) * 4 + e] = qn == 0 ? ag[j][e] : (qn == 1 ? ab[j][e] : ac[j][e]);
-    __syncthreads();
-    for (int c = threadIdx.x; c < H; c += 256) atomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+          for (int e = 0; e < 4; ++e) {
+            const float v = qn == 0 ? ag[j][e] : (qn == 1 ? ab[j][e] : ac[j][e]);
+            const int idx = (lane + 64 * j) * 4 + e;
+            rw[idx] = (r == 0) ? v : rw[idx] + v;
+          }
+      }
+      __syncthreads();
+    }
+    for (int c = threadIdx.x; c < H; c += WAVES * 64) atomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
     __syncthreads();
   }
 }
@@ -265,11 +277,15 @@ extern "C" int vault_layernorm_bwd(const vault_ln_bwd_args* a, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const RowMap dym{a->dy_rpg, a->dy_gstride, a->dy_goff}, xm{a->x_rpg, a->x_gstride, a->x_goff},
       dxm{a->dx_rpg, a->dx_gstride, a->dx_goff};
-  int rpb = (a->rows + 1023) / 1024;  // <= 1024 blocks
-  rpb = ((rpb + 3) / 4) * 4;
-  dim3 grid((a->rows + rpb - 1) / rpb), block(256);
+  static const int waves = [] { const char* e = getenv("VAULT_LN_WAVES"); return e ? atoi(e) : 16; }();   // development A/B switch
+  const int maxb = 4096 / waves;      // 16 resident waves per CU either way
+  int rpb = (a->rows + maxb - 1) / maxb;
+  rpb = ((rpb + waves - 1) / waves) * waves;
+  dim3 grid((a->rows + rpb - 1) / rpb), block(waves * 64);
 #define LN_BWD(V)                                                                                              \
-  hipLaunchKernelGGL(ln_bwd_kernel<V>, grid, block, 0, st, reinterpret_cast<const bf16*>(a->dy_bf16), a->dy_f32, \
+  if (waves == 16) LN_BWD_W(V, 16); else LN_BWD_W(V, 4)
+#define LN_BWD_W(V, W)                                                                                              \
+  hipLaunchKernelGGL((ln_bwd_kernel<V, W>), grid, block, 0, st, reinterpret_cast<const bf16*>(a->dy_bf16), a->dy_f32, \
                      dym, a->x, xm, a->mean, a->rstd, a->gamma, a->rows, a->H, a->dres, a->dx_f32,               \
                      reinterpret_cast<bf16*>(a->dx_bf16), dxm, a->dgamma, a->dbeta, a->dbias, rpb, a->drop_thresh,          \
                      a->drop_seed, a->drop_stream, a->drop_scale, a->drop_on_dy)
@@ -281,6 +297,7 @@ extern "C" int vault_layernorm_bwd(const vault_ln_bwd_args* a, void* stream) {
     case 6: LN_BWD(6); break;
   }
 #undef LN_BWD
+#undef LN_BWD_W
   return (int)hipGetLastError();
 }
 
