@@ -199,6 +199,10 @@ typedef struct vault_head_args {
   float* pooled; float* logits; float* loss_sum; float* dWc; float* dbc; void* dpre_bf16;
   int B, H, C; float loss_scale, grad_scale;
   uint32_t drop_thresh, drop_seed, drop_stream; float drop_scale;
+  /* ABI 5: loss_kind 1 = binary cross-entropy with logits on `targets` [B] (f32; C == 1), mean over the batch
+   * (nn.BCEWithLogitsLoss, ref: vault/models/vault/trainer.py:55-56: the n_classes = 1 fine-tune); 0 = cross-entropy
+   * on the int64 `labels` */
+  const float* targets; int loss_kind;
 } vault_head_args;
 int vault_head_fwd(const vault_head_args* args, void* stream);
 int vault_head_bwd(const vault_head_args* args, void* stream);
@@ -271,6 +275,92 @@ int vault_vilt_layer_fwd(const vault_layer_args* args, void* stream);
 int vault_vilt_layer_bwd(const vault_layer_bwd_args* args, void* stream);
 int vault_lm_layer_fwd(const vault_layer_args* args, void* stream);
 int vault_lm_layer_bwd(const vault_layer_bwd_args* args, void* stream);
+
+/* ---- stage-level entries (ABI 5): the stages around the encoder layers -------------------------------------------
+ * Same contract as the layer entries: the caller owns every buffer, the calls only enqueue on `stream`.  One struct per
+ * stage serves both directions (forward ignores the backward-only members).  Token-major f32 buffers; *_pad row counts
+ * are multiples of 256 with zero rows behind the valid ones.  Parameter gradients g_* are ACCUMULATED (+=); NULL skips.
+ *
+ * vault_lm_embed_fwd/bwd: BERT / RoBERTa embeddings, HF modeling_roberta.py:75-121 / modeling_bert.py:69-107:
+ *   esum = word[ids] (or inputs_embeds) + pos[position_ids] + type[token_type_ids or 0] ; y = dropout(LN(esum)).
+ *   pos_mode 1 = RoBERTa position ids (cumsum over non-pad tokens + pad_id), 0 = arange.  T <= 64.
+ *   backward: dy = dy_bf16 (optional) + dy_f32 -> desum [rows_pad][H] (= d inputs_embeds when those were given) and the
+ *   table gradients; rows whose rowmask ([B][T] f32, optional) is 0 are skipped in the scatter. */
+typedef struct vault_lm_embed_args {
+  int B, T, H, rows_pad, pos_mode, pad_id; float eps;
+  const int64_t* ids; const int64_t* token_type_ids; const float* inputs_embeds;
+  const float *word, *pos, *type, *lnw, *lnb;
+  int* pos_ids; float* esum; float* mean; float* rstd; float* y; void* y_bf16;
+  uint32_t drop_thresh, drop_seed, drop_stream; float drop_scale;
+  /* backward */
+  const void* dy_bf16; const float* dy_f32; float* desum; const float* rowmask;
+  float *g_word, *g_pos, *g_type, *g_lnw, *g_lnb;
+} vault_lm_embed_args;
+int vault_lm_embed_fwd(const vault_lm_embed_args* args, void* stream);
+int vault_lm_embed_bwd(const vault_lm_embed_args* args, void* stream);
+
+/* vault_vilt_text_embed_fwd/bwd: ViLT TextEmbeddings on the text rows of the fused sequence, HF modeling_vilt.py:237-269 as
+ * VaultMixin.forward calls it (ref: vault/models/vault/model.py:170-200: the LM's last hidden state arrives as
+ * inputs_embeds): vsum = text_src (or word[ids] when NULL) + type[token_type_ids or 0] (+ pos[t] when pos != NULL);
+ * x[b*S + t] = LN(vsum[b*T + t]) + mtype0  (modality type 0, modeling_vilt.py:204-207).
+ * backward over dx [B*S][H] (the fused-sequence gradient): dvsum [rows_pad][H] (= d text_src), table / LN gradients,
+ * g_mtype0; dbeta_scratch [H] f32. */
+typedef struct vault_text_embed_args {
+  int B, T, S, H, rows_pad; float eps;
+  const float* text_src; const int64_t* ids; const int64_t* token_type_ids;
+  const float *word, *pos, *type, *lnw, *lnb, *mtype0;
+  float* vsum; float* mean; float* rstd; float* x;
+  /* backward */
+  const float* dx; float* dvsum; float* dbeta_scratch;
+  float *g_word, *g_pos, *g_type, *g_lnw, *g_lnb, *g_mtype0;
+} vault_text_embed_args;
+int vault_vilt_text_embed_fwd(const vault_text_embed_args* args, void* stream);
+int vault_vilt_text_embed_bwd(const vault_text_embed_args* args, void* stream);
+
+/* vault_patch_embed_fwd/bwd: ViLT patch embedding on the square pre-training canvas (pixel_mask all ones), HF
+ * modeling_vilt.py:290-300 (Conv2d stride = kernel = ps as unfold + GEMM) + visual_embed's position / modality / CLS
+ * terms, modeling_vilt.py:160-166,204-215: writes rows b*S + T (CLS) and b*S + T + 1 + p of the fused sequence x.
+ * P = (IMG/ps)^2 ; apatch [pad256(B*P)][C*ps*ps] bf16 and addtab [P][H] f32 are saved for backward.
+ * backward over dx [B*S][H]: dyp scratch [pad256(B*P)][H] bf16 ; g_w [H][C*ps*ps], g_conv_bias [H], g_pos [(P+1)][H],
+ * g_mtype1 [H], g_cls [H].  (Padded batches of differently sized images: the op-level vault_im2col_sel family.) */
+typedef struct vault_patch_embed_args {
+  int B, C, IMG, ps, T, S, H;
+  const float* pixel_values; const void* w_bf16; const float *conv_bias, *pos_emb, *mtype1, *cls;
+  void* apatch; float* addtab; float* x; int persist;
+  /* backward */
+  const float* dx; void* dyp;
+  float *g_w, *g_conv_bias, *g_pos, *g_mtype1, *g_cls;
+} vault_patch_embed_args;
+int vault_patch_embed_fwd(const vault_patch_embed_args* args, void* stream);
+int vault_patch_embed_bwd(const vault_patch_embed_args* args, void* stream);
+
+/* vault_head_loss_fwd/bwd: final LayerNorm on the CLS rows, pooler (dense + tanh), classifier and loss: HF
+ * modeling_vilt.py ViltModel.forward tail + ViltPooler, ref: vault/models/vault/model.py:547-570, loss as
+ * in vault_head_args: cross-entropy on int64 labels, or BCE-with-logits on f32 targets when loss_kind = 1.
+ * x [B*S][H] = output of the last encoder layer; h0_bf16 / pre / pooled [pad256(B)][H]; loss [1] is zeroed by the call.
+ * backward: zeroes dx_f32 / dx_bf16 [seq_rows_pad][H], then writes the CLS rows' gradient into them; dpre / dh0 scratch
+ * [pad256(B)][H] bf16; g_bf_last = bias gradient of the last layer's FFN-out (column sums of dx). */
+typedef struct vault_head_loss_args {
+  int B, S, H, C, seq_rows_pad; float eps;
+  const float* x; const float *lnw, *lnb; const void* wp_bf16; const float* bp; const float *Wc, *bc;
+  const int64_t* labels; const float* targets; int loss_kind; float loss_scale, grad_scale;
+  void* h0_bf16; float* mean; float* rstd; float* pre; float* pooled; float* logits; float* loss;
+  uint32_t drop_thresh, drop_seed, drop_stream; float drop_scale; int persist;
+  /* backward */
+  void* dpre; void* dh0; float* dx_f32; void* dx_bf16;
+  float *g_Wc, *g_bc, *g_wp, *g_bp, *g_lnw, *g_lnb, *g_bf_last;
+} vault_head_loss_args;
+int vault_head_loss_fwd(const vault_head_loss_args* args, void* stream);
+int vault_head_loss_bwd(const vault_head_loss_args* args, void* stream);
+
+/* Bytes of device memory one forward (+ backward when train) pass over the stages needs for a batch of B items with T text
+ * tokens: every activation the stage structs name (saved tensors of all layers, embeddings, head) plus the backward
+ * scratch, each buffer rounded up to 256 bytes.  The caller allocates (one arena or many tensors) and hands out the
+ * pointers; the library allocates nothing. */
+typedef struct vault_model_dims {
+  int H, FF, heads, lm_layers, vilt_layers, IMG, ps, C, n_classes;
+} vault_model_dims;
+long long vault_workspace_bytes(const vault_model_dims* dims, int B, int T, int train);
 
 #ifdef __cplusplus
 }

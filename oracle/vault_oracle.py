@@ -335,7 +335,12 @@ def vault_forward(P, spec, batch: Dict[str, torch.Tensor], taps: Optional[dict] 
 
 def vault_loss(P, spec, batch, **kw):
     out = vault_forward(P, spec, batch, **kw)
-    loss = F.cross_entropy(out["logits"], batch["labels"])
+    if batch["labels"].dtype.is_floating_point:
+        # single-logit fine-tune (Bloomberg): logits.squeeze(-1) (ref: models/vault/model.py:569) under
+        # nn.BCEWithLogitsLoss (ref: models/vault/trainer.py:55-56)
+        loss = F.binary_cross_entropy_with_logits(out["logits"].squeeze(-1), batch["labels"])
+    else:
+        loss = F.cross_entropy(out["logits"], batch["labels"])
     return loss, out
 
 

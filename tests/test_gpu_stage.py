@@ -160,3 +160,137 @@ def test_lm_layer_one_c_call_forward_and_backward():
                       (gw["g_bo"], P[f"{pre}.attention.output.dense.bias"].grad), (gw["g_ln2w"], P[f"{pre}.output.LayerNorm.weight"].grad),
                       (gw["g_ln1b"], P[f"{pre}.attention.output.LayerNorm.bias"].grad)):
         assert (mine.cpu() - ref).norm() < 3e-2 * ref.norm() + 1e-6
+
+
+def test_embedding_and_head_stages_one_c_call_each_match_the_engine():
+    """ABI 5: vault_lm_embed / vault_vilt_text_embed / vault_patch_embed / vault_head_loss forward and backward, each ONE C
+    call bound through ctypes, on the inputs and parameters of an engine pass whose op-by-op results are pinned against the
+    oracle elsewhere (tests/test_gpu_model.py, test_gpu_train.py): forward outputs bit-identical (same kernels, same order),
+    gradients equal up to the order of the float atomics."""
+    from vault_amd.engine import VaultEngine
+    from vault_amd.spec import synthetic_batch
+    spec = VaultSpec.tiny(3, "bert")
+    spec.lm.hidden_dropout_prob = 0.0; spec.lm.attention_probs_dropout_prob = 0.0
+    lm, v = spec.lm, spec.vilt
+    B = 4
+    bn = synthetic_batch(spec, B, seed=5, n_classes=3)
+    bn["token_type_ids"] = (np.arange(bn["input_ids"].shape[1])[None, :] >= 20).astype(np.int64).repeat(B, 0)
+    state = build_state(spec, 9)
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    db = {k: torch.from_numpy(val).cuda() for k, val in bn.items() if k != "labels"}
+    labels = torch.from_numpy(bn["labels"]).cuda()
+    out = eng.forward(db, train=True, labels=labels)
+    eng.zero_grad(); eng.backward()
+    torch.cuda.synchronize()
+    ws, P = eng.last, eng.params
+    T, S, H, NP = ws["T"], ws["S"], ws["H"], ws["NP"]
+    Ml, Mlp, M, Mp = ws["Ml"], ws["Mlp"], ws["M"], ws["Mp"]
+    nl, nv = lm.num_hidden_layers, v.num_hidden_layers
+    dev = "cuda"
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+    bfl = torch.bfloat16
+
+    def close(mine, ref, tol=2e-5):
+        ref = ref.reshape(mine.shape).float()
+        assert (mine.float() - ref).norm().item() <= tol * ref.norm().item() + 1e-9
+
+    # ---- LM embeddings ------------------------------------------------------------------------------------------
+    e = ops.stage_args(
+        ops.LmEmbedArgs, B=B, T=T, H=H, rows_pad=Mlp, pos_mode=0, pad_id=lm.pad_token_id, eps=lm.layer_norm_eps, ids=ws["ids"],
+        token_type_ids=ws["tt"], word=P.w("bert.embeddings.word_embeddings.weight"), pos=P.w("bert.embeddings.position_embeddings.weight"),
+        type=P.w("bert.embeddings.token_type_embeddings.weight"), lnw=P.w("bert.embeddings.LayerNorm.weight"),
+        lnb=P.w("bert.embeddings.LayerNorm.bias"), pos_ids=z(B, T, dt=torch.int32), esum=z(Mlp, H), mean=z(Mlp), rstd=z(Mlp),
+        y=z(Mlp, H), y_bf16=z(Mlp, H, dt=bfl))
+    _call("vault_lm_embed_fwd", e)
+    torch.cuda.synchronize()
+    y_mine, yb_mine = e._keep[-2], e._keep[-1]
+    assert torch.equal(y_mine[:Ml], ws["lm_y"][0][:Ml]) and torch.equal(yb_mine[:Ml], ws["lm_yb"][0][:Ml])
+    gE = dict(g_word=z(lm.vocab_size, H), g_pos=z(lm.max_position_embeddings, H), g_type=z(lm.type_vocab_size, H), g_lnw=z(H), g_lnb=z(H))
+    desum = z(Mlp, H)
+    for k, val in dict(dy_bf16=ws["lm_dN"], dy_f32=ws["lm_dh1"], desum=desum, rowmask=ws["amf"], **gE).items():
+        setattr(e, k, val.data_ptr())
+    _call("vault_lm_embed_bwd", e)
+    torch.cuda.synchronize()
+    assert torch.equal(desum[:Ml], ws["lm_desum"][:Ml])
+    close(gE["g_word"], P.gr("bert.embeddings.word_embeddings.weight"))
+    close(gE["g_pos"], P.gr("bert.embeddings.position_embeddings.weight"))
+    close(gE["g_type"], P.gr("bert.embeddings.token_type_embeddings.weight"))
+    close(gE["g_lnw"], P.gr("bert.embeddings.LayerNorm.weight")); close(gE["g_lnb"], P.gr("bert.embeddings.LayerNorm.bias"))
+
+    # ---- ViLT text embeddings on the LM output -----------------------------------------------------------------
+    x_mine = z(Mp, H)
+    mt = P.w("embeddings.token_type_embeddings.weight")
+    use_pos = ws["use_pos"]
+    t = ops.stage_args(
+        ops.TextEmbedArgs, B=B, T=T, S=S, H=H, rows_pad=Mlp, eps=v.layer_norm_eps, text_src=ws["lm_y"][nl], ids=ws["ids"],
+        token_type_ids=ws["tt"], type=P.w("embeddings.text_embeddings.token_type_embeddings.weight"),
+        lnw=P.w("embeddings.text_embeddings.LayerNorm.weight"), lnb=P.w("embeddings.text_embeddings.LayerNorm.bias"), mtype0=mt[0],
+        vsum=z(Mlp, H), mean=z(Mlp), rstd=z(Mlp), x=x_mine,
+        **(dict(pos=P.w("embeddings.text_embeddings.position_embeddings.weight")) if use_pos else {}))
+    _call("vault_vilt_text_embed_fwd", t)
+    # ---- patch embedding into the same fused sequence ----------------------------------------------------------
+    Kp = v.num_channels * v.patch_size * v.patch_size
+    wpn = "embeddings.patch_embeddings.projection.weight"
+    pe = ops.stage_args(
+        ops.PatchEmbedArgs, B=B, C=v.num_channels, IMG=v.image_size, ps=v.patch_size, T=T, S=S, H=H, pixel_values=ws["pix"],
+        w_bf16=P.wb(wpn, shape=(H, Kp)), conv_bias=P.w("embeddings.patch_embeddings.projection.bias"),
+        pos_emb=P.w("embeddings.position_embeddings"), mtype1=mt[1], cls=P.w("embeddings.cls_token"),
+        apatch=z(_pad(B * NP), Kp, dt=bfl), addtab=z(NP, H), x=x_mine)
+    _call("vault_patch_embed_fwd", pe)
+    torch.cuda.synchronize()
+    assert torch.equal(x_mine[:M], ws["x"][0][:M])           # text rows, CLS rows and patch rows of every item
+    # backward of both over the engine's gradient at the fused sequence
+    dx0 = ws["dx_a"]
+    gT = dict(g_type=z(v.type_vocab_size, H), g_lnw=z(H), g_lnb=z(H), g_mtype0=z(H))
+    if use_pos:
+        gT["g_pos"] = z(v.max_position_embeddings, H)
+    dvsum = z(Mlp, H)
+    for k, val in dict(dx=dx0, dvsum=dvsum, dbeta_scratch=z(H), **gT).items():
+        setattr(t, k, val.data_ptr())
+    _call("vault_vilt_text_embed_bwd", t)
+    gP = dict(g_w=z(H, Kp), g_conv_bias=z(H), g_pos=z(NP + 1, H), g_mtype1=z(H), g_cls=z(H))
+    for k, val in dict(dx=dx0, dyp=z(_pad(B * NP), H, dt=bfl), **gP).items():
+        setattr(pe, k, val.data_ptr())
+    _call("vault_patch_embed_bwd", pe)
+    torch.cuda.synchronize()
+    assert torch.equal(dvsum[:Ml], ws["d_vt_sum"][:Ml])
+    close(gT["g_type"], P.gr("embeddings.text_embeddings.token_type_embeddings.weight"))
+    close(gT["g_lnw"], P.gr("embeddings.text_embeddings.LayerNorm.weight")); close(gT["g_lnb"], P.gr("embeddings.text_embeddings.LayerNorm.bias"))
+    gmt = P.gr("embeddings.token_type_embeddings.weight")
+    close(gT["g_mtype0"], gmt[0]); close(gP["g_mtype1"], gmt[1])
+    close(gP["g_w"], P.gr(wpn)); close(gP["g_conv_bias"], P.gr("embeddings.patch_embeddings.projection.bias"))
+    close(gP["g_pos"], P.gr("embeddings.position_embeddings")); close(gP["g_cls"], P.gr("embeddings.cls_token"))
+
+    # ---- head + loss ---------------------------------------------------------------------------------------------
+    Bp, Cn = _pad(B), spec.n_classes
+    h = ops.stage_args(
+        ops.HeadLossArgs, B=B, S=S, H=H, C=Cn, seq_rows_pad=Mp, eps=v.layer_norm_eps, x=ws["x"][nv], lnw=P.w("layernorm.weight"),
+        lnb=P.w("layernorm.bias"), wp_bf16=P.wb("pooler.dense.weight"), bp=P.w("pooler.dense.bias"), Wc=P.w("classifier.1.weight"),
+        bc=P.w("classifier.1.bias"), labels=ws["labels"], loss_kind=0, loss_scale=1.0 / B, grad_scale=1.0 / B,
+        h0_bf16=z(Bp, H, dt=bfl), mean=z(Bp), rstd=z(Bp), pre=z(Bp, H), pooled=z(Bp, H), logits=z(B, Cn), loss=z(1) + 7.0)
+    _call("vault_head_loss_fwd", h)
+    torch.cuda.synchronize()
+    pooled, logits, loss = h._keep[-3], h._keep[-2], h._keep[-1]
+    assert torch.equal(logits, out["logits"]) and torch.equal(pooled[:B], out["pooler_output"])
+    assert abs(float(loss) - float(out["loss"])) < 1e-6
+    gH = dict(g_Wc=z(Cn, H), g_bc=z(Cn), g_wp=z(H, H), g_bp=z(H), g_lnw=z(H), g_lnb=z(H), g_bf_last=z(H))
+    dxf, dxb = z(Mp, H) + 3.0, z(Mp, H, dt=bfl) + 3.0          # (the call zeroes them)
+    for k, val in dict(dpre=z(Bp, H, dt=bfl), dh0=z(Bp, H, dt=bfl), dx_f32=dxf, dx_bf16=dxb, **gH).items():
+        setattr(h, k, val.data_ptr())
+    _call("vault_head_loss_bwd", h)
+    torch.cuda.synchronize()
+    close(gH["g_Wc"], P.gr("classifier.1.weight")); close(gH["g_bc"], P.gr("classifier.1.bias"))
+    close(gH["g_wp"], P.gr("pooler.dense.weight")); close(gH["g_bp"], P.gr("pooler.dense.bias"))
+    close(gH["g_lnw"], P.gr("layernorm.weight")); close(gH["g_lnb"], P.gr("layernorm.bias"))
+    rows = torch.arange(B, device=dev) * S
+    other = torch.ones(Mp, dtype=torch.bool, device=dev); other[rows] = False
+    assert float(dxf[other].abs().max()) == 0.0 and float(dxf[rows].abs().max()) > 0.0
+    assert torch.equal(dxb, dxf.bfloat16())
+
+    # ---- workspace query ------------------------------------------------------------------------------------------
+    need = lambda b, tr: ops.workspace_bytes(768, 3072, 12, 12, 12, 384, 32, 3, 3, b, 40, tr)  # noqa: E731
+    layer = L.load().vault_layer_workspace_bytes
+    layer.restype = C.c_longlong
+    assert need(256, True) > 12 * layer(256, 185, 768, 3072, 12, 1, None) + 12 * layer(256, 40, 768, 3072, 12, 1, None)
+    assert need(8, False) < need(8, True) < need(64, True) < need(256, True) < 288e9
+    assert ops.workspace_bytes(768, 3072, 12, 12, 12, 384, 31, 3, 3, 8, 40, True) == -1

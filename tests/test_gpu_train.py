@@ -77,6 +77,56 @@ def test_two_step_trajectory_vs_oracle():
     assert float((torch.sign(dref[big]) == torch.sign(dmine[big])).float().mean()) > 0.97
 
 
+def test_bce_single_logit_fine_tune_step_vs_oracle():
+    """n_classes = 1 with float targets: the fused step's BCE-with-logits loss and its gradients (ref:
+    vault/models/vault/trainer.py:55-56 over model.py:567-570) against the fp32 oracle, eager and from the tape."""
+    spec = VaultSpec.tiny(1, "bert")
+    spec.lm.hidden_dropout_prob = 0.0; spec.lm.attention_probs_dropout_prob = 0.0
+    bn = synthetic_batch(spec, 6, seed=33, n_classes=2)
+    bn["labels"] = bn["labels"].astype(np.float32)            # 0. / 1. targets
+    state = build_state(spec, 2)
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
+    labels = torch.from_numpy(bn["labels"]).cuda()
+    # forward + backward: loss, logits and head / pooler gradients
+    out = eng.forward(db, train=True, labels=labels)
+    eng.zero_grad(); eng.backward()
+    P = O.to_torch_state(state, requires_grad=True)
+    loss_ref, out_ref = O.vault_loss(P, spec, O.torch_batch(bn))
+    loss_ref.backward()
+    assert out["logits"].shape == (6,)
+    np.testing.assert_allclose(out["logits"].cpu().numpy(), out_ref["logits"].detach().squeeze(-1).numpy(), atol=3e-3)
+    assert abs(float(out["loss"]) - float(loss_ref.detach())) < 2e-3
+    for name in ("classifier.1.weight", "classifier.1.bias", "pooler.dense.weight"):
+        g, gr = eng.params.gr(name).cpu().reshape(-1), P[name].grad.reshape(-1)
+        cos = float(torch.dot(g, gr) / (g.norm() * gr.norm() + 1e-30))
+        assert cos > 0.995 and abs(float(g.norm() / gr.norm()) - 1.0) < 0.02, (name, cos)
+    with pytest.raises(ValueError):     # float targets on a multi-class head
+        VaultEngine(VaultSpec.tiny(3, "bert"), "cuda:0", state=build_state(VaultSpec.tiny(3, "bert"), 0)).forward(
+            {k: torch.from_numpy(v).cuda() for k, v in synthetic_batch(VaultSpec.tiny(3, "bert"), 6, seed=33).items()
+             if k != "labels"}, train=True, labels=labels)
+    # three optimisation steps (step 2 and 3 replay the tape)
+    eng2 = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    step = TrainStep(eng2, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10)
+    losses = [float(step(db, labels)) for _ in range(3)]
+    P = O.to_torch_state(state, requires_grad=True)
+    m = {k: torch.zeros_like(v) for k, v in P.items()}; v2 = {k: torch.zeros_like(v) for k, v in P.items()}
+    ref_losses = []
+    for t in range(1, 4):
+        for p in P.values():
+            p.grad = None
+        loss, _ = O.vault_loss(P, spec, O.torch_batch(bn))
+        loss.backward()
+        ref_losses.append(float(loss.detach()))
+        with torch.no_grad():
+            for k, p in P.items():
+                if p.grad is not None:
+                    O.hf_adamw_step(p, p.grad, m[k], v2[k], O.linear_schedule_lr(5e-5, t - 1, 0, 10), t)
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) < 5e-3, (losses, ref_losses)
+    assert ref_losses[2] < ref_losses[0] and losses[2] < losses[0], (losses, ref_losses)
+
+
 def test_train_mode_dropout_is_active_and_reproducible():
     spec = VaultSpec.tiny(3, "roberta")
     bn = synthetic_batch(spec, 4, seed=22, n_classes=3)

@@ -61,7 +61,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     lib.vault_abi_version.restype = ctypes.c_int
-    assert lib.vault_abi_version() == 4
+    assert lib.vault_abi_version() == 5
 
 
 def test_ctypes_structures_match_the_c_header(tmp_path):
@@ -75,7 +75,10 @@ def test_ctypes_structures_match_the_c_header(tmp_path):
         pytest.skip("gcc not available")
     pairs = {"vault_gemm_args": L.GemmArgs, "vault_ln_fwd_args": ops.LnFwdArgs, "vault_ln_bwd_args": ops.LnBwdArgs,
              "vault_attn_args": ops.AttnArgs, "vault_gather_args": ops.GatherArgs, "vault_head_args": ops.HeadArgs,
-             "vault_layer_args": ops.LayerArgs, "vault_layer_bwd_args": ops.LayerBwdArgs}
+             "vault_layer_args": ops.LayerArgs, "vault_layer_bwd_args": ops.LayerBwdArgs,
+             "vault_lm_embed_args": ops.LmEmbedArgs, "vault_text_embed_args": ops.TextEmbedArgs,
+             "vault_patch_embed_args": ops.PatchEmbedArgs, "vault_head_loss_args": ops.HeadLossArgs,
+             "vault_model_dims": ops.ModelDims}
     hdr = os.path.join(ROOT, "include", "vault_hip.h")
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{hdr}"', 'int main(void) {']
     for cname, cls in pairs.items():

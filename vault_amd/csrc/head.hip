@@ -2,6 +2,7 @@
 //   pooled = tanh(pre)                 (pre = pooler dense output, from the GEMM)
 //   logits = dropout(pooled) Wc^T + bc (ref: vault/models/vault/model.py:547-550,567-570)
 //   loss   = mean CrossEntropy         (ref: vault/tmsc_utils/trainer.py:241-242)
+//            or mean BCE-with-logits  (ref: vault/models/vault/trainer.py:55-56; n_classes = 1, float targets)
 // and the backward of all three.  One wave per sample.
 #include "common.h"
 #include "../../include/vault_hip.h"
@@ -15,7 +16,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                                                        float* __restrict__ pooled, float* __restrict__ logits,
                                                        float* __restrict__ loss_sum, int B, int H, int C, float loss_scale,
                                                        uint32_t drop_thresh, uint32_t drop_seed, uint32_t drop_stream,
-                                                       float drop_scale) {
+                                                       float drop_scale, const float* __restrict__ targets) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -44,7 +45,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
       logits[(size_t)b * C + c] = acc[c];
       se += expf(acc[c] - mx);
     }
-    if (labels != nullptr && loss_sum != nullptr) {
+    if (targets != nullptr && loss_sum != nullptr) {
+      // BCE with logits, the numerically stable form torch uses: max(x, 0) - x y + log(1 + exp(-|x|))
+      const float x = acc[0], y = targets[b];
+      atomicAdd(loss_sum, (fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)))) * loss_scale);
+    } else if (labels != nullptr && loss_sum != nullptr) {
       const int y = (int)labels[b];
       float ly = 0.f;
       for (int c = 0; c < C; ++c) if (c == y) ly = acc[c];
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        float* __restrict__ dWc, float* __restrict__ dbc,
                                                        bf16* __restrict__ dpre, int B, int H, int C, float gscale,
                                                        uint32_t drop_thresh, uint32_t drop_seed, uint32_t drop_stream,
-                                                       float drop_scale) {
+                                                       float drop_scale, const float* __restrict__ targets) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -69,6 +74,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   if (dlogits_in != nullptr) {
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) dl[c] = (c < C) ? dlogits_in[(size_t)b * C + c] : 0.f;
+  } else if (targets != nullptr) {   // d BCE-with-logits / d logit = sigmoid(x) - y
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) dl[c] = 0.f;
+    const float x = logits[b];
+    dl[0] = (1.f / (1.f + expf(-x)) - targets[b]) * gscale;
   } else {
     float mx = -INFINITY;
 #pragma unroll
@@ -154,19 +164,23 @@ extern "C" int vault_head_fwd(const vault_head_args* a, void* stream) {
   if (!a || !a->pre || !a->pooled || a->B <= 0 || a->C > MAXC || a->C < 0) return VAULT_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a->C > 0 && (!a->Wc || !a->bc || !a->logits)) return VAULT_EINVAL;
+  if (a->loss_kind < 0 || a->loss_kind > 1 || (a->loss_kind == 1 && a->loss_sum && (a->C != 1 || !a->targets))) return VAULT_EINVAL;
   hipLaunchKernelGGL(head_fwd_kernel, dim3((a->B + 3) / 4), dim3(256), 0, st, a->pre, a->Wc, a->bc,
                      reinterpret_cast<const long long*>(a->labels), a->pooled, a->logits, a->loss_sum, a->B, a->H, a->C,
-                     a->loss_scale, a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale);
+                     a->loss_scale, a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale,
+                     a->loss_kind == 1 ? a->targets : nullptr);
   return (int)hipGetLastError();
 }
 
 extern "C" int vault_head_bwd(const vault_head_args* a, void* stream) {
   if (!a || !a->pooled || !a->dpre_bf16 || a->B <= 0 || a->C > MAXC || a->C <= 0) return VAULT_EINVAL;
-  if (a->dlogits == nullptr && (a->labels == nullptr || a->logits == nullptr)) return VAULT_EINVAL;
+  if (a->loss_kind < 0 || a->loss_kind > 1) return VAULT_EINVAL;
+  if (a->dlogits == nullptr && a->loss_kind == 1 && (a->C != 1 || a->targets == nullptr || a->logits == nullptr)) return VAULT_EINVAL;
+  if (a->dlogits == nullptr && a->loss_kind == 0 && (a->labels == nullptr || a->logits == nullptr)) return VAULT_EINVAL;
   hipLaunchKernelGGL(head_bwd_kernel, dim3((a->B + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      a->pooled, a->logits, a->dlogits, reinterpret_cast<const long long*>(a->labels), a->Wc, a->dWc,
                      a->dbc, reinterpret_cast<bf16*>(a->dpre_bf16), a->B, a->H, a->C, a->grad_scale, a->drop_thresh,
-                     a->drop_seed, a->drop_stream, a->drop_scale);
+                     a->drop_seed, a->drop_stream, a->drop_scale, a->loss_kind == 1 ? a->targets : nullptr);
   return (int)hipGetLastError();
 }
 

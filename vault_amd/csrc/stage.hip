@@ -11,39 +11,11 @@
 #include "common.h"
 #include "../../include/vault_hip.h"
 
+#include "stage_util.h"
+
+using namespace stage;
+
 namespace {
-
-int gemm(const void* A, const void* B, void* out, int M, int N, int K, int lda, int ldb, int ldo, int a_mode, int b_mode, int epi,
-         int m_valid, void* st, int persist, const float* bias = nullptr, const float* res = nullptr, const void* aux = nullptr,
-         void* out2 = nullptr, float* colsum = nullptr, int splits = 1, int accumulate = 0, int cfg = -1,
-         uint32_t dthr = 0, uint32_t dseed = 0, uint32_t dstream = 0, float dscale = 1.f) {
-  vault_gemm_args a{};
-  a.A = A; a.B = B; a.out = out; a.out2 = out2; a.bias = bias; a.res = res; a.aux = aux; a.colsum = colsum;
-  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldo = ldo; a.m_valid = m_valid;
-  a.a_mode = a_mode; a.b_mode = b_mode; a.epi = epi; a.cfg = cfg; a.splits = splits; a.accumulate = accumulate;
-  a.persist = persist;
-  a.drop_thresh = dthr; a.drop_seed = dseed; a.drop_stream = dstream; a.drop_scale = dscale;
-  return vault_gemm(&a, st);
-}
-
-int ln_fwd(const float* x, const float* g, const float* b, float eps, int rows, int H, void* y_bf16, float* y_f32, float* mean,
-           float* rstd, void* st) {
-  vault_ln_fwd_args a{};
-  a.x = x; a.gamma = g; a.beta = b; a.y_bf16 = y_bf16; a.y_f32 = y_f32; a.mean = mean; a.rstd = rstd;
-  a.rows = rows; a.H = H; a.eps = eps;
-  return vault_layernorm_fwd(&a, st);
-}
-
-int ln_bwd(const float* x, const float* mean, const float* rstd, const float* gamma, int rows, int H, const void* dy_bf16,
-           const float* dy_f32, const float* dres, float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, float* dbias,
-           void* st, uint32_t dthr = 0, uint32_t dseed = 0, uint32_t dstream = 0, float dscale = 1.f) {
-  vault_ln_bwd_args a{};
-  a.dy_bf16 = dy_bf16; a.dy_f32 = dy_f32; a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.dres = dres;
-  a.dx_f32 = dx_f32; a.dx_bf16 = dx_bf16; a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias;
-  a.rows = rows; a.H = H;
-  a.drop_thresh = dthr; a.drop_seed = dseed; a.drop_stream = dstream; a.drop_scale = dscale;
-  return vault_layernorm_bwd(&a, st);
-}
 
 int attn(const vault_layer_args* L, int bwd, const void* dctx, void* dqkv, void* st) {
   vault_attn_args a{};
@@ -55,8 +27,6 @@ int attn(const vault_layer_args* L, int bwd, const void* dctx, void* dqkv, void*
   }
   return bwd ? vault_attention_bwd(&a, st) : vault_attention_fwd(&a, st);
 }
-
-#define CHK(X) { const int rc_ = (X); if (rc_ != 0) return rc_; }
 
 bool bad(const vault_layer_args* L) {
   return !L || L->B <= 0 || L->S <= 0 || L->H <= 0 || (L->H & 255) || L->FF <= 0 || (L->FF & 127) || L->H != L->heads * 64 ||
@@ -89,21 +59,6 @@ extern "C" int vault_vilt_layer_fwd(const vault_layer_args* L, void* st) {
   CHK(gemm(L->n2, L->wi, L->act, Mp, FF, H, H, H, FF, 0, 0, 1, M, st, L->persist, L->bi, nullptr, nullptr, L->u));
   CHK(gemm(L->act, L->wf, L->x_out, Mp, H, FF, FF, FF, H, 0, 0, 3, M, st, L->persist, L->bf, L->xm));
   return VAULT_OK;
-}
-
-// dY side of the weight gradients: dW += dY^T X, accumulated (atomic epilogue) into the caller's f32 gradient
-static int wgrad(const void* dy, const void* x, float* dw, int Mp, int Nout, int Kin, void* st, int persist) {
-  if (!dw) return VAULT_OK;
-  const int tiles = (Nout / 256) * (Kin / 256);
-  int splits = 1, cfg = 0;
-  if (Nout % 256 == 0 && Kin % 256 == 0) {
-    cfg = 3;
-    splits = 256 / tiles; if (splits > Mp / 128) splits = Mp / 128; if (splits > 16) splits = 16; if (splits < 1) splits = 1;
-  } else {
-    splits = 768 / ((Nout / 128) * (Kin / 128) > 0 ? (Nout / 128) * (Kin / 128) : 1); if (splits < 1) splits = 1;
-    if (splits > Mp / 64) splits = Mp / 64;
-  }
-  return gemm(dy, x, dw, Nout, Kin, Mp, Nout, Kin, Kin, 1, 1, 5, 0, st, persist, nullptr, nullptr, nullptr, nullptr, nullptr, splits, 1, cfg);
 }
 
 extern "C" int vault_vilt_layer_bwd(const vault_layer_bwd_args* G, void* st) {

@@ -595,7 +595,7 @@ class VaultEngine:
         tt = batch.get("token_type_ids")
         ws["ids"], ws["pix"], ws["amf"] = ws["in_ids"], ws["in_pix"], ws["in_amf"]
         ws["tt"] = None if tt is None else buf("in_tt", (B, T), torch.int64).copy_(tt)
-        ws["labels"] = None if labels is None else buf("in_labels", (B,), torch.int64).copy_(labels)
+        ws["labels"] = self._stage_labels(buf, labels, B)
         return ws
 
     def _stage_text(self, ws, ids, temb, B, T, H):
@@ -638,8 +638,19 @@ class VaultEngine:
         tt = batch.get("token_type_ids")
         ws["ids"], ws["pix"], ws["amf"] = ws["in_ids"], None, ws["in_amf"]
         ws["tt"] = None if tt is None else buf("in_tt", (B, T), torch.int64).copy_(tt)
-        ws["labels"] = None if labels is None else buf("in_labels", (B,), torch.int64).copy_(labels)
+        ws["labels"] = self._stage_labels(buf, labels, B)
         return ws
+
+    def _stage_labels(self, buf, labels, B):
+        """int64 class labels (cross-entropy, ref: tmsc_utils/trainer.py:241-242) or float targets of the single-logit
+        head (BCE with logits, ref: models/vault/trainer.py:55-56), each in its own persistent buffer."""
+        if labels is None:
+            return None
+        if labels.dtype.is_floating_point:
+            if self.spec.n_classes != 1 or self.spec.head == "mlp":
+                raise ValueError("float targets (BCE-with-logits) need the single-logit classifier (n_classes = 1)")
+            return buf("in_targets", (B,), torch.float32).copy_(labels.reshape(B))
+        return buf("in_labels", (B,), torch.int64).copy_(labels.reshape(B))
 
     def input_buffers(self, B: int, T: int, train: bool = True) -> Dict[str, torch.Tensor]:
         """The persistent input staging buffers of the (B, T) workspace on the square pre-training canvas

@@ -229,7 +229,7 @@ class HeadArgs(C.Structure):
                 ("dbc", C.c_void_p), ("dpre_bf16", C.c_void_p),
                 ("B", C.c_int), ("H", C.c_int), ("C", C.c_int), ("loss_scale", C.c_float), ("grad_scale", C.c_float),
                 ("drop_thresh", C.c_uint32), ("drop_seed", C.c_uint32), ("drop_stream", C.c_uint32),
-                ("drop_scale", C.c_float)]
+                ("drop_scale", C.c_float), ("targets", C.c_void_p), ("loss_kind", C.c_int)]
 
 
 def position_ids(ids_i64, pos_i32, B, T, mode, pad):
@@ -316,6 +316,10 @@ def _head_args(pre, Wc, bc, labels, pooled, logits, loss_sum, B, H, Cc, loss_sca
                dWc=None, dbc=None, dpre=None, drop: Drop = NO_DROP):
     a = HeadArgs()
     a.pre, a.Wc, a.bc, a.labels, a.dlogits = _p(pre), _p(Wc), _p(bc), _p(labels), _p(dlogits)
+    if labels is not None and labels.dtype.is_floating_point:   # float targets: BCE-with-logits (n_classes = 1)
+        if labels.dtype != torch.float32:
+            raise TypeError("BCE targets must be float32")
+        a.labels, a.targets, a.loss_kind = None, _p(labels), 1
     a.pooled, a.logits, a.loss_sum, a.dWc, a.dbc, a.dpre_bf16 = (_p(pooled), _p(logits), _p(loss_sum), _p(dWc),
                                                                  _p(dbc), _p(dpre))
     a.B, a.H, a.C, a.loss_scale, a.grad_scale = B, H, Cc, loss_scale, grad_scale
@@ -400,6 +404,55 @@ class LayerBwdArgs(C.Structure):
                                            "dh1_bf16", "dmid_f32", "g_wqkv", "g_bqkv", "g_wo", "g_bo", "g_wi", "g_bi", "g_wf",
                                            "g_bf", "g_ln1w", "g_ln1b", "g_ln2w", "g_ln2b", "g_bf_below")] +
                 [("do_wgrad", C.c_int)])
+
+
+def _struct(name, doc, spec):
+    """ctypes.Structure from a compact field list: ``"i:a b c"`` ints, ``"f:..."`` floats, ``"p:..."`` pointers, ``"u:..."`` uint32."""
+    kinds = {"i": C.c_int, "f": C.c_float, "p": C.c_void_p, "u": C.c_uint32}
+    fields = []
+    for part in spec:
+        k, names = part.split(":")
+        fields += [(n, kinds[k]) for n in names.split()]
+    return type(name, (C.Structure,), {"_fields_": fields, "__doc__": doc})
+
+
+# ABI 5 stage structs (include/vault_hip.h), member for member
+LmEmbedArgs = _struct("LmEmbedArgs", "vault_lm_embed_args", [
+    "i:B T H rows_pad pos_mode pad_id", "f:eps", "p:ids token_type_ids inputs_embeds word pos type lnw lnb pos_ids esum mean rstd y y_bf16",
+    "u:drop_thresh drop_seed drop_stream", "f:drop_scale", "p:dy_bf16 dy_f32 desum rowmask g_word g_pos g_type g_lnw g_lnb"])
+TextEmbedArgs = _struct("TextEmbedArgs", "vault_text_embed_args", [
+    "i:B T S H rows_pad", "f:eps", "p:text_src ids token_type_ids word pos type lnw lnb mtype0 vsum mean rstd x",
+    "p:dx dvsum dbeta_scratch g_word g_pos g_type g_lnw g_lnb g_mtype0"])
+PatchEmbedArgs = _struct("PatchEmbedArgs", "vault_patch_embed_args", [
+    "i:B C IMG ps T S H", "p:pixel_values w_bf16 conv_bias pos_emb mtype1 cls apatch addtab x", "i:persist",
+    "p:dx dyp g_w g_conv_bias g_pos g_mtype1 g_cls"])
+HeadLossArgs = _struct("HeadLossArgs", "vault_head_loss_args", [
+    "i:B S H C seq_rows_pad", "f:eps", "p:x lnw lnb wp_bf16 bp Wc bc labels targets", "i:loss_kind", "f:loss_scale grad_scale",
+    "p:h0_bf16 mean rstd pre pooled logits loss", "u:drop_thresh drop_seed drop_stream", "f:drop_scale", "i:persist",
+    "p:dpre dh0 dx_f32 dx_bf16 g_Wc g_bc g_wp g_bp g_lnw g_lnb g_bf_last"])
+ModelDims = _struct("ModelDims", "vault_model_dims", ["i:H FF heads lm_layers vilt_layers IMG ps C n_classes"])
+
+
+def stage_args(struct_type, /, **kw):
+    """Fill one of the stage structs from tensors / numbers (``persist`` = the process-wide GEMM scheduling mode)."""
+    a = struct_type()
+    keep = []
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            keep.append(v)
+            v = _p(v)
+        setattr(a, k, v)
+    if hasattr(a, "persist"):
+        a.persist = GEMM_SCHED
+    a._keep = keep
+    return a
+
+
+def workspace_bytes(H, FF, heads, lm_layers, vilt_layers, IMG, ps, Cn, n_classes, B, T, train) -> int:
+    fn = L.load().vault_workspace_bytes
+    fn.restype = C.c_longlong
+    d = ModelDims(H, FF, heads, lm_layers, vilt_layers, IMG, ps, Cn, n_classes)
+    return int(fn(C.byref(d), C.c_int(B), C.c_int(T), C.c_int(1 if train else 0)))
 
 
 def layer_args(**kw) -> LayerArgs:

@@ -191,7 +191,7 @@ class TrainStep:
             # what the recorded launches bake in besides the buffers of the (B, T, geometry) workspace: whether token
             # types were given, the launch stream, the GEMM scheduling mode and the forward number format
             key = ws["key"] + (ws["tt"] is None, torch.cuda.current_stream().cuda_stream, ops.GEMM_SCHED,
-                               bool(eng.fp8_forward))
+                               bool(eng.fp8_forward), labels.dtype.is_floating_point)
             if self.use_tape and self._tape is not None and self._tape_key == key and self._tape_ws is ws:
                 eng.drop_seed = (eng.drop_seed + 1) & 0xFFFFFFFF
                 self._tape.replay(seed=eng.drop_seed)
