@@ -353,6 +353,29 @@ typedef struct vault_head_loss_args {
 int vault_head_loss_fwd(const vault_head_loss_args* args, void* stream);
 int vault_head_loss_bwd(const vault_head_loss_args* args, void* stream);
 
+/* ---- input pipeline (ABI 5): the image half of ViLT preprocessing for a batch of differently sized uint8 images ------
+ * Replaces the per-item CPU call `tokenizer.feature_extractor(image, return_tensors="pt")` of
+ * ref: vault/models/vault/dataset.py:337-341 (HF:models/vilt/image_processing_pil_vilt.py:70-98 output size, PIL
+ * antialiased bicubic resize, image_transforms.py:118-122 rescale, :417-439 normalise, image_processing_pil_vilt.py:
+ * 160-206 pad + pixel_mask) bit-exactly: 8-bit fixed-point resampling in two passes like Pillow's Resample.c.
+ * The HOST plans (vault_amd/preprocess.py): output sizes, and per image and axis the taps Pillow's precompute_coeffs
+ * gives - `plan` holds, at the descriptor's int32 offsets, bounds [out][2] = (first tap, tap count) and weights
+ * [out][ksize] in 22-bit fixed point.  src: the images back to back, [h_in][w_in][3] uint8 each; tmp: [h_in][w_out][3]
+ * uint8 per image (intermediate of the horizontal pass); lut [3][256] f32 = value of each 8-bit level per channel after
+ * rescale + normalise; pixel_values [B][3][H][W] f32 (zero in the bottom / right padding); pixel_mask [B][H][W] int64
+ * and / or f32 (optional).  max_h_in / max_w_out: maxima over the batch (launch bounds). */
+typedef struct vault_image_desc {
+  long long src_off, tmp_off;
+  int h_in, w_in, h_out, w_out, ksize_h, ksize_v;
+  int hb_off, hk_off, vb_off, vk_off;
+} vault_image_desc;
+typedef struct vault_preprocess_args {
+  const uint8_t* src; uint8_t* tmp; const int* plan; const vault_image_desc* desc; const float* lut;
+  float* pixel_values; int64_t* pixel_mask; float* pixel_mask_f32;
+  int B, H, W, max_h_in, max_w_out;
+} vault_preprocess_args;
+int vault_image_preprocess(const vault_preprocess_args* args, void* stream);
+
 /* Bytes of device memory one forward (+ backward when train) pass over the stages needs for a batch of B items with T text
  * tokens: every activation the stage structs name (saved tensors of all layers, embeddings, head) plus the backward
  * scratch, each buffer rounded up to 256 bytes.  The caller allocates (one arena or many tensors) and hands out the

@@ -70,7 +70,7 @@ def test_ctypes_structures_match_the_c_header(tmp_path):
     import ctypes as C
     import shutil
     import subprocess
-    from vault_amd import lib as L, ops
+    from vault_amd import lib as L, ops, preprocess
     if shutil.which("gcc") is None:
         pytest.skip("gcc not available")
     pairs = {"vault_gemm_args": L.GemmArgs, "vault_ln_fwd_args": ops.LnFwdArgs, "vault_ln_bwd_args": ops.LnBwdArgs,
@@ -78,7 +78,8 @@ def test_ctypes_structures_match_the_c_header(tmp_path):
              "vault_layer_args": ops.LayerArgs, "vault_layer_bwd_args": ops.LayerBwdArgs,
              "vault_lm_embed_args": ops.LmEmbedArgs, "vault_text_embed_args": ops.TextEmbedArgs,
              "vault_patch_embed_args": ops.PatchEmbedArgs, "vault_head_loss_args": ops.HeadLossArgs,
-             "vault_model_dims": ops.ModelDims}
+             "vault_model_dims": ops.ModelDims, "vault_image_desc": preprocess.ImageDesc,
+             "vault_preprocess_args": preprocess.PreprocessArgs}
     hdr = os.path.join(ROOT, "include", "vault_hip.h")
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{hdr}"', 'int main(void) {']
     for cname, cls in pairs.items():

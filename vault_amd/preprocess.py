@@ -1,0 +1,186 @@
+"""Device-side image preprocessing: a drop-in for the image half of ``ViltProcessor`` /
+``tokenizer.feature_extractor(image, return_tensors="pt")`` as the reference calls it per item
+(ref: vault/models/vault/dataset.py:337-341), for whole batches of differently sized uint8 images.
+
+The host plans - output sizes (HF:models/vilt/image_processing_pil_vilt.py:70-98) and, per image and axis, the taps of
+Pillow's antialiased bicubic filter (``Resample.c`` ``precompute_coeffs`` / ``normalize_coeffs_8bpc``, evaluated here in
+float64 with the same operation order) - the GPU does the byte work (csrc/preprocess.hip: ``vault_image_preprocess``).
+The result equals the HuggingFace processor's bit for bit (tests/test_gpu_preprocess.py against goldens generated from it).
+"""
+import ctypes as C
+from functools import lru_cache
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+PRECISION_BITS = 22
+
+
+class ImageDesc(C.Structure):
+    """vault_image_desc (include/vault_hip.h)."""
+    _fields_ = [("src_off", C.c_longlong), ("tmp_off", C.c_longlong)] + [
+        (n, C.c_int) for n in ("h_in", "w_in", "h_out", "w_out", "ksize_h", "ksize_v", "hb_off", "hk_off", "vb_off", "vk_off")]
+
+
+class PreprocessArgs(C.Structure):
+    """vault_preprocess_args (include/vault_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("src", "tmp", "plan", "desc", "lut", "pixel_values", "pixel_mask", "pixel_mask_f32")] + [
+        (n, C.c_int) for n in ("B", "H", "W", "max_h_in", "max_w_out")]
+
+
+def resize_output_size(h: int, w: int, shorter: int = 384, size_divisor: int = 32) -> Tuple[int, int]:
+    """Shorter side -> ``shorter``, longer side capped at int(1333 / 800 * shorter), both floored to multiples of
+    ``size_divisor`` (HF:models/vilt/image_processing_pil_vilt.py:70-98,150)."""
+    longer = int(1333 / 800 * shorter)
+    s = shorter / min(h, w)
+    nh, nw = (shorter, s * w) if h < w else (s * h, shorter)
+    if max(nh, nw) > longer:
+        s = longer / max(nh, nw)
+        nh, nw = s * nh, s * nw
+    nh, nw = int(nh + 0.5), int(nw + 0.5)
+    return nh // size_divisor * size_divisor, nw // size_divisor * size_divisor
+
+
+@lru_cache(maxsize=4096)
+def resample_taps(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray]:
+    """(bounds int32 [out][2] = first tap / tap count, weights int32 [out][ksize]) of Pillow's 8-bit bicubic resampling."""
+    scale = in_size / out_size
+    fscale = max(scale, 1.0)
+    support = 2.0 * fscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    center = (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)          # C's (int) truncation; arguments are > -1
+    xmin = np.where(center - support + 0.5 < 0, 0, xmin)
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size)
+    n = xmax - xmin
+    k = np.arange(ksize, dtype=np.float64)[None, :]
+    x = np.abs((k + xmin[:, None] - center[:, None] + 0.5) * (1.0 / fscale))
+    a = -0.5
+    w = np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1, np.where(x < 2.0, (((x - 5) * x + 8) * x - 4) * a, 0.0))
+    w = np.where(np.arange(ksize)[None, :] < n[:, None], w, 0.0)
+    ww = np.zeros(out_size, dtype=np.float64)
+    for j in range(ksize):                                                  # sequential sum, like the C loop
+        ww = ww + w[:, j]
+    w = np.where(ww[:, None] != 0.0, w / np.where(ww == 0.0, 1.0, ww)[:, None], w)
+    q = np.trunc(np.where(w < 0, -0.5 + w * (1 << PRECISION_BITS), 0.5 + w * (1 << PRECISION_BITS))).astype(np.int32)
+    bounds = np.stack([xmin, n], 1).astype(np.int32)
+    return bounds, q
+
+
+def normalise_lut(rescale_factor: float, mean: Sequence[float], std: Sequence[float]) -> np.ndarray:
+    """[3][256] float32: the value the HF processor produces for each 8-bit level (rescale in float64, cast to float32,
+    normalise in float32; HF:image_transforms.py:118-122,417-439)."""
+    v = (np.arange(256).astype(np.float64) * rescale_factor).astype(np.float32)
+    return np.stack([(v - np.float32(m)) / np.float32(s) for m, s in zip(mean, std)]).astype(np.float32)
+
+
+def _as_hwc_u8(img) -> np.ndarray:
+    if isinstance(img, torch.Tensor):
+        img = img.cpu().numpy()
+    if not isinstance(img, np.ndarray):               # PIL image
+        img = np.asarray(img.convert("RGB") if getattr(img, "mode", "RGB") != "RGB" else img)
+    if img.dtype != np.uint8 or img.ndim != 3:
+        raise TypeError("images must be 8-bit RGB: PIL images or [H][W][3] (or [3][H][W]) uint8 arrays")
+    if img.shape[2] != 3 and img.shape[0] == 3:
+        img = img.transpose(1, 2, 0)
+    if img.shape[2] != 3:
+        raise ValueError("images need three channels")
+    return np.ascontiguousarray(img)
+
+
+class DeviceImageProcessor:
+    """``processor(images, return_tensors="pt")`` -> ``{"pixel_values": [B,3,H,W] float32, "pixel_mask": [B,H,W] int64}`` on
+    the GPU, equal to ``ViltImageProcessor``'s output.  Keyword defaults are the dandelin/vilt-b32 checkpoints' settings."""
+
+    model_input_names = ["pixel_values", "pixel_mask"]
+
+    def __init__(self, device="cuda:0", shortest_edge: int = 384, size_divisor: int = 32, rescale_factor: float = 1 / 255,
+                 image_mean: Sequence[float] = (0.5, 0.5, 0.5), image_std: Sequence[float] = (0.5, 0.5, 0.5),
+                 mask_dtype: torch.dtype = torch.int64):
+        if not torch.cuda.is_available():
+            raise RuntimeError("DeviceImageProcessor needs a GPU (the HIP library has no CPU path)")
+        L.load()
+        self.device = torch.device(device)
+        self.shortest_edge, self.size_divisor = shortest_edge, size_divisor
+        self.mask_dtype = mask_dtype
+        self._lut = torch.from_numpy(normalise_lut(rescale_factor, image_mean, image_std)).to(self.device)
+
+    def plan(self, sizes: List[Tuple[int, int]]):
+        """Host plan of a batch: (descriptor bytes, plan int32 array, src bytes, tmp bytes, H, W, max_h_in, max_w_out)."""
+        descs = (ImageDesc * len(sizes))()
+        parts: List[np.ndarray] = []
+        off = 0
+
+        def put(a: np.ndarray) -> int:
+            nonlocal off
+            o = off
+            parts.append(a.reshape(-1))
+            off += a.size
+            return o
+
+        cache: Dict[Tuple[int, int], Tuple[int, int, int]] = {}
+        src_off = tmp_off = 0
+        H = W = max_h_in = max_w_out = 0
+        for i, (h, w) in enumerate(sizes):
+            oh, ow = resize_output_size(h, w, self.shortest_edge, self.size_divisor)
+            if oh <= 0 or ow <= 0:
+                raise ValueError(f"image {i} ({h} x {w}) resizes to an empty image")
+            d = descs[i]
+            d.src_off, d.tmp_off, d.h_in, d.w_in, d.h_out, d.w_out = src_off, tmp_off, h, w, oh, ow
+            for axis, (n_in, n_out) in (("h", (w, ow)), ("v", (h, oh))):
+                if (n_in, n_out) not in cache:
+                    b, q = resample_taps(n_in, n_out)
+                    cache[(n_in, n_out)] = (put(b), put(q), q.shape[1])
+                bo, ko, ks = cache[(n_in, n_out)]
+                if axis == "h":
+                    d.hb_off, d.hk_off, d.ksize_h = bo, ko, ks
+                else:
+                    d.vb_off, d.vk_off, d.ksize_v = bo, ko, ks
+            src_off += h * w * 3
+            tmp_off += h * ow * 3
+            H, W, max_h_in, max_w_out = max(H, oh), max(W, ow), max(max_h_in, h), max(max_w_out, ow)
+        if off >= 2 ** 31:
+            raise ValueError("plan too large")
+        return bytes(descs), np.concatenate(parts).astype(np.int32), src_off, tmp_off, H, W, max_h_in, max_w_out
+
+    def __call__(self, images, return_tensors: str = "pt", **unused) -> Dict[str, torch.Tensor]:
+        if return_tensors != "pt":
+            raise ValueError("the device processor returns torch tensors on the GPU (return_tensors='pt')")
+        if not isinstance(images, (list, tuple)):
+            images = [images]
+        imgs = [_as_hwc_u8(im) for im in images]
+        B = len(imgs)
+        desc_b, plan, src_bytes, tmp_bytes, H, W, max_h_in, max_w_out = self.plan([im.shape[:2] for im in imgs])
+        host = torch.empty(src_bytes, dtype=torch.uint8, pin_memory=True)
+        hv = host.numpy()
+        o = 0
+        for im in imgs:
+            hv[o:o + im.size] = im.reshape(-1)
+            o += im.size
+        dev = self.device
+        with torch.cuda.device(dev):
+            src = host.to(dev, non_blocking=True)
+            plan_d = torch.from_numpy(plan).to(dev, non_blocking=True)
+            desc_d = torch.frombuffer(bytearray(desc_b), dtype=torch.uint8).to(dev, non_blocking=True)
+            tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
+            pv = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
+            pm = torch.empty(B, H, W, dtype=self.mask_dtype, device=dev)
+            if self.mask_dtype not in (torch.int64, torch.float32):
+                raise ValueError("mask_dtype must be torch.int64 (HF) or torch.float32")
+            a = PreprocessArgs()
+            a.src, a.tmp, a.plan, a.desc, a.lut, a.pixel_values = (src.data_ptr(), tmp.data_ptr(), plan_d.data_ptr(), desc_d.data_ptr(),
+                                                                   self._lut.data_ptr(), pv.data_ptr())
+            if self.mask_dtype == torch.int64:
+                a.pixel_mask = pm.data_ptr()
+            else:
+                a.pixel_mask_f32 = pm.data_ptr()
+            a.B, a.H, a.W, a.max_h_in, a.max_w_out = B, H, W, max_h_in, max_w_out
+            L.check(L.load().vault_image_preprocess(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                    "vault_image_preprocess")
+            # the launches read src / plan / desc / tmp asynchronously: keep them alive until the stream has passed them
+            for t in (src, plan_d, desc_d, tmp):
+                t.record_stream(torch.cuda.current_stream())
+        return {"pixel_values": pv, "pixel_mask": pm}
