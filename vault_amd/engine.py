@@ -256,6 +256,7 @@ class VaultEngine:
     # rows; larger batches keep the per-kernel calls below (same kernels, same order) so that bench.py can bracket single
     # GEMM call sites with events.  VAULT_STAGE_ABI=0 / 1 forces either.
     STAGE_MAX_ROWS = 8192
+    WGRAD_STREAM_MAX_ROWS = 16384  # deferred weight gradients run on a second stream up to this many ViLT token rows (B <= 88)
     WGRAD_BATCH_MAX_ROWS = 131072  # the ViLT layers take the same route up to this many (padded) token rows (B <= 708:
                                    # 22 GB of per-layer dY operands at that size; 7.9 GB at B = 256)
 
@@ -294,6 +295,8 @@ class VaultEngine:
         self._ws: Dict[tuple, dict] = {}
         self.drop_seed = 0
         self.last: Optional[dict] = None
+        self._wgrad_stream, self._wgrad_pending = None, False
+        self._wgrad_side = False
         # optional live kernel timing (bench.py): {site: [(start, end, flops), ...]} of torch.cuda.Event pairs recorded
         # on the launch stream around every launch of a kernel instantiation.  Sites: "wgrad" = the ring kernel's
         # weight-gradient form gemm256_kernel<1,1,EPI_F32_ATOMIC,4> (every _wgrad launch that takes it), "ffn1" =
@@ -301,17 +304,42 @@ class VaultEngine:
         self.profile_events: Optional[Dict[str, list]] = None
         self._e0: Dict[str, torch.cuda.Event] = {}
 
-    def _prof_begin(self, site: str):
+    def _prof_begin(self, site: str, stream=None):
         if self.profile_events is not None and site in self.profile_events:
             e0 = torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e0.record(stream)          # (the launch stream: the recording closure captures it, replays run elsewhere)
             self._e0[site] = e0
 
-    def _prof_end(self, site: str, flops: float = 0.0):
+    def _prof_end(self, site: str, flops: float = 0.0, stream=None):
         if self.profile_events is not None and site in self.profile_events:
             e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
+            e1.record(stream)
             self.profile_events[site].append((self._e0[site], e1, flops))
+
+    # ---- deferred weight gradients on a second stream -------------------------------------------
+    def _wgrads_aside(self, launch, after_layer):
+        """Run ``launch()`` (the batched weight-gradient GEMMs of a group of layers) on the engine's second stream when the
+        backward chain leaves CUs idle (few token rows: a chain GEMM of a small batch is a single partial round of tiles).
+        Nothing in the chain reads the weight gradients: only the optimizer, which waits for the stream (_join_wgrads).
+        Not in data-parallel steps (``after_layer``: the reducer starts on the main stream's events)."""
+        if not self._wgrad_side or after_layer is not None:
+            launch()
+            return
+        if self._wgrad_stream is None:
+            self._wgrad_stream = torch.cuda.Stream(self.device)
+        side, main, ev = self._wgrad_stream, torch.cuda.current_stream(), torch.cuda.Event()
+        ops.pycall(lambda: ev.record(main))
+        ops.pycall(lambda: side.wait_event(ev))
+        with torch.cuda.stream(side):
+            launch()
+        self._wgrad_pending = True
+
+    def _join_wgrads(self):
+        if self._wgrad_pending:
+            side, main, ev = self._wgrad_stream, torch.cuda.current_stream(), torch.cuda.Event()
+            ops.pycall(lambda: ev.record(side))
+            ops.pycall(lambda: main.wait_event(ev))
+            self._wgrad_pending = False
 
     # ---- workspace --------------------------------------------------------------------------
     def _buf(self, ws, name, shape, dtype):
@@ -461,14 +489,15 @@ class VaultEngine:
         else:
             cfg, tiles = 0, (Nout // 128) * (Kin // 128) * G
             splits = max(1, min(8, Mtok_pad // 512, int(round(512.0 / tiles))))   # ~two resident 128x128 blocks per CU
+        st = torch.cuda.current_stream()
         if cfg == 3:
-            ops.pycall(lambda: self._prof_begin("wgrad"))
+            ops.pycall(lambda: self._prof_begin("wgrad", st))
         ops.gemm(dY_all[i0], X_all[i0], gw, Nout, Kin, Mtok_pad, Nout, Kin, Kin, 1, 1, ops.EPI_F32_ATOMIC, cfg=cfg,
                  splits=splits, accumulate=1, batch=G, batch_a=dY_all.stride(0), batch_b=X_all.stride(0),
                  batch_o=stride_o)
         if cfg == 3:
             fl = 2.0 * m_valid * Nout * Kin * G
-            ops.pycall(lambda: self._prof_end("wgrad", fl))
+            ops.pycall(lambda: self._prof_end("wgrad", fl, st))
 
     def _use_stage(self, rows_pad: int, pr: bool) -> bool:
         e = os.environ.get("VAULT_STAGE_ABI")
@@ -1084,6 +1113,11 @@ class VaultEngine:
         else:
             note = lambda tag: None  # noqa: E731
 
+        # deferred weight gradients beside the backward chain when its GEMMs are single partial rounds of tiles (same-box
+        # A/B: B = 8 9.76 -> 9.48 ms/step, B = 64 16.12 -> 15.69; B = 256 43.5 -> 43.2: within noise, and concurrent
+        # kernels would blur the per-kernel timings the roofline line is built on - serial there)
+        e = os.environ.get("VAULT_WGRAD_STREAM")      # development A/B switch
+        self._wgrad_side = (e == "1") if e in ("0", "1") else Mp <= self.WGRAD_STREAM_MAX_ROWS
         dx = [buf("dx_a", (Mp, H)), buf("dx_b", (Mp, H))]
         dxb = [buf("dxb_a", (Mp, H), bf), buf("dxb_b", (Mp, H), bf)]
         vbatch = self.LM_WGRAD_BATCHED and "act_all" in ws and P.gr(self.vl[0].fw) is not None
@@ -1157,11 +1191,11 @@ class VaultEngine:
                     note(f"vilt{i}")
                 elif i % vgroup == 0:
                     hi = min(nv, i + vgroup)
-                    for dY_all, X_all, wsel, Nout, Kin in ((dxbA_all, ws["act_all"], "fw", H, FF),
-                                                           (dU_all, ws["n2_all"], "iw", FF, H),
-                                                           (dxbB_all, ws["ctx_all"], "ow", H, H),
-                                                           (dqkv_all, ws["n1_all"], "qw", 3 * H, H)):
-                        self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.vl[i:hi]], i, Mp, Nout, Kin, M)
+                    def launch(i=i, hi=hi):
+                        for dY_all, X_all, wsel, Nout, Kin in ((dxbA_all, ws["act_all"], "fw", H, FF), (dU_all, ws["n2_all"], "iw", FF, H),
+                                                               (dxbB_all, ws["ctx_all"], "ow", H, H), (dqkv_all, ws["n1_all"], "qw", 3 * H, H)):
+                            self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.vl[i:hi]], i, Mp, Nout, Kin, M)
+                    self._wgrads_aside(launch, after_layer)
                     for j in reversed(range(i, hi)):
                         note(f"vilt{j}")
                 continue
@@ -1197,11 +1231,11 @@ class VaultEngine:
                 note(f"vilt{i}")
             elif i % vgroup == 0:
                 hi = min(nv, i + vgroup)
-                for dY_all, X_all, wsel, Nout, Kin in ((dxbA_all, ws["act_all"], "fw", H, FF),
-                                                       (dU_all, ws["n2_all"], "iw", FF, H),
-                                                       (dxbB_all, ws["ctx_all"], "ow", H, H),
-                                                       (dqkv_all, ws["n1_all"], "qw", 3 * H, H)):
-                    self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.vl[i:hi]], i, Mp, Nout, Kin, M)
+                def launch(i=i, hi=hi):
+                    for dY_all, X_all, wsel, Nout, Kin in ((dxbA_all, ws["act_all"], "fw", H, FF), (dU_all, ws["n2_all"], "iw", FF, H),
+                                                           (dxbB_all, ws["ctx_all"], "ow", H, H), (dqkv_all, ws["n1_all"], "qw", 3 * H, H)):
+                        self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.vl[i:hi]], i, Mp, Nout, Kin, M)
+                self._wgrads_aside(launch, after_layer)
                 for j in reversed(range(i, hi)):
                     note(f"vilt{j}")
 
@@ -1247,6 +1281,7 @@ class VaultEngine:
         ops.scatter_add(dvs, gt, Ml, H, period=T)
         note("vilt_embed")
         if spec.lm is None or self.freeze_lm:
+            self._join_wgrads()
             return
 
         # ------------------------------ language model ------------------------------
@@ -1289,11 +1324,11 @@ class VaultEngine:
                     note(f"lm{i}")
                 elif i % group == 0:
                     hi = min(nl, i + group)
-                    for dY_all, X_all, wsel, Nout, Kin in ((dhb_all, ws["lm_act_all"], "fw", H, FF),
-                                                           (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
-                                                           (dh1b_all, ws["lm_ctx_all"], "ow", H, H),
-                                                           (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H)):
-                        self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.ll[i:hi]], i, Mlp, Nout, Kin, Ml)
+                    def launch(i=i, hi=hi):
+                        for dY_all, X_all, wsel, Nout, Kin in ((dhb_all, ws["lm_act_all"], "fw", H, FF), (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
+                                                               (dh1b_all, ws["lm_ctx_all"], "ow", H, H), (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H)):
+                            self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.ll[i:hi]], i, Mlp, Nout, Kin, Ml)
+                    self._wgrads_aside(launch, after_layer)
                     for j in reversed(range(i, hi)):
                         note(f"lm{j}")
                 continue
@@ -1327,11 +1362,11 @@ class VaultEngine:
             elif i % group == 0:
                 # the weight gradients of layers i .. hi - 1, one launch per kind (dY, X: slices i.. of the stacks)
                 hi = min(nl, i + group)
-                for dY_all, X_all, wsel, Nout, Kin in ((dhb_all, ws["lm_act_all"], "fw", H, FF),
-                                                       (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
-                                                       (dh1b_all, ws["lm_ctx_all"], "ow", H, H),
-                                                       (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H)):
-                    self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.ll[i:hi]], i, Mlp, Nout, Kin, Ml)
+                def launch(i=i, hi=hi):
+                    for dY_all, X_all, wsel, Nout, Kin in ((dhb_all, ws["lm_act_all"], "fw", H, FF), (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
+                                                           (dh1b_all, ws["lm_ctx_all"], "ow", H, H), (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H)):
+                        self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.ll[i:hi]], i, Mlp, Nout, Kin, Ml)
+                self._wgrads_aside(launch, after_layer)
                 for j in reversed(range(i, hi)):
                     note(f"lm{j}")
         # embeddings: y0 = dropout(LN(esum))
@@ -1346,4 +1381,5 @@ class VaultEngine:
                                 (P.gr("bert.embeddings.position_embeddings.weight"), ws["lm_pos"]),
                                 (P.gr("bert.embeddings.token_type_embeddings.weight"), ws["lm_tt"])], Ml, H,
                         rowmask=amf)   # padded positions are masked keys everywhere: their gradient is exactly 0
+        self._join_wgrads()
         note("lm_embed")
