@@ -27,7 +27,7 @@ f_mean, f_n, f_per = collect(fd, "FETCH_SIZE")
 w_mean, w_n, w_per = collect(wd, "WRITE_SIZE")
 res = {
     "kernel": desc, "batch": int(batch), "lm": lm,
-    "command": "rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 1 "
+    "command": "rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-parity --no-h2d "
                f"--batch {batch} --no-cpu-baseline   (one pass per counter: FETCH_SIZE, WRITE_SIZE)",
     "launches": {"FETCH_SIZE": f_n, "WRITE_SIZE": w_n},
     "FETCH_SIZE_KB_mean_over_launches": round(f_mean, 1), "WRITE_SIZE_KB_mean_over_launches": round(w_mean, 1),
