@@ -102,6 +102,9 @@ typedef struct vault_ln_bwd_args {
   uint32_t drop_thresh, drop_seed, drop_stream; float drop_scale;
   int drop_on_dy;   /* 0: mask dx_bf16 (Linear -> dropout -> +res -> LN) ; 1: mask dy (LN -> dropout) */
   float* dbias;     /* optional: += column sums of dx_bf16 (bias gradient of the Linear fed by that branch) */
+  const void* dres_bf16;   /* ABI 5, optional: a residual gradient in bf16, added like dres (row map: dx's).  With it and
+                              dx_f32 = NULL the residual-gradient stream of a pre-LN stack lives in bf16 only: dx_bf16 is
+                              both the stream and the dY operand of the Linear below */
 } vault_ln_bwd_args;
 int vault_layernorm_bwd(const vault_ln_bwd_args* args, void* stream);
 
@@ -261,7 +264,9 @@ typedef struct vault_layer_args {
  * of d y, summed by the consumer: dx_bf16 = dqkv . Wqkv, dx_f32 = d h1).  Scratch: dU [rows_pad][FF] bf16, dN / dctx /
  * dmid_bf16 (LM also dh1_bf16) [rows_pad][H] bf16, dqkv [rows_pad][3H] bf16, dmid_f32 [rows_pad][H] f32.  Parameter gradients are ACCUMULATED (+=)
  * into the g_* f32 pointers; NULL skips one; do_wgrad = 0 leaves the four weight gradients to the caller (the engine
- * batches them over layers).  g_bf_below (ViLT): bias gradient of the layer below's FFN-out (= column sums of dx). */
+ * batches them over layers).  g_bf_below (ViLT): bias gradient of the layer below's FFN-out (= column sums of dx).
+ * ViLT with dy_f32 = NULL (ABI 5): the residual-gradient stream lives in bf16 only - dy_bf16 is the stream and the FFN-out dY at
+ * once, dmid_f32 is unused, dx_f32 is written only when given (the bottom layer, whose consumers read f32). */
 typedef struct vault_layer_bwd_args {
   const vault_layer_args* fwd;
   const void* dy_bf16; const float* dy_f32;

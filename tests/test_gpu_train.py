@@ -161,9 +161,13 @@ def test_tape_replay_matches_eager_steps():
         res[use_tape] = (losses, eng.params.p.clone())
     torch.cuda.synchronize()
     la, lb = res[False][0], res[True][0]
+    d = (res[False][1] - res[True][1]).abs()
+    print("eager vs tape: loss diffs", [f"{abs(a - b):.1e}" for a, b in zip(la, lb)], f"param diff mean {float(d.mean()):.2e}",
+          f"frac > 1e-5: {float((d > 1e-5).float().mean()):.4f}")
     # float atomics (split-K wgrad, LayerNorm dgamma) make two EAGER runs differ in the last bits too; AdamW's
-    # sign-like steps amplify that over steps: identical at step 1, ~1e-6 at step 2, ~1e-4 by step 4
-    assert abs(la[0] - lb[0]) < 1e-6 and abs(la[1] - lb[1]) < 1e-5, (la, lb)
+    # sign-like steps amplify that over steps: identical at step 1, 0 - 1.4e-5 at step 2 (a sign flip of a ~0 gradient in
+    # the classifier moves the loss by that much), ~1e-4 by step 4 (printed above)
+    assert abs(la[0] - lb[0]) < 1e-6 and abs(la[1] - lb[1]) < 5e-5, (la, lb)
     assert max(abs(a - b) for a, b in zip(la, lb)) < 5e-4, (la, lb)
     assert len(set(round(x, 4) for x in lb)) > 1                          # different batches -> different losses
     # sign-like AdamW steps flip on ~0 gradients whose float-atomic sums differ in the last bit: compare in bulk

@@ -73,6 +73,13 @@ for cfg in (3,):
                       lambda cfg=cfg, splits=splits: _gemm(Xf, X, dW, FF, H, M, FF, H, H, 1, 1, EPI_ATOMIC, cfg=cfg, splits=splits, accumulate=1)))
         cases.append((f"wgrad proj cfg{cfg} s{splits*4}", 2 * M * H * H,
                       lambda cfg=cfg, splits=splits: _gemm(X, X, dW, H, H, M, H, H, H, 1, 1, EPI_ATOMIC, cfg=cfg, splits=splits * 4, accumulate=1)))
+# split-K data gradients into an f32 accumulator (small M: the K = 3072 / 2304 loops of a single partial round of tiles)
+o_acc = torch.zeros(M, H, device="cuda")
+for splits in (2, 3, 4, 6, 8):
+    cases.append((f"dgrad ffn1 atomic cfg0 s{splits}", 2 * M * FF * H,
+                  lambda splits=splits: _gemm(Xf, W1, o_acc, M, H, FF, FF, H, H, 0, 1, EPI_ATOMIC, cfg=0, splits=splits, accumulate=1)))
+    cases.append((f"dgrad qkv  atomic cfg0 s{splits}", 2 * M * 3 * H * H,
+                  lambda splits=splits: _gemm(o_dqkv, Wqkv, o_acc, M, H, 3 * H, 3 * H, H, H, 0, 1, EPI_ATOMIC, cfg=0, splits=splits, accumulate=1)))
 for name, flops, fn in cases:
     t = timeit(fn)
     print(f"{name:28s} {t*1e6:9.1f} us  {flops/t/1e12:8.1f} TF/s")

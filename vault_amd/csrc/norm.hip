@@ -128,7 +128,7 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void ln_bwd_kernel(const bf
                                                      bf16* __restrict__ dx_bf16, RowMap dxmap, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, float* __restrict__ dbias,
                                                      int rows_per_block, uint32_t drop_thresh, uint32_t drop_seed, uint32_t drop_stream,
-                                                     float drop_scale, int drop_on_dy) {
+                                                     float drop_scale, int drop_on_dy, const bf16* __restrict__ dres_bf16) {
   __shared__ float red[4][VPT * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x4 gw[VPT], ag[VPT], ab[VPT], ac[VPT];
@@ -185,6 +185,11 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void ln_bwd_kernel(const bf
         const f32x4 rv = *reinterpret_cast<const f32x4*>(dres + orow + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] += rv[e];
+      }
+      if (dres_bf16) {   // residual-gradient stream kept in bf16 (the same tensor is the next Linear's dY operand)
+        const uint2 w = *reinterpret_cast<const uint2*>(dres_bf16 + orow + c);
+        const float2 a = unpack_bf16x2(w.x), b = unpack_bf16x2(w.y);
+        o[0] += a.x; o[1] += a.y; o[2] += b.x; o[3] += b.y;
       }
       if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + orow + c) = o;
       if (dx_bf16) {
@@ -288,7 +293,7 @@ extern "C" int vault_layernorm_bwd(const vault_ln_bwd_args* a, void* stream) {
   hipLaunchKernelGGL((ln_bwd_kernel<V, W>), grid, block, 0, st, reinterpret_cast<const bf16*>(a->dy_bf16), a->dy_f32, \
                      dym, a->x, xm, a->mean, a->rstd, a->gamma, a->rows, a->H, a->dres, a->dx_f32,               \
                      reinterpret_cast<bf16*>(a->dx_bf16), dxm, a->dgamma, a->dbeta, a->dbias, rpb, a->drop_thresh,          \
-                     a->drop_seed, a->drop_stream, a->drop_scale, a->drop_on_dy)
+                     a->drop_seed, a->drop_stream, a->drop_scale, a->drop_on_dy, reinterpret_cast<const bf16*>(a->dres_bf16))
   switch (a->H / 256) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;

@@ -64,9 +64,11 @@ extern "C" int vault_vilt_layer_fwd(const vault_layer_args* L, void* st) {
 extern "C" int vault_vilt_layer_bwd(const vault_layer_bwd_args* G, void* st) {
   if (!G || bad(G->fwd)) return VAULT_EINVAL;
   const vault_layer_args* L = G->fwd;
-  if (!L->u || !G->dy_bf16 || !G->dy_f32 || !G->dx_f32 || !G->dx_bf16 || !G->dU || !G->dN || !G->dmid_f32 || !G->dmid_bf16 ||
-      !G->dctx || !G->dqkv)
-    return VAULT_EINVAL;
+  if (!L->u || !G->dy_bf16 || !G->dx_bf16 || !G->dU || !G->dN || !G->dmid_bf16 || !G->dctx || !G->dqkv) return VAULT_EINVAL;
+  // dy_f32 == NULL: the residual-gradient stream lives in bf16 only (dy_bf16 is stream and FFN-out dY at once; dmid_f32 is
+  // not used; dx_f32 is written only if given - the stack's bottom layer, whose consumers read f32)
+  const bool bf16_stream = G->dy_f32 == nullptr;
+  if (!bf16_stream && (!G->dx_f32 || !G->dmid_f32)) return VAULT_EINVAL;
   const int M = L->rows, Mp = L->rows_pad, H = L->H, FF = L->FF;
   // FFN: dU = (dY . W2) * gelu'  (+ column sums = d b1) ; dN = dU . W1
   if (L->wf_t) { CHK(gemm(G->dy_bf16, L->wf_t, G->dU, Mp, FF, H, H, H, FF, 0, 0, 2, M, st, L->persist, nullptr, nullptr, L->u, nullptr, G->g_bi)); }
@@ -77,7 +79,8 @@ extern "C" int vault_vilt_layer_bwd(const vault_layer_bwd_args* G, void* st) {
   }
   CHK(gemm(G->dU, L->wi, G->dN, Mp, H, FF, FF, H, H, 0, 1, 0, M, st, L->persist));
   // x' = x + attn-out: LN2 backward adds the residual gradient; its bf16 output is attn-out's dY (column sums = d bo)
-  CHK(ln_bwd(L->xm, L->m2, L->r2, L->ln2w, M, H, G->dN, nullptr, G->dy_f32, G->dmid_f32, G->dmid_bf16, G->g_ln2w, G->g_ln2b, G->g_bo, st));
+  CHK(ln_bwd(L->xm, L->m2, L->r2, L->ln2w, M, H, G->dN, nullptr, G->dy_f32, bf16_stream ? nullptr : G->dmid_f32, G->dmid_bf16, G->g_ln2w,
+             G->g_ln2b, G->g_bo, st, 0, 0, 0, 1.f, bf16_stream ? G->dy_bf16 : nullptr));
   if (L->wo_t) { CHK(gemm(G->dmid_bf16, L->wo_t, G->dctx, Mp, H, H, H, H, H, 0, 0, 0, M, st, L->persist)); }
   else { CHK(gemm(G->dmid_bf16, L->wo, G->dctx, Mp, H, H, H, H, H, 0, 1, 0, M, st, L->persist)); }
   if (G->do_wgrad) CHK(wgrad(G->dmid_bf16, L->ctx, G->g_wo, Mp, H, H, st, L->persist));
@@ -86,7 +89,8 @@ extern "C" int vault_vilt_layer_bwd(const vault_layer_bwd_args* G, void* st) {
   if (G->do_wgrad) CHK(wgrad(G->dqkv, L->n1, G->g_wqkv, Mp, 3 * H, H, st, L->persist));
   if (G->g_bqkv) CHK(vault_colsum(G->dqkv, 3 * H, M, 3 * H, G->g_bqkv, st));
   // d x = LN1 backward (dN) + residual gradient; bf16 copy = dY of the layer below (column sums = its d b2)
-  CHK(ln_bwd(L->x_in, L->m1, L->r1, L->ln1w, M, H, G->dN, nullptr, G->dmid_f32, G->dx_f32, G->dx_bf16, G->g_ln1w, G->g_ln1b, G->g_bf_below, st));
+  CHK(ln_bwd(L->x_in, L->m1, L->r1, L->ln1w, M, H, G->dN, nullptr, bf16_stream ? nullptr : G->dmid_f32, G->dx_f32, G->dx_bf16, G->g_ln1w,
+             G->g_ln1b, G->g_bf_below, st, 0, 0, 0, 1.f, bf16_stream ? G->dmid_bf16 : nullptr));
   return VAULT_OK;
 }
 

@@ -31,8 +31,10 @@ inline int ln_fwd(const float* x, const float* g, const float* b, float eps, int
 
 inline int ln_bwd(const float* x, const float* mean, const float* rstd, const float* gamma, int rows, int H, const void* dy_bf16,
            const float* dy_f32, const float* dres, float* dx_f32, void* dx_bf16, float* dgamma, float* dbeta, float* dbias,
-           void* st, uint32_t dthr = 0, uint32_t dseed = 0, uint32_t dstream = 0, float dscale = 1.f) {
+           void* st, uint32_t dthr = 0, uint32_t dseed = 0, uint32_t dstream = 0, float dscale = 1.f,
+           const void* dres_bf16 = nullptr) {
   vault_ln_bwd_args a{};
+  a.dres_bf16 = dres_bf16;
   a.dy_bf16 = dy_bf16; a.dy_f32 = dy_f32; a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.dres = dres;
   a.dx_f32 = dx_f32; a.dx_bf16 = dx_bf16; a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias;
   a.rows = rows; a.H = H;

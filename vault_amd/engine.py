@@ -256,6 +256,7 @@ class VaultEngine:
     # rows; larger batches keep the per-kernel calls below (same kernels, same order) so that bench.py can bracket single
     # GEMM call sites with events.  VAULT_STAGE_ABI=0 / 1 forces either.
     STAGE_MAX_ROWS = 8192
+    GRAD_STREAM_BF16 = True        # ViLT residual-gradient stream in bf16 only (what bf16 autocast training carries): see _backward
     WGRAD_STREAM_MAX_ROWS = 16384  # deferred weight gradients run on a second stream up to this many ViLT token rows (B <= 88)
     WGRAD_BATCH_MAX_ROWS = 131072  # the ViLT layers take the same route up to this many (padded) token rows (B <= 708:
                                    # 22 GB of per-layer dY operands at that size; 7.9 GB at B = 256)
@@ -283,6 +284,8 @@ class VaultEngine:
             self.WGRAD_BATCH_RING = False
         if os.environ.get("VAULT_WGRAD_BATCH_MAX_ROWS"):
             self.WGRAD_BATCH_MAX_ROWS = int(os.environ["VAULT_WGRAD_BATCH_MAX_ROWS"])
+        if os.environ.get("VAULT_GRAD_STREAM_BF16") in ("0", "1"):   # development override (same-box A/B)
+            self.GRAD_STREAM_BF16 = os.environ["VAULT_GRAD_STREAM_BF16"] == "1"
         if os.environ.get("VAULT_WGRAD_GROUP"):   # layers per batched weight-gradient launch (tuning knob for DP runs)
             self.LM_WGRAD_GROUP = int(os.environ["VAULT_WGRAD_GROUP"])
         self.vl = [_LayerNames(f"encoder.layer.{i}", "vilt") for i in range(spec.vilt.num_hidden_layers)]
@@ -1167,6 +1170,10 @@ class VaultEngine:
             dU = buf("dU", (Mp, FF), bf); dqkv = buf("dqkv", (Mp, 3 * H), bf)
         km = ws["keymask"]
         cur = 0
+        # Residual-gradient stream of the pre-LN ViLT stack in bf16 only (GRAD_STREAM_BF16): a layer's incoming gradient is ONE
+        # bf16 tensor - stream and FFN-out dY at once -, the LayerNorm backward adds it as `dres_bf16` and writes only the bf16
+        # result (10 instead of 16 B per element); the bottom layer also writes f32 for the embedding backward.
+        gbf = self.GRAD_STREAM_BF16
         for i in reversed(range(nv)):
             ln = self.vl[i]
             g = lambda k: ws[f"{k}{i}"]  # noqa: E731
@@ -1178,9 +1185,10 @@ class VaultEngine:
             if ws.get("vilt_stage"):
                 # the whole layer backward in one C call (csrc/stage.hip: the same kernels in the same order as below)
                 nxt = cur ^ 1
+                stream_f32 = {} if gbf else dict(dy_f32=dx[cur], dmid_f32=dx[nxt])
                 gb = ops.layer_bwd_args(
-                    ws[f"stage_vilt{i}"], dy_bf16=dyA, dy_f32=dx[cur], dx_f32=dx[cur], dx_bf16=dyN, dU=dU, dN=dN, dctx=dctx,
-                    dqkv=dqkv, dmid_bf16=dyB, dmid_f32=dx[nxt], do_wgrad=0 if vbatch else 1,
+                    ws[f"stage_vilt{i}"], dy_bf16=dyA, dx_f32=dx[cur] if (not gbf or i == 0) else None, dx_bf16=dyN, dU=dU, dN=dN,
+                    dctx=dctx, dqkv=dqkv, dmid_bf16=dyB, do_wgrad=0 if vbatch else 1, **stream_f32,
                     g_wqkv=P.gr(ln.qw, n_elems=3 * H * H, shape=(3 * H, H)), g_bqkv=P.gr(ln.qb, n_elems=3 * H, shape=(3 * H,)),
                     g_wo=P.gr(ln.ow), g_bo=P.gr(ln.ob), g_wi=P.gr(ln.iw), g_bi=P.gr(ln.ib), g_wf=P.gr(ln.fw),
                     g_ln1w=P.gr(ln.ln1w), g_ln1b=P.gr(ln.ln1b), g_ln2w=P.gr(ln.ln2w), g_ln2b=P.gr(ln.ln2b),
@@ -1209,9 +1217,13 @@ class VaultEngine:
             if not vbatch:
                 self._wgrad(dU, g("n2"), ln.iw, None, Mp, FF, H, M)
             nxt = cur ^ 1
-            ops.layernorm_bwd(g("xm"), g("m2"), g("r2"), P.w(ln.ln2w), M, H, dy_bf16=dN, dres=dx[cur], dx_f32=dx[nxt],
-                              dx_bf16=dyB, dgamma=P.gr(ln.ln2w), dbeta=P.gr(ln.ln2b), dbias=P.gr(ln.ob))
-            cur = nxt
+            if gbf:
+                ops.layernorm_bwd(g("xm"), g("m2"), g("r2"), P.w(ln.ln2w), M, H, dy_bf16=dN, dres_bf16=dyA, dx_bf16=dyB,
+                                  dgamma=P.gr(ln.ln2w), dbeta=P.gr(ln.ln2b), dbias=P.gr(ln.ob))
+            else:
+                ops.layernorm_bwd(g("xm"), g("m2"), g("r2"), P.w(ln.ln2w), M, H, dy_bf16=dN, dres=dx[cur], dx_f32=dx[nxt],
+                                  dx_bf16=dyB, dgamma=P.gr(ln.ln2w), dbeta=P.gr(ln.ln2b), dbias=P.gr(ln.ob))
+                cur = nxt
             # attention
             self._dgrad(dyB, ln.ow, dctx, Mp, H, H, ops.EPI_BF16, M)
             if not vbatch:
@@ -1223,10 +1235,15 @@ class VaultEngine:
             else:
                 ops.colsum(dqkv, 3 * H, M, 3 * H, P.gr(ln.qb, n_elems=3 * H, shape=(3 * H,)))
             nxt = cur ^ 1
-            ops.layernorm_bwd(x[i], g("m1"), g("r1"), P.w(ln.ln1w), M, H, dy_bf16=dN, dres=dx[cur], dx_f32=dx[nxt],
-                              dx_bf16=dyN, dgamma=P.gr(ln.ln1w), dbeta=P.gr(ln.ln1b),
-                              dbias=P.gr(self.vl[i - 1].fb) if i > 0 else None)
-            cur = nxt
+            if gbf:
+                ops.layernorm_bwd(x[i], g("m1"), g("r1"), P.w(ln.ln1w), M, H, dy_bf16=dN, dres_bf16=dyB,
+                                  dx_f32=dx[cur] if i == 0 else None, dx_bf16=dyN, dgamma=P.gr(ln.ln1w), dbeta=P.gr(ln.ln1b),
+                                  dbias=P.gr(self.vl[i - 1].fb) if i > 0 else None)
+            else:
+                ops.layernorm_bwd(x[i], g("m1"), g("r1"), P.w(ln.ln1w), M, H, dy_bf16=dN, dres=dx[cur], dx_f32=dx[nxt],
+                                  dx_bf16=dyN, dgamma=P.gr(ln.ln1w), dbeta=P.gr(ln.ln1b),
+                                  dbias=P.gr(self.vl[i - 1].fb) if i > 0 else None)
+                cur = nxt
             if not vbatch:
                 note(f"vilt{i}")
             elif i % vgroup == 0:

@@ -33,7 +33,7 @@ class LnBwdArgs(C.Structure):
                 ("x_rpg", C.c_int), ("x_gstride", C.c_int), ("x_goff", C.c_int),
                 ("dx_rpg", C.c_int), ("dx_gstride", C.c_int), ("dx_goff", C.c_int),
                 ("drop_thresh", C.c_uint32), ("drop_seed", C.c_uint32), ("drop_stream", C.c_uint32),
-                ("drop_scale", C.c_float), ("drop_on_dy", C.c_int), ("dbias", C.c_void_p)]
+                ("drop_scale", C.c_float), ("drop_on_dy", C.c_int), ("dbias", C.c_void_p), ("dres_bf16", C.c_void_p)]
 
 
 class AttnArgs(C.Structure):
@@ -178,8 +178,9 @@ def layernorm_fwd(x, gamma, beta, eps, rows, H, *, y_bf16=None, y_f32=None, mean
 
 def layernorm_bwd(x, mean, rstd, gamma, rows, H, *, dy_bf16=None, dy_f32=None, dres=None, dx_f32=None, dx_bf16=None,
                   dgamma=None, dbeta=None, dymap=(0, 0, 0), xmap=(0, 0, 0), dxmap=(0, 0, 0), drop: Drop = NO_DROP,
-                  drop_on_dy: bool = False, dbias=None):
+                  drop_on_dy: bool = False, dbias=None, dres_bf16=None):
     a = LnBwdArgs()
+    a.dres_bf16 = _p(dres_bf16)
     a.dy_bf16, a.dy_f32, a.x, a.mean, a.rstd, a.gamma, a.dres = (_p(dy_bf16), _p(dy_f32), _p(x), _p(mean),
                                                                   _p(rstd), _p(gamma), _p(dres))
     a.dx_f32, a.dx_bf16, a.dgamma, a.dbeta = _p(dx_f32), _p(dx_bf16), _p(dgamma), _p(dbeta)
