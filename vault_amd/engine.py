@@ -1131,7 +1131,9 @@ class VaultEngine:
             dU_all = self._stack(ws, "v_dU", nv, (Mp, FF), bf); dqkv_all = self._stack(ws, "v_dqkv", nv, (Mp, 3 * H), bf)
             vgroup = self.LM_WGRAD_GROUP if self.LM_WGRAD_GROUP > 0 else nv
         dxb_top = dxbA_all[nv - 1] if vbatch else dxb[0]
-        ops.pycall(dx[0].zero_)
+        gbf = self.GRAD_STREAM_BF16       # the ViLT residual-gradient stream lives in bf16 only (below)
+        if not gbf:
+            ops.pycall(dx[0].zero_)
         ops.pycall(dxb_top.zero_)
         # ------------------------------ tail ------------------------------
         if spec.add_pooling_layer and (spec.n_classes > 0 or dpooled is not None):
@@ -1153,13 +1155,15 @@ class VaultEngine:
             dh0 = buf("dh0", (Bp, H), bf)
             self._dgrad(dpre, "pooler.dense.weight", dh0, Bp, H, H, ops.EPI_BF16, B)
             ops.layernorm_bwd(x[nv], ws["f_mean"], ws["f_rstd"], P.w("layernorm.weight"), B, H, dy_bf16=dh0,
-                              dx_f32=dx[0], dx_bf16=dxb_top, dgamma=P.gr("layernorm.weight"),
+                              dx_f32=None if gbf else dx[0], dx_bf16=dxb_top, dgamma=P.gr("layernorm.weight"),
                               dbeta=P.gr("layernorm.bias"), xmap=(1, S, 0), dxmap=(1, S, 0),
                               dbias=None if dhidden is not None else P.gr(self.vl[nv - 1].fb))
         if dhidden is not None:
             # gradient w.r.t. last_hidden_state (all rows): LN backward over all rows, added on top
             ops.layernorm_bwd(x[nv], ws["f_mean_all"], ws["f_rstd_all"], P.w("layernorm.weight"), M, H,
-                              dy_f32=dhidden.contiguous().view(M, H), dres=dx[0], dx_f32=dx[0], dx_bf16=dxb_top,
+                              dy_f32=dhidden.contiguous().view(M, H), dres=None if gbf else dx[0],
+                              dres_bf16=dxb_top if gbf else None,        # (in place: every element is read, then written, by one lane)
+                              dx_f32=None if gbf else dx[0], dx_bf16=dxb_top,
                               dgamma=P.gr("layernorm.weight"), dbeta=P.gr("layernorm.bias"),
                               dbias=P.gr(self.vl[nv - 1].fb))
         note("head")
@@ -1173,7 +1177,6 @@ class VaultEngine:
         # Residual-gradient stream of the pre-LN ViLT stack in bf16 only (GRAD_STREAM_BF16): a layer's incoming gradient is ONE
         # bf16 tensor - stream and FFN-out dY at once -, the LayerNorm backward adds it as `dres_bf16` and writes only the bf16
         # result (10 instead of 16 B per element); the bottom layer also writes f32 for the embedding backward.
-        gbf = self.GRAD_STREAM_BF16
         for i in reversed(range(nv)):
             ln = self.vl[i]
             g = lambda k: ws[f"{k}{i}"]  # noqa: E731
