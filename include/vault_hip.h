@@ -57,8 +57,15 @@ typedef struct vault_gemm_args {
                   the ring kernel's layer-major work list keeps a layer's operand panels in one XCD's L2.
                   0 / 1 = a single GEMM */
   long long batch_a, batch_b, batch_o;
+  int aux_u8;  /* ABI 5, kernels 5 / 6 only: the gelu' tensor (out2 of epi 1, aux of epi 2) is 8-bit in tile-native order - an
+                  opaque M x N x (4/3 at 192-wide tiles) byte image that only the epi-2 GEMM of the SAME M, N and kernel (cfg)
+                  can read back: q = rne(200 g + 26), step 0.005 over -0.13 .. 1.145 (0, 0.5, 1 exact).  Halves the bytes the
+                  FFN-in forward writes for backward and the gelu'-product dgrad reads.  Ask vault_gemm_plan which kernel a
+                  call would take and pass that cfg explicitly to both calls. */
 } vault_gemm_args;
 int vault_gemm(const vault_gemm_args* args, void* stream);
+/* the kernel / tile configuration vault_gemm would run these arguments on (the resolved `cfg`, 0..6), or -EINVAL */
+int vault_gemm_plan(const vault_gemm_args* args);
 
 /* ---- MXFP8 forward GEMM (BASELINE config "fp8 MFMA forward, bf16 backward") -------------------------------------
  * OCP microscaling format: e4m3 elements [rows][K] (K contiguous) + one E8M0 scale byte per 32 consecutive k,

@@ -16,9 +16,10 @@ EPI_BF16, EPI_GELU, EPI_DGELU, EPI_RES, EPI_PATCH, EPI_ATOMIC = range(6)
 
 def _gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, cfg=-1, m_valid=0, splits=1, bias=None,
           res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, accumulate=0, colsum=None, persist=0, batch=0,
-          batch_a=0, batch_b=0, batch_o=0):
+          batch_a=0, batch_b=0, batch_o=0, aux_u8=0, plan_only=False):
     lib = L.load()
     a = L.GemmArgs()
+    a.aux_u8 = aux_u8
     a.A, a.B, a.out = A.data_ptr(), B.data_ptr(), out.data_ptr()
     a.out2 = out2.data_ptr() if out2 is not None else None
     a.bias = bias.data_ptr() if bias is not None else None
@@ -31,6 +32,8 @@ def _gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, cfg=-1, m_vali
     a.rpg, a.gstride, a.goff = rpg, gstride, goff
     a.persist = persist
     a.batch, a.batch_a, a.batch_b, a.batch_o = batch, batch_a, batch_b, batch_o
+    if plan_only:
+        return int(lib.vault_gemm_plan(C.byref(a)))
     st = torch.cuda.current_stream().cuda_stream
     L.check(lib.vault_gemm(C.byref(a), C.c_void_p(st)), "vault_gemm")
 
@@ -448,3 +451,49 @@ def test_8wave_kernel_refuses_what_it_does_not_take():
         _gemm(A, A, out, 256, 256, 64, 256, 256, 256, 0, 0, EPI_BF16, cfg=5)
     with pytest.raises(RuntimeError):      # N not a multiple of 192
         _gemm(A, A, out, 256, 256, 128, 256, 256, 256, 0, 0, EPI_BF16, cfg=6)
+
+
+@pytest.mark.parametrize("cfg", [5, 6])
+@pytest.mark.parametrize("shape", [(512, 768, 256, 500), (1024, 1536, 768, 1024), (2560, 768, 192, 2309)])
+def test_8wave_kernel_8bit_gelu_prime_round_trip(cfg, shape):
+    """aux_u8: the FFN-in forward (epi 1) leaves gelu' as an 8-bit tile-native image, the gelu'-product dgrad (epi 2) of the same
+    M, N and kernel reads it back: dX = (dY W2) * gelu'(z) against the exact derivative, within bf16 rounding + half a
+    quantisation step (0.0025) of the product; the activation output is bit-identical to the bf16-gelu' form; column sums
+    (bias gradient) follow the stored values."""
+    M, N, K, mv = shape
+    A = _rand(M, K, seed=41).bfloat16()
+    W = _rand(N, K, scale=0.08, seed=42).bfloat16()
+    bias = _rand(N, seed=43)
+    act8 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"); act16 = torch.zeros_like(act8)
+    u8 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")      # (2 M N bytes: covers M N (256-wide) and 4/3 M N (192-wide))
+    u16 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    assert _gemm(A, W, act8, M, N, K, K, K, N, 0, 0, EPI_GELU, cfg=cfg, bias=bias, out2=u8, aux_u8=1, plan_only=True) == cfg
+    _gemm(A, W, act8, M, N, K, K, K, N, 0, 0, EPI_GELU, cfg=cfg, m_valid=mv, bias=bias, out2=u8, aux_u8=1)
+    _gemm(A, W, act16, M, N, K, K, K, N, 0, 0, EPI_GELU, cfg=cfg, m_valid=mv, bias=bias, out2=u16)
+    torch.cuda.synchronize()
+    assert torch.equal(act8, act16)
+    z = A.float() @ W.float().t() + bias
+    gprime = 0.5 * (1 + torch.erf(z / math.sqrt(2))) + z * torch.exp(-0.5 * z * z) / math.sqrt(2 * math.pi)
+    # backward GEMM of the same output shape: dX[M, N] = dY[M, K2] . W2t[N, K2]^T, times gelu'
+    K2 = 256
+    dY = _rand(M, K2, seed=44).bfloat16()
+    W2t = _rand(N, K2, scale=0.05, seed=45).bfloat16()
+    dX8 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"); dX16 = torch.zeros_like(dX8)
+    cs8 = torch.zeros(N, device="cuda"); cs16 = torch.zeros(N, device="cuda")
+    _gemm(dY, W2t, dX8, M, N, K2, K2, K2, N, 0, 0, EPI_DGELU, cfg=cfg, m_valid=mv, aux=u8, aux_u8=1, colsum=cs8)
+    _gemm(dY, W2t, dX16, M, N, K2, K2, K2, N, 0, 0, EPI_DGELU, cfg=cfg, m_valid=mv, aux=u16, colsum=cs16)
+    torch.cuda.synchronize()
+    pre = dY.float() @ W2t.float().t()
+    ref = (pre * gprime)[:mv]
+    tol = ref.abs().max().item() * 2 ** -7 + 0.0026 * pre.abs().max().item()
+    assert (dX8[:mv].float() - ref).abs().max().item() <= tol
+    assert (dX16[:mv].float() - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7 + 2 ** -8 * pre.abs().max().item()
+    assert dX8[mv:].abs().max().item() == 0.0 if mv < M else True
+    # quantisation error is unbiased to first order: the mean product error stays far below the step
+    assert abs((dX8[:mv].float() - ref).mean().item()) < 2e-4 * pre.abs().max().item()
+    want = dX8[:mv].float().sum(0)
+    assert (cs8 - want).abs().max().item() <= 2e-3 * want.abs().max().item() + 2e-2
+    # the 8-bit form exists in the 8-wave kernel's tile order only
+    assert _gemm(A, W, act8, M, N, K, K, K, N, 0, 0, EPI_GELU, cfg=3, bias=bias, out2=u8, aux_u8=1, plan_only=True) < 0
+    with pytest.raises(RuntimeError):
+        _gemm(A, W, act8, M, N, K, K, K, N, 0, 0, EPI_BF16, cfg=cfg, bias=bias, aux_u8=1)

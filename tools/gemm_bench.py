@@ -66,6 +66,8 @@ for c8 in [c for c in CFGS if c in (5, 6)]:
             (f"fwd proj  {tag}", 2 * M * H * H, lambda persist=persist, c8=c8: _gemm(X, Wo, o_h32, M, H, H, H, H, H, 0, 0, EPI_RES, cfg=c8, bias=bias_h, res=res, persist=persist)),
             (f"fwd ffn1  {tag}", 2 * M * FF * H, lambda persist=persist, c8=c8: _gemm(X, W1, o_f, M, FF, H, H, H, FF, 0, 0, EPI_GELU, cfg=c8, bias=bias_f, out2=o_f2, persist=persist)),
             (f"fwd ffn2  {tag}", 2 * M * FF * H, lambda persist=persist, c8=c8: _gemm(Xf, W2, o_h32, M, H, FF, FF, FF, H, 0, 0, EPI_RES, cfg=c8, bias=bias_h, res=res, persist=persist)),
+            (f"fwd ffn1  {tag} u8", 2 * M * FF * H, lambda persist=persist, c8=c8: _gemm(X, W1, o_f, M, FF, H, H, H, FF, 0, 0, EPI_GELU, cfg=c8, bias=bias_f, out2=o_f2, persist=persist, aux_u8=1)),
+            (f"dgrad ffn2(T) {tag} u8", 2 * M * FF * H, lambda persist=persist, c8=c8: _gemm(X, W2t, o_f, M, FF, H, H, H, FF, 0, 0, EPI_DGELU, cfg=c8, aux=o_f2, colsum=csum_f, persist=persist, aux_u8=1)),
         ]
 for cfg in (3,):
     for splits in (4, 7):

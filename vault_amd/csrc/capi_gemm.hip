@@ -22,12 +22,21 @@ static GemmParams params_of(const vault_gemm_args* a) {
   p.gn = a->gn;
   p.persist = a->persist;
   p.batch = a->batch; p.batch_a = a->batch_a; p.batch_b = a->batch_b; p.batch_o = a->batch_o;
+  p.aux_u8 = a->aux_u8;
   return p;
 }
 
 extern "C" int vault_gemm(const vault_gemm_args* a, void* stream) {
   if (a == nullptr) return VAULT_EINVAL;
   return vault_gemm_launch(params_of(a), a->a_mode, a->b_mode, a->epi, a->cfg, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg);
+
+extern "C" int vault_gemm_plan(const vault_gemm_args* a) {
+  if (a == nullptr) return -VAULT_EINVAL;
+  GemmParams p = params_of(a);
+  return vault_gemm_resolve(p, a->a_mode, a->b_mode, a->epi, a->cfg);
 }
 
 extern "C" int vault_gemm_mxfp8(const vault_gemm_args* a, const void* a_scale, const void* b_scale, void* stream) {

@@ -12,6 +12,8 @@ enum GemmEpi {
   EPI_F32_PATCH = 4,   // out_f32[rowmap(m)] = acc + addtab[m % rpg]   (patch embedding into the fused sequence)
   EPI_F32_ATOMIC = 5,  // out_f32 += acc   (wgrad; split-K partials by float atomics)
   EPI_BF16_GELU_INF = 6,  // internal (ring kernel): EPI_BF16_GELU without the gelu' output, picked by the launcher when out2 == null
+  EPI_BF16_GELU_U8 = 7,   // internal (8-wave kernel): EPI_BF16_GELU with the gelu' output as 8-bit values in tile-native order
+  EPI_BF16_DGELU_U8 = 8,  // internal (8-wave kernel): EPI_BF16_DGELU reading that 8-bit gelu'
 };
 
 struct GemmParams {
@@ -44,6 +46,7 @@ struct GemmParams {
   // batch * splits; ring kernel: (problem, split, tile) work items, problem-major.  batch <= 1: a single GEMM.
   int batch;
   long long batch_a, batch_b, batch_o;
+  int aux_u8;       // 8-wave kernel only: gelu' (out2 of EPI_BF16_GELU, aux of EPI_BF16_DGELU) is the 8-bit tile-native form
 };
 
 #ifdef __HIPCC__

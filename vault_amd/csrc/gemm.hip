@@ -250,18 +250,18 @@ int vault_gemm256_launch(const GemmParams& p, int a_mode, int b_mode, int epi, i
 bool vault_gemm8w_supports(const GemmParams& p, int a_mode, int b_mode, int epi, int ntw);
 int vault_gemm8w_launch(const GemmParams& p, int epi, int ntw, hipStream_t st);
 
-int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, int cfg, hipStream_t st) {
-  GemmParams p = p_in;
+// argument checks + kernel choice: the resolved cfg (0..6), or -VAULT_EINVAL
+int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) {
   if (p.splits < 1) p.splits = 1;
-  if (p.A == nullptr || p.B == nullptr || p.out == nullptr) return VAULT_EINVAL;
-  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return VAULT_EINVAL;
-  if ((p.lda & 7) || (p.ldb & 7) || (p.ldo & 7)) return VAULT_EINVAL;
+  if (p.A == nullptr || p.B == nullptr || p.out == nullptr) return -VAULT_EINVAL;
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -VAULT_EINVAL;
+  if ((p.lda & 7) || (p.ldb & 7) || (p.ldo & 7)) return -VAULT_EINVAL;
   if (p.batch > 1) {   // batched weight gradients: double-buffered kernel, atomic epilogue only
     if (epi != EPI_F32_ATOMIC || cfg == 4 || (p.batch_a & 7) || (p.batch_b & 7) || (p.batch_o & 3) ||
         (long long)p.batch * p.splits > 65535)
-      return VAULT_EINVAL;
+      return -VAULT_EINVAL;
     if (cfg < 0) cfg = (p.M % 256 == 0 && p.N % 256 == 0) ? 3 : ((p.M % 128 == 0 && p.N % 128 == 0) ? 0 : -1);
-    if (cfg < 0) return VAULT_EINVAL;
+    if (cfg < 0) return -VAULT_EINVAL;
   }
   const bool auto_cfg = cfg < 0;
   if (cfg < 0) {
@@ -311,9 +311,19 @@ int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, i
   if ((cfg == 3 || cfg == 4) && epi == EPI_F32_RES && p.res == nullptr) cfg = (p.N % 256 == 0) ? 2 : 1;
   if (cfg == 5 || cfg == 6) {   // 8-wave kernel with register-direct epilogue (gemm8w.hip), 256- / 192-wide tiles:
     const int ntw = (cfg == 5) ? 4 : 3;   // forward-form operands only
-    if (!vault_gemm8w_supports(p, a_mode, b_mode, epi, ntw)) return VAULT_EINVAL;
-    return vault_gemm8w_launch(p, epi, ntw, st);
+    if (!vault_gemm8w_supports(p, a_mode, b_mode, epi, ntw)) return -VAULT_EINVAL;
+  } else if (p.aux_u8) {
+    return -VAULT_EINVAL;       // the 8-bit gelu' exists in the 8-wave kernel's tile order only
   }
+  if (cfg < 0 || cfg > 6) return -VAULT_EINVAL;
+  return cfg;
+}
+
+int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, int cfg_in, hipStream_t st) {
+  GemmParams p = p_in;
+  const int cfg = vault_gemm_resolve(p, a_mode, b_mode, epi, cfg_in);
+  if (cfg < 0) return -cfg;
+  if (cfg == 5 || cfg == 6) return vault_gemm8w_launch(p, epi, cfg == 5 ? 4 : 3, st);
   if (cfg == 3) return vault_gemm256_launch(p, a_mode, b_mode, epi, 4, st);
   if (cfg == 4) return vault_gemm256_launch(p, a_mode, b_mode, epi, 3, st);
   const int key = a_mode * 2 + b_mode;

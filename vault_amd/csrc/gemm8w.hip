@@ -304,10 +304,17 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
     if constexpr (!F32OUT) {
       // lane: row m = mw + 16 mt + l15.  Unit 0 of a row = tiles 0, 1: the 8 columns nc + {0..7}; unit 1 = tiles 2, 3:
       // nc + 32 + {0..7} (NTW == 4) or tile 2 alone: the 4 columns nc + 32 - 4 g + {0..3} (NTW == 3).
-      constexpr bool HAS_AUX = (EPI == EPI_BF16_DGELU);
-      constexpr bool HAS_CSUM = (EPI == EPI_BF16 || EPI == EPI_BF16_DGELU);   // (the GELU forms have no registers for it)
+      constexpr bool HAS_AUX = (EPI == EPI_BF16_DGELU || EPI == EPI_BF16_DGELU_U8);
+      constexpr bool GELU2 = (EPI == EPI_BF16_GELU || EPI == EPI_BF16_GELU_U8);   // gelu and gelu' come out
+      // 8-bit gelu' in TILE-NATIVE order (EPI_*_U8): one 16-byte slot per (tile, wave, mt, lane) holding the lane's 16 (12 at
+      // NTW == 3) values of row-tile mt as q = rne(200 g + 26) (0, 0.5 and 1 are grid points; step 0.005, range -0.13 .. 1.145),
+      // written here by the FFN-in forward and read back by the gelu'-product dgrad of the same shape and tile width: half the
+      // bytes of the bf16 tensor and one 1-KiB-contiguous store / load per wave and mt instead of two
+      constexpr bool U8 = (EPI == EPI_BF16_GELU_U8 || EPI == EPI_BF16_DGELU_U8);
+      constexpr bool HAS_CSUM = (EPI == EPI_BF16 || HAS_AUX);   // (the GELU forms have no registers for it)
       constexpr int U = 16, PD = 4;                                 // units per wave tile ; aux prefetch distance (units)
-      constexpr int SU = (EPI == EPI_BF16_GELU) ? 2 : 1;            // stores per unit
+      constexpr int PDM = 2;                                        // 8-bit aux: prefetch distance in row tiles
+      constexpr int SU = (EPI == EPI_BF16_GELU) ? 2 : 1;            // stores per unit (the 8-bit form: + one per mt)
       constexpr int NV1 = (NTW == 4) ? 8 : 4;                       // values of unit 1
       const int nc = n0 + wc * 16 * NTW + 8 * eg;
       const uint32_t c1 = (NTW == 4) ? 64u : (uint32_t)(64 - 8 * eg);   // byte offset of unit 1 behind unit 0 (bf16)
@@ -326,11 +333,23 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
       const char* outp = reinterpret_cast<const char*>(p.out);
       const char* out2p = reinterpret_cast<const char*>(p.out2);
       const char* auxp = reinterpret_cast<const char*>(p.aux);
+      // 8-bit gelu' slots of this wave's tile: uniform base + lane * 16 (+ 1024 mt)
+      const char* u8p = (GELU2 ? out2p : auxp) + ((size_t)((m0 >> 8) * tiles_n + n0 / BN) * 8 + wave) * 8192;
+      const uint32_t voff8 = (uint32_t)eln * 16u;
       auto run = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         const char* const o1_ = outp;     // (named here: an asm operand alone does not capture in a generic lambda)
         const char* const o2_ = out2p;
         const char* const ax_ = auxp;
+        const char* const u8_ = u8p;
+        const uint32_t v8_ = voff8;
+        uint32_t q8a = 0u, q8b = 0u;      // 8-bit gelu' of unit 0, held until unit 1 completes the slot
+        u32x4 a8q[(HAS_AUX && U8) ? PDM : 1];
+        u32x4 a8 = {0u, 0u, 0u, 0u};
+        auto aux8_load = [&](int mt) {
+          const uint32_t o = v8_ + (uint32_t)mt * 1024u;
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(a8q[mt % PDM]) : "v"(o), "s"(u8_));
+        };
         // prefetch queue of the gelu' operand: slot u % PD (PD even: odd slots always hold odd units - with 192-wide
         // tiles those are the 8-byte tails, kept in their own registers: an asm load's destination must be consumed
         // as it is, behind the wait - a copy into a wider register would read it before the data arrives)
@@ -346,7 +365,10 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
           if ((u & 1) && NTW == 3) asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(axh[u % PD]) : "v"(o), "s"(ax_));
           else asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(axq[u % PD]) : "v"(o), "s"(ax_));
         };
-        if constexpr (HAS_AUX) {
+        if constexpr (HAS_AUX && U8) {
+#pragma unroll
+          for (int mt = 0; mt < PDM; ++mt) aux8_load(mt);
+        } else if constexpr (HAS_AUX) {
 #pragma unroll
           for (int u = 0; u < PD; ++u) aux_load(u);
         }
@@ -356,7 +378,17 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
           const int m = mw + mt * 16 + el15;
           const int nv = (j == 0) ? 8 : NV1;
           bf16x8 ax;
-          if constexpr (HAS_AUX) {
+          if constexpr (HAS_AUX && U8) {
+            if (j == 0) {
+              // behind load mt: the loads mt + 1 .. mt + PDM - 1 and the stores of the units since it was issued
+              const int loads_behind = (mt + PDM - 1 < 8 ? PDM - 1 : 7 - mt);
+              const int stores_behind = 2 * (mt < PDM ? mt : PDM);
+              if (FULL) { W8_VMCNT_CASES(loads_behind + stores_behind) } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+              a8 = a8q[mt % PDM];
+              asm volatile("" : "+v"(a8));
+              if (mt + PDM < 8) aux8_load(mt + PDM);
+            }
+          } else if constexpr (HAS_AUX) {
             // operations behind load u: the loads u+1 .. u+PD-1 issued so far (load u+PD is issued below, after the
             // wait) and the stores of the units since load u was issued
             const int loads_behind = (u + PD - 1 < U ? PD - 1 : U - 1 - u);
@@ -381,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
           }
           u32x4 w2 = {0u, 0u, 0u, 0u};
           float gp4[4] = {0.f, 0.f, 0.f, 0.f};
-          if constexpr (EPI == EPI_BF16_GELU) {
+          if constexpr (GELU2) {
             float gp[8];
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
@@ -392,9 +424,20 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
                 gp[e] = d2[0]; gp[e + 1] = d2[1];
               } else { gp[e] = 0.f; gp[e + 1] = 0.f; }
             }
-            w2 = u32x4{pack_bf16x2(gp[0], gp[1]), pack_bf16x2(gp[2], gp[3]), pack_bf16x2(gp[4], gp[5]),
-                       pack_bf16x2(gp[6], gp[7])};
-            gp4[0] = gp[0]; gp4[1] = gp[1]; gp4[2] = gp[2]; gp4[3] = gp[3];
+            if constexpr (U8) {
+              uint32_t d0 = 0u, d1 = 0u;     // v_cvt_pk_u8_f32: round to nearest even, saturating (tools/micro/cvt_probe.hip)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                d0 = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(gp[e], 200.f, 26.f), (uint32_t)e, d0);
+                d1 = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(gp[4 + e], 200.f, 26.f), (uint32_t)e, d1);
+              }
+              if (j == 0) { q8a = d0; q8b = d1; }
+              else w2 = u32x4{q8a, q8b, d0, d1};
+            } else {
+              w2 = u32x4{pack_bf16x2(gp[0], gp[1]), pack_bf16x2(gp[2], gp[3]), pack_bf16x2(gp[4], gp[5]),
+                         pack_bf16x2(gp[6], gp[7])};
+              gp4[0] = gp[0]; gp4[1] = gp[1]; gp4[2] = gp[2]; gp4[3] = gp[3];
+            }
           } else if constexpr (EPI == EPI_BF16_GELU_INF) {
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
@@ -403,6 +446,13 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
                 const f32x2 y2 = x2 * norm_cdf_f2(x2);
                 v[e] = y2[0]; v[e + 1] = y2[1];
               }
+            }
+          } else if constexpr (EPI == EPI_BF16_DGELU_U8) {
+            const uint32_t b0 = j ? a8[2] : a8[0], b1 = j ? a8[3] : a8[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] *= __builtin_fmaf((float)((b0 >> (8 * e)) & 255u), 0.005f, -0.13f);
+              if (4 + e < nv) v[4 + e] *= __builtin_fmaf((float)((b1 >> (8 * e)) & 255u), 0.005f, -0.13f);
             }
           } else if constexpr (EPI == EPI_BF16_DGELU) {
 #pragma unroll
@@ -437,11 +487,18 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
               asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(o), "v"(h1), "s"(o1_) : "memory");
             }
           }
+          if constexpr (EPI == EPI_BF16_GELU_U8) {
+            if (j == 1) {   // the row tile's slot is complete (every lane stores: the slot array covers whole tiles)
+              const uint32_t o8 = v8_ + (uint32_t)mt * 1024u;
+              asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(o8), "v"(w2), "s"(u8_) : "memory");
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);   // one unit at a time: interleaved units do not fit 128 registers
         }
       };
       if (full) run(std::true_type{}); else run(std::false_type{});
-      extra = full ? (16 * SU + (HAS_AUX ? 16 : 0)) : 0;   // stores (+ gelu' loads) of a fully valid wave tile
+      // stores (+ gelu' loads) of a fully valid wave tile
+      extra = full ? (U8 ? 24 : (16 * SU + (HAS_AUX ? 16 : 0))) : 0;
       if (HAS_CSUM && p.colsum != nullptr) {   // uniform: bias gradient = column sums of the stored values
         // fold the 16 lanes (rows) of each column group (DPP: no LDS traffic, no index registers)
 #pragma unroll
@@ -544,8 +601,10 @@ int dispatch8w(const GemmParams& p, int epi, hipStream_t st) {
   switch (epi) {
     case EPI_BF16: return launch8w<EPI_BF16, NTW>(p, st);
     case EPI_BF16_GELU:
+      if (p.aux_u8) return p.out2 != nullptr ? launch8w<EPI_BF16_GELU_U8, NTW>(p, st) : VAULT_EINVAL;
       return p.out2 != nullptr ? launch8w<EPI_BF16_GELU, NTW>(p, st) : launch8w<EPI_BF16_GELU_INF, NTW>(p, st);
-    case EPI_BF16_DGELU: return launch8w<EPI_BF16_DGELU, NTW>(p, st);
+    case EPI_BF16_DGELU:
+      return p.aux_u8 ? launch8w<EPI_BF16_DGELU_U8, NTW>(p, st) : launch8w<EPI_BF16_DGELU, NTW>(p, st);
     case EPI_F32_RES: return launch8w<EPI_F32_RES, NTW>(p, st);
     default: return VAULT_EINVAL;
   }
@@ -560,6 +619,7 @@ bool vault_gemm8w_supports(const GemmParams& p, int a_mode, int b_mode, int epi,
   if ((p.M & 255) || (p.N % (64 * ntw)) || (p.K & 63) || p.K < 128 || p.splits > 1 || p.split3 || p.batch > 1) return false;
   if ((long long)p.M * p.ldo * 4 >= (1ll << 32) || p.m_valid < 1) return false;
   if (p.bias == nullptr && p.N > 8192) return false;   // (W8_ZERO_BIAS)   // 32-bit byte offsets in the epilogue
+  if (p.aux_u8 && !(epi == EPI_BF16_DGELU || (epi == EPI_BF16_GELU && p.out2 != nullptr))) return false;
   if (epi == EPI_F32_RES) return p.res != nullptr && p.drop_thresh == 0u && p.colsum == nullptr;
   if (epi == EPI_BF16_DGELU) return p.aux != nullptr;
   if (epi == EPI_BF16_GELU) return p.colsum == nullptr;

@@ -256,6 +256,7 @@ class VaultEngine:
     # rows; larger batches keep the per-kernel calls below (same kernels, same order) so that bench.py can bracket single
     # GEMM call sites with events.  VAULT_STAGE_ABI=0 / 1 forces either.
     STAGE_MAX_ROWS = 8192
+    GELU8 = True                   # ViLT FFN: gelu' kept for backward as the 8-wave kernel's 8-bit tile-native image (vault_gemm aux_u8)
     GRAD_STREAM_BF16 = True        # ViLT residual-gradient stream in bf16 only (what bf16 autocast training carries): see _backward
     WGRAD_STREAM_MAX_ROWS = 16384  # deferred weight gradients run on a second stream up to this many ViLT token rows (B <= 88)
     WGRAD_BATCH_MAX_ROWS = 131072  # the ViLT layers take the same route up to this many (padded) token rows (B <= 708:
@@ -284,6 +285,8 @@ class VaultEngine:
             self.WGRAD_BATCH_RING = False
         if os.environ.get("VAULT_WGRAD_BATCH_MAX_ROWS"):
             self.WGRAD_BATCH_MAX_ROWS = int(os.environ["VAULT_WGRAD_BATCH_MAX_ROWS"])
+        if os.environ.get("VAULT_GELU8") in ("0", "1"):   # development override (same-box A/B)
+            self.GELU8 = os.environ["VAULT_GELU8"] == "1"
         if os.environ.get("VAULT_GRAD_STREAM_BF16") in ("0", "1"):   # development override (same-box A/B)
             self.GRAD_STREAM_BF16 = os.environ["VAULT_GRAD_STREAM_BF16"] == "1"
         if os.environ.get("VAULT_WGRAD_GROUP"):   # layers per batched weight-gradient launch (tuning knob for DP runs)
@@ -501,6 +504,25 @@ class VaultEngine:
         if cfg == 3:
             fl = 2.0 * m_valid * Nout * Kin * G
             ops.pycall(lambda: self._prof_end("wgrad", fl, st))
+
+    def _plan_gelu8(self, ws, n2, act, u, ln, Mp, M):
+        """Kernel configuration (5 / 6) on which BOTH the FFN-in forward and the gelu'-product data gradient of this ViLT
+        workspace run with the 8-bit tile-native gelu' (vault_gemm aux_u8: an opaque image only the same kernel and shape reads
+        back), or None: asked from the library once per workspace (vault_gemm_plan) - the automatic kernel choice must land on
+        the 8-wave kernel with equal tile width for both (not in data-parallel steps, small batches, fp8-forward)."""
+        if "gelu8_cfg" in ws:
+            return ws["gelu8_cfg"]
+        P, H, FF = self.params, ws["H"], ws["FF"]
+        cfg, wt = None, P.pbT.get(ln.fw)
+        if self.GELU8 and u is not None and wt is not None and not self.fp8_forward and Mp % 256 == 0:
+            c1 = ops.gemm(n2, P.wb(ln.iw, n_elems=FF * H, shape=(FF, H)), act, Mp, FF, H, H, H, FF, 0, 0, ops.EPI_BF16_GELU,
+                          m_valid=M, bias=P.w(ln.ib), out2=u, aux_u8=True, plan_only=True)
+            c2 = ops.gemm(n2, wt, act, Mp, FF, H, H, H, FF, 0, 0, ops.EPI_BF16_DGELU, m_valid=M, aux=u,
+                          colsum=P.gr(ln.ib), aux_u8=True, plan_only=True)
+            if c1 in (5, 6) and c1 == c2:
+                cfg = c1
+        ws["gelu8_cfg"] = cfg
+        return cfg
 
     def _use_stage(self, rows_pad: int, pr: bool) -> bool:
         e = os.environ.get("VAULT_STAGE_ABI")
@@ -898,8 +920,10 @@ class VaultEngine:
                               y_split3=n2 if pr else None, mean=buf(f"m2{sfx}", (Mp,)), rstd=buf(f"r2{sfx}", (Mp,)),
                               y_q=q8[0], y_scale=q8[1])
             ops.pycall(lambda: self._prof_begin("ffn1"))
+            g8 = None if pr else self._plan_gelu8(ws, n2, act, u, ln, Mp, M)
+            g8kw = dict(cfg=g8, aux_u8=True) if g8 is not None else {}
             self._linear(n2, ln.iw, act, Mp, FF, H, ops.EPI_BF16_GELU, M, bias=P.w(ln.ib), out2=u, precise=pr,
-                         split3=pr, ldo=W3 * FF, prequant=q8[0] is not None)
+                         split3=pr, ldo=W3 * FF, prequant=q8[0] is not None, **g8kw)
             fl_v = 2.0 * M * FF * H * W3
             ops.pycall(lambda: self._prof_end("ffn1", fl_v))
             self._linear(act, ln.fw, x[i + 1], Mp, H, FF, ops.EPI_F32_RES, M, bias=P.w(ln.fb), res=xm, precise=pr)
@@ -1213,7 +1237,9 @@ class VaultEngine:
             # FFN
             # (bias gradients are column sums of dY: fused into the kernel that PRODUCES dY - the LayerNorm
             #  backward for the residual-stream gradient, the GEMM epilogue for dU)
-            self._dgrad(dyA, ln.fw, dU, Mp, FF, H, ops.EPI_BF16_DGELU, M, aux=g("u"), colsum=P.gr(ln.ib))
+            g8 = ws.get("gelu8_cfg")
+            g8kw = dict(cfg=g8, aux_u8=True) if g8 is not None else {}
+            self._dgrad(dyA, ln.fw, dU, Mp, FF, H, ops.EPI_BF16_DGELU, M, aux=g("u"), colsum=P.gr(ln.ib), **g8kw)
             if not vbatch:
                 self._wgrad(dyA, g("act"), ln.fw, None, Mp, H, FF, M)
             self._dgrad(dU, ln.iw, dN, Mp, H, FF, ops.EPI_BF16, M)

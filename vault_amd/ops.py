@@ -128,8 +128,9 @@ GEMM_SCHED = int(__import__("os").environ.get("VAULT_GEMM_SCHED", "0"))   # env:
 
 def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_valid=0, splits=1, accumulate=0,
          bias=None, res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, drop: Drop = NO_DROP,
-         colsum=None, split3=False, batch=0, batch_a=0, batch_b=0, batch_o=0):
+         colsum=None, split3=False, batch=0, batch_a=0, batch_b=0, batch_o=0, aux_u8=False, plan_only=False):
     a = L.GemmArgs()
+    a.aux_u8 = 1 if aux_u8 else 0
     a.A, a.B, a.out, a.out2 = _p(A), _p(B), _p(out), _p(out2)
     a.bias, a.res, a.aux, a.addtab = _p(bias), _p(res), _p(aux), _p(addtab)
     a.colsum = _p(colsum)
@@ -140,6 +141,8 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_va
     a.persist = GEMM_SCHED
     a.batch, a.batch_a, a.batch_b, a.batch_o = batch, batch_a, batch_b, batch_o   # batched weight gradients (ABI 3)
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
+    if plan_only:      # the kernel configuration these arguments would run on (vault_gemm_plan): >= 0, or -EINVAL
+        return int(L.load().vault_gemm_plan(C.byref(a)))
     _invoke("vault_gemm", C.byref(a), _stream(), struct=a, drop=drop)
 
 
