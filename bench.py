@@ -309,7 +309,7 @@ def main():
                                 f"dW[N x K] += dY[tokens][N]^T X[tokens][K] - batched launches of 6 layers each ({M} ViLT tokens / "
                                 f"{B * 40} LM tokens per layer; FFN-out, FFN-in, attention-out, QKV) and the patch projection",
                        "r02_pmc_gemm_wgrad.json")
-        r_ffn1 = roof("ffn1", "gemm8w_kernel<1,4> (EPI_BF16_GELU, 256-wide tiles, register-direct epilogue): FFN-in forward, ViLT "
+        r_ffn1 = roof("ffn1", "gemm8w_kernel<7,4> / <1,4> (GELU epilogue with the 8-bit tile-native / bf16 gelu', 256-wide tiles, register-direct): FFN-in forward, ViLT "
                               f"[{M}x{v.intermediate_size}x{v.hidden_size}] + LM [{B * 40}x{v.intermediate_size}x{v.hidden_size}]",
                       "r02_pmc_gemm_ffn1.json")
         out = {

@@ -1,6 +1,6 @@
 """Build profiles/<name>.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py (development tool).
 
-  python tools/make_pmc_json.py <fetch_dir> <write_dir> <kernel substring> <out.json> <batch> <lm> "<description>"
+  python tools/make_pmc_json.py <fetch_dir> <write_dir> <kernel substring[|substring...]> <out.json> <batch> <lm> "<description>"
 
 Averages the counters over ALL launches of the kernel (like bench.py's live timing and rocprofv3 --stats do), and per
 grid size.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE under-counts wide coalesced reads by 2x.
@@ -14,7 +14,7 @@ def collect(d, counter):
     per = collections.defaultdict(lambda: [0, 0.0])
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") != counter or pat not in r["Kernel_Name"]:
+            if r.get("Counter_Name") != counter or not any(q in r["Kernel_Name"] for q in pat.split("|")):
                 continue
             v = float(r["Counter_Value"])
             tot += v; n += 1
