@@ -593,6 +593,8 @@ def test_full_size_batch_48_forward_backward_vs_oracle():
     eng.backward()
     torch.cuda.synchronize()
     assert "act_all" in eng.last and "lm_act_all" in eng.last          # the deferred, batched weight gradients ran
+    assert eng.last.get("gelu8_cfg") in (5, 6)                         # ... with the 8-bit tile-native gelu' in the ViLT FFN
+    assert eng.GRAD_STREAM_BF16                                        # ... and the bf16 residual-gradient stream
     torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
     P = O.to_torch_state(state, requires_grad=True)
     loss, ref = O.vault_loss(P, spec, O.torch_batch(bn))

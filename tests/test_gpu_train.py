@@ -415,3 +415,38 @@ def test_full_size_loss_trajectory_20_steps_vs_fp32_oracle():
     assert ref[-1] < ref[0] and losses[-1] < losses[0]                 # both trajectories descend
     # the drop over the run agrees within 15 %
     assert abs((losses[0] - losses[-1]) - (ref[0] - ref[-1])) < 0.15 * abs(ref[0] - ref[-1]) + 2e-3
+
+
+def test_8bit_gelu_prime_is_off_where_its_kernel_does_not_run():
+    """The 8-bit tile-native gelu' needs the 8-wave kernel on both FFN GEMMs: data-parallel GEMM scheduling (ring kernel with
+    dynamic tiles) and small batches (128x128 tiles / stage-level layer calls) keep the bf16 tensor - and give the same loss."""
+    from vault_amd.spec import LMSpec, ViltSpec
+    spec = VaultSpec(vilt=ViltSpec(num_hidden_layers=1), lm=LMSpec.bertweet_base(), n_classes=3)
+    spec.lm.num_hidden_layers = 1
+    spec.lm.hidden_dropout_prob = 0.0; spec.lm.attention_probs_dropout_prob = 0.0
+    state = build_state(spec, 1)
+    bn = synthetic_batch(spec, 48, seed=9, n_classes=3)
+    db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
+    labels = torch.from_numpy(bn["labels"]).cuda()
+    losses, cfgs, grads = [], [], []
+    for sched in (0, 3):
+        old = ops.GEMM_SCHED
+        ops.GEMM_SCHED = sched
+        try:
+            eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+            out = eng.forward(db, train=True, labels=labels, need_hidden=False)
+            eng.zero_grad(); eng.backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.GEMM_SCHED = old
+        losses.append(float(out["loss"])); cfgs.append(eng.last.get("gelu8_cfg"))
+        grads.append(eng.params.gr("encoder.layer.0.intermediate.dense.weight").clone())
+    assert cfgs[0] in (5, 6) and cfgs[1] is None, cfgs
+    assert abs(losses[0] - losses[1]) < 1e-4
+    rel = float((grads[0] - grads[1]).norm() / grads[1].norm())
+    assert rel < 2e-2, rel                       # 8-bit against bf16 gelu', 8-wave against ring kernel: bf16-level agreement
+    small = VaultEngine(VaultSpec.tiny(3, "bert"), "cuda:0", state=build_state(VaultSpec.tiny(3, "bert"), 0))
+    sb = synthetic_batch(VaultSpec.tiny(3, "bert"), 4, seed=1)
+    small.forward({k: torch.from_numpy(v).cuda() for k, v in sb.items() if k != "labels"}, train=True,
+                  labels=torch.from_numpy(sb["labels"]).cuda())
+    assert small.last.get("gelu8_cfg") is None
