@@ -125,7 +125,11 @@ def run_reference(model, spec, batch_np):
     finally:
         emb.visual_embed = orig_ve
     logits = model.classifier(enc.pooler_output).squeeze(-1)
-    loss = torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(batch_np["labels"]))
+    if spec.n_classes == 1:
+        # the single-logit fine-tune (Bloomberg): ref vault/models/vault/trainer.py:55-56 (BCEWithLogitsLoss on float labels)
+        loss = torch.nn.BCEWithLogitsLoss()(logits, torch.from_numpy(batch_np["labels"]).float())
+    else:
+        loss = torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(batch_np["labels"]))
     loss.backward()
     T = batch_np["input_ids"].shape[1]
     out = {
@@ -171,6 +175,7 @@ CASES = {
     "tiny_roberta": (lambda: VaultSpec.tiny(3, "roberta"), 3, 11),
     "tiny_bert": (lambda: VaultSpec.tiny(3, "bert"), 3, 12),
     "full_bertweet_b2": (lambda: VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3), 2, 13),
+    "tiny_bert_bce_n1": (lambda: VaultSpec.tiny(1, "bert"), 5, 15),     # n_classes = 1: logits [B], BCE-with-logits, 0/1 labels
 }
 # BASELINE config 4: bert-base-uncased shapes (vocab 30522, 512 positions, 2 token types, eps 1e-12) with the LM frozen
 # the way the reference's from_pretrained(freeze_lm=True) freezes it (ref: vault/models/vault/model.py:124-126:
@@ -491,7 +496,7 @@ def main():
             continue
         spec = mk()
         model, _ = build_reference_model(ref, spec, seed=0)
-        batch = synthetic_batch(spec, B, seed=dseed, n_classes=spec.n_classes)
+        batch = synthetic_batch(spec, B, seed=dseed, n_classes=max(spec.n_classes, 2))   # (single logit: 0 / 1 targets)
         # make sure one caption is short so padding/masking is exercised
         out = run_reference(model, spec, batch)
         out["meta_batch"] = np.int64(B)

@@ -127,6 +127,29 @@ def test_bce_single_logit_fine_tune_step_vs_oracle():
     assert ref_losses[2] < ref_losses[0] and losses[2] < losses[0], (losses, ref_losses)
 
 
+def test_bce_single_logit_against_reference_golden():
+    """The fused head's BCE-with-logits on the golden the reference itself produced (VaultForTMSC(n_classes=1) +
+    nn.BCEWithLogitsLoss, ref: vault/models/vault/trainer.py:55-56; tests/golden/tiny_bert_bce_n1.npz): logits, loss and
+    per-parameter gradient norms."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_bert_bce_n1.npz"))
+    spec = VaultSpec.tiny(1, "bert")
+    spec.lm.hidden_dropout_prob = 0.0; spec.lm.attention_probs_dropout_prob = 0.0
+    bn = synthetic_batch(spec, int(g["meta_batch"]), seed=int(g["meta_data_seed"]), n_classes=2)
+    eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0), classifier_dropout=0.0)
+    db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
+    out = eng.forward(db, train=True, labels=torch.from_numpy(bn["labels"].astype(np.float32)).cuda())
+    eng.zero_grad(); eng.backward()
+    torch.cuda.synchronize()
+    assert np.abs(out["logits"].cpu().numpy() - g["logits"]).max() < 3e-3
+    assert abs(float(out["loss"]) - float(g["loss"])) < 2e-3
+    for n, rn in zip([str(x) for x in g["grad_names"]], g["grad_norms"]):
+        if ".key.bias" in n:
+            continue
+        mine = float(eng.params.gr(n).double().norm())
+        assert abs(mine - rn) <= 0.08 * rn + 1e-7, (n, mine, rn)
+
+
 def test_train_mode_dropout_is_active_and_reproducible():
     spec = VaultSpec.tiny(3, "roberta")
     bn = synthetic_batch(spec, 4, seed=22, n_classes=3)

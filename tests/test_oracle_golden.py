@@ -15,12 +15,16 @@ CASES = {
     "tiny_roberta": lambda: VaultSpec.tiny(3, "roberta"),
     "tiny_bert": lambda: VaultSpec.tiny(3, "bert"),
     "full_bertweet_b2": lambda: VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3),
+    "tiny_bert_bce_n1": lambda: VaultSpec.tiny(1, "bert"),      # single logit, BCE-with-logits (ref: models/vault/trainer.py:55-56)
 }
 
 
 def _run_oracle(spec, g):
     B = int(g["meta_batch"])
-    batch = O.torch_batch(synthetic_batch(spec, B, seed=int(g["meta_data_seed"]), n_classes=spec.n_classes))
+    bn = synthetic_batch(spec, B, seed=int(g["meta_data_seed"]), n_classes=max(spec.n_classes, 2))
+    if spec.n_classes == 1:
+        bn["labels"] = bn["labels"].astype(np.float32)          # float targets: the oracle takes the BCE branch
+    batch = O.torch_batch(bn)
     P = O.to_torch_state(build_state(spec, 0), requires_grad=True)
     loss, out = O.vault_loss(P, spec, batch)
     loss.backward()
@@ -38,7 +42,7 @@ def test_oracle_matches_reference_golden(name):
     P, loss, out, batch = _run_oracle(spec, g)
     T = batch["input_ids"].shape[1]
     # fp32 vs fp32, different op order (sdpa vs eager softmax, fused vs unfused): 2e-5 abs
-    np.testing.assert_allclose(out["logits"].detach().numpy(), g["logits"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(out["logits"].detach().numpy().reshape(g["logits"].shape), g["logits"], atol=2e-5, rtol=0)
     np.testing.assert_allclose(out["pooler_output"].detach().numpy(), g["pooler_output"], atol=2e-5, rtol=0)
     np.testing.assert_allclose(out["last_hidden_state"][:, : T + 1].detach().numpy(), g["hidden_text_cls"],
                                atol=1e-4, rtol=0)
@@ -87,7 +91,7 @@ def test_oracle_matches_reference_golden_padded_images(name):
     sel, valid, hw, grid, L = select_patches(bn["pixel_mask"], spec.vilt.patch_size)
     assert out["last_hidden_state"].shape[1] == T + 1 + L
     np.testing.assert_array_equal(valid.sum(axis=1), g["valid_patch_counts"])
-    np.testing.assert_allclose(out["logits"].detach().numpy(), g["logits"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(out["logits"].detach().numpy().reshape(g["logits"].shape), g["logits"], atol=2e-5, rtol=0)
     np.testing.assert_allclose(out["pooler_output"].detach().numpy(), g["pooler_output"], atol=2e-5, rtol=0)
     np.testing.assert_allclose(out["last_hidden_state"][:, : T + 1].detach().numpy(), g["hidden_text_cls"],
                                atol=1e-4, rtol=0)
