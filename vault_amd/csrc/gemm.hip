@@ -284,8 +284,7 @@ int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) 
   // weight shadow - the FFN-out (gelu' product) and attention-out data gradients): the 8-wave kernel whose epilogue
   // stores from registers (tools/gemm_bench.py at M = 47360, same box: QKV 168 against 193-198 us, FFN-in 299 against
   // 355-388, gelu'-product dgrad 282 against 294-317, N = K = 768 dgrad 55 against ~90).  Not the f32-residual forms
-  // (bound by their HBM bytes: the ring kernel's 192-wide form is as fast), not K = 3072 (ring: better main loop) and not
-  // with dynamic tile scheduling requested (data-parallel runs beside RCCL kernels: the ring kernel's ticket scheduler).
+  // (bound by their HBM bytes: the ring kernel's 192-wide form is as fast) and not K = 3072 (ring: better main loop).
   // Few row tiles (LM stack at batch <= 128, both stacks at batch 8): the 256-row kernels leave most CUs idle and a
   // block's K loop runs alone on its CU - 128x128 tiles spread the same work over 4x the blocks (tools/gemm_bench.py,
   // M = 2560: attention-out 13.4 against 21.0 us, FFN-out 36.3 against 53.3, FFN-in 23.4 against 26.6, gelu'-product
@@ -298,7 +297,10 @@ int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) 
     if (small) cfg = 0;
   }
   static const bool use8w = [] { const char* e = getenv("VAULT_GEMM8W"); return !(e && e[0] == '0'); }();   // development A/B switch
-  if (auto_cfg && !small && use8w && (p.persist & 1) == 0 && a_mode == 0 && b_mode == 0 && p.K <= 1024 && p.M >= 2048 &&
+  // (also in data-parallel steps - persist bit 0 -: its static tile walk under an RCCL kernel that holds 8-64 CUs costs what the
+  //  ring kernel's dynamic scheduler costs there, 235-250 against 207-240 us for the QKV shape, and nothing when the GPU is
+  //  not shared, 165 against 196-239 us: tools/contention_test.py)
+  if (auto_cfg && !small && use8w && a_mode == 0 && b_mode == 0 && p.K <= 1024 && p.M >= 2048 &&
       (epi == EPI_BF16 || epi == EPI_BF16_GELU || epi == EPI_BF16_DGELU)) {
     auto eff8 = [](long tiles) { return (double)tiles / (double)(((tiles + 255) / 256) * 256); };
     const bool ok4 = vault_gemm8w_supports(p, a_mode, b_mode, epi, 4), ok3 = vault_gemm8w_supports(p, a_mode, b_mode, epi, 3);
