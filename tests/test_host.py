@@ -241,6 +241,19 @@ def _dp_worker(rank, world, port, q):
     red.finish()
     expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
     ok = bool(torch.equal(g, expect))
+    # second step: the lowest stage arrives BEFORE the stage above it (embedding backward ahead of the last group's deferred
+    # weight gradients): its range is reduced at once, the stage above closes the gap
+    g.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+    order = []
+    for tag in ["head", "vilt1", "vilt0", "vilt_embed", "lm1", "lm_embed", "lm0"]:
+        red.on_stage(tag)
+        order = list(red.launched)
+    x = red.finish_upper()
+    ok = ok and order[-2] == (0, 400) and order[-1][0] == 400 and x == order[-1][1]
+    red.finish()
+    ok = ok and bool(torch.equal(g, expect))
+    cover2 = sorted(order)
+    ok = ok and cover2[0][0] == 0 and cover2[-1][1] == n and all(a[1] == b[0] for a, b in zip(cover2, cover2[1:]))
     # ranges are contiguous, descending and cover [0, n) exactly once
     cover = sorted(launched)
     ok = ok and cover[0][0] == 0 and cover[-1][1] == n and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))

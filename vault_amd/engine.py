@@ -1349,6 +1349,21 @@ class VaultEngine:
         ldN = buf("lm_dN", (Mlp, H), bf); ldctx = buf("lm_dctx", (Mlp, H), bf)
         dyb = None          # bf16 part of d y2 (from the next layer's QKV dgrad)
         dyf = dvs           # f32 part of d y2
+        embed_done = False
+
+        def embed_backward(dyb_, dyf_):
+            # embeddings: y0 = dropout(LN(esum))
+            desum = buf("lm_desum", (Mlp, H))
+            ops.layernorm_bwd(ws["lm_esum"], ws["lm_emean"], ws["lm_erstd"], P.w("bert.embeddings.LayerNorm.weight"), Ml, H,
+                              dy_bf16=dyb_, dy_f32=dyf_, dx_f32=desum, dgamma=P.gr("bert.embeddings.LayerNorm.weight"),
+                              dbeta=P.gr("bert.embeddings.LayerNorm.bias"), drop=self._drop(pdh, 1, True), drop_on_dy=True)
+            if ws.get("txt_embeds") is not None:
+                ws["d_inputs_embeds"] = desum[:Ml].view(B, T, H)
+            ops.scatter_add(desum, [None if ws.get("txt_embeds") is not None else
+                                    (P.gr("bert.embeddings.word_embeddings.weight"), ws["ids"]),
+                                    (P.gr("bert.embeddings.position_embeddings.weight"), ws["lm_pos"]),
+                                    (P.gr("bert.embeddings.token_type_embeddings.weight"), ws["lm_tt"])], Ml, H,
+                            rowmask=amf)   # padded positions are masked keys everywhere: their gradient is exactly 0
         for i in reversed(range(nl)):
             ln = self.ll[i]
             g = lambda k: ws[f"lm_{k}{i}"]  # noqa: E731
@@ -1370,6 +1385,12 @@ class VaultEngine:
                     note(f"lm{i}")
                 elif i % group == 0:
                     hi = min(nl, i + group)
+                    if i == 0 and after_layer is not None:
+                        # data-parallel step: the embedding tables' gradient (a third of the bytes on the wire) first, so
+                        # that its all-reduce runs under the last group's weight-gradient launches (train.BucketReducer)
+                        embed_backward(dyb, dyf)
+                        embed_done = True
+                        note("lm_embed")
                     def launch(i=i, hi=hi):
                         for dY_all, X_all, wsel, Nout, Kin in ((dhb_all, ws["lm_act_all"], "fw", H, FF), (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
                                                                (dh1b_all, ws["lm_ctx_all"], "ow", H, H), (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H)):
@@ -1408,6 +1429,10 @@ class VaultEngine:
             elif i % group == 0:
                 # the weight gradients of layers i .. hi - 1, one launch per kind (dY, X: slices i.. of the stacks)
                 hi = min(nl, i + group)
+                if i == 0 and after_layer is not None:     # (data-parallel step: embedding gradient first, see above)
+                    embed_backward(dyb, dyf)
+                    embed_done = True
+                    note("lm_embed")
                 def launch(i=i, hi=hi):
                     for dY_all, X_all, wsel, Nout, Kin in ((dhb_all, ws["lm_act_all"], "fw", H, FF), (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
                                                            (dh1b_all, ws["lm_ctx_all"], "ow", H, H), (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H)):
@@ -1415,17 +1440,8 @@ class VaultEngine:
                 self._wgrads_aside(launch, after_layer)
                 for j in reversed(range(i, hi)):
                     note(f"lm{j}")
-        # embeddings: y0 = dropout(LN(esum))
-        desum = buf("lm_desum", (Mlp, H))
-        ops.layernorm_bwd(ws["lm_esum"], ws["lm_emean"], ws["lm_erstd"], P.w("bert.embeddings.LayerNorm.weight"), Ml, H,
-                          dy_bf16=dyb, dy_f32=dyf, dx_f32=desum, dgamma=P.gr("bert.embeddings.LayerNorm.weight"),
-                          dbeta=P.gr("bert.embeddings.LayerNorm.bias"), drop=self._drop(pdh, 1, True), drop_on_dy=True)
-        if ws.get("txt_embeds") is not None:
-            ws["d_inputs_embeds"] = desum[:Ml].view(B, T, H)
-        ops.scatter_add(desum, [None if ws.get("txt_embeds") is not None else
-                                (P.gr("bert.embeddings.word_embeddings.weight"), ws["ids"]),
-                                (P.gr("bert.embeddings.position_embeddings.weight"), ws["lm_pos"]),
-                                (P.gr("bert.embeddings.token_type_embeddings.weight"), ws["lm_tt"])], Ml, H,
-                        rowmask=amf)   # padded positions are masked keys everywhere: their gradient is exactly 0
+        if not embed_done:
+            embed_backward(dyb, dyf)
         self._join_wgrads()
-        note("lm_embed")
+        if not embed_done:
+            note("lm_embed")

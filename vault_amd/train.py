@@ -83,7 +83,10 @@ class BucketReducer:
         self.g, self.stage_lo, self.last_tag, self.bucket_elems = flat_grad, stage_lo, last_tag, bucket_elems
         self.dist, self.group, self.comm_stream, self.device = dist, group, comm_stream, compute_device
         self.n = flat_grad.numel()
-        self.hi = self.n
+        self.hi = self.n          # everything at or above is launched (top-down frontier)
+        self.bottom = 0           # everything below is launched (the lowest stage may finish ahead of the one above it)
+        above = [v for t, v in stage_lo.items() if t != last_tag and v > stage_lo.get(last_tag, 0)]
+        self.above_last = min(above) if above else self.n      # where the stage above the lowest one starts
         self.works: List = []
         self.launched: List[Tuple[int, int]] = []
 
@@ -91,12 +94,23 @@ class BucketReducer:
         lo = self.stage_lo.get(tag)
         if lo is None:
             return
-        final = tag == self.last_tag
+        if tag == self.last_tag and self.hi > self.above_last and self.bottom == 0:
+            # the lowest stage (the embedding tables: a third of the gradient bytes) became final BEFORE the stage above it -
+            # the engine runs the embedding backward ahead of the deferred weight gradients of the last group of layers in
+            # data-parallel steps, so that this all-reduce runs under them: reduce [0, above_last) now
+            self._launch(0, self.above_last)
+            self.bottom = self.above_last
+            return
+        final = lo <= self.bottom
         if final:
-            lo = 0
+            lo = self.bottom
         if self.hi <= lo or (not final and (self.hi - lo) < self.bucket_elems):
             return
-        view = self.g[lo:self.hi]
+        self._launch(lo, self.hi)
+        self.hi = lo
+
+    def _launch(self, lo: int, hi: int):
+        view = self.g[lo:hi]
         if self.comm_stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
@@ -105,8 +119,7 @@ class BucketReducer:
                 self.works.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self.works.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
-        self.launched.append((lo, self.hi))
-        self.hi = lo
+        self.launched.append((lo, hi))
 
     def finish_upper(self) -> int:
         """Wait for every launched all-reduce except the LAST one (the lowest addresses: it is launched when
@@ -125,8 +138,8 @@ class BucketReducer:
         self.works.clear()
         if self.comm_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
-        assert self.hi == 0, "gradient range [0, %d) was never reduced" % self.hi
-        self.hi = self.n
+        assert self.hi == self.bottom, "gradient range [%d, %d) was never reduced" % (self.bottom, self.hi)
+        self.hi, self.bottom = self.n, 0
         self.launched.clear()
 
 
