@@ -632,6 +632,53 @@ def test_full_size_batch_48_forward_backward_vs_oracle():
     assert (tot_err / tot_ref) ** 0.5 < 2.5e-2                         # global relative L2 (1.0 % at B = 2)
 
 
+def test_full_size_batch_256_equals_its_sub_batches():
+    """BASELINE's headline shape itself (full size, per-GPU batch 256: 47,360 fused tokens = 185 row tiles, several rounds of
+    every persistent GEMM, un-split batched weight gradients, 3,072 attention items, the 8-bit gelu', the bf16 gradient stream)
+    through a size-independent property: a batch is its samples - the eval logits of every sample and the training loss equal
+    those of the same samples run in 8 sub-batches of 32 (oracle-pinned code paths of a smaller shape, other kernels and tiles),
+    and the gradient of the mean loss equals the mean of the sub-batch gradients."""
+    spec = _nodrop(VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3))
+    B, SB = 256, 32
+    bn = synthetic_batch(spec, B, seed=2024, n_classes=3)
+    state = build_state(spec, 0)
+    big = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    db = _dev(bn)
+    ev_big = big.forward(db, train=False)["logits"].clone()
+    out = big.forward(db, train=True, labels=db["labels"], need_hidden=False)
+    big.zero_grad(); big.backward()
+    torch.cuda.synchronize()
+    assert big.last.get("gelu8_cfg") in (5, 6) and "act_all" in big.last
+    loss_big = float(out["loss"]); tr_big = out["logits"].clone()
+    g_big = big.params.g[: big.params.n_train].clone()
+    names = list(big.params.trainable)
+    views = {n: big.params.gr(n).clone() for n in names if big.params.gr(n).numel() >= 768 * 768}
+    del big, out
+    torch.cuda.empty_cache()
+    small = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    small.zero_grad()
+    ev, tr, losses = [], [], []
+    for k in range(0, B, SB):
+        sb = {n: v[k:k + SB].contiguous() for n, v in db.items()}
+        ev.append(small.forward(sb, train=False)["logits"].clone())
+        o = small.forward(sb, train=True, labels=sb["labels"], need_hidden=False)
+        small.backward(grad_scale=1.0 / B)                  # accumulates: sum over sub-batches of sum_i dloss_i / B
+        tr.append(o["logits"].clone()); losses.append(float(o["loss"]))
+    torch.cuda.synchronize()
+    ev, tr = torch.cat(ev), torch.cat(tr)
+    # same samples, same weights, different kernels / tile shapes / summation orders: bf16-level agreement
+    assert float((ev_big - ev).abs().max()) < 2.5e-3 and float((tr_big - tr).abs().max()) < 2.5e-3
+    assert abs(loss_big - sum(losses) / len(losses)) < 2e-4
+    g_small = small.params.g[: small.params.n_train]
+    rel = float((g_big - g_small).norm() / g_small.norm())
+    print(f"B=256 against 8 x 32: |dlogits| {float((tr_big - tr).abs().max()):.2e}, gradient relative L2 {rel:.2e}")
+    assert rel < 1.5e-2
+    for n, gb in views.items():
+        gs = small.params.gr(n)
+        cos = float((gb * gs).sum() / (gb.norm() * gs.norm() + 1e-30))
+        assert cos > 0.9995, (n, cos)
+
+
 def test_experiment_script_call_sequence(tmp_path):
     """The model-side calls of the reference's driver (ref: experiments/clsf_vault.py:196-220): from_pretrained with the
     script's keyword arguments -> resize_token_embeddings(len(tokenizer)) -> integrate_entities_into_model (resize, get,
