@@ -252,6 +252,51 @@ def main():
                "what": "the same steps with a fresh pinned host batch per step copied host->device on a side stream "
                        "(double-buffered, overlapped with the previous step) + one device-to-device copy into the staging buffers"}
 
+    # ---- third loop: the input pipeline from uint8 images: per step a pinned host batch of 8-bit RGB images
+    #      (480 x 480, what a JPEG decoder leaves) is copied host->device on the side stream (177 MB instead of 453 MB of
+    #      float pixels) and resized / normalised / padded THERE by vault_image_preprocess straight into the double-buffered
+    #      device batch - what HuggingFace's processor does per item on CPU workers in the reference
+    #      (ref: vault/models/vault/dataset.py:337-341), bit-identically (tests/test_gpu_preprocess.py)
+    u8 = None
+    if not args.no_h2d and not args.fp8_forward:
+        from vault_amd.preprocess import DeviceImageProcessor
+        proc = DeviceImageProcessor(dev)
+        HW = 480
+        rng = np.random.default_rng(99 + rank)
+        himg = [torch.from_numpy(rng.integers(0, 256, size=(B, HW, HW, 3), dtype=np.uint8)).pin_memory() for _ in range(nb)]
+        sizes = [(HW, HW)] * B
+
+        def prefetch_u8(k):
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(consumed[k % nb])
+                for name in ("input_ids", "attention_mask", "labels"):
+                    devb[k % nb][name].copy_(host[k % nb][name], non_blocking=True)
+                proc.from_packed(himg[k % nb].view(-1), sizes, out=devb[k % nb])
+                ready[k % nb].record(copy_stream)
+
+        for i in range(nb):
+            consumed[i].record(torch.cuda.current_stream(dev))
+        prefetch_u8(0)
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            if k + 1 < args.steps:
+                prefetch_u8(k + 1)
+            torch.cuda.current_stream(dev).wait_event(ready[k % nb])
+            d = devb[k % nb]
+            stepper({n_: d[n_] for n_ in ("input_ids", "attention_mask", "pixel_values", "pixel_mask")}, d["labels"])
+            consumed[k % nb].record(torch.cuda.current_stream(dev))
+        sync_all()
+        dt3 = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt3], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt3 = float(t.item())
+        u8 = {"value": round(B * world * args.steps / dt3, 2), "ms_per_step": round(dt3 / args.steps * 1e3, 3),
+              "what": f"the same steps fed from pinned uint8 images ({HW} x {HW} x 3 per sample, {B * HW * HW * 3 / 1e6:.0f} MB per step): "
+                      "host->device copy + GPU resize / normalise / pad (vault_image_preprocess, bit-identical to the HF ViLT "
+                      "processor) on a side stream, double-buffered, overlapped with the previous step"}
+
     precise_fwd = None
     if rank == 0 and not args.no_parity and not args.fp8_forward:
         # throughput of the mode that meets the north star's 1e-3: eval forward, split-bf16 GEMMs, at the bench batch
@@ -333,6 +378,8 @@ def main():
             out["parity"] = parity
         if h2d is not None:
             out["with_h2d_input_copies"] = h2d
+        if u8 is not None:
+            out["with_uint8_input_pipeline"] = u8
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(spec)

@@ -60,3 +60,27 @@ def test_preprocessed_batch_feeds_the_model():
     eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0))
     out = eng.forward(batch, train=False)
     assert out["logits"].shape == (2, 3) and torch.isfinite(out["logits"]).all()
+
+
+def test_packed_host_buffer_into_preallocated_outputs_on_a_side_stream():
+    """The loader-facing form: one pinned uint8 tensor + sizes, results written into preallocated tensors (the engine's input
+    staging buffers in a training loop), on a non-default stream, twice with the same geometry (cached device-side plan) and
+    once with another."""
+    rng = np.random.default_rng(11)
+    proc = DeviceImageProcessor()
+    side = torch.cuda.Stream()
+    for sizes in ([(480, 480)] * 3, [(480, 480)] * 3, [(100, 150), (384, 384)]):
+        imgs = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in sizes]
+        host = torch.from_numpy(np.concatenate([im.reshape(-1) for im in imgs])).pin_memory()
+        pv_ref, pm_ref = PO.preprocess(imgs)
+        out = {"pixel_values": torch.full(pv_ref.shape, 7.0, device="cuda"),
+               "pixel_mask": torch.full(pm_ref.shape, 7, dtype=torch.int64, device="cuda")}
+        with torch.cuda.stream(side):
+            res = proc.from_packed(host, sizes, out=out)
+        side.synchronize()
+        assert res["pixel_values"] is out["pixel_values"]
+        assert np.array_equal(out["pixel_values"].cpu().numpy(), pv_ref) and np.array_equal(out["pixel_mask"].cpu().numpy(), pm_ref)
+    with pytest.raises(ValueError):
+        proc.from_packed(host[:-3], sizes)
+    with pytest.raises(ValueError):
+        proc.from_packed(host, sizes, out={"pixel_values": torch.zeros(2, 3, 8, 8, device="cuda"), "pixel_mask": out["pixel_mask"]})

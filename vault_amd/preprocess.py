@@ -107,6 +107,7 @@ class DeviceImageProcessor:
         self.shortest_edge, self.size_divisor = shortest_edge, size_divisor
         self.mask_dtype = mask_dtype
         self._lut = torch.from_numpy(normalise_lut(rescale_factor, image_mean, image_std)).to(self.device)
+        self._plan_key, self._plan_dev = None, None        # device-side plan of the last batch geometry (loaders repeat it)
 
     def plan(self, sizes: List[Tuple[int, int]]):
         """Host plan of a batch: (descriptor bytes, plan int32 array, src bytes, tmp bytes, H, W, max_h_in, max_w_out)."""
@@ -152,22 +153,38 @@ class DeviceImageProcessor:
         if not isinstance(images, (list, tuple)):
             images = [images]
         imgs = [_as_hwc_u8(im) for im in images]
-        B = len(imgs)
-        desc_b, plan, src_bytes, tmp_bytes, H, W, max_h_in, max_w_out = self.plan([im.shape[:2] for im in imgs])
-        host = torch.empty(src_bytes, dtype=torch.uint8, pin_memory=True)
+        host = torch.empty(sum(im.size for im in imgs), dtype=torch.uint8, pin_memory=True)
         hv = host.numpy()
         o = 0
         for im in imgs:
             hv[o:o + im.size] = im.reshape(-1)
             o += im.size
+        return self.from_packed(host, [im.shape[:2] for im in imgs])
+
+    def from_packed(self, host_u8: torch.Tensor, sizes, out: Dict[str, torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """The loader-facing form: ``host_u8`` = the images back to back ([h][w][3] uint8 each, ``sizes`` = their (h, w)) in ONE
+        host tensor - pinned, as a decoder writing straight into a staging buffer leaves them - copied and processed on the
+        current stream.  ``out``: optional preallocated ``pixel_values`` / ``pixel_mask`` of the batch's padded shape (e.g. the
+        engine's own input staging buffers: no device-to-device copy afterwards)."""
+        sizes = [tuple(int(v) for v in hw) for hw in sizes]
+        B = len(sizes)
+        key = tuple(sizes)
+        if self._plan_key != key:
+            desc_b, plan, src_bytes, tmp_bytes, H, W, max_h_in, max_w_out = self.plan(sizes)
+            dev = self.device
+            self._plan_key, self._plan_dev = key, (
+                torch.from_numpy(plan).to(dev), torch.frombuffer(bytearray(desc_b), dtype=torch.uint8).to(dev),
+                torch.empty(tmp_bytes, dtype=torch.uint8, device=dev), src_bytes, H, W, max_h_in, max_w_out)
+        plan_d, desc_d, tmp, src_bytes, H, W, max_h_in, max_w_out = self._plan_dev
+        if host_u8.dtype != torch.uint8 or host_u8.numel() != src_bytes:
+            raise ValueError("host_u8 must hold exactly the images of `sizes`, uint8")
         dev = self.device
         with torch.cuda.device(dev):
-            src = host.to(dev, non_blocking=True)
-            plan_d = torch.from_numpy(plan).to(dev, non_blocking=True)
-            desc_d = torch.frombuffer(bytearray(desc_b), dtype=torch.uint8).to(dev, non_blocking=True)
-            tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=dev)
-            pv = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
-            pm = torch.empty(B, H, W, dtype=self.mask_dtype, device=dev)
+            src = host_u8.to(dev, non_blocking=True)
+            pv = out["pixel_values"] if out is not None else torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
+            pm = out["pixel_mask"] if out is not None else torch.empty(B, H, W, dtype=self.mask_dtype, device=dev)
+            if tuple(pv.shape) != (B, 3, H, W) or pv.dtype != torch.float32 or tuple(pm.shape) != (B, H, W) or pm.dtype != self.mask_dtype:
+                raise ValueError(f"out tensors must be pixel_values [{B},3,{H},{W}] float32 and pixel_mask [{B},{H},{W}] {self.mask_dtype}")
             if self.mask_dtype not in (torch.int64, torch.float32):
                 raise ValueError("mask_dtype must be torch.int64 (HF) or torch.float32")
             a = PreprocessArgs()
@@ -180,7 +197,7 @@ class DeviceImageProcessor:
             a.B, a.H, a.W, a.max_h_in, a.max_w_out = B, H, W, max_h_in, max_w_out
             L.check(L.load().vault_image_preprocess(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                     "vault_image_preprocess")
-            # the launches read src / plan / desc / tmp asynchronously: keep them alive until the stream has passed them
-            for t in (src, plan_d, desc_d, tmp):
-                t.record_stream(torch.cuda.current_stream())
+            # (src is freed on this stream after the launches; plan / descriptors / intermediate belong to the cached plan: a
+            #  batch of other sizes on ANOTHER stream must not start before this one has passed them)
+            src.record_stream(torch.cuda.current_stream())
         return {"pixel_values": pv, "pixel_mask": pm}
