@@ -372,10 +372,11 @@ int vault_head_loss_bwd(const vault_head_loss_args* args, void* stream);
  * 160-206 pad + pixel_mask) bit-exactly: 8-bit fixed-point resampling in two passes like Pillow's Resample.c.
  * The HOST plans (vault_amd/preprocess.py): output sizes, and per image and axis the taps Pillow's precompute_coeffs
  * gives - `plan` holds, at the descriptor's int32 offsets, bounds [out][2] = (first tap, tap count) and weights
- * [out][ksize] in 22-bit fixed point.  src: the images back to back, [h_in][w_in][3] uint8 each; tmp: [h_in][w_out][3]
- * uint8 per image (intermediate of the horizontal pass); lut [3][256] f32 = value of each 8-bit level per channel after
+ * [out][ksize] in 22-bit fixed point.  src: the images back to back, [h_in][w_in][3] uint8 each (4-byte aligned base); tmp: [h_in][align4(3 w_out)]
+ * uint8 per image (intermediate of the horizontal pass, rows padded to 4-byte multiples, tmp_off multiples of 4); lut [3][256] f32 = value of each 8-bit level per channel after
  * rescale + normalise; pixel_values [B][3][H][W] f32 (zero in the bottom / right padding); pixel_mask [B][H][W] int64
- * and / or f32 (optional).  max_h_in / max_w_out: maxima over the batch (launch bounds). */
+ * and / or f32 (optional); W % 4 == 0 (output sizes are multiples of the size divisor).  max_h_in / max_w_in / max_w_out: maxima
+ * over the batch (launch bounds, LDS row buffers). */
 typedef struct vault_image_desc {
   long long src_off, tmp_off;
   int h_in, w_in, h_out, w_out, ksize_h, ksize_v;
@@ -385,6 +386,7 @@ typedef struct vault_preprocess_args {
   const uint8_t* src; uint8_t* tmp; const int* plan; const vault_image_desc* desc; const float* lut;
   float* pixel_values; int64_t* pixel_mask; float* pixel_mask_f32;
   int B, H, W, max_h_in, max_w_out;
+  int max_w_in; long long src_bytes;   /* widest source row of the batch; size of src (rows are read as aligned dwords) */
 } vault_preprocess_args;
 int vault_image_preprocess(const vault_preprocess_args* args, void* stream);
 

@@ -34,6 +34,7 @@ a = PreprocessArgs()
 a.src, a.tmp, a.plan, a.desc, a.lut, a.pixel_values, a.pixel_mask = (src.data_ptr(), tmp.data_ptr(), plan_d.data_ptr(), desc_d.data_ptr(),
                                                                        proc._lut.data_ptr(), pv.data_ptr(), pm.data_ptr())
 a.B, a.H, a.W, a.max_h_in, a.max_w_out = B, H, W, mh, mw
+a.max_w_in, a.src_bytes = max(im.shape[1] for im in imgs), src_bytes
 fn = L.load().vault_image_preprocess
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for _ in range(3):

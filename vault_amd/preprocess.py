@@ -28,7 +28,7 @@ class ImageDesc(C.Structure):
 class PreprocessArgs(C.Structure):
     """vault_preprocess_args (include/vault_hip.h)."""
     _fields_ = [(n, C.c_void_p) for n in ("src", "tmp", "plan", "desc", "lut", "pixel_values", "pixel_mask", "pixel_mask_f32")] + [
-        (n, C.c_int) for n in ("B", "H", "W", "max_h_in", "max_w_out")]
+        (n, C.c_int) for n in ("B", "H", "W", "max_h_in", "max_w_out", "max_w_in")] + [("src_bytes", C.c_longlong)]
 
 
 def resize_output_size(h: int, w: int, shorter: int = 384, size_divisor: int = 32) -> Tuple[int, int]:
@@ -103,6 +103,8 @@ class DeviceImageProcessor:
         if not torch.cuda.is_available():
             raise RuntimeError("DeviceImageProcessor needs a GPU (the HIP library has no CPU path)")
         L.load()
+        if size_divisor % 4:
+            raise ValueError("size_divisor must be a multiple of 4 (the kernels write four pixels per thread)")
         self.device = torch.device(device)
         self.shortest_edge, self.size_divisor = shortest_edge, size_divisor
         self.mask_dtype = mask_dtype
@@ -141,7 +143,7 @@ class DeviceImageProcessor:
                 else:
                     d.vb_off, d.vk_off, d.ksize_v = bo, ko, ks
             src_off += h * w * 3
-            tmp_off += h * ow * 3
+            tmp_off += h * ((ow * 3 + 3) & ~3)            # intermediate rows padded to 4-byte multiples
             H, W, max_h_in, max_w_out = max(H, oh), max(W, ow), max(max_h_in, h), max(max_w_out, ow)
         if off >= 2 ** 31:
             raise ValueError("plan too large")
@@ -195,6 +197,7 @@ class DeviceImageProcessor:
             else:
                 a.pixel_mask_f32 = pm.data_ptr()
             a.B, a.H, a.W, a.max_h_in, a.max_w_out = B, H, W, max_h_in, max_w_out
+            a.max_w_in, a.src_bytes = max(w for _, w in sizes), src_bytes
             L.check(L.load().vault_image_preprocess(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                     "vault_image_preprocess")
             # (src is freed on this stream after the launches; plan / descriptors / intermediate belong to the cached plan: a
