@@ -7,6 +7,9 @@ RCCL all-reduce of gradients).
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...          (no torchrun environment: starts the N ranks itself, fails when the node has < N GPUs)
+  python bench.py --config {2,3,4,5}    (BASELINE.json configs: per-GPU batch 64 | 64 x N ranks | frozen bert-base-uncased,
+                                         batch 128 | MXFP8 forward, batch 256)
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").  `roofline` is the dominant kernel of the
 step by GPU time (rocprofv3 --stats, profiles/): the weight-gradient instantiation of the bf16 MFMA ring
@@ -121,12 +124,92 @@ def measure_parity(eng, spec, args, dev):
     return name, out
 
 
+CONFIGS = {   # BASELINE.json `configs` (1 is the CPU plumbing case: a test, not a bench line)
+    2: dict(batch=64, what="config 2: bf16 fine-tune, batch 64, 1 GPU"),
+    3: dict(batch=64, what="config 3: bf16 fine-tune, global batch 64 x ranks (512 at DP = 8)"),
+    4: dict(batch=128, lm="bert-base-uncased", freeze_lm=True, what="config 4: frozen bert-base-uncased LM, batch 128"),
+    5: dict(batch=256, fp8_forward=True, what="config 5: MXFP8 forward GEMMs, bf16 backward, batch 256"),
+}
+
+
+def _self_launch(n: int, argv):
+    """`--gpus N` outside a torchrun environment: this process has made no GPU call (counting devices does not
+    initialise the runtime) - it starts N fresh ranks through torch.distributed.run and exits with their code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} needs {n} devices, this node shows {have}: refusing to measure fewer ranks than asked for",
+              file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    sys.exit(subprocess.run(cmd).returncode)
+
+
+def quick_config(cfg: int, dev, world: int, steps: int = 10, warmup: int = 3):
+    """A short timed loop of another BASELINE configuration on its own engine (freed afterwards): the same step,
+    inputs resident, barrier + synchronize on both sides, max over ranks."""
+    c = CONFIGS[cfg]
+    lm = LMSpec.bert_base_uncased() if c.get("lm") == "bert-base-uncased" else LMSpec.bertweet_base()
+    spec = VaultSpec(vilt=ViltSpec(), lm=lm, n_classes=3)
+    B = c["batch"]
+    eng = VaultEngine(spec, dev, seed=0, freeze_lm=c.get("freeze_lm", False), classifier_dropout=0.1,
+                      fp8_forward=c.get("fp8_forward", False))
+    stepper = TrainStep(eng, learning_rate=2e-5, warmup_ratio=0.1, total_steps=steps + warmup, assume_full_pixel_mask=True)
+    rank = int(os.environ.get("RANK", "0"))
+    bn = synthetic_batch(spec, B, seed=1234 + rank, n_classes=3)
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in bn.items() if k != "labels"}
+    labels = torch.from_numpy(bn["labels"]).to(dev)
+    stage = eng.input_buffers(B, batch["input_ids"].shape[1], True)
+    for k in ("input_ids", "pixel_values"):
+        stage[k].copy_(batch[k])
+        batch[k] = stage[k]
+    stage["labels"].copy_(labels)
+
+    def sync_all():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(warmup):
+        stepper(batch, stage["labels"])
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        stepper(batch, stage["labels"])
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    flop = 106.96e9 if c.get("freeze_lm") else FLOP_PER_SAMPLE_TRAIN
+    sps = B * world * steps / dt
+    out = {"what": c["what"], "value": round(sps, 2), "unit": "samples/s", "ms_per_step": round(dt / steps * 1e3, 3),
+           "per_gpu_batch": B, "global_batch": B * world, "steps": steps, "warmup": warmup,
+           "step_mfma_frac": round(sps / world * flop / PEAK_BF16, 4), "final_loss": round(float(stepper.loss.item()), 5)}
+    del stepper, eng, batch, stage
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 256: the metric's)")
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
+                    help="a BASELINE.json configuration as the timed workload (sets batch / LM / freeze / fp8 as it states)")
+    ap.add_argument("--wire", default=None, choices=["fp32", "bf16"],
+                    help="data-parallel gradient wire format (default fp32 all-reduce; bf16 = reduce-scatter + all-gather "
+                         "with bf16 on the wire, f32 accumulation)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short loops of the other BASELINE configurations (`other_configs`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--freeze-lm", action="store_true")
     ap.add_argument("--fp8-forward", action="store_true",
@@ -135,13 +218,25 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the golden-batch parity measurement and the precise-mode timing")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second timed loop with pipelined host->device input copies")
     args = ap.parse_args()
+    if args.config is not None:
+        c = CONFIGS[args.config]
+        args.batch = args.batch or c["batch"]
+        args.lm = c.get("lm", args.lm)
+        args.freeze_lm = args.freeze_lm or c.get("freeze_lm", False)
+        args.fp8_forward = args.fp8_forward or c.get("fp8_forward", False)
+    args.batch = args.batch or 256
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _self_launch(args.gpus, sys.argv[1:])          # (never returns)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if local_rank >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} needs device {local_rank}, this node shows {torch.cuda.device_count()}", file=sys.stderr)
+        sys.exit(2)
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     pg = None
@@ -150,13 +245,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != world:
+            raise RuntimeError(f"RCCL reports {dist.get_world_size()} ranks, expected {world}")
 
     lm = LMSpec.bertweet_base() if args.lm == "bertweet" else LMSpec.bert_base_uncased()
     spec = VaultSpec(vilt=ViltSpec(), lm=lm, n_classes=3)
     eng = VaultEngine(spec, dev, seed=0, freeze_lm=args.freeze_lm, classifier_dropout=0.1, fp8_forward=args.fp8_forward)
     total = args.steps + args.warmup
     stepper = TrainStep(eng, learning_rate=2e-5, warmup_ratio=0.1, total_steps=max(total, 10), process_group=pg,
-                       assume_full_pixel_mask=True)   # synthetic 384x384 images, all-ones masks: no per-step mask check
+                       assume_full_pixel_mask=True,   # synthetic 384x384 images, all-ones masks: no per-step mask check
+                       wire=args.wire)
 
     B = args.batch
     parity = None
@@ -203,10 +301,19 @@ def main():
     eng.profile_events = None
     loss = float(stepper.loss.item())
 
+    ms_by_rank = [round(dt / args.steps * 1e3, 3)]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(allt, t)
+        ms_by_rank = [round(float(x.item()) / args.steps * 1e3, 3) for x in allt]
+        dt = max(float(x.item()) for x in allt)          # MAX over ranks
+    exchange = None
+    if stepper.reducer is not None:
+        dense = 2 * 4 * eng.params.n_train * (world - 1) // max(world, 1)
+        exchange = {"wire": stepper.wire, "sparse_word_embedding": stepper.reducer.sparse is not None,
+                    "bytes_sent_per_rank_and_step": int(stepper.reducer.wire_bytes),
+                    "dense_f32_all_reduce_would_send": int(dense), "rccl_world_size": torch.distributed.get_world_size()}
 
     # ---- second loop: the same K steps with the input copies inside the loop (ref: tmsc_utils/trainer.py:183-202,353
     #      batch_to_device): a fresh host batch per step from pinned memory, copied on a side stream into one of two
@@ -320,6 +427,21 @@ def main():
         precise_fwd = {"precise_forward_samples_per_s": round(B / tp, 1), "fast_forward_samples_per_s": round(B / tf, 1),
                        "batch": B}
 
+    # ---- the other BASELINE configurations, each a short loop on its own engine (rank 0 prints them in `other_configs`):
+    #      per-GPU batch 64 (config 2 on one GPU, config 3's per-GPU shape on N), and on one GPU the frozen-LM and fp8-forward ones
+    others = None
+    if not args.no_other_configs and args.config is None and B == 256 and args.lm == "bertweet" and not args.freeze_lm \
+            and not args.fp8_forward:
+        del stepper
+        eng._ws.clear()
+        torch.cuda.empty_cache()
+        others = {}
+        for cfg in ((2, 4, 5) if world == 1 else (3,)):
+            try:
+                others[f"config{cfg}"] = quick_config(cfg, dev, world)
+            except Exception as e:  # pragma: no cover
+                others[f"config{cfg}"] = {"error": repr(e)}
+
     if rank == 0:
         sps = B * world * args.steps / dt
         v = spec.vilt
@@ -367,11 +489,17 @@ def main():
                                    f"40 text tokens + 384x384 image (185-token fused sequence), "
                                    f"{'frozen LM' if args.freeze_lm else 'all weights trained'}"
                                    f"{', MXFP8 forward Linears' if args.fp8_forward else ''}",
-                       "global_batch": B * world, "seq_len": 185, "parallelism": f"dp{world}"},
+                       "global_batch": B * world, "seq_len": 185, "parallelism": f"dp{world}",
+                       **({"baseline_config": args.config} if args.config is not None else {})},
+            "ms_per_step_by_rank": ms_by_rank,
             "roofline": r_wgrad, "roofline_ffn1": r_ffn1,
             "step_mfma_frac": round(sps / world * flop_per_sample / PEAK_BF16, 4),
             "final_loss": round(loss, 5),
         }
+        if exchange is not None:
+            out["gradient_exchange"] = exchange
+        if others is not None:
+            out["other_configs"] = others
         if parity is not None:
             if precise_fwd is not None:
                 parity["precise_mode"].update(precise_fwd)

@@ -233,6 +233,23 @@ int vault_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, long 
                      float beta2, float eps, float weight_decay, float bias_corr_factor, float grad_scale,
                      int zero_grad, void* stream);
 int vault_cast_bf16(const float* x, void* y_bf16, long long n, void* stream);
+/* ---- data-parallel gradient exchange (ABI 6) -------------------------------------------------------------------
+ * The reference is single-device (ref: vault/tmsc_utils/trainer.py:353-369: backward -> optimizer.step on one GPU); these
+ * serve the build's own data-parallel step, between the RCCL collectives that vault_amd/train.py issues.
+ *   vault_rows_union      sorted list of the distinct values of keys[0..n_keys) that lie in [0, V) (the token ids of ALL
+ *                         ranks after an all-gather: the rows of an embedding table any rank touched) -> uniq[0..*count);
+ *                         flags_zeroed: V zero ints of scratch, left zeroed.  Same list on every rank.
+ *   vault_rows_gather_f32 out[j][0..H) = table[idx[j]][0..H)     (compact image of the touched gradient rows)
+ *   vault_rows_scatter_f32 table[idx[j]][0..H) = src[j][0..H)    (the all-reduced rows back into the dense gradient)
+ *   vault_sum_chunks_bf16 out[i] = bf16(sum_k f32(src[k * chunk + i])), k = 0..n_src-1 in that order (f32 accumulation of
+ *                         the peers' bf16 gradient chunks after an all-to-all; chunk % 8 == 0)
+ *   vault_widen_bf16      y[i] = f32(x[i])  (n % 4 == 0) */
+int vault_rows_union(const long long* keys, long long n_keys, int V, int* flags_zeroed, long long* uniq, int* count,
+                     void* stream);
+int vault_rows_gather_f32(const float* table, const long long* idx, int n_rows, int H, float* out, void* stream);
+int vault_rows_scatter_f32(const float* src, const long long* idx, int n_rows, int H, float* table, void* stream);
+int vault_sum_chunks_bf16(const void* src_bf16, int n_src, long long chunk, void* out_bf16, void* stream);
+int vault_widen_bf16(const void* x_bf16, float* y, long long n, void* stream);
 /* ABI 4: dst[b][c][r] = src[b][r][c] for `batch` bf16 matrices of rows x cols (multiples of 64) at uniform element strides
  * (8-aligned): the transposed weight shadow W^T [in][out] of a Linear.  The data gradient dX = dY . W (autograd of
  * HF:models/vilt/modeling_vilt.py:355-414) then runs as a forward-form GEMM (b_mode 0) on the register-direct kernel
@@ -376,7 +393,8 @@ int vault_head_loss_bwd(const vault_head_loss_args* args, void* stream);
  * uint8 per image (intermediate of the horizontal pass, rows padded to 4-byte multiples, tmp_off multiples of 4); lut [3][256] f32 = value of each 8-bit level per channel after
  * rescale + normalise; pixel_values [B][3][H][W] f32 (zero in the bottom / right padding); pixel_mask [B][H][W] int64
  * and / or f32 (optional); W % 4 == 0 (output sizes are multiples of the size divisor).  max_h_in / max_w_in / max_w_out: maxima
- * over the batch (launch bounds, LDS row buffers). */
+ * over the batch (launch bounds, LDS row buffers) - trusted: an image whose descriptor exceeds them is skipped by the LDS
+ * kernel (left unwritten) rather than overrunning its row buffers. */
 typedef struct vault_image_desc {
   long long src_off, tmp_off;
   int h_in, w_in, h_out, w_out, ksize_h, ksize_v;

@@ -238,7 +238,7 @@ def test_train_step_on_padded_image_batches_mixed_with_square_ones():
 
 
 
-def _dp_worker(rank, world, port, out_path, kind, nsteps, use_tape):
+def _dp_worker(rank, world, port, out_path, kind, nsteps, use_tape, wire, sparse):
     """One data-parallel rank (both ranks share cuda:0; gloo carries the device tensors): its half of every batch."""
     import os
     import torch.distributed as dist
@@ -250,32 +250,42 @@ def _dp_worker(rank, world, port, out_path, kind, nsteps, use_tape):
         spec.lm.hidden_dropout_prob = 0.0
         spec.lm.attention_probs_dropout_prob = 0.0
         eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0), classifier_dropout=0.0)
-        step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10, use_tape=use_tape, bucket_mb=0.25)
+        step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10, use_tape=use_tape, bucket_mb=0.25,
+                         wire=wire, sparse_embedding=sparse)
         assert step.world == world and step.reducer is not None and ops.GEMM_SCHED == 3
-        losses = []
+        assert (step.reducer.sparse is not None) == sparse and step.reducer.wire == wire
+        losses, wire_bytes = [], []
         for i in range(nsteps):
             bn = synthetic_batch(spec, 8, seed=90 + i, n_classes=3)
             lo, hi = rank * 4, rank * 4 + 4
             db = {k: torch.from_numpy(v[lo:hi]).cuda() for k, v in bn.items() if k != "labels"}
             losses.append(float(step(db, torch.from_numpy(bn["labels"][lo:hi]).cuda())))
+            wire_bytes.append(step.reducer.wire_bytes)
         torch.cuda.synchronize()
-        torch.save({"p": eng.params.p.cpu(), "losses": losses}, f"{out_path}.{rank}")
+        torch.save({"p": eng.params.p.cpu(), "losses": losses, "wire_bytes": wire_bytes, "n_train": eng.params.n_train},
+                   f"{out_path}.{rank}")
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_tape", [False, True])
-def test_data_parallel_two_ranks_equal_one_rank_on_the_global_batch(tmp_path, use_tape):
+@pytest.mark.parametrize("use_tape,wire,sparse", [(False, "fp32", True), (True, "fp32", True), (True, "fp32", False),
+                                                  (True, "bf16", True), (False, "bf16", False)])
+def test_data_parallel_two_ranks_equal_one_rank_on_the_global_batch(tmp_path, use_tape, wire, sparse):
     """The whole N > 1 path on real kernels: two processes (sharing the one GPU, gloo as the transport) each step
-    half of a global batch of 8 - bucketed gradient all-reduce from inside backward on a side stream, dynamic GEMM
-    scheduling, AdamW dividing by the world size - and must land where ONE process stepping the 8 samples lands."""
+    half of a global batch of 8 - bucketed gradient exchange from inside backward on a side stream (f32 all-reduce or
+    bf16 reduce-scatter + all-gather; the word-embedding table row-sparse or dense), dynamic GEMM scheduling, AdamW
+    dividing by the world size - and must land where ONE process stepping the 8 samples lands."""
     import torch.multiprocessing as mp
     nsteps = 3
     out = str(tmp_path / "dp")
-    port = 29600 + (1 if use_tape else 0)
-    mp.spawn(_dp_worker, args=(2, port, out, "roberta", nsteps, use_tape), nprocs=2, join=True)
+    port = 29600 + (1 if use_tape else 0) + (2 if wire == "bf16" else 0) + (4 if sparse else 0)
+    mp.spawn(_dp_worker, args=(2, port, out, "roberta", nsteps, use_tape, wire, sparse), nprocs=2, join=True)
     r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
     assert torch.equal(r0["p"], r1["p"])                       # replicas stay bit-identical
+    dense_fp32 = 4 * r0["n_train"]                             # bytes a rank sends in a dense f32 ring all-reduce at world 2
+    print(f"wire bytes per step and rank: {r0['wire_bytes']} (dense f32 all-reduce: {dense_fp32})")
+    if sparse or wire == "bf16":
+        assert max(r0["wire_bytes"]) < (0.8 if wire == "fp32" else 0.5) * dense_fp32
     spec = VaultSpec.tiny(3, "roberta")
     spec.lm.hidden_dropout_prob = 0.0
     spec.lm.attention_probs_dropout_prob = 0.0
@@ -291,9 +301,51 @@ def test_data_parallel_two_ranks_equal_one_rank_on_the_global_batch(tmp_path, us
     for a, b, c in zip(r0["losses"], r1["losses"], ref_losses):
         assert abs(0.5 * (a + b) - c) < 5e-4, (a, b, c)
     d = (r0["p"] - eng.params.p.cpu()).abs()
-    # same tolerance as tape-vs-eager: float-atomic summation order + sign-like AdamW steps on ~0 gradients
-    assert float(d.mean()) < 2e-6 and float((d > 1e-5).float().mean()) < 0.03
+    if wire == "fp32":
+        # same tolerance as tape-vs-eager: float-atomic summation order + sign-like AdamW steps on ~0 gradients
+        assert float(d.mean()) < 2e-6 and float((d > 1e-5).float().mean()) < 0.03
+    else:
+        # bf16 on the wire: every summed gradient element carries one bf16 rounding (2^-9 relative) into AdamW
+        print(f"bf16 wire: mean |dp| {float(d.mean()):.2e}, share above 2e-5: {float((d > 2e-5).float().mean()):.4f}")
+        assert float(d.mean()) < 4e-6 and float((d > 2e-5).float().mean()) < 0.03
 
+
+def test_exchange_kernels_match_their_host_restatements():
+    """csrc/exchange.hip against the torch restatements the gloo CPU test drives the reducer with (tests/test_host.py
+    HostKernels): union of token ids, row gather / scatter, f32 sum of bf16 chunks in rank order, widening."""
+    from tests.test_host import HostKernels as HK
+    from vault_amd.train import ExchangeKernels as DK
+    g = torch.Generator().manual_seed(5)
+    V, H, n = 64001, 768, 4 * 1280
+    keys = torch.randint(0, V, (n,), generator=g, dtype=torch.int64)
+    keys[::7] = 1
+    keys[5], keys[6] = -3, V + 2                                 # outside the table: ignored
+    flags_h, uniq_h, cnt_h = torch.zeros(V, dtype=torch.int32), torch.zeros(n, dtype=torch.int64), torch.zeros(1, dtype=torch.int32)
+    HK.rows_union(keys, n, V, flags_h, uniq_h, cnt_h)
+    flags_d = torch.zeros(V, dtype=torch.int32, device="cuda"); uniq_d = torch.zeros(n, dtype=torch.int64, device="cuda")
+    cnt_d = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for _ in range(2):                                           # (the scratch flags are left zeroed: second call equal)
+        DK.rows_union(keys.cuda(), n, V, flags_d, uniq_d, cnt_d)
+        U = int(cnt_d.item())
+        assert U == int(cnt_h[0]) and torch.equal(uniq_d[:U].cpu(), uniq_h[:U]) and int(flags_d.abs().sum()) == 0
+    table = torch.randn(V, H, generator=g)
+    td = table.cuda()
+    comp_d = torch.zeros(U * H, device="cuda")
+    DK.rows_gather(td, uniq_d, U, H, comp_d)
+    assert torch.equal(comp_d.cpu().view(U, H), table[uniq_h[:U]])
+    comp_d.mul_(2.0)
+    DK.rows_scatter(comp_d, uniq_d, U, H, td)
+    want = table.clone(); want[uniq_h[:U]] *= 2.0
+    assert torch.equal(td.cpu(), want)
+    W, chunk = 8, 8 * 1237
+    src = (torch.randn(W * chunk, generator=g) * 3.0).to(torch.bfloat16)
+    out_h = torch.zeros(chunk, dtype=torch.bfloat16); out_d = torch.zeros(chunk, dtype=torch.bfloat16, device="cuda")
+    HK.sum_chunks(src, W, chunk, out_h)
+    DK.sum_chunks(src.cuda(), W, chunk, out_d)
+    assert torch.equal(out_d.cpu(), out_h)
+    wide = torch.zeros(chunk, device="cuda")
+    DK.widen(out_d, wide, chunk)
+    assert torch.equal(wide.cpu(), out_h.float())
 
 
 def test_evaluate_pass_matches_oracle_predictions():
@@ -361,7 +413,8 @@ def test_frozen_lm_train_step_trajectory_vs_oracle():
     assert float((torch.sign(dref[big]) == torch.sign((w - w0)[big])).float().mean()) > 0.97
 
 
-def test_train_step_over_rccl_single_rank():
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_train_step_over_rccl_single_rank(wire):
     """The data-parallel path on its production transport: ``torch.distributed`` backend "nccl" (= RCCL on ROCm) with one
     rank and VAULT_FORCE_DP=1 - bucketed all-reduce launched from inside backward on a side stream, split optimizer step
     (upper range while the last bucket is on the wire).  With one rank the all-reduce is the identity: the parameters
@@ -376,8 +429,10 @@ def test_train_step_over_rccl_single_rank():
 
     def run(dp):
         eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0), classifier_dropout=0.0)
-        st = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10, bucket_mb=0.05)
+        st = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10, bucket_mb=0.05, wire=wire)
         assert (st.reducer is not None) == dp
+        if dp:   # RCCL's all_gather_into_tensor (token ids) + all_reduce / all_to_all_single + all_gather_into_tensor
+            assert st.reducer.native_a2a and st.reducer.sparse is not None and st.reducer.wire == wire
         ls = [float(st(db, labels)) for _ in range(3)]
         torch.cuda.synchronize()
         if dp:
@@ -385,7 +440,7 @@ def test_train_step_over_rccl_single_rank():
         return ls, eng.params.p.clone()
 
     ref_l, ref_p = run(False)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", VAULT_FORCE_DP="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29641" if wire == "fp32" else "29642", VAULT_FORCE_DP="1")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
         dp_l, dp_p = run(True)
@@ -396,7 +451,10 @@ def test_train_step_over_rccl_single_rank():
     #  a few 1e-5 in the later losses)
     assert max(abs(a - b) for a, b in zip(dp_l, ref_l)) < 5e-4
     d = (dp_p - ref_p).abs()
-    assert float(d.mean()) < 2e-6 and float((d > 1e-5).float().mean()) < 0.03   # float-atomic summation order only
+    if wire == "fp32":
+        assert float(d.mean()) < 2e-6 and float((d > 1e-5).float().mean()) < 0.03   # float-atomic summation order only
+    else:                                                                          # + one bf16 rounding of every gradient
+        assert float(d.mean()) < 4e-6 and float((d > 2e-5).float().mean()) < 0.03
 
 
 def test_full_size_loss_trajectory_20_steps_vs_fp32_oracle():

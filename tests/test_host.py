@@ -61,7 +61,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     lib.vault_abi_version.restype = ctypes.c_int
-    assert lib.vault_abi_version() == 5
+    assert lib.vault_abi_version() == 6
 
 
 def test_ctypes_structures_match_the_c_header(tmp_path):
@@ -224,23 +224,59 @@ def test_evaluation_metrics_match_sklearn():
         assert abs(m["macro_f1_score"] - f1) < 1e-12 and abs(m["eval_accuracy"] - float(np.mean(t == p))) < 1e-12
 
 
-# ---- data parallel: bucketed all-reduce over gloo, world_size 2 ---------------------------------
+# ---- data parallel: bucketed gradient exchange over gloo, world_size 2 ---------------------------------
+class HostKernels:
+    """Stand-ins (host tensors, torch ops) for the exchange's device kernels (csrc/exchange.hip), so that the bucket /
+    sparse-table / wire logic of BucketReducer can run over gloo on the CPU.  Test harness only; the device kernels are
+    compared with the same restatements in tests/test_gpu_train.py."""
+
+    @staticmethod
+    def narrow(src, dst, n):
+        dst[:n].copy_(src[:n].to(torch.bfloat16))
+
+    @staticmethod
+    def widen(src, dst, n):
+        dst[:n].copy_(src[:n].float())
+
+    @staticmethod
+    def sum_chunks(src, n_src, chunk, out):
+        acc = torch.zeros(chunk, dtype=torch.float32)
+        for k in range(n_src):
+            acc += src[k * chunk:(k + 1) * chunk].float()
+        out[:chunk].copy_(acc.to(torch.bfloat16))
+
+    @staticmethod
+    def rows_union(keys, n, V, flags, uniq, count):
+        u = torch.unique(keys[:n][(keys[:n] >= 0) & (keys[:n] < V)])
+        uniq[:u.numel()].copy_(u)
+        count[0] = u.numel()
+
+    @staticmethod
+    def rows_gather(table, idx, n_rows, H, out):
+        out[:n_rows * H].view(n_rows, H).copy_(table.view(-1, H)[idx[:n_rows]])
+
+    @staticmethod
+    def rows_scatter(src, idx, n_rows, H, table):
+        table.view(-1, H)[idx[:n_rows]] = src[:n_rows * H].view(n_rows, H)
+
+
 def _dp_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vault_amd.train import SparseTable
     n = 10_000
     stage_lo = {"head": 9000, "vilt1": 6000, "vilt0": 3000, "vilt_embed": 2500, "lm1": 1500, "lm0": 400, "lm_embed": 0}
     g = torch.arange(n, dtype=torch.float32) * (rank + 1)
-    red = BucketReducer(g, stage_lo, "lm_embed", bucket_elems=2500, dist=dist)
+    red = BucketReducer(g, stage_lo, "lm_embed", bucket_elems=2500, dist=dist, kernels=HostKernels)
     launched = []
     for tag in ["head", "vilt1", "vilt0", "vilt_embed", "lm1", "lm0", "lm_embed"]:
         red.on_stage(tag)
         launched = list(red.launched)
     red.finish()
     expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
-    ok = bool(torch.equal(g, expect))
+    ok = {"normal order": bool(torch.equal(g, expect))}
     # second step: the lowest stage arrives BEFORE the stage above it (embedding backward ahead of the last group's deferred
     # weight gradients): its range is reduced at once, the stage above closes the gap
     g.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
@@ -249,16 +285,91 @@ def _dp_worker(rank, world, port, q):
         red.on_stage(tag)
         order = list(red.launched)
     x = red.finish_upper()
-    ok = ok and order[-2] == (0, 400) and order[-1][0] == 400 and x == order[-1][1]
+    ok["early bottom: ranges"] = order[-2] == (0, 400) and order[-1][0] == 400 and x == order[-1][1]
     red.finish()
-    ok = ok and bool(torch.equal(g, expect))
+    ok["early bottom: sum"] = bool(torch.equal(g, expect))
     cover2 = sorted(order)
-    ok = ok and cover2[0][0] == 0 and cover2[-1][1] == n and all(a[1] == b[0] for a, b in zip(cover2, cover2[1:]))
+    ok["early bottom: cover"] = cover2[0][0] == 0 and cover2[-1][1] == n and all(a[1] == b[0] for a, b in zip(cover2, cover2[1:]))
     # ranges are contiguous, descending and cover [0, n) exactly once
     cover = sorted(launched)
-    ok = ok and cover[0][0] == 0 and cover[-1][1] == n and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
-    ok = ok and all(hi - lo >= 2500 for lo, hi in launched[:-1])
-    q.put((rank, ok, launched))
+    ok["cover"] = cover[0][0] == 0 and cover[-1][1] == n and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    ok["bucket size"] = all(hi - lo >= 2500 for lo, hi in launched[:-1])
+
+    # a bucket larger than the whole buffer, stages in the normal order: everything is pending when the lowest stage
+    # arrives - with and without a language model below the ViLT embeddings (regression: the "lowest stage arrived early"
+    # branch must not fire here and strand [above_last, hi))
+    for last, tags in (("lm_embed", ["head", "vilt1", "vilt0", "vilt_embed", "lm1", "lm0", "lm_embed"]),
+                       ("vilt_embed", ["head", "vilt1", "vilt0", "vilt_embed"])):
+        lo_map = {t: stage_lo[t] for t in tags}
+        if last == "vilt_embed":
+            lo_map = {t: v - 2500 for t, v in lo_map.items()}
+        m = n if last == "lm_embed" else n - 2500
+        g2 = torch.arange(m, dtype=torch.float32) * (rank + 1)
+        r2 = BucketReducer(g2, lo_map, last, bucket_elems=10 * n, dist=dist, kernels=HostKernels)
+        for rep in range(2):
+            for tag in tags:
+                r2.on_stage(tag)
+            ok[f"huge bucket {last} x{rep}: one launch"] = r2.launched == [(0, m)]
+            xx = r2.finish_upper()
+            r2.finish()
+            ok[f"huge bucket {last} x{rep}: upper"] = xx == m
+        ok[f"huge bucket {last}: sum"] = bool(torch.equal(g2, torch.arange(m, dtype=torch.float32) * 6.0))   # (3x, then 2x)
+    # per-layer LM order with lm0 still pending below the bucket size when lm_embed arrives in the normal order
+    g3 = torch.ones(n) * (rank + 1)
+    r3 = BucketReducer(g3, stage_lo, "lm_embed", bucket_elems=3000, dist=dist, kernels=HostKernels)
+    for tag in ["head", "vilt1", "vilt0", "vilt_embed", "lm1", "lm0", "lm_embed"]:
+        r3.on_stage(tag)
+    r3.finish()
+    ok["pending lm0"] = bool(torch.equal(g3, torch.ones(n) * 3))
+
+    # bf16 wire: reduce-scatter + all-gather, f32 accumulation of the bf16 images in rank order, one rounding
+    vals = [torch.sin(torch.arange(n, dtype=torch.float32) * 0.37 + r) * (1.0 + r) for r in range(world)]
+    g4 = vals[rank].clone()
+    r4 = BucketReducer(g4, stage_lo, "lm_embed", bucket_elems=2500, dist=dist, wire="bf16", kernels=HostKernels)
+    r4.WIRE_PIECE = 4096                                   # several rounds per range, ragged last one
+    for tag in ["head", "vilt1", "vilt0", "vilt_embed", "lm1", "lm_embed", "lm0"]:
+        r4.on_stage(tag)
+    r4.finish()
+    want = sum(v.to(torch.bfloat16).float() for v in vals).to(torch.bfloat16).float()
+    ok["bf16 wire"] = bool(torch.equal(g4, want))
+    exact = sum(vals)
+    ok["bf16 wire: close to the f32 sum"] = float((g4 - exact).abs().max()) < 2.0 ** -7 * float(exact.abs().max())
+
+    # row-sparse table: rows [0, 20) x 50 at the bottom of the buffer, each rank touches its own ids
+    H, V = 50, 20
+    sp = SparseTable(0, V, H)
+    lo5 = {"head": 9000, "vilt_embed": 2500, "lm0": 1000, "lm_embed": 0}
+    for wire in ("fp32", "bf16"):
+        ids = torch.tensor([[3, 7, 7, 1], [19, 3, 0, 1]][rank], dtype=torch.int64)
+        g5 = torch.zeros(n)
+        g5[1000:] = torch.arange(n - 1000, dtype=torch.float32) * (rank + 1)
+        tab = g5[:V * H].view(V, H)
+        tab[ids] = torch.arange(H, dtype=torch.float32) + 10.0 * (rank + 1)          # only the touched rows are non-zero
+        dense = g5.clone()
+        dist.all_reduce(dense)
+        r5 = BucketReducer(g5, lo5, "lm_embed", bucket_elems=2500, dist=dist, wire=wire, sparse=sp, kernels=HostKernels)
+        for rep, tags in enumerate((["head", "vilt_embed", "lm0", "lm_embed"], ["head", "vilt_embed", "lm_embed", "lm0"])):
+            if rep:
+                g5.zero_()
+                g5[1000:] = torch.arange(n - 1000, dtype=torch.float32) * (rank + 1)
+                tab[ids] = torch.arange(H, dtype=torch.float32) + 10.0 * (rank + 1)
+            r5.begin_step(ids)
+            for tag in tags:
+                r5.on_stage(tag)
+            r5.finish()
+            if wire == "fp32":
+                ok[f"sparse table {wire} x{rep}"] = bool(torch.equal(g5, dense))
+            else:
+                ok[f"sparse table {wire} x{rep}"] = float((g5 - dense).abs().max()) <= 2.0 ** -7 * float(dense.abs().max())
+            ok[f"sparse table {wire} x{rep}: bytes"] = r5.wire_bytes < (4 if wire == "fp32" else 2) * n
+        # a step without token ids (inputs_embeds): the table's gradient is zero everywhere, nothing is exchanged for it
+        g5.zero_()
+        r5.begin_step(None)
+        for tag in ["head", "vilt_embed", "lm0", "lm_embed"]:
+            r5.on_stage(tag)
+        r5.finish()
+        ok[f"sparse table {wire}: no ids"] = float(g5.abs().max()) == 0.0
+    q.put((rank, all(ok.values()), [k for k, v in ok.items() if not v], launched))
     dist.destroy_process_group()
 
 
@@ -273,8 +384,8 @@ def test_bucket_reducer_gloo_world2():
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert all(ok for _, ok, _ in res), res
-    assert res[0][2] == res[1][2]
+    assert all(ok for _, ok, _, _ in res), [bad for _, _, bad, _ in res]
+    assert res[0][3] == res[1][3]
 
 
 def test_embedding_surgery_api_and_vault_alias_package():

@@ -574,9 +574,9 @@ template <int EPI, int NTW>
 int launch8w(const GemmParams& p, hipStream_t st) {
   constexpr int LDS = 2 * (W8_A_BYTES + 64 * NTW * 128);
   auto kern = gemm8w_kernel<EPI, NTW>;
-  static bool attr_done[16] = {};
+  static bool attr_done[64] = {};
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return VAULT_EINVAL;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VAULT_EINVAL;
   if (!attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;

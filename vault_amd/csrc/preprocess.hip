@@ -31,6 +31,8 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict
   const vault_image_desc d = desc[blockIdx.y];
   const int y = blockIdx.x;
   if (y >= d.h_in) return;
+  // the launcher chose this kernel from the caller's max_w_in / max_w_out: a descriptor beyond them would overrun the LDS rows
+  if (d.w_in * 3 + 3 > H_IN_MAX || d.w_out * 3 + 3 > H_OUT_MAX) return;
   const long long start = d.src_off + (long long)y * d.w_in * 3;
   const long long abase = start & ~3ll;
   const int mis = (int)(start - abase);

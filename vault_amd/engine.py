@@ -424,7 +424,8 @@ class VaultEngine:
             aq, asc = self._fp8_scratch(M, K)
             if not prequant:          # (the LayerNorm in front wrote the MXFP8 image of its bf16 output itself)
                 ops.quant_mxfp8(a_bf16, M, K, K, aq, asc)
-            kw.pop("split3", None)   # (only set in precise mode)
+            for k in ("split3", "cfg", "aux_u8"):   # (precise mode / the bf16 8-wave kernel's 8-bit gelu' only)
+                kw.pop(k, None)
             ops.gemm_mxfp8(aq, asc, wq, wsc, out, M, N, K, N, epi, m_valid=m_valid, bias=bias, **kw)
         else:
             ops.gemm(a_bf16, P.wb(wname, n_elems=N * K, shape=(N, K)), out, M, N, K, K, K, N if ldo is None else ldo,
@@ -510,8 +511,10 @@ class VaultEngine:
         workspace run with the 8-bit tile-native gelu' (vault_gemm aux_u8: an opaque image only the same kernel and shape reads
         back), or None: asked from the library once per workspace (vault_gemm_plan) - the automatic kernel choice must land on
         the 8-wave kernel with equal tile width for both (not in data-parallel steps, small batches, fp8-forward)."""
-        if "gelu8_cfg" in ws:
+        mode = (bool(self.fp8_forward), ops.GEMM_SCHED, self.GELU8)
+        if ws.get("gelu8_mode") == mode:
             return ws["gelu8_cfg"]
+        ws["gelu8_mode"] = mode
         P, H, FF = self.params, ws["H"], ws["FF"]
         cfg, wt = None, P.pbT.get(ln.fw)
         if self.GELU8 and u is not None and wt is not None and not self.fp8_forward and Mp % 256 == 0:

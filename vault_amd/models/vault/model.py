@@ -506,7 +506,8 @@ class VaultMixin(nn.Module):
     def _refresh_if_params_changed(self):
         """An external optimizer (``torch.optim`` on ``model.parameters()``, the reference trainer's loop) writes the
         fp32 master buffer in place; every GEMM reads the bf16 shadows: re-derive them when any parameter's version
-        counter moved since the last forward."""
+        counter moved since the last forward.  Writes through ``p.data`` (``p.data.copy_`` / ``add_``) do not bump the
+        counter: call :meth:`refresh_weights` after those."""
         if self._engine is None:
             return
         v = self._param_version()
@@ -726,6 +727,7 @@ class VaultForImagesAndTextClassification(VaultMixin):
             raise ValueError("Make sure to match the number of images in the model with the number of images in the input.")
         pm = kwargs.get("pixel_mask")
         pooled = []
+        self._refresh_if_params_changed()     # (an external optimizer may have stepped the fp32 master since the last call)
         for i in range(self.num_images):
             kw = dict(kwargs)
             kw["pixel_values"] = pix[:, i]

@@ -85,10 +85,18 @@ def stop_tape() -> Optional[Tape]:
 
 
 def pycall(fn):
-    """Run a host-side action now and, when recording, put it on the tape (must return None / 0)."""
-    if _TAPE is not None:
-        _TAPE.calls.append((fn, ()))
-    fn()
+    """Run a host-side action now and, when recording, put it on the tape (must return None / 0).  Kernel launches made
+    INSIDE the action are live every time it runs (they are not recorded a second time): the data-parallel gradient
+    exchange launches its pack / unpack kernels from such callbacks."""
+    global _TAPE
+    t = _TAPE
+    if t is not None:
+        t.calls.append((fn, ()))
+    _TAPE = None
+    try:
+        fn()
+    finally:
+        _TAPE = t
 
 
 def _invoke(name: str, *args, struct=None, drop=None):
@@ -122,7 +130,7 @@ NO_DROP = Drop()
 # GEMM scheduling mode (vault_gemm_args.persist): 3 while the GEMMs share the GPU with RCCL collectives on another
 # stream (train.TrainStep sets it for world size > 1): tiles are handed out dynamically / one block per tile, so a CU
 # held by the collective costs its share of throughput instead of a second pass over a static tile list
-# (tools/contention_test.py: 196-230 us instead of 271-281 us with 8-64 CUs held, 189 us alone)
+# (tools/contention_probe.py: 196-230 us instead of 271-281 us with 8-64 CUs held, 189 us alone)
 GEMM_SCHED = int(__import__("os").environ.get("VAULT_GEMM_SCHED", "0"))   # env: exercise the mode on one GPU
 
 
@@ -369,6 +377,31 @@ def adamw_step(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay, bias_
 
 def cast_bf16(x, y_bf16, n):
     _invoke("vault_cast_bf16", C.c_void_p(_p(x)), C.c_void_p(_p(y_bf16)), C.c_longlong(n), _stream())
+
+
+# ---- data-parallel gradient exchange (csrc/exchange.hip) ----
+def rows_union(keys_i64, n_keys, V, flags_i32, uniq_i64, count_i32):
+    _invoke("vault_rows_union", C.c_void_p(_p(keys_i64)), C.c_longlong(n_keys), C.c_int(V), C.c_void_p(_p(flags_i32)),
+            C.c_void_p(_p(uniq_i64)), C.c_void_p(_p(count_i32)), _stream())
+
+
+def rows_gather(table_f32, idx_i64, n_rows, H, out_f32):
+    _invoke("vault_rows_gather_f32", C.c_void_p(_p(table_f32)), C.c_void_p(_p(idx_i64)), C.c_int(n_rows), C.c_int(H),
+            C.c_void_p(_p(out_f32)), _stream())
+
+
+def rows_scatter(src_f32, idx_i64, n_rows, H, table_f32):
+    _invoke("vault_rows_scatter_f32", C.c_void_p(_p(src_f32)), C.c_void_p(_p(idx_i64)), C.c_int(n_rows), C.c_int(H),
+            C.c_void_p(_p(table_f32)), _stream())
+
+
+def sum_chunks_bf16(src_bf16, n_src, chunk, out_bf16):
+    _invoke("vault_sum_chunks_bf16", C.c_void_p(_p(src_bf16)), C.c_int(n_src), C.c_longlong(chunk), C.c_void_p(_p(out_bf16)),
+            _stream())
+
+
+def widen_bf16(x_bf16, y_f32, n):
+    _invoke("vault_widen_bf16", C.c_void_p(_p(x_bf16)), C.c_void_p(_p(y_f32)), C.c_longlong(n), _stream())
 
 
 def split3_bf16(x_f32, out_bf16, rows, K, layout):

@@ -71,33 +71,201 @@ class GradBuckets:
         self.n = P.n_train
 
 
-class BucketReducer:
-    """Launches an all-reduce for each contiguous gradient range as soon as it is final.
+class SparseTable:
+    """An embedding table inside the flat gradient buffer whose gradient is exchanged row-sparse: rows x H floats at
+    element offset ``lo``; only the rows named by some rank's token ids of the step are non-zero."""
 
-    Device-agnostic on purpose (CPU tensors + gloo in the tests, HIP tensors + RCCL in production):
-    ``on_stage(tag)`` is the engine's ``after_layer`` callback, ``finish()`` waits for everything.
+    def __init__(self, lo: int, rows: int, H: int):
+        self.lo, self.rows, self.H = int(lo), int(rows), int(H)
+        self.hi = self.lo + self.rows * self.H
+
+
+class ExchangeKernels:
+    """Pack / unpack kernels of the exchange on DEVICE tensors (csrc/exchange.hip).  The reducer takes them as an object so
+    that its bucket logic can be driven with host tensors over gloo in the CPU tests (which bring their own stand-ins)."""
+    narrow = staticmethod(ops.cast_bf16)              # (src_f32, dst_bf16, n)
+    widen = staticmethod(ops.widen_bf16)              # (src_bf16, dst_f32, n)
+    sum_chunks = staticmethod(ops.sum_chunks_bf16)    # (src_bf16, n_src, chunk, out_bf16)
+    rows_union = staticmethod(ops.rows_union)         # (keys, n_keys, V, flags, uniq, count)
+    rows_gather = staticmethod(ops.rows_gather)       # (table, idx, n_rows, H, out)
+    rows_scatter = staticmethod(ops.rows_scatter)     # (src, idx, n_rows, H, table)
+
+
+class BucketReducer:
+    """Sums each contiguous gradient range over the ranks as soon as it is final.
+
+    ``on_stage(tag)`` is the engine's ``after_layer`` callback, ``finish()`` waits for everything.  Two things keep the
+    bytes on the wire down:
+      * ``sparse``: the word-embedding table (a fifth of the gradient elements, of which a step touches at most
+        world x B x T rows) is exchanged as the union of the touched rows: all-gather of the token ids at the START of the
+        step (``begin_step``), sorted union on every rank, gather -> all-reduce of the compact [U, H] rows -> scatter.
+        Exact: untouched rows are zero on every rank.
+      * ``wire="bf16"``: reduce-scatter + all-gather with bf16 on the wire and f32 accumulation - all-to-all of the
+        bf16 chunks (every peer link carries its own chunk: point-to-point xGMI, no ring), f32 sum in rank order,
+        rounded to bf16 once, all-gather, widened back into the f32 gradient.  Half the bytes of the f32 all-reduce;
+        every rank ends with the same bits.  ``wire="fp32"`` is a plain sum all-reduce.
+    Device-agnostic on purpose (CPU tensors + gloo in the tests, HIP tensors + RCCL in production).
     """
 
+    WIRE_PIECE = 1 << 25      # bf16 wire: elements per reduce-scatter / all-gather round (64 MiB of bf16 scratch x 2)
+
     def __init__(self, flat_grad: torch.Tensor, stage_lo: Dict[str, int], last_tag: str, bucket_elems: int,
-                 dist, group=None, comm_stream=None, compute_device=None):
+                 dist, group=None, comm_stream=None, compute_device=None, wire: str = "fp32",
+                 sparse: Optional[SparseTable] = None, kernels=ExchangeKernels):
+        if wire not in ("fp32", "bf16"):
+            raise ValueError("wire must be 'fp32' or 'bf16'")
         self.g, self.stage_lo, self.last_tag, self.bucket_elems = flat_grad, stage_lo, last_tag, bucket_elems
         self.dist, self.group, self.comm_stream, self.device = dist, group, comm_stream, compute_device
+        self.wire, self.sparse, self.k = wire, sparse, kernels
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.native_a2a = dist.get_backend(group) != "gloo"      # gloo has no all-to-all: emulated with all-gather (tests)
         self.n = flat_grad.numel()
         self.hi = self.n          # everything at or above is launched (top-down frontier)
         self.bottom = 0           # everything below is launched (the lowest stage may finish ahead of the one above it)
         above = [v for t, v in stage_lo.items() if t != last_tag and v > stage_lo.get(last_tag, 0)]
         self.above_last = min(above) if above else self.n      # where the stage above the lowest one starts
-        self.works: List = []
+        self.min_seen = self.n    # lowest stage_lo among the stages noted in this step
+        self.done: List = []      # per launch: event on the communication stream (None on the host)
         self.launched: List[Tuple[int, int]] = []
+        self.wire_bytes = 0       # bytes this rank put on the wire in the current step (diagnostics)
+        self._scratch: Dict[str, torch.Tensor] = {}
+        self._union_ready = None
+        self._n_keys = 0
 
+    # ---- plumbing -------------------------------------------------------------------------------------------
+    def _buf(self, name: str, n: int, dtype) -> torch.Tensor:
+        t = self._scratch.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.zeros(n, dtype=dtype, device=self.g.device)
+            self._scratch[name] = t
+        return t[:n]
+
+    def _on_comm_stream(self, fn):
+        """Run ``fn`` with the communication stream current, ordered behind everything enqueued on the compute stream so
+        far; returns the event that marks its end (None on the host).  Collectives inside ``fn`` are waited for on the
+        stream (``Work.wait()`` blocks the stream, not the host, with RCCL; it blocks the host with gloo)."""
+        if self.comm_stream is None:
+            fn()
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ev)
+            fn()
+            end = torch.cuda.Event()
+            end.record(self.comm_stream)
+        return end
+
+    def _all_to_all(self, recv: torch.Tensor, send: torch.Tensor, chunk: int):
+        if self.native_a2a:
+            self.dist.all_to_all_single(recv, send, group=self.group, async_op=True).wait()
+            return
+        parts = [torch.empty_like(send) for _ in range(self.world)]
+        self.dist.all_gather(parts, send, group=self.group)
+        for k in range(self.world):
+            recv[k * chunk:(k + 1) * chunk].copy_(parts[k][self.rank * chunk:(self.rank + 1) * chunk])
+
+    def _all_gather(self, full: torch.Tensor, part: torch.Tensor):
+        if self.native_a2a:
+            self.dist.all_gather_into_tensor(full, part, group=self.group, async_op=True).wait()
+            return
+        parts = [torch.empty_like(part) for _ in range(self.world)]
+        self.dist.all_gather(parts, part, group=self.group)
+        n = part.numel()
+        for k in range(self.world):
+            full[k * n:(k + 1) * n].copy_(parts[k])
+
+    def _sum_over_ranks(self, view: torch.Tensor):
+        """view (contiguous f32, 4-element aligned) <- its sum over the ranks, in the configured wire format."""
+        n = view.numel()
+        if n == 0:
+            return
+        if self.wire == "fp32":
+            self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
+            self.wire_bytes += 2 * 4 * n * (self.world - 1) // self.world
+            return
+        W = self.world
+        for p0 in range(0, n, self.WIRE_PIECE):
+            m = min(self.WIRE_PIECE, n - p0)
+            chunk = -(-m // (8 * W)) * 8                      # elements per rank, 16-byte multiples
+            send = self._buf("send", chunk * W, torch.bfloat16)
+            recv = self._buf("recv", chunk * W, torch.bfloat16)
+            red = self._buf("red", chunk, torch.bfloat16)
+            if chunk * W > m:
+                send[m - (m % 4):].zero_()                    # the padding behind the range (and a ragged tail) adds zeros
+            m4 = m - (m % 4)
+            if m4:
+                self.k.narrow(view[p0:p0 + m4], send, m4)
+            if m % 4:                                         # (never for the engine's 64-aligned ranges)
+                send[m4:m].copy_(view[p0 + m4:p0 + m])
+            self._all_to_all(recv, send, chunk)               # recv[k] = rank k's bf16 image of MY chunk
+            self.k.sum_chunks(recv, W, chunk, red)            # f32 accumulation in rank order, one rounding
+            self._all_gather(send, red)                       # (the send buffer is free again: it takes the result)
+            if m4:
+                self.k.widen(send, view[p0:p0 + m4], m4)
+            if m % 4:
+                view[p0 + m4:p0 + m].copy_(send[m4:m])
+            self.wire_bytes += 2 * 2 * chunk * (W - 1)
+
+    # ---- row-sparse table -----------------------------------------------------------------------------------
+    def begin_step(self, keys: Optional[torch.Tensor]):
+        """Start of a step: ``keys`` = this rank's token ids (int64, any shape; None: this step touches no row of the table,
+        on EVERY rank alike).  Their all-gather and the union run on the communication stream at once; the host reads the
+        union's size only when the table's gradient is final (``_exchange_table``)."""
+        self.wire_bytes = 0
+        self._union_ready, self._n_keys = None, 0
+        if self.sparse is None or keys is None:
+            return
+        keys = keys.reshape(-1)
+        n = keys.numel()
+        W, V = self.world, self.sparse.rows
+        allk = self._buf("keys", n * W, torch.int64)
+        flags = self._buf("flags", V, torch.int32)
+        uniq = self._buf("uniq", min(V, n * W), torch.int64)
+        cnt = self._buf("count", 1, torch.int32)
+        host = self._scratch.get("count_host")
+        if host is None:
+            host = torch.zeros(1, dtype=torch.int32)
+            if self.comm_stream is not None:
+                host = host.pin_memory()
+            self._scratch["count_host"] = host
+
+        def go():
+            self._all_gather(allk, keys)
+            self.k.rows_union(allk, n * W, V, flags, uniq, cnt)
+            host.copy_(cnt, non_blocking=True)
+
+        self._union_ready = self._on_comm_stream(go)
+        self._n_keys = n * W
+        self.wire_bytes += 8 * n * (W - 1)
+
+    def _exchange_table(self):
+        sp = self.sparse
+        if self._n_keys == 0:
+            return                                            # no row touched on any rank: the gradient is zero everywhere
+        if self._union_ready is not None:
+            self._union_ready.synchronize()                   # (enqueued at the start of the step: long done)
+        U = int(self._scratch["count_host"][0])
+        if U == 0:
+            return
+        table = self.g[sp.lo:sp.hi]
+        uniq = self._scratch["uniq"]
+        compact = self._buf("rows", min(sp.rows, self._n_keys) * sp.H, torch.float32)[:U * sp.H]
+        self.k.rows_gather(table, uniq, U, sp.H, compact)
+        self._sum_over_ranks(compact)
+        self.k.rows_scatter(compact, uniq, U, sp.H, table)
+
+    # ---- bucket logic ---------------------------------------------------------------------------------------
     def on_stage(self, tag: str):
         lo = self.stage_lo.get(tag)
         if lo is None:
             return
-        if tag == self.last_tag and self.hi > self.above_last and self.bottom == 0:
-            # the lowest stage (the embedding tables: a third of the gradient bytes) became final BEFORE the stage above it -
-            # the engine runs the embedding backward ahead of the deferred weight gradients of the last group of layers in
-            # data-parallel steps, so that this all-reduce runs under them: reduce [0, above_last) now
+        early = tag == self.last_tag and self.min_seen > self.above_last and self.bottom == 0 and self.above_last < self.hi
+        self.min_seen = min(self.min_seen, lo)
+        if early:
+            # the lowest stage (the embedding tables) became final BEFORE the stage above it was noted - the engine runs the
+            # embedding backward ahead of the deferred weight gradients of the last group of layers in data-parallel
+            # steps, so that this exchange runs under them: reduce [0, above_last) now
             self._launch(0, self.above_last)
             self.bottom = self.above_last
             return
@@ -110,36 +278,40 @@ class BucketReducer:
         self.hi = lo
 
     def _launch(self, lo: int, hi: int):
-        view = self.g[lo:hi]
-        if self.comm_stream is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ev)
-                self.works.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
-        else:
-            self.works.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        sp = self.sparse
+
+        def go():
+            if sp is not None and lo < sp.hi and hi > sp.lo:
+                self._sum_over_ranks(self.g[lo:max(lo, sp.lo)])
+                self._exchange_table()
+                self._sum_over_ranks(self.g[min(hi, sp.hi):hi])
+            else:
+                self._sum_over_ranks(self.g[lo:hi])
+
+        self.done.append(self._on_comm_stream(go))
         self.launched.append((lo, hi))
 
+    def _wait(self, events):
+        for ev in events:
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+
     def finish_upper(self) -> int:
-        """Wait for every launched all-reduce except the LAST one (the lowest addresses: it is launched when
-        backward ends, nothing is left to hide it behind) and return its upper bound x: gradients in [x, n) are
-        final and reduced, so the optimizer can already run on them while [0, x) is still on the wire."""
-        if len(self.works) < 2:
-            return self.n if not self.works else self.launched[-1][1]
-        for w in self.works[:-1]:
-            w.wait()
-        del self.works[:-1]
+        """Make the compute stream wait for every launched range except the LAST one (the lowest addresses: launched when
+        backward ends, nothing is left to hide it behind) and return its upper bound x: gradients in [x, n) are final
+        and reduced, so the optimizer can already run on them while [0, x) is still on the wire."""
+        if len(self.done) < 2:
+            return self.n if not self.done else self.launched[-1][1]
+        self._wait(self.done[:-1])
+        del self.done[:-1]
         return self.launched[-1][1]
 
     def finish(self):
-        for w in self.works:
-            w.wait()
-        self.works.clear()
-        if self.comm_stream is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
-        assert self.hi == self.bottom, "gradient range [%d, %d) was never reduced" % (self.bottom, self.hi)
-        self.hi, self.bottom = self.n, 0
+        self._wait(self.done)
+        self.done.clear()
+        if self.hi != self.bottom:
+            raise RuntimeError("gradient range [%d, %d) was never reduced" % (self.bottom, self.hi))
+        self.hi, self.bottom, self.min_seen = self.n, 0, self.n
         self.launched.clear()
 
 
@@ -148,7 +320,7 @@ class TrainStep:
                  adam_beta2: float = 0.999, adam_epsilon: float = 1e-8, weight_decay: float = 0.0,
                  correct_bias: bool = False, warmup_ratio: float = 0.1, total_steps: int = 1000,
                  process_group=None, bucket_mb: float = 64.0, constant_lr: bool = False, use_tape: bool = True,
-                 assume_full_pixel_mask: bool = False):
+                 assume_full_pixel_mask: bool = False, wire: Optional[str] = None, sparse_embedding: Optional[bool] = None):
         self.engine = engine
         self.lr, self.b1, self.b2, self.eps, self.wd = learning_rate, adam_beta1, adam_beta2, adam_epsilon, weight_decay
         self.correct_bias = correct_bias
@@ -166,6 +338,7 @@ class TrainStep:
         self.assume_full_pixel_mask = assume_full_pixel_mask
         self._loss_buf = None
         self.world = 1
+        self.wire = None
         self.reducer: Optional[BucketReducer] = None
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
@@ -184,8 +357,25 @@ class TrainStep:
             # upper group's gradient range is all-reduced under the backward of the layers below it)
         if self.world > 1 or (os.environ.get("VAULT_FORCE_DP") == "1" and dist.is_available() and dist.is_initialized()):
             b = GradBuckets(engine, bucket_mb)
-            self.reducer = BucketReducer(engine.params.g[:engine.params.n_train], b.stage_lo, b.last_tag, b.bucket_elems, dist, process_group,
-                                         torch.cuda.Stream(device=engine.device), engine.device)
+            # wire format of the dense ranges ("fp32": sum all-reduce; "bf16": reduce-scatter + all-gather with bf16 on the
+            # wire and f32 accumulation) and the row-sparse exchange of the word-embedding table: BucketReducer
+            self.wire = wire or os.environ.get("VAULT_DP_WIRE", "fp32")
+            if sparse_embedding is None:
+                sparse_embedding = os.environ.get("VAULT_DP_SPARSE_EMBEDDING", "1") != "0"
+            self._sparse_name = None
+            sparse = None
+            if sparse_embedding:
+                P = engine.params
+                name = ("bert.embeddings.word_embeddings.weight" if engine.spec.lm is not None
+                        else "embeddings.text_embeddings.word_embeddings.weight")
+                # (a tied MLM decoder puts a DENSE gradient on ViLT's own table)
+                if P.has_grad(name) and not (engine.spec.lm is None and engine.spec.head == "mlm"):
+                    o, shp = P.offsets[name]
+                    sparse = SparseTable(o, shp[0], shp[1])
+                    self._sparse_name = name
+            self.reducer = BucketReducer(engine.params.g[:engine.params.n_train], b.stage_lo, b.last_tag, b.bucket_elems, dist,
+                                         process_group, torch.cuda.Stream(device=engine.device), engine.device,
+                                         wire=self.wire, sparse=sparse)
 
     def current_lr(self) -> float:
         if self.constant_lr:
@@ -205,6 +395,10 @@ class TrainStep:
             # types were given, the launch stream, the GEMM scheduling mode and the forward number format
             key = ws["key"] + (ws["tt"] is None, torch.cuda.current_stream().cuda_stream, ops.GEMM_SCHED,
                                bool(eng.fp8_forward), labels.dtype.is_floating_point)
+            if self.reducer:
+                # the token ids of every rank name the rows of the word-embedding table this step touches: their
+                # all-gather + union start now on the communication stream (inputs_embeds: no row is touched)
+                self.reducer.begin_step(ws["ids"] if ws.get("txt_embeds") is None else None)
             if self.use_tape and self._tape is not None and self._tape_key == key and self._tape_ws is ws:
                 eng.drop_seed = (eng.drop_seed + 1) & 0xFFFFFFFF
                 self._tape.replay(seed=eng.drop_seed)
