@@ -59,26 +59,145 @@ def to_torch_state(state: Dict[str, np.ndarray], requires_grad: bool = False) ->
 # Optional emulation of the HIP path's number format: every matmul operand (activations and
 # weights of each Linear, Q/K/V/P of attention) is rounded to bf16 before an exact fp32 product,
 # exactly where the kernels round.  Off by default (pure fp32 = the reference's arithmetic).
+# ``backward=True`` also restates the number format of the HIP BACKWARD pass (what autograd does for
+# ref: vault/models/vault/model.py:557-570 in fp32): bf16 dY operands of every data / weight gradient
+# GEMM, bf16 data-gradient outputs, the saved bf16 operands, gelu' as stored (bf16, or the 8-bit grid
+# q = rne(200 g + 26) of the ViLT FFN at large batch), the recomputed attention probabilities with bf16
+# dS / P operands, and the bf16 residual-gradient stream of the pre-LN ViLT stack.
 _EMULATE_BF16 = False
+_EMULATE_BWD = False
+_EMULATE_GELU8 = False
+# mutation check of the parity bounds (tests only): (weight-name substring, factor) scales the DATA gradient of the matching
+# Linear in the emulated backward - the tests assert that their bounds notice a 1 % error of one data-gradient GEMM
+_INJECT_DGRAD = None
 
 
 class emulate_bf16:
-    """``with emulate_bf16():`` - run the oracle with bf16-rounded matmul operands."""
+    """``with emulate_bf16():`` - run the oracle with bf16-rounded matmul operands; ``backward=True``: gradients in the
+    HIP backward's number format too (``gelu8``: the ViLT FFN keeps gelu' on the 8-bit grid)."""
+
+    def __init__(self, backward: bool = False, gelu8: bool = False):
+        self.backward, self.gelu8 = backward, gelu8
 
     def __enter__(self):
-        global _EMULATE_BF16
-        self._old, _EMULATE_BF16 = _EMULATE_BF16, True
+        global _EMULATE_BF16, _EMULATE_BWD, _EMULATE_GELU8
+        self._old = (_EMULATE_BF16, _EMULATE_BWD, _EMULATE_GELU8)
+        _EMULATE_BF16, _EMULATE_BWD, _EMULATE_GELU8 = True, self.backward, self.gelu8
 
     def __exit__(self, *a):
-        global _EMULATE_BF16
-        _EMULATE_BF16 = self._old
+        global _EMULATE_BF16, _EMULATE_BWD, _EMULATE_GELU8
+        _EMULATE_BF16, _EMULATE_BWD, _EMULATE_GELU8 = self._old
+
+
+def _rb(x):
+    return x.bfloat16().float()
+
+
+class _RoundST(torch.autograd.Function):
+    """y = bf16(x); the gradient passes unchanged (the kernels round where they store, not where they differentiate)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _rb(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundGrad(torch.autograd.Function):
+    """y = x; the (accumulated) gradient is rounded to bf16 once: a tensor the HIP backward keeps in bf16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rb(g)
+
+
+class _LinearEmu(torch.autograd.Function):
+    """y = bf16(x) bf16(W)^T + b with the HIP backward: dX = bf16(dY) bf16(W) (stored bf16 when ``round_dx``),
+    dW = bf16(dY)^T bf16(x) in fp32, db = column sums of dY."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, round_dx, scale_dx=1.0):
+        xr, wr = _rb(x), _rb(w)
+        ctx.save_for_backward(xr, wr)
+        ctx.round_dx, ctx.has_b, ctx.scale_dx = round_dx, b is not None, scale_dx
+        return F.linear(xr, wr, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xr, wr = ctx.saved_tensors
+        gr = _rb(gy)
+        dx = torch.matmul(gr, wr) * ctx.scale_dx
+        if ctx.round_dx:
+            dx = _rb(dx)
+        dw = torch.matmul(gr.reshape(-1, gr.shape[-1]).t(), xr.reshape(-1, xr.shape[-1]))
+        db = gy.reshape(-1, gy.shape[-1]).sum(0) if ctx.has_b else None
+        return dx, dw, db, None, None
+
+
+class _GeluEmu(torch.autograd.Function):
+    """act = gelu(z) on the fp32 pre-activation; backward multiplies by gelu'(z) AS STORED by the forward epilogue (bf16, or
+    the 8-bit grid (rne(200 g + 26) - 26) / 200 saturating at 0 / 255) and stores the product in bf16."""
+
+    @staticmethod
+    def forward(ctx, z, u8):
+        cdf = 0.5 * (1.0 + torch.erf(z * 0.7071067811865476))
+        gp = cdf + z * torch.exp(-0.5 * z * z) * 0.3989422804014327
+        if u8:
+            gp = torch.clamp(torch.round(gp * 200.0 + 26.0), 0.0, 255.0) * 0.005 - 0.13   # (torch.round: half to even)
+        else:
+            gp = _rb(gp)
+        ctx.save_for_backward(gp)
+        return z * cdf
+
+    @staticmethod
+    def backward(ctx, g):
+        (gp,) = ctx.saved_tensors
+        return _rb(g * gp), None
+
+
+class _AttnEmu(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d) + mask) v on bf16 q, k, v with bf16 probabilities in the PV product; backward as the HIP
+    kernels: P recomputed in fp32, D = rowsum(dO o O) on the stored bf16 O, dS and P rounded to bf16 as operands of
+    dQ = dS K, dK = dS^T Q, dV = P^T dO, results stored in bf16."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask_add, scale):
+        s = torch.matmul(q, k.transpose(-1, -2)) * scale + mask_add
+        p = torch.softmax(s, dim=-1)
+        o = torch.matmul(_rb(p), v)
+        ctx.save_for_backward(q, k, v, p, _rb(o))
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v, p, o = ctx.saved_tensors
+        go = _rb(go)
+        dp = torch.matmul(go, v.transpose(-1, -2))
+        dsum = (go * o).sum(-1, keepdim=True)
+        ds = _rb(p * (dp - dsum))
+        dq = torch.matmul(ds, k) * ctx.scale
+        dk = torch.matmul(ds.transpose(-1, -2), q) * ctx.scale
+        dv = torch.matmul(_rb(p).transpose(-1, -2), go)
+        return _rb(dq), _rb(dk), _rb(dv), None, None
 
 
 def _r(x):
+    if _EMULATE_BWD:
+        return _RoundST.apply(x)
     return x.bfloat16().float() if _EMULATE_BF16 else x
 
 
-def _lin(x, w, b=None):
+def _lin(x, w, b=None, round_dx=True, name=""):
+    if _EMULATE_BWD:
+        sc = _INJECT_DGRAD[1] if (_INJECT_DGRAD is not None and _INJECT_DGRAD[0] in name) else 1.0
+        return _LinearEmu.apply(x, w, b, round_dx, sc)
     return F.linear(_r(x), _r(w), b)
 
 
@@ -90,10 +209,30 @@ def _ln(x, w, b, eps):
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
 
+def _ffn(x, wi, bi, wf, bf_, u8=False):
+    """Linear - exact-erf GELU - Linear (HF ViltIntermediate / ViltOutput.dense, RobertaIntermediate / Output.dense)."""
+    if _EMULATE_BWD:
+        act = _GeluEmu.apply(_lin(x, wi, bi), u8)
+        return _lin(act, wf, bf_, round_dx=False)      # (its data gradient is rounded after the gelu' product)
+    return _lin(F.gelu(_r(_lin(x, wi, bi))), wf, bf_)
+
+
+def _grad_bf16(x):
+    """Marks a tensor whose gradient the HIP backward holds in bf16 only (the pre-LN ViLT residual-gradient stream)."""
+    return _RoundGrad.apply(x) if _EMULATE_BWD else x
+
+
 def _mha(x, mask_add, P, pre, heads, att_name):
     """softmax(QK^T/sqrt(d) + mask) V ; returns context [B,S,H] (before output dense)."""
     B, S, H = x.shape
     d = H // heads
+    if _EMULATE_BWD:
+        # one fused [3H, H] projection like the kernels: its data gradient sums the three parts in fp32, one rounding
+        w = torch.cat([P[f"{pre}.{att_name}.{n}.weight"] for n in ("query", "key", "value")], dim=0)
+        b = torch.cat([P[f"{pre}.{att_name}.{n}.bias"] for n in ("query", "key", "value")], dim=0)
+        qkv = _RoundST.apply(_lin(x, w, b, name=f"{pre}.{att_name}.qkv")).view(B, S, 3, heads, d).permute(2, 0, 3, 1, 4)
+        c = _AttnEmu.apply(qkv[0], qkv[1], qkv[2], mask_add, 1.0 / math.sqrt(d))
+        return c.permute(0, 2, 1, 3).reshape(B, S, H)
     q = _r(_lin(x, P[f"{pre}.{att_name}.query.weight"], P[f"{pre}.{att_name}.query.bias"]))
     k = _r(_lin(x, P[f"{pre}.{att_name}.key.weight"], P[f"{pre}.{att_name}.key.bias"]))
     v = _r(_lin(x, P[f"{pre}.{att_name}.value.weight"], P[f"{pre}.{att_name}.value.bias"]))
@@ -145,8 +284,8 @@ def lm_forward(P, spec, input_ids, attention_mask, token_type_ids=None, taps: Op
         a = _lin(c, P[f"{pre}.attention.output.dense.weight"], P[f"{pre}.attention.output.dense.bias"])
         x = _ln(a + x, P[f"{pre}.attention.output.LayerNorm.weight"], P[f"{pre}.attention.output.LayerNorm.bias"],
                 lm.layer_norm_eps)
-        h = F.gelu(_r(_lin(x, P[f"{pre}.intermediate.dense.weight"], P[f"{pre}.intermediate.dense.bias"])))
-        o = _lin(h, P[f"{pre}.output.dense.weight"], P[f"{pre}.output.dense.bias"])
+        o = _ffn(x, P[f"{pre}.intermediate.dense.weight"], P[f"{pre}.intermediate.dense.bias"],
+                 P[f"{pre}.output.dense.weight"], P[f"{pre}.output.dense.bias"])
         x = _ln(o + x, P[f"{pre}.output.LayerNorm.weight"], P[f"{pre}.output.LayerNorm.bias"], lm.layer_norm_eps)
         if taps is not None:
             taps[f"lm_layer{i}"] = x
@@ -209,10 +348,18 @@ def vilt_embed(P, spec, text_in, attention_mask, token_type_ids, pixel_values, t
         img_mask = (torch.ones(img.shape[:2], dtype=attention_mask.dtype) if pixel_mask is None
                     else pixel_mask.flatten(1).to(attention_mask.dtype))
         return torch.cat([text, img], dim=1), torch.cat([attention_mask, img_mask], dim=1)
-    pe = F.conv2d(_r(pixel_values), _r(P["embeddings.patch_embeddings.projection.weight"]),
-                  P["embeddings.patch_embeddings.projection.bias"], stride=v.patch_size)
-    gh, gw = pe.shape[2], pe.shape[3]
-    pe = pe.flatten(2).transpose(1, 2)                      # [B, gh*gw, H], row-major patch order
+    if _EMULATE_BWD:
+        # the same convolution as an unfold + Linear (the kernels' im2col GEMM): bf16 dY / patch operands in its weight gradient
+        ps = v.patch_size
+        gh, gw = pixel_values.shape[2] // ps, pixel_values.shape[3] // ps
+        cols = F.unfold(pixel_values, kernel_size=ps, stride=ps).transpose(1, 2)          # [B, gh*gw, C*ps*ps]
+        wp = P["embeddings.patch_embeddings.projection.weight"]
+        pe = _lin(cols, wp.reshape(wp.shape[0], -1), P["embeddings.patch_embeddings.projection.bias"])
+    else:
+        pe = F.conv2d(_r(pixel_values), _r(P["embeddings.patch_embeddings.projection.weight"]),
+                      P["embeddings.patch_embeddings.projection.bias"], stride=v.patch_size)
+        gh, gw = pe.shape[2], pe.shape[3]
+        pe = pe.flatten(2).transpose(1, 2)                      # [B, gh*gw, H], row-major patch order
     pos = P["embeddings.position_embeddings"]               # [1, 1+g*g, H]
     g = v.image_size // v.patch_size
     full = pixel_mask is None or (gh == g and gw == g and bool((pixel_mask != 0).all()))
@@ -251,16 +398,18 @@ def vilt_encoder(P, spec, x, mask, taps=None):
     mask_add = (1.0 - mask[:, None, None, :].float()) * torch.finfo(torch.float32).min
     for i in range(v.num_hidden_layers):
         pre = f"encoder.layer.{i}"
+        if i > 0:
+            x = _grad_bf16(x)      # (the bottom layer also writes its input gradient in f32, for the embedding backward)
         n1 = _ln(x, P[f"{pre}.layernorm_before.weight"], P[f"{pre}.layernorm_before.bias"], v.layer_norm_eps)
         c = _mha(n1, mask_add, P, pre, v.num_attention_heads, "attention.attention")
         a = _lin(c, P[f"{pre}.attention.output.dense.weight"], P[f"{pre}.attention.output.dense.bias"])
-        x = a + x
+        x = _grad_bf16(a + x)
         n2 = _ln(x, P[f"{pre}.layernorm_after.weight"], P[f"{pre}.layernorm_after.bias"], v.layer_norm_eps)
-        h = F.gelu(_r(_lin(n2, P[f"{pre}.intermediate.dense.weight"], P[f"{pre}.intermediate.dense.bias"])))
-        x = _lin(h, P[f"{pre}.output.dense.weight"], P[f"{pre}.output.dense.bias"]) + x
+        x = _ffn(n2, P[f"{pre}.intermediate.dense.weight"], P[f"{pre}.intermediate.dense.bias"],
+                 P[f"{pre}.output.dense.weight"], P[f"{pre}.output.dense.bias"], u8=_EMULATE_GELU8) + x
         if taps is not None:
             taps[f"vilt_layer{i}"] = x
-    return x
+    return _grad_bf16(x)
 
 
 def vault_forward(P, spec, batch: Dict[str, torch.Tensor], taps: Optional[dict] = None,

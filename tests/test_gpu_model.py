@@ -34,6 +34,52 @@ def _dev(bn):
     return {k: torch.from_numpy(v).cuda() for k, v in bn.items()}
 
 
+def _grad_errors(eng, P):
+    """HIP gradients against an oracle's: global relative L2 error and the per-parameter relative errors (largest first);
+    the key biases are left out (their gradient is analytically zero: softmax is invariant to a per-query shift)."""
+    tot_e = tot_r = 0.0
+    per = []
+    for n in eng.params.trainable:
+        gr = P[n].grad
+        if gr is None or ".key.bias" in n:
+            continue
+        mine = eng.params.gr(n).cpu().double().reshape(gr.shape)
+        e, r = float((mine - gr.double()).norm()), float(gr.double().norm())
+        tot_e += e * e; tot_r += r * r
+        per.append((e / (r + 1e-30), n))
+    return (tot_e / tot_r) ** 0.5, sorted(per, reverse=True)
+
+
+def _emulated_backward(spec, state, bn, gelu8=False, inject=None):
+    """Oracle loss + gradients in the HIP path's own number format, forward AND backward (oracle.emulate_bf16(backward=True));
+    ``inject`` = (weight-name substring, factor): the mutation check's scaled data gradient."""
+    P = O.to_torch_state(state, requires_grad=True)
+    O._INJECT_DGRAD = inject
+    try:
+        with O.emulate_bf16(backward=True, gelu8=gelu8):
+            loss, ref = O.vault_loss(P, spec, O.torch_batch(bn))
+            loss.backward()
+    finally:
+        O._INJECT_DGRAD = None
+    return P, float(loss.detach())
+
+
+def _assert_same_format_gradients(eng, spec, state, bn, tag, glob_bound, per_bound, gelu8=False, mutate="encoder.layer.1.attention.attention.qkv"):
+    """The backward pinned to its own number format: against the emulating oracle the gradients agree to `glob_bound` globally
+    and `per_bound` per parameter - and those bounds would notice a 1 % error in ONE data-gradient GEMM (the same comparison
+    against an oracle whose `mutate` dgrad is scaled by 1.01 breaks the per-parameter bound)."""
+    Pe, _ = _emulated_backward(spec, state, bn, gelu8)
+    glob, per = _grad_errors(eng, Pe)
+    print(f"{tag}: gradients vs the bf16-emulating oracle (forward + backward): global rel L2 {glob:.2e}, worst parameters "
+          + ", ".join(f"{n} {e:.2e}" for e, n in per[:3]))
+    assert glob < glob_bound, glob
+    assert per[0][0] < per_bound, per[:5]
+    Pm, _ = _emulated_backward(spec, state, bn, gelu8, inject=(mutate, 1.01))
+    _, perm = _grad_errors(eng, Pm)
+    print(f"{tag}: with a 1 % error injected into the {mutate} data gradient: worst parameter {perm[0][1]} {perm[0][0]:.2e}")
+    assert perm[0][0] > per_bound, perm[:3]
+
+
 @pytest.mark.parametrize("kind,seed", [("roberta", 11), ("bert", 12)])
 def test_tiny_forward_backward_vs_oracle(kind, seed):
     spec = _nodrop(VaultSpec.tiny(3, kind))
@@ -74,6 +120,8 @@ def test_tiny_forward_backward_vs_oracle(kind, seed):
         dot += float((mine * r).sum()); n1 += float(mine.pow(2).sum())
     assert (num / den) ** 0.5 < 6e-2
     assert dot / (n1 ** 0.5 * den ** 0.5) > 0.995
+    # ... and against the oracle in the HIP backward's own number format (bounds: measured + margin, printed)
+    _assert_same_format_gradients(eng, spec, state, bn, f"tiny {kind}", 5e-3, 8e-3)
     # parameters without gradient in the reference have none here either
     assert not eng.params.has_grad("embeddings.text_embeddings.word_embeddings.weight")
     assert not eng.params.has_grad("embeddings.text_embeddings.position_embeddings.weight")
@@ -394,6 +442,11 @@ def test_full_size_against_reference_golden():
             mine = eng.params.gr(k[6:]).cpu().numpy().reshape(g[k].shape)
             rel = np.linalg.norm(mine - g[k]) / (np.linalg.norm(g[k]) + 1e-12)
             assert rel < 8e-2, (k, rel)
+    # the 8 % / 8e-2 bounds above are the fp32 comparison (bf16 operands against the reference's fp32 arithmetic); the
+    # backward itself is pinned against the oracle run in the same number format
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    _assert_same_format_gradients(eng, spec, build_state(spec, 0), bn, "full size B=2", 5e-3, 1.5e-2,
+                                  mutate="encoder.layer.6.attention.attention.qkv")
 
 
 def test_single_image_and_caption_through_vaultmodel_full_size():
@@ -630,6 +683,9 @@ def test_full_size_batch_48_forward_backward_vs_oracle():
     assert not bad, bad[:5]
     print(f"full size B=48: gradient global relative L2 error {(tot_err / tot_ref) ** 0.5:.3e}")
     assert (tot_err / tot_ref) ** 0.5 < 2.5e-2                         # global relative L2 (1.0 % at B = 2)
+    # same number format (8-bit gelu' grid in the ViLT FFN, bf16 gradient stream, bf16 dY / saved operands): the tight bound
+    _assert_same_format_gradients(eng, spec, state, bn, "full size B=48", 5e-3, 1.5e-2, gelu8=True,
+                                  mutate="encoder.layer.6.attention.attention.qkv")
 
 
 def test_full_size_batch_256_equals_its_sub_batches():
