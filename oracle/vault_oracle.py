@@ -169,8 +169,12 @@ class _AttnEmu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, mask_add, scale):
         s = torch.matmul(q, k.transpose(-1, -2)) * scale + mask_add
-        p = torch.softmax(s, dim=-1)
-        o = torch.matmul(_rb(p), v)
+        # the forward kernel feeds the UNNORMALISED exponentials exp(s - max) to the matrix pipe in bf16 and divides the
+        # output by their fp32 row sum afterwards; backward recomputes the normalised probabilities from the log-sum-exp
+        e = torch.exp(s - s.max(dim=-1, keepdim=True).values)
+        lsum = e.sum(-1, keepdim=True)
+        o = torch.matmul(_rb(e), v) / lsum
+        p = e / lsum
         ctx.save_for_backward(q, k, v, p, _rb(o))
         ctx.scale = scale
         return o

@@ -64,20 +64,59 @@ def _emulated_backward(spec, state, bn, gelu8=False, inject=None):
     return P, float(loss.detach())
 
 
-def _assert_same_format_gradients(eng, spec, state, bn, tag, glob_bound, per_bound, gelu8=False, mutate="encoder.layer.1.attention.attention.qkv"):
-    """The backward pinned to its own number format: against the emulating oracle the gradients agree to `glob_bound` globally
-    and `per_bound` per parameter - and those bounds would notice a 1 % error in ONE data-gradient GEMM (the same comparison
-    against an oracle whose `mutate` dgrad is scaled by 1.01 breaks the per-parameter bound)."""
+# per-parameter relative error bounds of the same-format gradient comparison, by class (measured + margin; the tests print
+# the measured values)
+SAME_FORMAT_CLASS_BOUNDS = {"layernorm": 6e-3, "attention q/k": 1.5e-2, "other": 1e-2}
+SAME_FORMAT_DEEP_BOUNDS = {"layernorm": 1.3e-2, "attention q/k": 3e-2, "other": 1.8e-2}     # 12 + 12 layers (see the tests)
+
+
+def _param_class(n):
+    """Gradient classes by conditioning: LayerNorm scales / shifts and the FFN / output matrices are sums of same-signed-ish
+    large terms; the attention query / key gradients of a random-init model are differences of nearly equal numbers (the
+    softmax is almost uniform: dS is tiny against P dP), relatively the noisiest."""
+    if "ayer" in n and ("norm" in n.lower()):
+        return "layernorm"
+    if ".query." in n or ".key." in n:
+        return "attention q/k"
+    return "other"
+
+
+def _assert_same_format_gradients(spec, state, bn, tag, glob_bound, class_bounds, gelu8=None,
+                                  mutate="encoder.layer.1.attention.attention.qkv"):
+    """The backward pinned to its own number format.  A fresh HIP forward + backward of `bn` with every label set to class 0
+    (per-sample gradients then add up instead of cancelling: a relative bound means something) against the oracle emulating
+    the HIP number format forward AND backward (oracle.emulate_bf16(backward=True)): global relative L2 <= glob_bound and per
+    parameter <= its class bound - and those bounds notice a 1 % error in ONE data-gradient GEMM: the same comparison against
+    an oracle whose `mutate` dgrad is scaled by 1.01 breaks the LayerNorm-class bound (that dgrad feeds the LayerNorm below it)."""
+    bn = dict(bn)
+    bn["labels"] = np.zeros_like(bn["labels"])
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    db = _dev(bn)
+    eng.forward(db, train=True, labels=db["labels"], need_hidden=False)
+    eng.zero_grad()
+    eng.backward()
+    torch.cuda.synchronize()
+    if gelu8 is None:
+        gelu8 = eng.last.get("gelu8_cfg") is not None
     Pe, _ = _emulated_backward(spec, state, bn, gelu8)
     glob, per = _grad_errors(eng, Pe)
-    print(f"{tag}: gradients vs the bf16-emulating oracle (forward + backward): global rel L2 {glob:.2e}, worst parameters "
-          + ", ".join(f"{n} {e:.2e}" for e, n in per[:3]))
+    worst = {}
+    for e, n in per:
+        worst.setdefault(_param_class(n), (e, n))
+    print(f"{tag}: gradients vs the bf16-emulating oracle (forward + backward): global rel L2 {glob:.2e}; worst per class: "
+          + "; ".join(f"{c}: {n} {e:.2e}" for c, (e, n) in worst.items()))
     assert glob < glob_bound, glob
-    assert per[0][0] < per_bound, per[:5]
+    for c, (e, n) in worst.items():
+        assert e < class_bounds[c], (c, n, e)
+    if mutate is None:
+        del eng
+        return
     Pm, _ = _emulated_backward(spec, state, bn, gelu8, inject=(mutate, 1.01))
-    _, perm = _grad_errors(eng, Pm)
-    print(f"{tag}: with a 1 % error injected into the {mutate} data gradient: worst parameter {perm[0][1]} {perm[0][0]:.2e}")
-    assert perm[0][0] > per_bound, perm[:3]
+    globm, perm = _grad_errors(eng, Pm)
+    wm = max((e, n) for e, n in perm if _param_class(n) == "layernorm")
+    print(f"{tag}: with a 1 % error injected into the {mutate} data gradient: global {globm:.2e}, worst LayerNorm parameter {wm[1]} {wm[0]:.2e}")
+    assert wm[0] > class_bounds["layernorm"], wm
+    del eng
 
 
 @pytest.mark.parametrize("kind,seed", [("roberta", 11), ("bert", 12)])
@@ -121,7 +160,7 @@ def test_tiny_forward_backward_vs_oracle(kind, seed):
     assert (num / den) ** 0.5 < 6e-2
     assert dot / (n1 ** 0.5 * den ** 0.5) > 0.995
     # ... and against the oracle in the HIP backward's own number format (bounds: measured + margin, printed)
-    _assert_same_format_gradients(eng, spec, state, bn, f"tiny {kind}", 5e-3, 8e-3)
+    _assert_same_format_gradients(spec, state, bn, f"tiny {kind}", 5e-3, SAME_FORMAT_CLASS_BOUNDS)
     # parameters without gradient in the reference have none here either
     assert not eng.params.has_grad("embeddings.text_embeddings.word_embeddings.weight")
     assert not eng.params.has_grad("embeddings.text_embeddings.position_embeddings.weight")
@@ -445,8 +484,12 @@ def test_full_size_against_reference_golden():
     # the 8 % / 8e-2 bounds above are the fp32 comparison (bf16 operands against the reference's fp32 arithmetic); the
     # backward itself is pinned against the oracle run in the same number format
     torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
-    _assert_same_format_gradients(eng, spec, build_state(spec, 0), bn, "full size B=2", 5e-3, 1.5e-2,
-                                  mutate="encoder.layer.6.attention.attention.qkv")
+    del eng
+    # (24 layers deep the two runs no longer round the same values: one flipped bf16 rounding perturbs everything behind it
+    #  by 2^-9 relative, which flips roundings wholesale a layer later - the same-format comparison decays towards the
+    #  fp32 one with depth (measured 7.1e-3 here against 1.0e-2); the tight bounds and the mutation check are on the
+    #  shallow full-width models of test_full_width_shallow_same_format_gradients)
+    _assert_same_format_gradients(spec, build_state(spec, 0), bn, "full size B=2", 1e-2, SAME_FORMAT_DEEP_BOUNDS, mutate=None)
 
 
 def test_single_image_and_caption_through_vaultmodel_full_size():
@@ -684,8 +727,23 @@ def test_full_size_batch_48_forward_backward_vs_oracle():
     print(f"full size B=48: gradient global relative L2 error {(tot_err / tot_ref) ** 0.5:.3e}")
     assert (tot_err / tot_ref) ** 0.5 < 2.5e-2                         # global relative L2 (1.0 % at B = 2)
     # same number format (8-bit gelu' grid in the ViLT FFN, bf16 gradient stream, bf16 dY / saved operands): the tight bound
-    _assert_same_format_gradients(eng, spec, state, bn, "full size B=48", 5e-3, 1.5e-2, gelu8=True,
-                                  mutate="encoder.layer.6.attention.attention.qkv")
+    del eng
+    _assert_same_format_gradients(spec, state, bn, "full size B=48", 1e-2, SAME_FORMAT_DEEP_BOUNDS, gelu8=True, mutate=None)
+
+
+@pytest.mark.parametrize("B", [2, 48])
+def test_full_width_shallow_same_format_gradients(B):
+    """The backward pinned to its own number format at FULL WIDTH (hidden 768, FFN 3072, 185-token fused sequence, 12 heads)
+    and 2 + 2 layers: B = 2 runs the stage-level layer calls with 128 x 128 tiles and bf16 gelu', B = 48 the kernels of the
+    B = 256 bench (8-wave / ring GEMMs, 8-bit gelu', batched weight gradients, resident attention backward, bf16 gradient
+    stream).  HIP gradients against the oracle emulating the HIP number format forward and backward: <= 5e-3 global relative L2,
+    per-parameter class bounds, and the bounds notice a 1 % error in one data-gradient GEMM."""
+    spec = _nodrop(VaultSpec(vilt=ViltSpec(num_hidden_layers=2), lm=LMSpec.bertweet_base(), n_classes=3))
+    spec.lm.num_hidden_layers = 2
+    state = build_state(spec, 3)
+    bn = synthetic_batch(spec, B, seed=500 + B, n_classes=3)
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    _assert_same_format_gradients(spec, state, bn, f"full width 2+2 layers B={B}", 5e-3, SAME_FORMAT_CLASS_BOUNDS)
 
 
 def test_full_size_batch_256_equals_its_sub_batches():

@@ -17,6 +17,9 @@
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
+#ifndef ATTN_ABLATE
+#define ATTN_ABLATE 0     // development (resident backward kernels): 1 = memory traffic only, 2 = arithmetic only (every block on item 0..heads-1)
+#endif
 
 __device__ __forceinline__ int swz_row(int row) { return (row >> 1) & 3; }  // 32-byte block XOR key
 
@@ -54,6 +57,19 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* img, int T, int dt, int g,
   const int row = 32 * T + 4 * g + qq;
   const int x = (2 * (g & 1) + (qq >> 1)) & 3;  // == swz_row(row) and == swz_row(row + 16)
   const char* a = img + row * 128 + ((dt ^ x) << 5) + pp * 8;
+  return cat_tr(lds_read_tr16(a), lds_read_tr16(a + 16 * 128));
+}
+
+// transposed fragment with the d columns PERMUTED so that an output lane ends up with 8 consecutive d: MFMA tile
+// t = 2 half + odd takes d = 32 half + 8 (i >> 2) + 4 odd + (i & 3) for its row i.  The accumulator lane (g, l15) of tiles
+// (2 half, 2 half + 1) then holds d = 32 half + 8 g + 0..7 of row l15: one 16-byte store instead of two 8-byte ones, 64
+// contiguous bytes per row and instruction (the output rows are 128 bytes per head).  Costs a 2-way bank conflict on
+// these reads (two of the four rows of a lane group share a 64-byte half of the swizzled image).
+__device__ __forceinline__ bf16x8 frag_tr8(const char* img, int T, int half, int odd, int g, int l15) {
+  const int qq = l15 >> 2, pp = l15 & 3;
+  const int row = 32 * T + 4 * g + qq;
+  const int x = (2 * (g & 1) + (qq >> 1)) & 3;  // == swz_row(row) and == swz_row(row + 16)
+  const char* a = img + row * 128 + (((4 * half + pp) ^ (x << 1)) << 4) + odd * 8;
   return cat_tr(lds_read_tr16(a), lds_read_tr16(a + 16 * 128));
 }
 
@@ -392,6 +408,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
   u32x4 rq[NC], rk[NC], rv[NC], rd[NC], ro[NC];
   float rl = 0.f, rm = 0.f;
   auto fetch = [&](int item) {
+#if ATTN_ABLATE == 2
+    item = item % heads;
+#endif
     const int b = item / heads, h = item - b * heads;
     const size_t row0 = (size_t)b * S;
     const bf16* qb = qkv + row0 * ld + h * 64;
@@ -443,7 +462,11 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
       mb[tid] = (tid < S && rm != 0.f) ? 0.f : -INFINITY;
       lse_s[tid] = -rl * LOG2E;      // -inf for rows >= S
     }
+#if ATTN_ABLATE == 2
+    const int b = 0, h = item % heads;
+#else
     const int b = item / heads, h = item - b * heads;
+#endif
     const uint32_t bh = (uint32_t)item;
     bf16* dqbase = dqkv + (size_t)b * S * ld + h * 64;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (no vmcnt wait: the previous item's stores stay in flight)
@@ -464,7 +487,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
         for (int dt = 0; dt < 4; ++dt) o[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll 1
-      for (int T = 0; T < NKT; ++T) {
+      for (int T = 0; T < (ATTN_ABLATE == 1 ? 0 : NKT); ++T) {
         f32x4 ds2[TPW][2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -533,7 +556,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
         }
       }
 #pragma unroll 1
-      for (int T = 0; T < NKT; ++T) {
+      for (int T = 0; T < (ATTN_ABLATE == 1 ? 0 : NKT); ++T) {
         f32x4 p2[TPW][2], ds2[TPW][2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -602,6 +625,330 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the images before the next item overwrites them
   }
 }
+
+// Backward, single-pass resident form (round 3; 64 < S <= 192).  The two-pass kernel above recomputes the scores, the
+// probabilities and dP twice (once per orientation) and is bound by its own instruction stream: with the HBM traffic of a
+// launch served from L2 it still takes 180 us at B = 256, with the arithmetic removed 143 us (tools/attn_bench.py on the
+// ATTN_ABLATE builds) - the exp / dS arithmetic of BOTH passes saturates the vector issue of a SIMD (3 waves x ~100 VALU
+// per 32 keys against 28 MFMAs).  Here every score is computed ONCE:
+//   phase 1 (wave = one 16-key tile): S^T, P, dP, dS for all queries; dK, dV accumulate in registers; dS goes to LDS as a
+//            row-major [key][query] bf16 image (416-byte rows: conflict-free for the 8-byte stores and the transposed reads);
+//   phase 2 (wave = one 16-query tile): dQ = dS K from that image and the K image, both read k-strided
+//            (ds_read_b64_tr_b16): 4 MFMAs per 32 keys and no vector arithmetic.
+// V never enters LDS (a wave needs only its own 16 rows, as MFMA fragments: loaded straight into registers with the
+// prefetch of the next item); Q, K, dO images + dS + row statistics = 152 KiB.  The mask is the initial accumulator of the
+// score MFMA (0 / -inf per key), the 1/sqrt(d) factor is applied to dQ / dK once per output element.  The operands of the
+// next item are prefetched into registers under the current item's arithmetic; its Q / dO images and statistics are
+// written at the start of phase 2 (phase 2 reads only K and dS), its K image after phase 2.
+#ifndef ATTN_ST_NT
+#define ATTN_ST_NT 0      // development: 1 = non-temporal output stores
+#endif
+#ifndef ATTN_LOADS_FIRST
+#define ATTN_LOADS_FIRST 0   // development: 1 = the next items' loads are issued in front of the dK / dV stores
+#endif
+#if ATTN_ST_NT
+#define ATTN_STORE16(ptr, val) __builtin_nontemporal_store((val), reinterpret_cast<u32x4*>(ptr))
+#else
+#define ATTN_STORE16(ptr, val) (*reinterpret_cast<u32x4*>(ptr) = (val))
+#endif
+constexpr int DS_LD = 416;   // bytes per row of the dS^T image (192 queries x 2 B = 384, padded)
+
+// Global loads and LDS-DMA of the single-pass kernel through inline asm: scalar base + 32-bit lane offset (no 64-bit
+// address registers: the kernel lives at the 168-register edge of three waves per SIMD), and - the point - hipcc keeps no
+// record of them, so it never answers an unrelated use with `s_waitcnt vmcnt(0)`: `vmcnt` counts loads, stores and DMA
+// in issue order, and a conservative wait in the wrong place serialises an item's memory traffic with its arithmetic
+// (the two-pass kernel: scratch reloads and exec-masked loads make hipcc wait for the whole prefetch right after
+// issuing it).  Every wait on these loads is explicit and counted below.
+__device__ __forceinline__ void attn_glds16(const char* sbase, uint32_t voff, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :: "v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
+}
+__device__ __forceinline__ void attn_gload16(u32x4& dst, const char* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void attn_gload4(float& dst, const char* sbase, uint32_t voff) {
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+// a pointer that is uniform by construction, pinned to scalar registers (asm "s" operands)
+__device__ __forceinline__ const char* attn_uniform(const void* p) {
+  const uint64_t u = (uint64_t)p;
+  return reinterpret_cast<const char*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u));
+}
+
+template <int NKT, int NWV, bool DROP = true>
+__global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_one_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
+                                                         const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
+                                                         const float* __restrict__ lse, bf16* __restrict__ dqkv, int S,
+                                                         int H, int heads, int items, float scale, AttnDrop dr) {
+  constexpr int SK = NKT * 32;
+  constexpr int NT = NWV * 64;
+  constexpr int NC = (SK * 8) / NT;   // 16-byte chunks per thread and matrix
+  static_assert(2 * NKT == NWV, "one 16-row tile per wave");
+  static_assert((SK * 8) % NT == 0 && SK <= NT && NC == 2, "chunk / row bookkeeping (two 1 KiB DMA pieces per wave)");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* Ks = smem + SK * 128;
+  char* Ds = smem + 2 * SK * 128;   // dO
+  char* dSs = smem + 3 * SK * 128;  // dS^T [key][query], DS_LD bytes per row
+  float* mb = reinterpret_cast<float*>(smem + 3 * SK * 128 + SK * DS_LD);
+  float* lse_s = mb + SK;          // -lse * log2e ; -inf for q >= S
+  float* dl_s = lse_s + SK;        // delta[q]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int ld = 3 * H;
+  const float sl2 = scale * LOG2E;
+  const uint32_t ks_lds = (uint32_t)(size_t)LDS_PTR(char, Ks);
+  const int G = (int)gridDim.x;
+  const bool wave_rows = __builtin_amdgcn_readfirstlane((int)(wave * 16 < (ATTN_ABLATE == 5 ? -S : S))) != 0;   // this wave's tile has rows to store
+
+  u32x4 rq[NC], rd[NC], ro[NC];    // Q, dO, O chunks of the item after next (rows >= S: row S - 1 again, see below)
+  u32x4 rkf[2], rvf[2];            // this wave's own K / V tile of the next item as MFMA fragments
+  float rl = 0.f, rm = 1.f;
+  // Rows >= S are never zero-filled: they re-read row S - 1.  Finite stand-ins are enough - a query row >= S has -lse = -inf,
+  // so its probabilities and dS are exactly 0; a key row >= S has the -inf mask as initial accumulator - and unconditional
+  // loads keep the number of memory operations per wave fixed, which the counted waits below rely on.
+  uint32_t off_q[NC], off_o[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = tid + i * NT, row = min(c >> 3, S - 1), pos = c & 7;
+    off_q[i] = (uint32_t)row * (uint32_t)(ld * 2) + (uint32_t)pos * 16u;
+    off_o[i] = (uint32_t)row * (uint32_t)(H * 2) + (uint32_t)pos * 16u;
+  }
+  const uint32_t off_frag = (uint32_t)min(wave * 16 + l15, S - 1) * (uint32_t)(ld * 2) + (uint32_t)g * 16u;   // own key row, d = 8 g (+ 32 s)
+  const uint32_t off_out = (uint32_t)(wave * 16 + l15) * (uint32_t)(ld * 2) + (uint32_t)g * 16u;             // own row, d = 8 g (+ 32 hf)
+  // (measured with wrong addresses, 8 lanes per 128-byte row: whole-line stores would take another 5-8 % off the kernel;
+  //  they need a transposition of the output tiles through LDS, which has 8 KiB to spare here)
+  const uint32_t off_stat = (uint32_t)min(tid, S - 1) * 4u;
+  auto item_bh = [&](int item, int& b, int& h) {
+#if ATTN_ABLATE == 2 || ATTN_ABLATE == 6
+    item = item % heads;
+#endif
+    b = item / heads; h = item - b * heads;
+  };
+  auto fetch_q_do = [&](int item) {      // 2 NC + NC + 2 = 8 loads per wave, unconditional
+    int b, h;
+    item_bh(item, b, h);
+    const size_t row0 = (size_t)b * S;
+    const char* qb = attn_uniform(qkv + row0 * ld + h * 64);
+    const char* ob = attn_uniform(ctx + row0 * H + h * 64);
+    const char* db = attn_uniform(dctx + row0 * H + h * 64);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      attn_gload16(rq[i], qb, off_q[i]);
+      attn_gload16(rd[i], db, off_o[i]);
+      attn_gload16(ro[i], ob, off_o[i]);
+    }
+    attn_gload4(rl, attn_uniform(lse + (size_t)item * S), off_stat);
+    attn_gload4(rm, attn_uniform(keymask != nullptr ? keymask + (size_t)b * S : lse + (size_t)item * S), off_stat);
+  };
+  auto fetch_kv_frags = [&](int item) {  // 4 loads per wave, unconditional
+    int b, h;
+    item_bh(item, b, h);
+    const char* kb = attn_uniform(qkv + (size_t)b * S * ld + h * 64 + H);
+    const char* vb = attn_uniform(qkv + (size_t)b * S * ld + h * 64 + 2 * H);
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      attn_gload16(rkf[s_], kb, off_frag + 64u * s_);
+      attn_gload16(rvf[s_], vb, off_frag + 64u * s_);
+    }
+  };
+  // the K image of an item by LDS-DMA: two 1 KiB pieces (8 rows) per wave, XOR swizzle on the source chunk; rows >= S are
+  // never written (they stay zero from the start of the kernel)
+  auto dma_k = [&](int item) {
+    int b, h;
+    item_bh(item, b, h);
+    const char* kb = attn_uniform(qkv + (size_t)b * S * ld + h * 64 + H);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int pc = wave * NC + i, row = pc * 8 + (lane >> 3), slot = lane & 7;
+      const uint32_t voff = (uint32_t)row * (uint32_t)(ld * 2) + (uint32_t)((slot ^ (swz_row(row) << 1)) << 4);
+      if (row < S) attn_glds16(kb, voff, (uint32_t)__builtin_amdgcn_readfirstlane((int)(ks_lds + pc * 1024)));
+    }
+  };
+  // registers -> the images phase 2 does not read: Q, dO, delta, key bias, -lse (call only behind a wait for the loads)
+  auto write_q_do = [&]() {
+    asm volatile("" : "+v"(rq[0]), "+v"(rq[1]), "+v"(rd[0]), "+v"(rd[1]), "+v"(ro[0]), "+v"(ro[1]), "+v"(rl), "+v"(rm));
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = tid + i * NT, row = c >> 3, pos = c & 7;
+      const int off = row * 128 + ((pos ^ (swz_row(row) << 1)) << 4);
+      *reinterpret_cast<u32x4*>(Qs + off) = rq[i];
+      *reinterpret_cast<u32x4*>(Ds + off) = rd[i];
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float2 a = unpack_bf16x2(ro[i][w]), d = unpack_bf16x2(rd[i][w]);
+        s += a.x * d.x + a.y * d.y;
+      }
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      if (pos == 0) dl_s[row] = s;
+    }
+    if (tid < SK) {
+      mb[tid] = (tid < S && (keymask == nullptr || rm != 0.f)) ? 0.f : -INFINITY;
+      lse_s[tid] = (tid < S) ? -rl * LOG2E : -INFINITY;
+    }
+  };
+
+  int item = blockIdx.x;
+  if (item >= items) return;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) *reinterpret_cast<u32x4*>(Ks + (tid + i * NT) * 16) = u32x4{0u, 0u, 0u, 0u};
+  fetch_q_do(item);
+  fetch_kv_frags(item);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // loads landed; the zeros are in place before the first DMA
+  dma_k(item);
+  write_q_do();
+  if (item + G < items) fetch_q_do(item + G);
+  for (; item < items; item += G) {
+    asm volatile("" : "+v"(rkf[0]), "+v"(rkf[1]), "+v"(rvf[0]), "+v"(rvf[1]));   // (landed: waited for in front of the DMA / above)
+    const bf16x8 kf0 = __builtin_bit_cast(bf16x8, rkf[0]), kf1 = __builtin_bit_cast(bf16x8, rkf[1]);
+    const bf16x8 vf0 = __builtin_bit_cast(bf16x8, rvf[0]), vf1 = __builtin_bit_cast(bf16x8, rvf[1]);
+    int b, h;
+    item_bh(item, b, h);
+#if ATTN_ABLATE == 2
+    b = 0;
+#elif ATTN_ABLATE == 6
+    b = item / heads; h = item - b * heads;
+#endif
+    const uint32_t bh = (uint32_t)item;
+    char* dqbase = reinterpret_cast<char*>(dqkv + (size_t)b * S * ld + h * 64);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // Q / dO images + statistics of this item complete
+    const bool more = item + G < items, more2 = item + 2 * G < items;
+
+    // ---------------- phase 1: wave = key tile `wave`; dK, dV in registers, dS^T -> LDS ----------------
+    const float mk = mb[wave * 16 + l15];
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    {
+      char* dsrow = dSs + (wave * 16 + l15) * DS_LD + 8 * g;
+#pragma unroll 1
+      for (int T = 0; T < ((ATTN_ABLATE == 1 || ATTN_ABLATE == 4) ? 0 : NKT); ++T) {
+        f32x4 p2[2], ds2[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int qt = 2 * T + hh;
+          const bf16x8 q0 = frag_rows(Qs, qt, 0, g, l15), q1 = frag_rows(Qs, qt, 1, g, l15);
+          const bf16x8 d0 = frag_rows(Ds, qt, 0, g, l15), d1 = frag_rows(Ds, qt, 1, g, l15);
+          const f32x4 nl4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * g);
+          const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dl_s + qt * 16 + 4 * g);
+          f32x4 a = {mk, mk, mk, mk}, dp = {0.f, 0.f, 0.f, 0.f};     // (the key mask is the initial accumulator)
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, kf0, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, kf1, a, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf0, dp, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf1, dp, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(a[r], sl2, nl4[r]));
+            float dpv = dp[r];
+            if (DROP && dr.thresh != 0u) {
+              const uint32_t k_l = (uint32_t)(wave * 16 + l15);
+              const uint32_t idx = (bh * (uint32_t)S + (uint32_t)(qt * 16 + 4 * g + r)) * (uint32_t)S + k_l;
+              const bool keep = dropout_keep(dr.seed, dr.stream, idx, dr.thresh);
+              dpv = keep ? dpv * dr.scale : 0.f;
+              ds2[hh][r] = pv * (dpv - dl4[r]);
+              pv = keep ? pv * dr.scale : 0.f;
+            } else {
+              ds2[hh][r] = pv * (dpv - dl4[r]);
+            }
+            p2[hh][r] = pv;
+          }
+        }
+        const bf16x8 pf = pack_frag(p2[0], p2[1]);
+        const bf16x8 dsf = pack_frag(ds2[0], ds2[1]);
+        // dS^T[key = this lane's][queries 32 T + 16 hh + 4 g + 0..3]: two 8-byte stores
+        const u32x4 dsw = __builtin_bit_cast(u32x4, dsf);
+        *reinterpret_cast<uint2*>(dsrow + T * 64) = uint2{dsw[0], dsw[1]};
+        *reinterpret_cast<uint2*>(dsrow + T * 64 + 32) = uint2{dsw[2], dsw[3]};
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Ds, T, dt >> 1, dt & 1, g, l15), pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Qs, T, dt >> 1, dt & 1, g, l15), dsf, dk[dt], 0, 0, 0);
+        }
+      }
+    }
+    // dS^T complete, every wave done with Q, dO and the statistics.  vmcnt(0): what is outstanding here - the K image of
+    // this item (DMA issued an item ago), the Q / dO / O registers of the next item (requested an item ago) and old stores -
+    // is needed right behind the barrier; phase 1 issued no memory operation
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (more) write_q_do();                                           // images of the next item: phase 2 reads only K and dS^T
+#if ATTN_LOADS_FIRST
+    if (more) fetch_kv_frags(item + G);
+    if (more2) fetch_q_do(item + 2 * G);
+#endif
+    if (wave * 16 + l15 < (ATTN_ABLATE == 5 ? -S : S)) {
+      char* dstk = dqbase + 2 * H;        // (byte offsets: K part at + H elements, V part at + 2 H elements)
+      char* dstv = dqbase + 4 * H;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {    // tiles (2 hf, 2 hf + 1): d = 32 hf + 8 g + 0..7 of this lane's row
+        const f32x4 ka = dk[2 * hf], kb2 = dk[2 * hf + 1], va = dv[2 * hf], vb2 = dv[2 * hf + 1];
+        const u32x4 wk = {pack_bf16x2(ka[0] * scale, ka[1] * scale), pack_bf16x2(ka[2] * scale, ka[3] * scale),
+                          pack_bf16x2(kb2[0] * scale, kb2[1] * scale), pack_bf16x2(kb2[2] * scale, kb2[3] * scale)};
+        const u32x4 wv = {pack_bf16x2(va[0], va[1]), pack_bf16x2(va[2], va[3]), pack_bf16x2(vb2[0], vb2[1]), pack_bf16x2(vb2[2], vb2[3])};
+        ATTN_STORE16(dstk + (off_out + 64u * hf), wk);
+        ATTN_STORE16(dstv + (off_out + 64u * hf), wv);
+      }
+    }
+    // requests of the following items, issued here so that they are in flight for a whole item: the K / V fragments of the
+    // next item first (4 loads), then the Q / dO / O chunks + statistics of the item after next (8 loads)
+#if !ATTN_LOADS_FIRST
+    if (more) fetch_kv_frags(item + G);
+    if (more2) fetch_q_do(item + 2 * G);
+#endif
+    // ---------------- phase 2: wave = query tile `wave`; dQ = dS K ----------------
+    {
+      f32x4 o[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const char* dsb = dSs + (4 * g + (l15 >> 2)) * DS_LD + wave * 32 + (l15 & 3) * 8;
+#pragma unroll
+      for (int T = 0; T < ((ATTN_ABLATE == 1 || ATTN_ABLATE == 3) ? 0 : NKT); ++T) {
+        const char* a = dsb + T * 32 * DS_LD;
+        const bf16x8 dsB = cat_tr(lds_read_tr16(a), lds_read_tr16(a + 16 * DS_LD));
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Ks, T, dt >> 1, dt & 1, g, l15), dsB, o[dt], 0, 0, 0);
+      }
+      if (wave * 16 + l15 < (ATTN_ABLATE == 5 ? -S : S)) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const f32x4 qa = o[2 * hf], qb2 = o[2 * hf + 1];
+          const u32x4 w = {pack_bf16x2(qa[0] * scale, qa[1] * scale), pack_bf16x2(qa[2] * scale, qa[3] * scale),
+                           pack_bf16x2(qb2[0] * scale, qb2[1] * scale), pack_bf16x2(qb2[2] * scale, qb2[3] * scale)};
+          ATTN_STORE16(dqbase + (off_out + 64u * hf), w);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with K and dS^T
+    if (more) {
+      // the next item's K / V fragments must have landed; behind them in the (in-order) counter: 8 loads of the item after
+      // next if requested, and this wave's 2 dQ stores if its tile has rows - both wave-uniform, so the count is exact
+#if ATTN_LOADS_FIRST   // (+ the 4 dK / dV stores)
+      if (more2) {
+        if (wave_rows) asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        if (wave_rows) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+#else
+      if (more2) {
+        if (wave_rows) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        if (wave_rows) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+#endif
+      dma_k(item + G);
+    }
+  }
+}
+
+template <int NKT>
+constexpr int attn_one_lds_bytes() { return NKT * 32 * 128 * 3 + NKT * 32 * DS_LD + NKT * 32 * 4 * 3; }
 
 template <int NKT>
 constexpr int attn_res_lds_bytes() { return NKT * 32 * 128 * 4 + NKT * 32 * 4 * 3; }
@@ -676,11 +1023,31 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
                          reinterpret_cast<const bf16*>(a->dctx), a->lse, reinterpret_cast<bf16*>(a->dqkv), a->S, a->H,        \
                          a->heads, items, scale, dr);                                                                         \
     }
+#define ONE_V(DR)                                                                                                             \
+    {                                                                                                                         \
+      auto kern = attn_bwd_one_kernel<6, 12, DR>;   /* 152 KiB of LDS: one 12-wave workgroup per CU, persistent */            \
+      static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];                                                                                          \
+      if (!attr_done) {                                                                                                       \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                           attn_one_lds_bytes<6>());                                                          \
+        if (e != hipSuccess) return (int)e;                                                                                   \
+        attr_done = true;                                                                                                     \
+      }                                                                                                                       \
+      hipLaunchKernelGGL(kern, dim3(items < 256 ? items : 256), dim3(768), attn_one_lds_bytes<6>(), st,                       \
+                         reinterpret_cast<const bf16*>(a->qkv), a->keymask, reinterpret_cast<const bf16*>(a->ctx),            \
+                         reinterpret_cast<const bf16*>(a->dctx), a->lse, reinterpret_cast<bf16*>(a->dqkv), a->S, a->H,        \
+                         a->heads, items, scale, dr);                                                                         \
+    }
   if (a->S <= 64) {
     if (drop) OLD_V(2, true); else OLD_V(2, false);
   } else if (a->S <= 192) {
     const int items = a->B * a->heads;
-    if (drop) RES_V(true) else RES_V(false)
+    static const bool one_pass = [] { const char* e = getenv("VAULT_ATTN_BWD"); return !(e && e[0] == '0'); }();   // development A/B switch: 0 = the two-pass resident kernel
+    if (one_pass) {
+      if (drop) ONE_V(true) else ONE_V(false)
+    } else {
+      if (drop) RES_V(true) else RES_V(false)
+    }
   } else {
     auto kern = attn_bwd_kernel<10, 4, 1>;
     static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];
@@ -696,5 +1063,6 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
   }
 #undef OLD_V
 #undef RES_V
+#undef ONE_V
   return (int)hipGetLastError();
 }

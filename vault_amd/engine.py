@@ -256,6 +256,7 @@ class VaultEngine:
     # rows; larger batches keep the per-kernel calls below (same kernels, same order) so that bench.py can bracket single
     # GEMM call sites with events.  VAULT_STAGE_ABI=0 / 1 forces either.
     STAGE_MAX_ROWS = 8192
+    QKV_BIAS_SHORTCUT = True       # ViLT QKV bias gradient: value part from the dctx GEMM's epilogue, key part zero (see _backward)
     GELU8 = True                   # ViLT FFN: gelu' kept for backward as the 8-wave kernel's 8-bit tile-native image (vault_gemm aux_u8)
     GRAD_STREAM_BF16 = True        # ViLT residual-gradient stream in bf16 only (what bf16 autocast training carries): see _backward
     WGRAD_STREAM_MAX_ROWS = 16384  # deferred weight gradients run on a second stream up to this many ViLT token rows (B <= 88)
@@ -1257,15 +1258,23 @@ class VaultEngine:
                                   dx_bf16=dyB, dgamma=P.gr(ln.ln2w), dbeta=P.gr(ln.ln2b), dbias=P.gr(ln.ob))
                 cur = nxt
             # attention
-            self._dgrad(dyB, ln.ow, dctx, Mp, H, H, ops.EPI_BF16, M)
+            # QKV bias gradient without a pass over all of dqkv (QKV_BIAS_SHORTCUT; the ViLT stack has no attention dropout,
+            # D2): softmax rows sum to one, so  sum_keys dV = sum_queries dO  - the value bias gradient is the column sum of
+            # dctx, taken in the epilogue of the GEMM that produces dctx; sum_keys dS = 0 for every query, so the key bias
+            # gradient is zero (the reference's autograd leaves rounding noise of 1e-9 there); only the query third is summed
+            short = vbatch and self.QKV_BIAS_SHORTCUT
+            gqb = P.gr(ln.qb, n_elems=3 * H, shape=(3 * H,))
+            self._dgrad(dyB, ln.ow, dctx, Mp, H, H, ops.EPI_BF16, M, **(dict(colsum=gqb[2 * H:]) if short else {}))
             if not vbatch:
                 self._wgrad(dyB, g("ctx"), ln.ow, None, Mp, H, H, M)
             ops.attention_bwd(g("qkv"), km, g("ctx"), g("lse"), dctx, dqkv, B, S, H, heads)
             self._dgrad(dqkv, ln.qw, dN, Mp, H, 3 * H, ops.EPI_BF16, M)
             if not vbatch:
                 self._wgrad(dqkv, g("n1"), ln.qw, ln.qb, Mp, 3 * H, H, M)
+            elif short:
+                ops.colsum(dqkv, 3 * H, M, H, gqb[:H])
             else:
-                ops.colsum(dqkv, 3 * H, M, 3 * H, P.gr(ln.qb, n_elems=3 * H, shape=(3 * H,)))
+                ops.colsum(dqkv, 3 * H, M, 3 * H, gqb)
             nxt = cur ^ 1
             if gbf:
                 ops.layernorm_bwd(x[i], g("m1"), g("r1"), P.w(ln.ln1w), M, H, dy_bf16=dN, dres_bf16=dyB,
