@@ -32,7 +32,18 @@ constexpr int BK = 64;
 
 template <int EPI> struct EpiTraits;
 
-template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, int EPI>
+// 16-byte LDS-DMA through inline asm for the deep-pipeline form (NS > 2): hipcc keeps no record of it, so it does not put
+// `s_waitcnt vmcnt(0)` in front of the barrier / the fragment reads (which would drain every stage in flight); the loop
+// waits with counted `vmcnt` instead.  gptr: per-lane global address, lds: uniform LDS byte address (lane l lands at + 16 l).
+__device__ __forceinline__ void gemm_glds16_asm(const void* gptr, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gptr), "s"(lds) : "memory", "m0");
+}
+
+// NS = 2: double buffered, two blocks of 128 x 128 per CU.  NS = 4 (round 3): four stages, three K tiles in flight, one block
+// per CU - for the launches whose K loop runs (nearly) alone on its CU: a block of the double-buffered form waits a full
+// L2 / MALL round trip per K tile (1.3 us per 64-deep step at M = 2560, K = 3072: 10 % of the matrix rate of its tile),
+// three tiles in flight divide that by three.
+template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, int EPI, int NS = 2>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p_in) {
   GemmParams p = p_in;
   int split_z = blockIdx.z;
@@ -125,13 +136,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p_in
   const size_t a_step = (A_MODE == 0) ? (size_t)BK : (size_t)BK * p.lda;
   const size_t b_step = (B_MODE == 0) ? (size_t)BK : (size_t)BK * p.ldb;
 
+  const uint32_t lds0 = (uint32_t)(size_t)LDS_PTR(char, smem);
   auto stage = [&](int buf, int t) {
-    char* sa = smem + buf * STAGE + wave * NIA * 1024;
-    char* sb = smem + buf * STAGE + A_BYTES + wave * NIB * 1024;
+    if constexpr (NS == 2) {
+      char* sa = smem + buf * STAGE + wave * NIA * 1024;
+      char* sb = smem + buf * STAGE + A_BYTES + wave * NIB * 1024;
 #pragma unroll
-    for (int i = 0; i < NIA; ++i) glds16(a_src[i] + (size_t)t * a_step, sa + i * 1024);
+      for (int i = 0; i < NIA; ++i) glds16(a_src[i] + (size_t)t * a_step, sa + i * 1024);
 #pragma unroll
-    for (int i = 0; i < NIB; ++i) glds16(b_src[i] + (size_t)t * b_step, sb + i * 1024);
+      for (int i = 0; i < NIB; ++i) glds16(b_src[i] + (size_t)t * b_step, sb + i * 1024);
+    } else {
+      const uint32_t sa = lds0 + (uint32_t)(buf * STAGE + wave * NIA * 1024);
+      const uint32_t sb = lds0 + (uint32_t)(buf * STAGE + A_BYTES + wave * NIB * 1024);
+#pragma unroll
+      for (int i = 0; i < NIA; ++i) gemm_glds16_asm(a_src[i] + (size_t)t * a_step, (uint32_t)__builtin_amdgcn_readfirstlane((int)(sa + i * 1024)));
+#pragma unroll
+      for (int i = 0; i < NIB; ++i) gemm_glds16_asm(b_src[i] + (size_t)t * b_step, (uint32_t)__builtin_amdgcn_readfirstlane((int)(sb + i * 1024)));
+    }
   };
 
   // ---- per-lane fragment read offsets (bytes inside the A / B image of a stage)
@@ -163,11 +184,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p_in
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (nk > 0) stage(0, 0);
+  if constexpr (NS == 2) {
+    if (nk > 0) stage(0, 0);
+  } else {
+#pragma unroll
+    for (int s_ = 0; s_ < NS - 1; ++s_)
+      if (s_ < nk) stage(s_, s_);
+  }
   for (int t = 0; t < nk; ++t) {
-    __syncthreads();  // tile t has landed (vmcnt(0) precedes the barrier) and buffer (t+1)&1 is free
-    if (t + 1 < nk) stage((t + 1) & 1, t + 1);
-    const char* As = smem + (t & 1) * STAGE;
+    if constexpr (NS == 2) {
+      __syncthreads();  // tile t has landed (vmcnt(0) precedes the barrier) and buffer (t+1)&1 is free
+      if (t + 1 < nk) stage((t + 1) & 1, t + 1);
+    } else {
+      // tile t has landed when at most the DMA pieces of the younger tiles in flight (min(nk - 1 - t, NS - 2) tiles of
+      // NIA + NIB pieces per wave) are outstanding; the barrier also frees buffer (t - 1) % NS for tile t + NS - 1
+      static_assert(NS == 4 && NIA + NIB <= 16, "counted waits below are written for two tiles in flight");
+      const int younger = min(nk - 1 - t, NS - 2);
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (NIA + NIB)) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NIA + NIB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (t + NS - 1 < nk) stage((t + NS - 1) % NS, t + NS - 1);
+    }
+    const char* As = smem + (t % NS) * STAGE;
     const char* Bs = As + A_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -205,12 +244,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p_in
   }
 }
 
-template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, int EPI>
+template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, int EPI, int NS = 2>
 int launch_cfg(const GemmParams& p, hipStream_t st) {
   if (p.M % BM || p.N % BN || p.K % BK) return VAULT_EINVAL;
   constexpr int STAGE = (BM + BN) * BK * 2;
-  constexpr int LDS = 2 * STAGE;
-  auto kern = gemm_kernel<BM, BN, WM, WN, A_MODE, B_MODE, EPI>;
+  constexpr int LDS = NS * STAGE;
+  auto kern = gemm_kernel<BM, BN, WM, WN, A_MODE, B_MODE, EPI, NS>;
   static bool attr_done[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VAULT_EINVAL;
@@ -237,7 +276,19 @@ int launch_cfg(const GemmParams& p, hipStream_t st) {
 template <int A_MODE, int B_MODE, int EPI>
 int launch_modes(const GemmParams& p, int cfg, hipStream_t st) {
   switch (cfg) {
-    case 0: return launch_cfg<128, 128, 2, 2, A_MODE, B_MODE, EPI>(p, st);
+    case 0: {
+      // four-stage form for forward / data-gradient launches (development A/B switch: VAULT_GEMM_DEEP=0 keeps two stages)
+      static const bool deep = [] { const char* e = getenv("VAULT_GEMM_DEEP"); return !(e && e[0] == '0'); }();
+      // ... where one block per CU covers the launch and the K loop is long: M = 2560 (tools/gemm_bench.py, same box) FFN-in
+      // dgrad 50.0 -> 34.1 us, QKV dgrad 38.6 -> 26.3, FFN-out forward 36.6 -> 34.7; with more tiles than CUs two
+      // double-buffered blocks per CU are faster (QKV forward 20.3 against 23.3 us), and a single block's K loop stays bound
+      // by its CU's L2 -> LDS rate (32 KiB per 2.1 MFLOP step)
+      if constexpr (A_MODE == 0 && EPI != EPI_F32_ATOMIC) {
+        if (deep && p.splits <= 1 && (long)(p.M / 128) * (p.N / 128) <= 256 && p.K >= 1536)
+          return launch_cfg<128, 128, 2, 2, A_MODE, B_MODE, EPI, 4>(p, st);
+      }
+      return launch_cfg<128, 128, 2, 2, A_MODE, B_MODE, EPI>(p, st);
+    }
     case 1: return launch_cfg<256, 128, 4, 2, A_MODE, B_MODE, EPI>(p, st);
     case 2: return launch_cfg<256, 256, 2, 4, A_MODE, B_MODE, EPI>(p, st);
     default: return VAULT_EINVAL;
