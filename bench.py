@@ -373,12 +373,17 @@ def main():
         himg = [torch.from_numpy(rng.integers(0, 256, size=(B, HW, HW, 3), dtype=np.uint8)).pin_memory() for _ in range(nb)]
         sizes = [(HW, HW)] * B
 
+        # the resize kernel writes the patch-embedding GEMM's bf16 operand itself (no f32 pixel tensor, no unfold pass)
+        Kp = spec.vilt.num_channels * spec.vilt.patch_size ** 2
+        devp = [torch.empty(B * spec.vilt.num_patches, Kp, dtype=torch.bfloat16, device=dev) for _ in range(nb)]
+
         def prefetch_u8(k):
             with torch.cuda.stream(copy_stream):
                 copy_stream.wait_event(consumed[k % nb])
                 for name in ("input_ids", "attention_mask", "labels"):
                     devb[k % nb][name].copy_(host[k % nb][name], non_blocking=True)
-                proc.from_packed(himg[k % nb].view(-1), sizes, out=devb[k % nb])
+                proc.from_packed(himg[k % nb].view(-1), sizes, out=devb[k % nb], patch_out=devp[k % nb],
+                                 patch_size=spec.vilt.patch_size)
                 ready[k % nb].record(copy_stream)
 
         for i in range(nb):
@@ -391,7 +396,7 @@ def main():
                 prefetch_u8(k + 1)
             torch.cuda.current_stream(dev).wait_event(ready[k % nb])
             d = devb[k % nb]
-            stepper({n_: d[n_] for n_ in ("input_ids", "attention_mask", "pixel_values", "pixel_mask")}, d["labels"])
+            stepper({"input_ids": d["input_ids"], "attention_mask": d["attention_mask"], "pixel_patches": devp[k % nb]}, d["labels"])
             consumed[k % nb].record(torch.cuda.current_stream(dev))
         sync_all()
         dt3 = time.perf_counter() - t0
@@ -402,7 +407,8 @@ def main():
         u8 = {"value": round(B * world * args.steps / dt3, 2), "ms_per_step": round(dt3 / args.steps * 1e3, 3),
               "what": f"the same steps fed from pinned uint8 images ({HW} x {HW} x 3 per sample, {B * HW * HW * 3 / 1e6:.0f} MB per step): "
                       "host->device copy + GPU resize / normalise / pad (vault_image_preprocess, bit-identical to the HF ViLT "
-                      "processor) on a side stream, double-buffered, overlapped with the previous step"}
+                      "processor) on a side stream, double-buffered, overlapped with the previous step; the resize kernel writes the "
+                      "patch-embedding GEMM's bf16 operand directly (no f32 pixel tensor, no unfold pass)"}
 
     precise_fwd = None
     if rank == 0 and not args.no_parity and not args.fp8_forward:

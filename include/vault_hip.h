@@ -405,6 +405,11 @@ typedef struct vault_preprocess_args {
   float* pixel_values; int64_t* pixel_mask; float* pixel_mask_f32;
   int B, H, W, max_h_in, max_w_out;
   int max_w_in; long long src_bytes;   /* widest source row of the batch; size of src (rows are read as aligned dwords) */
+  /* ABI 6, optional: the patch-embedding GEMM's A operand written straight from the vertical pass - the bf16 unfold
+   * [B * (H/ps) * (W/ps)][3 ps ps] of the padded canvas (row = image, patch row, patch column; k = channel, y in patch, x in
+   * patch: the Conv2d weight's own order, HF:models/vilt/modeling_vilt.py:290-300).  With it pixel_values may be NULL: the
+   * f32 NCHW tensor and the separate unfold pass (vault_im2col) are skipped.  H, W multiples of ps; ps % 4 == 0. */
+  void* patch_unfold_bf16; int ps;
 } vault_preprocess_args;
 int vault_image_preprocess(const vault_preprocess_args* args, void* stream);
 

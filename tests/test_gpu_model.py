@@ -728,7 +728,8 @@ def test_full_size_batch_48_forward_backward_vs_oracle():
     assert (tot_err / tot_ref) ** 0.5 < 2.5e-2                         # global relative L2 (1.0 % at B = 2)
     # same number format (8-bit gelu' grid in the ViLT FFN, bf16 gradient stream, bf16 dY / saved operands): the tight bound
     del eng
-    _assert_same_format_gradients(spec, state, bn, "full size B=48", 1e-2, SAME_FORMAT_DEEP_BOUNDS, gelu8=True, mutate=None)
+    # (at B = 48 the per-sample rounding noise averages out: measured 1.5e-3 globally, inside the 5e-3 of the shallow models)
+    _assert_same_format_gradients(spec, state, bn, "full size B=48", 5e-3, SAME_FORMAT_DEEP_BOUNDS, gelu8=True, mutate=None)
 
 
 @pytest.mark.parametrize("B", [2, 48])

@@ -60,6 +60,18 @@ def test_preprocessed_batch_feeds_the_model():
     eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0))
     out = eng.forward(batch, train=False)
     assert out["logits"].shape == (2, 3) and torch.isfinite(out["logits"]).all()
+    # the loader-facing form also returns the valid sizes it padded from: with that host-side hint the engine builds the patch
+    # grid of the mask itself (no device -> host read of pixel_mask per step) - same result; and the patch bookkeeping of a
+    # repeated geometry comes from the engine's cache
+    lg = out["logits"].clone()
+    host = torch.from_numpy(np.concatenate([im.reshape(-1) for im in imgs])).pin_memory()
+    px2 = DeviceImageProcessor(shortest_edge=96, size_divisor=16).from_packed(host, [im.shape[:2] for im in imgs])
+    assert px2["valid_hw"] == [(96, 144), (128, 96)]
+    n_cached = len(eng._sel_cache)
+    out2 = eng.forward(dict(batch, valid_hw=px2["valid_hw"]), train=False)
+    assert torch.equal(out2["logits"], lg) and len(eng._sel_cache) == n_cached == 1
+    with pytest.raises(ValueError):
+        eng.forward(dict(batch, valid_hw=[(96, 144)]), train=False)
 
 
 def test_packed_host_buffer_into_preallocated_outputs_on_a_side_stream():
@@ -84,3 +96,53 @@ def test_packed_host_buffer_into_preallocated_outputs_on_a_side_stream():
         proc.from_packed(host[:-3], sizes)
     with pytest.raises(ValueError):
         proc.from_packed(host, sizes, out={"pixel_values": torch.zeros(2, 3, 8, 8, device="cuda"), "pixel_mask": out["pixel_mask"]})
+
+
+def test_patch_unfold_straight_from_the_resize_kernel():
+    """``from_packed(patch_out=...)``: the patch-embedding GEMM's bf16 operand written by the vertical resize pass itself
+    (no f32 ``pixel_values`` tensor, no ``vault_im2col`` pass) equals bf16(unfold(pixel_values)) of the HF-exact pixels bit
+    for bit, for square and for padded non-square canvases; fed to the engine as ``pixel_patches`` it gives the logits of the
+    ``pixel_values`` path exactly, in ``TrainStep`` too."""
+    import torch.nn.functional as F
+    from vault_amd.engine import VaultEngine
+    from vault_amd.spec import VaultSpec, build_state, synthetic_batch
+    from vault_amd.train import TrainStep
+    rng = np.random.default_rng(21)
+    for sizes, kw, ps in (([(480, 480)] * 3, {}, 32), ([(100, 150), (384, 384), (200, 120)], {}, 32),
+                          ([(260, 260)] * 4, dict(shortest_edge=192, size_divisor=16), 16)):   # the tiny model's 192 x 192 canvas
+        proc = DeviceImageProcessor(**kw)
+        imgs = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in sizes]
+        host = torch.from_numpy(np.concatenate([im.reshape(-1) for im in imgs])).pin_memory()
+        ref = proc.from_packed(host, sizes)
+        pv = ref["pixel_values"]
+        B, _, H, W = pv.shape
+        rows, Kp = B * (H // ps) * (W // ps), 3 * ps * ps
+        want = F.unfold(pv, kernel_size=ps, stride=ps).transpose(1, 2).reshape(rows, Kp).bfloat16()
+        po = torch.full((rows, Kp), 7.0, dtype=torch.bfloat16, device="cuda")
+        res = proc.from_packed(host, sizes, patch_out=po, patch_size=ps)
+        torch.cuda.synchronize()
+        assert res["pixel_patches"] is po and "pixel_values" not in res and res["canvas"] == (H, W)
+        assert torch.equal(po, want) and torch.equal(res["pixel_mask"], ref["pixel_mask"])
+    # the tiny model (96 x 96 canvases, 16-pixel patches): same logits and the same training steps from either input form
+    spec = VaultSpec.tiny(3, "roberta")
+    spec.lm.hidden_dropout_prob = 0.0; spec.lm.attention_probs_dropout_prob = 0.0
+    bn = synthetic_batch(spec, 4, seed=2, n_classes=3)
+    ids, am = torch.from_numpy(bn["input_ids"]).cuda(), torch.from_numpy(bn["attention_mask"]).cuda()
+    labels = torch.from_numpy(bn["labels"]).cuda()
+    state = build_state(spec, 0)
+    outs, params = [], []
+    for form in ("pixel_values", "pixel_patches"):
+        eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+        img = {"pixel_values": pv} if form == "pixel_values" else {"pixel_patches": po}
+        batch = dict(input_ids=ids, attention_mask=am, **img)
+        outs.append(eng.forward(batch, train=False)["logits"].clone())
+        step = TrainStep(eng, learning_rate=1e-4, warmup_ratio=0.0, total_steps=10, assume_full_pixel_mask=True)
+        for _ in range(3):
+            step(batch, labels)
+        torch.cuda.synchronize()
+        params.append(eng.params.p.clone())
+    assert torch.equal(outs[0], outs[1])
+    d = (params[0] - params[1]).abs()
+    assert float(d.mean()) < 2e-6 and float((d > 2e-5).float().mean()) < 0.03      # float-atomic summation order only
+    with pytest.raises(ValueError):
+        eng.forward(dict(input_ids=ids, attention_mask=am, pixel_patches=po[:-1]), train=False)

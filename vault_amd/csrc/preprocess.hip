@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void resize_v_norm_pad_kernel(const uint8_t* _
                                                                 const vault_image_desc* __restrict__ desc,
                                                                 const float* __restrict__ lut, float* __restrict__ out,
                                                                 long long* __restrict__ mask, float* __restrict__ mask_f32,
-                                                                int H, int W) {
+                                                                int H, int W, bf16* __restrict__ unfold, int ps) {
   __shared__ float slut[3 * 256];
   for (int i = threadIdx.x; i < 3 * 256; i += 256) slut[i] = lut[i];
   __syncthreads();
@@ -132,9 +132,19 @@ __global__ __launch_bounds__(256) void resize_v_norm_pad_kernel(const uint8_t* _
 #pragma unroll
       for (int c = 0; c < 3; ++c) v[c][px] = slut[256 * c + clip8(acc[3 * px + c] >> PREC)];
   }
-  *reinterpret_cast<f32x4*>(out + o) = v[0];
-  *reinterpret_cast<f32x4*>(out + o + plane) = v[1];
-  *reinterpret_cast<f32x4*>(out + o + 2 * plane) = v[2];
+  if (out) {
+    *reinterpret_cast<f32x4*>(out + o) = v[0];
+    *reinterpret_cast<f32x4*>(out + o + plane) = v[1];
+    *reinterpret_cast<f32x4*>(out + o + 2 * plane) = v[2];
+  }
+  if (unfold) {   // four consecutive x of one patch row: four consecutive k of the unfold row, per channel
+    const int gw = W / ps, py = y / ps, px = x / ps;
+    const size_t row = ((size_t)b * (H / ps) + py) * gw + px;
+    bf16* u = unfold + row * (size_t)(3 * ps * ps) + (size_t)(y - py * ps) * ps + (x - px * ps);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      *reinterpret_cast<uint2*>(u + (size_t)c * ps * ps) = uint2{pack_bf16x2(v[c][0], v[c][1]), pack_bf16x2(v[c][2], v[c][3])};
+  }
   const size_t mo = (size_t)b * plane + (size_t)y * W + x;
   if (mask) {
     const long long m = inside ? 1 : 0;
@@ -147,7 +157,8 @@ __global__ __launch_bounds__(256) void resize_v_norm_pad_kernel(const uint8_t* _
 }  // namespace
 
 extern "C" int vault_image_preprocess(const vault_preprocess_args* a, void* stream) {
-  if (!a || !a->src || !a->tmp || !a->plan || !a->desc || !a->lut || !a->pixel_values || a->B <= 0 || a->H <= 0 || a->W <= 0 ||
+  if (!a || !a->src || !a->tmp || !a->plan || !a->desc || !a->lut || (!a->pixel_values && !a->patch_unfold_bf16) ||
+      (a->patch_unfold_bf16 && (a->ps <= 0 || (a->ps & 3) || a->H % a->ps || a->W % a->ps)) || a->B <= 0 || a->H <= 0 || a->W <= 0 ||
       a->max_h_in <= 0 || a->max_w_out <= 0 || a->max_h_in > 65535 || a->H > 65535 || a->B > 65535 || a->max_w_out > a->W ||
       (a->W & 3) || a->src_bytes <= 0 || a->max_w_in <= 0)
     return VAULT_EINVAL;
@@ -158,6 +169,7 @@ extern "C" int vault_image_preprocess(const vault_preprocess_args* a, void* stre
     hipLaunchKernelGGL(resize_h_wide_kernel, dim3((a->max_w_out + 255) / 256, a->max_h_in, a->B), dim3(256), 0, st, a->src, a->tmp,
                        a->plan, a->desc);
   hipLaunchKernelGGL(resize_v_norm_pad_kernel, dim3((a->W / 4 + 255) / 256, a->H, a->B), dim3(256), 0, st, a->tmp, a->plan, a->desc,
-                     a->lut, a->pixel_values, reinterpret_cast<long long*>(a->pixel_mask), a->pixel_mask_f32, a->H, a->W);
+                     a->lut, a->pixel_values, reinterpret_cast<long long*>(a->pixel_mask), a->pixel_mask_f32, a->H, a->W,
+                     reinterpret_cast<bf16*>(a->patch_unfold_bf16), a->ps);
   return (int)hipGetLastError();
 }

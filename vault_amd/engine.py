@@ -300,6 +300,7 @@ class VaultEngine:
             with torch.cuda.device(self.device):
                 self.params.enable_transposed([[getattr(ln, k) for ln in st] for st in stacks for k in ("ow", "fw")])
         self._ws: Dict[tuple, dict] = {}
+        self._sel_cache: Dict[tuple, dict] = {}      # patch bookkeeping of padded image batches, per patch-grid mask
         self.drop_seed = 0
         self.last: Optional[dict] = None
         self._wgrad_stream, self._wgrad_pending = None, False
@@ -590,6 +591,8 @@ class VaultEngine:
         iemb = batch.get("image_embeds")           # [B, L, H] f32 instead of pixels (HF modeling_vilt.py:190-207)
         if iemb is not None:
             return self._stage_image_embeds(batch, train, labels, ws_tag, ids, temb, iemb, B, T)
+        if batch.get("pixel_patches") is not None:
+            return self._stage_pixel_patches(batch, train, labels, ws_tag, ids, temb, B, T)
         pix = batch["pixel_values"]
         if pix.dim() != 4 or pix.shape[1] != v.num_channels or pix.shape[2] % v.patch_size or pix.shape[3] % v.patch_size:
             raise ValueError(f"pixel_values must be [B,{v.num_channels},HP,WP] with HP, WP multiples of the patch size "
@@ -607,23 +610,47 @@ class VaultEngine:
         # only the patch grid of the mask matters (nearest-neighbour interpolation reads pixel_mask[:, ::ps, ::ps]):
         # subsample on the device, bring B x gh x gw bytes to the host
         grid_h = None
-        if pm is not None and (validate or not square):
+        vhw = batch.get("valid_hw")    # host-side hint: the valid (h, w) pixels of every image, top-left on the canvas (what an
+        #                                image processor knows when it pads: DeviceImageProcessor returns it) - the patch
+        #                                grid of the mask is then built on the host, no device -> host read of pixel_mask
+        if vhw is not None:
+            vhw = tuple((int(h_), int(w_)) for h_, w_ in vhw)
+            if len(vhw) != B or any(h_ <= 0 or w_ <= 0 or h_ > HP or w_ > WP for h_, w_ in vhw):
+                raise ValueError("valid_hw must list (h, w) <= the canvas for every image of the batch")
+            ps = v.patch_size
+            grid_h = np.zeros((B, HP // ps, WP // ps), np.uint8)
+            for b_, (h_, w_) in enumerate(vhw):      # nearest-neighbour subsampling reads pixel (i ps, j ps): valid iff < (h, w)
+                grid_h[b_, :(h_ + ps - 1) // ps, :(w_ + ps - 1) // ps] = 1
+        elif pm is not None and (validate or not square):
             grid_h = (pm[:, ::v.patch_size, ::v.patch_size] != 0).to(torch.uint8).cpu().numpy()
         ragged = (not square) or (grid_h is not None and not bool(grid_h.all()))
         geom = (0, 0, 0)
         if ragged:
             if grid_h is None:
                 grid_h = np.ones((B, HP // v.patch_size, WP // v.patch_size), np.uint8)
-            sel, valid, hw, (gh, gw), L0 = select_patches(grid_h, 1, getattr(v, "max_image_length", -1))
-            # round the image part up to a multiple of 8 rows with more masked padding (fewer distinct geometries);
-            # the attention kernels hold at most 320 keys
-            cap = 320 - T - 1
-            if L0 > cap:
-                raise ValueError(f"fused sequence {T + 1 + L0} exceeds the attention kernels' 320 keys")
-            L = min(((L0 + 7) // 8) * 8, cap)
-            if L > L0:   # extra rows repeat the last slot and are masked like any padding
-                sel = np.concatenate([sel, np.repeat(sel[:, -1:], L - L0, axis=1)], axis=1)
-                valid = np.concatenate([valid, np.zeros((B, L - L0), np.int32)], axis=1)
+            # the bookkeeping of a batch depends on its patch-grid mask only: cached per mask (a data loader that buckets by
+            # size repeats geometries; a repeated batch costs a dictionary lookup instead of the per-sample host loops)
+            ckey = (T, grid_h.shape, grid_h.tobytes())
+            hit = self._sel_cache.get(ckey)
+            if hit is None:
+                sel, valid, hw, (gh, gw), L0 = select_patches(grid_h, 1, getattr(v, "max_image_length", -1))
+                # round the image part up to a multiple of 8 rows with more masked padding (fewer distinct geometries);
+                # the attention kernels hold at most 320 keys
+                cap = 320 - T - 1
+                if L0 > cap:
+                    raise ValueError(f"fused sequence {T + 1 + L0} exceeds the attention kernels' 320 keys")
+                L = min(((L0 + 7) // 8) * 8, cap)
+                if L > L0:   # extra rows repeat the last slot and are masked like any padding
+                    sel = np.concatenate([sel, np.repeat(sel[:, -1:], L - L0, axis=1)], axis=1)
+                    valid = np.concatenate([valid, np.zeros((B, L - L0), np.int32)], axis=1)
+                hit = dict(L=L, gw=gw, n_valid=valid.sum(axis=1),
+                           sel=torch.from_numpy(np.ascontiguousarray(sel)).to(self.device),
+                           hw=torch.from_numpy(np.ascontiguousarray(hw)).to(self.device),
+                           valid=torch.from_numpy(valid.astype(np.float32)).to(self.device))
+                if len(self._sel_cache) >= 64:
+                    self._sel_cache.pop(next(iter(self._sel_cache)))
+                self._sel_cache[ckey] = hit
+            L, gw = hit["L"], hit["gw"]
             geom = (L, HP, WP)
             NP = L
         else:
@@ -636,6 +663,7 @@ class VaultEngine:
         self._stage_text(ws, ids, temb, B, T, H)
         buf("in_pix", tuple(pix.shape)).copy_(pix)
         ws["img_embeds"] = None
+        ws["patches_in"] = False
         km = buf("keymask", (B, S))
         am = batch.get("attention_mask")
         if am is None:
@@ -645,10 +673,10 @@ class VaultEngine:
             km[:, T:] = 1.0
         if ragged:
             ws["gw"] = gw
-            buf("in_sel", (B, NP), torch.int32).copy_(torch.from_numpy(np.ascontiguousarray(sel)))
-            buf("in_hw", (B, 2), torch.int32).copy_(torch.from_numpy(np.ascontiguousarray(hw)))
-            km[:, T + 1:] = torch.from_numpy(valid.astype(np.float32)).to(km.device)
-            ws["sel"], ws["hw"], ws["n_valid"] = ws["in_sel"], ws["in_hw"], valid.sum(axis=1)
+            buf("in_sel", (B, NP), torch.int32).copy_(hit["sel"])      # (device-to-device from the cached bookkeeping)
+            buf("in_hw", (B, 2), torch.int32).copy_(hit["hw"])
+            km[:, T + 1:] = hit["valid"]
+            ws["sel"], ws["hw"], ws["n_valid"] = ws["in_sel"], ws["in_hw"], hit["n_valid"]
         buf("in_amf", (B, T)).copy_(km[:, :T])
         tt = batch.get("token_type_ids")
         ws["ids"], ws["pix"], ws["amf"] = ws["in_ids"], ws["in_pix"], ws["in_amf"]
@@ -668,6 +696,41 @@ class VaultEngine:
             idb.fill_(pad + 1)
             ws["txt_embeds"] = self._buf(ws, "in_temb", (_pad(B * T), H), torch.float32)
             ws["txt_embeds"][:B * T].copy_(temb.reshape(B * T, H))
+
+    def _stage_pixel_patches(self, batch, train, labels, ws_tag, ids, temb, B, T):
+        """Staging for images that arrive as the patch-embedding GEMM's operand: ``pixel_patches`` = the bf16 unfold
+        [B * patches, C ps ps] of square, fully valid ``image_size`` canvases (what ``vault_image_preprocess`` writes straight
+        from its resize kernel: ``DeviceImageProcessor.from_packed(patch_out=...)``).  The f32 pixel tensor and the unfold pass
+        do not exist on this path; a ``pixel_mask``, if given, must be all ones (not checked: it would synchronise)."""
+        v = self.spec.vilt
+        H, FF, heads = v.hidden_size, v.intermediate_size, v.num_attention_heads
+        NP, Kp = v.num_patches, v.num_channels * v.patch_size * v.patch_size
+        pp = batch["pixel_patches"]
+        if pp.dtype != torch.bfloat16 or pp.numel() != B * NP * Kp:
+            raise ValueError(f"pixel_patches must be bf16 [{B} * {NP}, {Kp}] (square {v.image_size} x {v.image_size} canvases)")
+        S = T + 1 + NP
+        ws = self.workspace(B, T, train, (0, 0, 0), ws_tag)
+        ws.update(S=S, M=B * S, Mp=_pad(B * S), H=H, FF=FF, heads=heads, NP=NP, train=train, Ml=B * T, Mlp=_pad(B * T),
+                  ragged=False, HP=v.image_size, WP=v.image_size)
+        buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
+        self._stage_text(ws, ids, temb, B, T, H)
+        ap = buf("apatch", (_pad(B * NP), Kp), torch.bfloat16)
+        ap[:B * NP].copy_(pp.reshape(B * NP, Kp))          # (onto itself when the caller wrote into input_buffers()["pixel_patches"])
+        ws["img_embeds"] = None
+        km = buf("keymask", (B, S))
+        am = batch.get("attention_mask")
+        if am is None:
+            km.fill_(1.0)
+        else:
+            km[:, :T] = am
+            km[:, T:] = 1.0
+        buf("in_amf", (B, T)).copy_(km[:, :T])
+        tt = batch.get("token_type_ids")
+        ws["ids"], ws["pix"], ws["amf"] = ws["in_ids"], None, ws["in_amf"]
+        ws["tt"] = None if tt is None else buf("in_tt", (B, T), torch.int64).copy_(tt)
+        ws["labels"] = self._stage_labels(buf, labels, B)
+        ws["patches_in"] = True
+        return ws
 
     def _stage_image_embeds(self, batch, train, labels, ws_tag, ids, temb, iemb, B, T):
         """Staging for externally supplied image embeddings: the image part of the fused sequence is ``image_embeds`` +
@@ -718,8 +781,11 @@ class VaultEngine:
         v = self.spec.vilt
         ws = self.workspace(B, T, train)
         buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
+        Kp = v.num_channels * v.patch_size * v.patch_size
         return {"input_ids": buf("in_ids", (B, T), torch.int64),
                 "pixel_values": buf("in_pix", (B, v.num_channels, v.image_size, v.image_size)),
+                # (alternative image input: the bf16 patch unfold, _stage_pixel_patches - the patch-embedding GEMM's own operand)
+                "pixel_patches": buf("apatch", (_pad(B * v.num_patches), Kp), torch.bfloat16)[:B * v.num_patches],
                 "labels": buf("in_labels", (B,), torch.int64)}
 
     def _forward(self, batch, train, labels, need_hidden, loss_scale, precise=False, ws_tag=0, image_type_idx=1,
@@ -875,7 +941,11 @@ class VaultEngine:
             ops.image_sel_consts(P.w("embeddings.patch_embeddings.projection.bias"), P.w("embeddings.position_embeddings"),
                                  mt[ws.get("img_type", 1)], P.w("embeddings.cls_token"), addtab, x[0], NP, H, B, S, T)
         else:
-            ops.im2col(pix, apatch, B, v.num_channels, v.image_size, v.patch_size, split3=pr)
+            if ws.get("patches_in"):
+                if pr:
+                    raise ValueError("pixel_patches carry bf16 pixels: the precise (split-bf16) mode needs pixel_values")
+            else:
+                ops.im2col(pix, apatch, B, v.num_channels, v.image_size, v.patch_size, split3=pr)
             ops.image_consts(P.w("embeddings.patch_embeddings.projection.bias"), P.w("embeddings.position_embeddings"),
                              mt[ws.get("img_type", 1)], P.w("embeddings.cls_token"), addtab, x[0], NP, H, B, S, T)
         ops.gemm(apatch, P.wb3(wpn, H, Kp) if pr else P.wb(wpn, shape=(H, Kp)), x[0], Mpp, H, W3 * Kp, W3 * Kp, W3 * Kp,

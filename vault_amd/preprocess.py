@@ -9,7 +9,7 @@ The result equals the HuggingFace processor's bit for bit (tests/test_gpu_prepro
 """
 import ctypes as C
 from functools import lru_cache
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -28,7 +28,8 @@ class ImageDesc(C.Structure):
 class PreprocessArgs(C.Structure):
     """vault_preprocess_args (include/vault_hip.h)."""
     _fields_ = [(n, C.c_void_p) for n in ("src", "tmp", "plan", "desc", "lut", "pixel_values", "pixel_mask", "pixel_mask_f32")] + [
-        (n, C.c_int) for n in ("B", "H", "W", "max_h_in", "max_w_out", "max_w_in")] + [("src_bytes", C.c_longlong)]
+        (n, C.c_int) for n in ("B", "H", "W", "max_h_in", "max_w_out", "max_w_in")] + [("src_bytes", C.c_longlong),
+                                                                                        ("patch_unfold_bf16", C.c_void_p), ("ps", C.c_int)]
 
 
 def resize_output_size(h: int, w: int, shorter: int = 384, size_divisor: int = 32) -> Tuple[int, int]:
@@ -161,13 +162,18 @@ class DeviceImageProcessor:
         for im in imgs:
             hv[o:o + im.size] = im.reshape(-1)
             o += im.size
-        return self.from_packed(host, [im.shape[:2] for im in imgs])
+        out = self.from_packed(host, [im.shape[:2] for im in imgs])
+        return {"pixel_values": out["pixel_values"], "pixel_mask": out["pixel_mask"]}   # (the HF processor's keys only)
 
-    def from_packed(self, host_u8: torch.Tensor, sizes, out: Dict[str, torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    def from_packed(self, host_u8: torch.Tensor, sizes, out: Dict[str, torch.Tensor] = None,
+                    patch_out: Optional[torch.Tensor] = None, patch_size: int = 32) -> Dict[str, torch.Tensor]:
         """The loader-facing form: ``host_u8`` = the images back to back ([h][w][3] uint8 each, ``sizes`` = their (h, w)) in ONE
         host tensor - pinned, as a decoder writing straight into a staging buffer leaves them - copied and processed on the
         current stream.  ``out``: optional preallocated ``pixel_values`` / ``pixel_mask`` of the batch's padded shape (e.g. the
-        engine's own input staging buffers: no device-to-device copy afterwards)."""
+        engine's own input staging buffers: no device-to-device copy afterwards).  ``patch_out``: a bf16
+        [B * (H / ps) * (W / ps), 3 ps ps] tensor that receives the patch-embedding GEMM's operand (the unfold of the
+        padded canvas) straight from the resize kernel; the f32 ``pixel_values`` tensor is then not written at all
+        (the returned dict carries ``pixel_patches`` instead): hand that to the engine as ``batch["pixel_patches"]``."""
         sizes = [tuple(int(v) for v in hw) for hw in sizes]
         B = len(sizes)
         key = tuple(sizes)
@@ -183,15 +189,24 @@ class DeviceImageProcessor:
         dev = self.device
         with torch.cuda.device(dev):
             src = host_u8.to(dev, non_blocking=True)
-            pv = out["pixel_values"] if out is not None else torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
+            pv = None
+            if patch_out is None:
+                pv = out["pixel_values"] if out is not None else torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
+            else:
+                ps = int(patch_size)
+                if H % ps or W % ps or ps % 4 or patch_out.dtype != torch.bfloat16 or not patch_out.is_contiguous() or \
+                        patch_out.numel() < B * (H // ps) * (W // ps) * 3 * ps * ps:
+                    raise ValueError(f"patch_out must be contiguous bf16 with >= {B * (H // ps) * (W // ps)} rows of {3 * ps * ps}")
             pm = out["pixel_mask"] if out is not None else torch.empty(B, H, W, dtype=self.mask_dtype, device=dev)
-            if tuple(pv.shape) != (B, 3, H, W) or pv.dtype != torch.float32 or tuple(pm.shape) != (B, H, W) or pm.dtype != self.mask_dtype:
+            if (pv is not None and (tuple(pv.shape) != (B, 3, H, W) or pv.dtype != torch.float32)) or tuple(pm.shape) != (B, H, W) or pm.dtype != self.mask_dtype:
                 raise ValueError(f"out tensors must be pixel_values [{B},3,{H},{W}] float32 and pixel_mask [{B},{H},{W}] {self.mask_dtype}")
             if self.mask_dtype not in (torch.int64, torch.float32):
                 raise ValueError("mask_dtype must be torch.int64 (HF) or torch.float32")
             a = PreprocessArgs()
             a.src, a.tmp, a.plan, a.desc, a.lut, a.pixel_values = (src.data_ptr(), tmp.data_ptr(), plan_d.data_ptr(), desc_d.data_ptr(),
-                                                                   self._lut.data_ptr(), pv.data_ptr())
+                                                                   self._lut.data_ptr(), None if pv is None else pv.data_ptr())
+            if patch_out is not None:
+                a.patch_unfold_bf16, a.ps = patch_out.data_ptr(), int(patch_size)
             if self.mask_dtype == torch.int64:
                 a.pixel_mask = pm.data_ptr()
             else:
@@ -203,4 +218,9 @@ class DeviceImageProcessor:
             # (src is freed on this stream after the launches; plan / descriptors / intermediate belong to the cached plan: a
             #  batch of other sizes on ANOTHER stream must not start before this one has passed them)
             src.record_stream(torch.cuda.current_stream())
-        return {"pixel_values": pv, "pixel_mask": pm}
+        # valid_hw: the resized (h, w) of every image on the padded canvas, known on the host - passed on to the engine
+        # (batch["valid_hw"]) it replaces the device -> host read of the pixel mask in the padded-image path
+        valid_hw = [resize_output_size(h, w, self.shortest_edge, self.size_divisor) for h, w in sizes]
+        if patch_out is not None:
+            return {"pixel_patches": patch_out, "pixel_mask": pm, "canvas": (H, W), "valid_hw": valid_hw}
+        return {"pixel_values": pv, "pixel_mask": pm, "valid_hw": valid_hw}

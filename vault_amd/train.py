@@ -394,7 +394,7 @@ class TrainStep:
             # what the recorded launches bake in besides the buffers of the (B, T, geometry) workspace: whether token
             # types were given, the launch stream, the GEMM scheduling mode and the forward number format
             key = ws["key"] + (ws["tt"] is None, torch.cuda.current_stream().cuda_stream, ops.GEMM_SCHED,
-                               bool(eng.fp8_forward), labels.dtype.is_floating_point)
+                               bool(eng.fp8_forward), labels.dtype.is_floating_point, bool(ws.get("patches_in")))
             if self.reducer:
                 # the token ids of every rank name the rows of the word-embedding table this step touches: their
                 # all-gather + union start now on the communication stream (inputs_embeds: no row is touched)
