@@ -651,7 +651,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
 #else
 #define ATTN_STORE16(ptr, val) (*reinterpret_cast<u32x4*>(ptr) = (val))
 #endif
-constexpr int DS_LD = 416;   // bytes per row of the dS^T image (192 queries x 2 B = 384, padded)
+// bytes per row of the dS^T image: SK queries x 2 B + 32 of padding - 104 dwords at SK = 192, 40 at SK = 64, both = 40 mod 64:
+// the 8 rows a transposed read touches per cycle then start 40 r mod 64 = 0, 40, 16, 56, 32, 8, 48, 24 dwords apart
+// (8 disjoint runs of 8 banks), and the 8-byte stores of 16 consecutive keys are at most 2-way
+template <int SK> constexpr int ds_ld() { return SK * 2 + 32; }
 
 // Global loads and LDS-DMA of the single-pass kernel through inline asm: scalar base + 32-bit lane offset (no 64-bit
 // address registers: the kernel lives at the 168-register edge of three waves per SIMD), and - the point - hipcc keeps no
@@ -676,12 +679,13 @@ __device__ __forceinline__ const char* attn_uniform(const void* p) {
                                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u));
 }
 
-template <int NKT, int NWV, bool DROP = true>
-__global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_one_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
+template <int NKT, int NWV, bool DROP = true, int WPE = 1>
+__global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
                                                          const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
                                                          const float* __restrict__ lse, bf16* __restrict__ dqkv, int S,
                                                          int H, int heads, int items, float scale, AttnDrop dr) {
   constexpr int SK = NKT * 32;
+  constexpr int DS_LD = ds_ld<SK>();
   constexpr int NT = NWV * 64;
   constexpr int NC = (SK * 8) / NT;   // 16-byte chunks per thread and matrix
   static_assert(2 * NKT == NWV, "one 16-row tile per wave");
@@ -948,7 +952,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_one_kernel(const bf16* _
 }
 
 template <int NKT>
-constexpr int attn_one_lds_bytes() { return NKT * 32 * 128 * 3 + NKT * 32 * DS_LD + NKT * 32 * 4 * 3; }
+constexpr int attn_one_lds_bytes() { return NKT * 32 * 128 * 3 + NKT * 32 * ds_ld<NKT * 32>() + NKT * 32 * 4 * 3; }
 
 template <int NKT>
 constexpr int attn_res_lds_bytes() { return NKT * 32 * 128 * 4 + NKT * 32 * 4 * 3; }
@@ -1038,7 +1042,21 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
                          reinterpret_cast<const bf16*>(a->dctx), a->lse, reinterpret_cast<bf16*>(a->dqkv), a->S, a->H,        \
                          a->heads, items, scale, dr);                                                                         \
     }
-  if (a->S <= 64) {
+  static const bool one_pass_s = [] { const char* e = getenv("VAULT_ATTN_BWD_S"); return !(e && e[0] == '0'); }();   // development A/B switch
+  if (a->S <= 64 && one_pass_s) {
+    // text-only sequences (the LM stack): the single-pass kernel with four waves per workgroup (one 16-key tile each) and
+    // three workgroups per CU (35 KiB of LDS, <= 168 registers), persistent over the (batch, head) items
+    const int items = a->B * a->heads;
+    const int grid = items < 768 ? items : 768;
+    if (drop) hipLaunchKernelGGL((attn_bwd_one_kernel<2, 4, true, 3>), dim3(grid), dim3(256), attn_one_lds_bytes<2>(), st,
+                                 reinterpret_cast<const bf16*>(a->qkv), a->keymask, reinterpret_cast<const bf16*>(a->ctx),
+                                 reinterpret_cast<const bf16*>(a->dctx), a->lse, reinterpret_cast<bf16*>(a->dqkv), a->S, a->H,
+                                 a->heads, items, scale, dr);
+    else hipLaunchKernelGGL((attn_bwd_one_kernel<2, 4, false, 3>), dim3(grid), dim3(256), attn_one_lds_bytes<2>(), st,
+                            reinterpret_cast<const bf16*>(a->qkv), a->keymask, reinterpret_cast<const bf16*>(a->ctx),
+                            reinterpret_cast<const bf16*>(a->dctx), a->lse, reinterpret_cast<bf16*>(a->dqkv), a->S, a->H,
+                            a->heads, items, scale, dr);
+  } else if (a->S <= 64) {
     if (drop) OLD_V(2, true); else OLD_V(2, false);
   } else if (a->S <= 192) {
     const int items = a->B * a->heads;
