@@ -512,6 +512,37 @@ def test_single_image_and_caption_through_vaultmodel_full_size():
     np.testing.assert_allclose(pn, g["hidden_patch_sorted_norms"][:1], rtol=5e-3)
 
 
+def test_output_hidden_states_against_the_oracle_taps():
+    """``VaultModel(..., output_hidden_states=True)``: HF's tuple of num_hidden_layers + 1 tensors - the embedding output and
+    every ViLT layer's output (the residual stream before the final LayerNorm) - against the oracle's taps of the same
+    quantities, in eval mode (the engine then keeps one buffer per layer instead of ping-ponging) and in train mode;
+    ``output_attentions`` still raises."""
+    from vault_amd.models.vault import VaultModel
+    spec = _nodrop(VaultSpec.tiny(0, "roberta"))
+    bn = synthetic_batch(spec, 3, seed=8)
+    state = build_state(spec, 0)
+    m = VaultModel(spec.vilt, bert_config=spec.lm, vilt_dropout_prob=0.0)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    m = m.to("cuda")
+    kw = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
+    taps = {}
+    ref = O.vault_forward(O.to_torch_state(state), spec, O.torch_batch(bn), taps=taps)
+    want = [taps["vilt_embed"]] + [taps[f"vilt_layer{i}"] for i in range(spec.vilt.num_hidden_layers)]
+    for mode in ("eval", "train"):
+        (m.eval() if mode == "eval" else m.train())
+        import contextlib
+        with (torch.no_grad() if mode == "eval" else contextlib.nullcontext()):
+            o = m(**kw, output_hidden_states=True)
+            plain = m(**kw)
+        assert plain.hidden_states is None and len(o.hidden_states) == spec.vilt.num_hidden_layers + 1
+        assert torch.equal(o.last_hidden_state, plain.last_hidden_state)
+        for got, w in zip(o.hidden_states, want):
+            assert got.shape == w.shape and not got.requires_grad
+            assert (got.cpu() - w).abs().max() < 1e-2 * w.abs().max()
+    with pytest.raises(NotImplementedError):
+        m(**kw, output_attentions=True)
+
+
 def test_eval_determinism_and_no_lm():
     spec = VaultSpec.tiny(3, "roberta")
     spec_nolm = VaultSpec(vilt=spec.vilt, lm=None, n_classes=0)

@@ -300,6 +300,7 @@ class VaultEngine:
             with torch.cuda.device(self.device):
                 self.params.enable_transposed([[getattr(ln, k) for ln in st] for st in stacks for k in ("ow", "fw")])
         self._ws: Dict[tuple, dict] = {}
+        self.keep_layer_outputs = False              # eval-mode forward: one residual-stream buffer per layer (output_hidden_states)
         self._sel_cache: Dict[tuple, dict] = {}      # patch bookkeeping of padded image batches, per patch-grid mask
         self.drop_seed = 0
         self.last: Optional[dict] = None
@@ -910,7 +911,7 @@ class VaultEngine:
 
         # ------------------------------ ViLT embeddings ------------------------------
         nv = v.num_hidden_layers
-        x = [buf(f"x{i}" if train else f"x{i % 2}", (Mp, H)) for i in range(nv + 1)]
+        x = [buf(f"x{i}" if (train or self.keep_layer_outputs) else f"x{i % 2}", (Mp, H)) for i in range(nv + 1)]
         vsum = buf("vt_sum", (Mlp, H))
         ops.gather_sum(text_src, vsum, tables, Ml, H, period=T)
         mt = P.w("embeddings.token_type_embeddings.weight")

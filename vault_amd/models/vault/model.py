@@ -24,7 +24,7 @@ rows in ``last_hidden_state`` is row-major (the reference's is random), padding 
 ``inputs_embeds`` (text embeddings in place of token ids: fed to the LM, or to ViLT's text embeddings without one) and
 ``image_embeds`` (image-token embeddings in place of pixels, ``pixel_mask`` [B, L] as their key mask: only the modality
 type is added, as in HF ``ViltEmbeddings.forward``) are taken, and their gradients flow back to the caller.
-Not implemented in this build (raise): ``head_mask``, ``output_attentions`` / ``output_hidden_states``.
+Not implemented in this build (raise): ``head_mask``, ``output_attentions``; ``output_hidden_states`` returns detached copies.
 
 There is no CPU or eager-PyTorch compute path: forward raises if the model is not on a GPU or the
 HIP library is missing.
@@ -480,8 +480,12 @@ class VaultMixin(nn.Module):
             raise ValueError("You have to specify either pixel_values or image_embeds")
         if (pix if pix is not None else iemb).shape[0] != (ids if ids is not None else emb).shape[0]:
             raise ValueError("The text inputs and image inputs need to have the same batch size")
-        if kw.get("output_attentions") or kw.get("output_hidden_states"):
-            raise NotImplementedError("output_attentions / output_hidden_states are not implemented in this build")
+        if kw.get("output_attentions"):
+            raise NotImplementedError("output_attentions is not implemented in this build (attention probabilities never leave registers)")
+        # output_hidden_states: the f32 residual stream entering every ViLT layer + the last layer's output (HF's tuple of
+        # num_hidden_layers + 1 tensors), returned detached by VaultModel.forward; the task heads return logits only, like the
+        # reference's (ref model.py:567-570), so for them the flag changes nothing
+        self._want_hidden_states = bool(kw.get("output_hidden_states"))
         if self._engine is None:
             raise RuntimeError("VaultModel has no CPU path: move the model to a GPU (model.to('cuda')) first")
         dev = self._engine.device
@@ -527,15 +531,24 @@ class VaultMixin(nn.Module):
         return self.forward(*args, **kwargs)
 
     def forward(self, *args, **kwargs):
+        if self._engine is not None:
+            # (decided before the pass: an eval-mode forward otherwise ping-pongs between two residual-stream buffers)
+            # (positional index 10 of the pinned ViltModel.forward signature, see _collect_batch)
+            self._engine.keep_layer_outputs = bool(kwargs.get("output_hidden_states", args[10] if len(args) > 10 else None))
         out = self._run(args, kwargs, want_logits=False)
         if isinstance(out, tuple):
             hid, pooled = out
         else:
             hid, pooled = out, None
+        hs = None
+        if getattr(self, "_want_hidden_states", False):
+            ws = self._engine.last
+            B, S, H = hid.shape
+            hs = tuple(x[:B * S].view(B, S, H).clone() for x in ws["x"])      # detached copies of the engine's buffers
         rd = kwargs.get("return_dict", True)
         if rd is False:
-            return (hid, pooled)
-        return BaseModelOutputWithPooling(last_hidden_state=hid, pooler_output=pooled)
+            return (hid, pooled) if hs is None else (hid, pooled, hs)
+        return BaseModelOutputWithPooling(last_hidden_state=hid, pooler_output=pooled, hidden_states=hs)
 
 
 class _Cfg:
