@@ -235,24 +235,31 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void ln_bwd_kernel(const bf
   }
 }
 
-// out[n] += sum over rows < rows of in[row][n]  (bias gradients); N % 256 == 0
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ in, int ld, int rows, int rows_per_block,
-                                                     float* __restrict__ out) {
-  __shared__ float red[4][256];
+// out[n] += sum over rows < rows of in[row][n]  (bias gradients); N % 256 == 0.  16-wave blocks, 256 row blocks: the float
+// atomics of all row blocks land on the same N addresses (thousands of adds per address serialise in the memory-side
+// atomic units: 3072 four-wave blocks took 30 us for 73 MB, the adds alone ~25 of them), so few, wide blocks
+__global__ __launch_bounds__(1024) void colsum_kernel(const bf16* __restrict__ in, int ld, int rows, int rows_per_block,
+                                                      float* __restrict__ out) {
+  __shared__ float red[16][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c0 = blockIdx.x * 256 + lane * 4;
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  for (int r = r0 + wave; r < r1; r += 4) {
+  for (int r = r0 + wave; r < r1; r += 16) {
     const uint2 w = *reinterpret_cast<const uint2*>(in + (size_t)r * ld + c0);
     const float2 x = unpack_bf16x2(w.x), y = unpack_bf16x2(w.y);
     a0 += x.x; a1 += x.y; a2 += y.x; a3 += y.y;
   }
   red[wave][lane * 4] = a0; red[wave][lane * 4 + 1] = a1; red[wave][lane * 4 + 2] = a2; red[wave][lane * 4 + 3] = a3;
   __syncthreads();
-  const int c = threadIdx.x;
-  atomicAdd(out + blockIdx.x * 256 + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  if (threadIdx.x < 256) {
+    const int c = threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][c];
+    atomicAdd(out + blockIdx.x * 256 + c, t);
+  }
 }
 
 }  // namespace
@@ -309,13 +316,11 @@ extern "C" int vault_layernorm_bwd(const vault_ln_bwd_args* a, void* stream) {
 
 extern "C" int vault_colsum(const void* in_bf16, int ld, int rows, int N, float* out, void* stream) {
   if (!in_bf16 || !out || N % 256 || rows <= 0) return VAULT_EINVAL;
-  // ~3072 blocks whatever the width (a wave walks its rows one 512-byte read at a time: few blocks = latency-bound;
-  // N = 768 with 128 row blocks took 41 us for a third of the bytes the N = 2304 launch moves in 30 us)
-  const int row_blocks = std::max(128, 3072 / (N / 256));
+  const int row_blocks = 256;
   int rpb = (rows + row_blocks - 1) / row_blocks;
-  rpb = ((rpb + 3) / 4) * 4;
+  rpb = ((rpb + 15) / 16) * 16;
   dim3 grid(N / 256, (rows + rpb - 1) / rpb);
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<const bf16*>(in_bf16), ld, rows, rpb, out);
   return (int)hipGetLastError();
 }
