@@ -264,7 +264,9 @@ def main():
                   "mode": ("mxfp8 forward GEMMs" if args.fp8_forward else "bf16 MFMA operands, fp32 accumulate (the timed mode)"),
                   "max_abs_dlogits": round(par["fast"]["max_abs_dlogits"], 6), "dloss": round(par["fast"]["dloss"], 6),
                   "north_star_tolerance": 1e-3,
-                  "precise_mode": {"what": "inference-only split-bf16 (bf16x3) GEMMs: fp32-class products on the bf16 MFMA path",
+                  "precise_mode": {"what": "split-bf16 (bf16x3) forward GEMMs: fp32-class products on the bf16 MFMA path - as an inference "
+                                           "mode, and as a training mode (TrainStep(precise_forward=True): this forward + the bf16 "
+                                           "backward; precise_forward_train_samples_per_s)",
                                    "max_abs_dlogits": round(par["precise"]["max_abs_dlogits"], 6),
                                    "dloss": round(par["precise"]["dloss"], 6)}}
     bn = synthetic_batch(spec, B, seed=1234 + rank, n_classes=3)
@@ -432,6 +434,19 @@ def main():
         tf = (time.perf_counter() - t0) / 5
         precise_fwd = {"precise_forward_samples_per_s": round(B / tp, 1), "fast_forward_samples_per_s": round(B / tf, 1),
                        "batch": B}
+        if world == 1:
+            # ... and as a TRAINING mode: split-bf16 forward GEMMs (logits / loss of the step inside 1e-3), bf16 backward
+            pstep = TrainStep(eng, learning_rate=2e-5, warmup_ratio=0.1, total_steps=100, assume_full_pixel_mask=True,
+                              precise_forward=True)
+            for _ in range(2):
+                pstep(batch, labels)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                pstep(batch, labels)
+            torch.cuda.synchronize(dev)
+            precise_fwd["precise_forward_train_samples_per_s"] = round(B * 5 / (time.perf_counter() - t0), 1)
+            del pstep
 
     # ---- the other BASELINE configurations, each a short loop on its own engine (rank 0 prints them in `other_configs`):
     #      per-GPU batch 64 (config 2 on one GPU, config 3's per-GPU shape on N), and on one GPU the frozen-LM and fp8-forward ones
@@ -481,10 +496,10 @@ def main():
         r_wgrad = roof("wgrad", "gemm256_kernel<1,1,5,4> (A[K][M]^T B[K][N], EPI_F32_ATOMIC): the weight-gradient GEMMs, "
                                 f"dW[N x K] += dY[tokens][N]^T X[tokens][K] - batched launches of 6 layers each ({M} ViLT tokens / "
                                 f"{B * 40} LM tokens per layer; FFN-out, FFN-in, attention-out, QKV) and the patch projection",
-                       "r02_pmc_gemm_wgrad.json")
+                       "r03_pmc_gemm_wgrad.json")
         r_ffn1 = roof("ffn1", "gemm8w_kernel<7,4> / <1,4> (GELU epilogue with the 8-bit tile-native / bf16 gelu', 256-wide tiles, register-direct): FFN-in forward, ViLT "
                               f"[{M}x{v.intermediate_size}x{v.hidden_size}] + LM [{B * 40}x{v.intermediate_size}x{v.hidden_size}]",
-                      "r02_pmc_gemm_ffn1.json")
+                      "r03_pmc_gemm_ffn1.json")
         out = {
             "metric": "train samples/sec (img+text pairs) ViLT-B32+BERTweet, bs256, 1/2/4/8 MI355X",
             "value": round(sps, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -659,6 +659,73 @@ def test_precise_mode_meets_the_1e3_logits_bar():
     assert np.abs(out2["logits"].cpu().numpy() - g["logits"]).max() < 8e-3
 
 
+def test_precise_forward_training_step_meets_the_1e3_bar_with_bf16_level_gradients():
+    """A TRAINING step whose logits / loss are inside the north star's 1e-3: split-bf16 forward GEMMs (``precise=True`` with
+    ``train=True``), bf16 backward on the plain bf16 operands kept beside the split ones.  Full size against the reference
+    golden: logits / loss < 1e-3 in train mode, gradients at the fast mode's bf16 level; then ``TrainStep(precise_forward=True)``
+    for three steps against the fp32 oracle's trajectory (tape replay included: the split weight shadow is re-derived from the
+    weights the optimizer wrote in every step)."""
+    from vault_amd.train import TrainStep
+    # three optimisation steps on the tiny model, against the fp32 oracle stepping with the HF-AdamW formula
+    spec = _nodrop(VaultSpec.tiny(3, "roberta"))
+    bn = synthetic_batch(spec, 4, seed=31, n_classes=3)
+    state = build_state(spec, 0)
+    tb = O.torch_batch(bn)
+    P = O.to_torch_state(state, requires_grad=True)
+    m = {k: torch.zeros_like(v) for k, v in P.items()}; v2 = {k: torch.zeros_like(v) for k, v in P.items()}
+    ref = []
+    for t in range(1, 4):
+        for p_ in P.values():
+            p_.grad = None
+        loss, _ = O.vault_loss(P, spec, tb)
+        loss.backward()
+        ref.append(float(loss.detach()))
+        with torch.no_grad():
+            for k, p_ in P.items():
+                if p_.grad is not None:
+                    O.hf_adamw_step(p_, p_.grad, m[k], v2[k], 5e-5, t)
+    db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
+    labels = torch.from_numpy(bn["labels"]).cuda()
+    for use_tape in (False, True):
+        eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+        step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10, constant_lr=True, use_tape=use_tape,
+                         precise_forward=True)
+        losses = [float(step(db, labels)) for _ in range(3)]
+        assert abs(losses[0] - ref[0]) < 2e-4, (losses, ref)            # the first loss is a pure forward quantity: fp32 class
+        assert max(abs(a - b) for a, b in zip(losses, ref)) < 2e-3, (losses, ref)
+        del eng, step
+    # ---- full size, reference golden
+    g = np.load(os.path.join(GOLD, "full_bertweet_b2.npz"))
+    spec = _nodrop(VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3))
+    B = int(g["meta_batch"])
+    bn = synthetic_batch(spec, B, seed=int(g["meta_data_seed"]), n_classes=3)
+    state = build_state(spec, 0)
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    db = _dev(bn)
+    out = eng.forward(db, train=True, labels=db["labels"], need_hidden=False, precise=True)
+    eng.zero_grad()
+    eng.backward()
+    torch.cuda.synchronize()
+    dl = np.abs(out["logits"].cpu().numpy() - g["logits"]).max()
+    dloss = abs(float(out["loss"]) - float(g["loss"]))
+    print(f"precise-forward training step: |dlogits| {dl:.2e} |dloss| {dloss:.2e}")
+    assert dl < 1e-3 and dloss < 1e-3
+    names = [str(n) for n in g["grad_names"]]
+    bad = []
+    for n, rn in zip(names, g["grad_norms"]):
+        if ".key.bias" in n:
+            continue
+        mine = float(eng.params.gr(n).double().norm())
+        if abs(mine - rn) > 0.08 * rn + 1e-7:
+            bad.append((n, mine, rn))
+    assert not bad, bad[:5]
+    for k in g.files:
+        if k.startswith("grad::") and ".key.bias" not in k:
+            mine = eng.params.gr(k[6:]).cpu().numpy().reshape(g[k].shape)
+            rel = np.linalg.norm(mine - g[k]) / (np.linalg.norm(g[k]) + 1e-12)
+            assert rel < 8e-2, (k, rel)
+
+
 @pytest.mark.parametrize("kind,seed", [("roberta", 11), ("bert", 12)])
 def test_precise_mode_tiny(kind, seed):
     spec = _nodrop(VaultSpec.tiny(3, kind))

@@ -257,7 +257,7 @@ def _dp_worker(rank, world, port, out_path, kind, nsteps, use_tape, wire, sparse
         losses, wire_bytes = [], []
         for i in range(nsteps):
             bn = synthetic_batch(spec, 8, seed=90 + i, n_classes=3)
-            lo, hi = rank * 4, rank * 4 + 4
+            lo, hi = rank * (8 // world), (rank + 1) * (8 // world)
             db = {k: torch.from_numpy(v[lo:hi]).cuda() for k, v in bn.items() if k != "labels"}
             losses.append(float(step(db, torch.from_numpy(bn["labels"][lo:hi]).cuda())))
             wire_bytes.append(step.reducer.wire_bytes)
@@ -268,21 +268,24 @@ def _dp_worker(rank, world, port, out_path, kind, nsteps, use_tape, wire, sparse
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_tape,wire,sparse", [(False, "fp32", True), (True, "fp32", True), (True, "fp32", False),
-                                                  (True, "bf16", True), (False, "bf16", False)])
-def test_data_parallel_two_ranks_equal_one_rank_on_the_global_batch(tmp_path, use_tape, wire, sparse):
-    """The whole N > 1 path on real kernels: two processes (sharing the one GPU, gloo as the transport) each step
-    half of a global batch of 8 - bucketed gradient exchange from inside backward on a side stream (f32 all-reduce or
+@pytest.mark.parametrize("use_tape,wire,sparse,world", [(False, "fp32", True, 2), (True, "fp32", True, 2), (True, "fp32", False, 2),
+                                                        (True, "bf16", True, 2), (False, "bf16", False, 2), (True, "bf16", True, 4),
+                                                        (True, "fp32", True, 4)])
+def test_data_parallel_two_ranks_equal_one_rank_on_the_global_batch(tmp_path, use_tape, wire, sparse, world):
+    """The whole N > 1 path on real kernels: two (or four) processes (sharing the one GPU, gloo as the transport) each step
+    their share of a global batch of 8 - bucketed gradient exchange from inside backward on a side stream (f32 all-reduce or
     bf16 reduce-scatter + all-gather; the word-embedding table row-sparse or dense), dynamic GEMM scheduling, AdamW
     dividing by the world size - and must land where ONE process stepping the 8 samples lands."""
     import torch.multiprocessing as mp
     nsteps = 3
     out = str(tmp_path / "dp")
-    port = 29600 + (1 if use_tape else 0) + (2 if wire == "bf16" else 0) + (4 if sparse else 0)
-    mp.spawn(_dp_worker, args=(2, port, out, "roberta", nsteps, use_tape, wire, sparse), nprocs=2, join=True)
-    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
-    assert torch.equal(r0["p"], r1["p"])                       # replicas stay bit-identical
-    dense_fp32 = 4 * r0["n_train"]                             # bytes a rank sends in a dense f32 ring all-reduce at world 2
+    port = 29600 + (1 if use_tape else 0) + (2 if wire == "bf16" else 0) + (4 if sparse else 0) + (8 if world == 4 else 0)
+    mp.spawn(_dp_worker, args=(world, port, out, "roberta", nsteps, use_tape, wire, sparse), nprocs=world, join=True)
+    rs = [torch.load(out + f".{r}") for r in range(world)]
+    r0, r1 = rs[0], rs[1]
+    for r in rs[1:]:
+        assert torch.equal(r0["p"], r["p"])                    # replicas stay bit-identical
+    dense_fp32 = 2 * 4 * r0["n_train"] * (world - 1) // world  # bytes a rank sends in a dense f32 ring all-reduce
     print(f"wire bytes per step and rank: {r0['wire_bytes']} (dense f32 all-reduce: {dense_fp32})")
     if sparse:        # (the tiny model's table is 1 % of its gradient: the saving is small here, 197 MB of 890 MB at full size)
         assert max(r0["wire_bytes"]) < (1.0 if wire == "fp32" else 0.55) * dense_fp32
@@ -300,8 +303,9 @@ def test_data_parallel_two_ranks_equal_one_rank_on_the_global_batch(tmp_path, us
         ref_losses.append(float(step(db, torch.from_numpy(bn["labels"]).cuda())))
     torch.cuda.synchronize()
     # the global mean loss is the mean of the two local means
-    for a, b, c in zip(r0["losses"], r1["losses"], ref_losses):
-        assert abs(0.5 * (a + b) - c) < 5e-4, (a, b, c)
+    for i, c in enumerate(ref_losses):
+        mean_local = sum(r["losses"][i] for r in rs) / world
+        assert abs(mean_local - c) < 5e-4, (mean_local, c)
     d = (r0["p"] - eng.params.p.cpu()).abs()
     if wire == "fp32":
         # same tolerance as tape-vs-eager: float-atomic summation order + sign-like AdamW steps on ~0 gradients

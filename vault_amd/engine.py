@@ -414,6 +414,12 @@ class VaultEngine:
                 wq, wsc = self._w8[wname]
                 ops.quant_mxfp8(P.wb(wname, n_elems=N * K, shape=(N, K)), N, K, K, wq, wsc)
 
+    @staticmethod
+    def _keep_hi(split3: torch.Tensor, plain: torch.Tensor, K: int):
+        """plain[:, :] = the `hi` third of a [rows, 3K] = [hi | lo | hi] split-bf16 operand: the bf16 value the fast mode would
+        have stored (a strided device copy, no arithmetic) - what the bf16 backward reads in a precise-forward training step."""
+        ops.pycall(lambda: plain.copy_(split3[:, :K]))
+
     def _linear(self, a_bf16, wname, out, M, N, K, epi, m_valid, bias=None, precise=False, ldo=None, prequant=False,
                 **kw):
         """out = epilogue(A . W^T).  ``precise``: A is a [M, 3K] = [hi | lo | hi] split-bf16 operand and the
@@ -791,8 +797,8 @@ class VaultEngine:
 
     def _forward(self, batch, train, labels, need_hidden, loss_scale, precise=False, ws_tag=0, image_type_idx=1,
                  advance_seed=True):
-        if precise and train:
-            raise ValueError("precise (split-bf16) mode is inference-only")
+        # (precise + train: split-bf16 FORWARD GEMMs - logits / loss at fp32 class - with the bf16 backward; every operand the
+        #  backward reads is also kept in its plain bf16 form, see forward_staged)
         if not 0 < image_type_idx < self.spec.vilt.modality_type_vocab_size:
             raise ValueError("image_token_type_idx outside the modality type table")
         ws = self.stage_inputs(batch, train, labels, ws_tag=ws_tag)
@@ -816,6 +822,11 @@ class VaultEngine:
         ws["drop_seed"] = self.drop_seed
         pr = precise
         W3 = 3 if pr else 1   # operand width multiplier of the split-bf16 path
+        pt = pr and train     # precise forward of a training step: the plain bf16 operands of the backward are kept beside the split ones
+        if pr:
+            if pt:
+                self.params._pb3_fresh = False   # (a recorded train step must carry the re-split of the weights the optimizer just wrote)
+            self.params.ensure_split3()
         if self.fp8_forward and not pr:
             self._fp8_refresh_weights()
 
@@ -835,7 +846,7 @@ class VaultEngine:
                                       (P.w("bert.embeddings.token_type_embeddings.weight"), lm_tt)], Ml, H)
             keep = train and not self.freeze_lm
             nl = lm.num_hidden_layers
-            if keep and not pr and self.LM_WGRAD_BATCHED and H % 128 == 0 and FF % 128 == 0:
+            if keep and self.LM_WGRAD_BATCHED and H % 128 == 0 and FF % 128 == 0:
                 # X operands of the deferred, batched weight gradients: one tensor per kind, a layer per slice
                 self._stack(ws, "lm_yb", nl + 1, (Mlp, H), bf)
                 for base, width in (("lm_ctx", H), ("lm_y1b", H), ("lm_act", FF)):
@@ -843,11 +854,12 @@ class VaultEngine:
             y = [buf(f"lm_y{i}" if keep else f"lm_y{i % 2}", (Mlp, H)) for i in range(nl + 1)]
             yb = [buf((f"lm_yb{i}" if keep else f"lm_yb{i % 2}") + ("_3" if pr else ""), (Mlp, W3 * H), bf)
                   for i in range(nl + 1)]
+            ybs = [buf(f"lm_yb{i}" if keep else f"lm_yb{i % 2}", (Mlp, H), bf) for i in range(nl + 1)] if pt else None
             lm_train = train   # dropout stays active in a frozen LM too (ref: model.py:189 only disables grad)
             pdh, pda = lm.hidden_dropout_prob, lm.attention_probs_dropout_prob
             q8l = self._fp8_scratch(Mlp, H) if (self.fp8_forward and not pr and Mlp % 256 == 0) else (None, None)
             ops.layernorm_fwd(esum, P.w("bert.embeddings.LayerNorm.weight"), P.w("bert.embeddings.LayerNorm.bias"),
-                              lm.layer_norm_eps, Ml, H, y_f32=y[0], y_bf16=None if pr else yb[0],
+                              lm.layer_norm_eps, Ml, H, y_f32=y[0], y_bf16=(ybs[0] if pt else None) if pr else yb[0],
                               y_split3=yb[0] if pr else None, mean=buf("lm_emean", (Mlp,)),
                               rstd=buf("lm_erstd", (Mlp,)), drop=self._drop(pdh, 1, lm_train),
                               y_q=q8l[0], y_scale=q8l[1])
@@ -878,21 +890,31 @@ class VaultEngine:
                              bias=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)), precise=pr, prequant=q8l[0] is not None)
                 ops.attention_fwd(qkv, amf, None if pr else ctx, lse, B, T, H, heads,
                                   drop=self._drop(pda, 16 * i + 2, lm_train), ctx_split3=ctx if pr else None)
+                if pt:
+                    self._keep_hi(ctx, buf(f"lm_ctx{sfx}", (Mlp, H), bf), H)
                 self._linear(ctx, ln.ow, h1, Mlp, H, H, ops.EPI_F32_RES, Ml, bias=P.w(ln.ob), res=y[i],
                              drop=self._drop(pdh, 16 * i + 3, lm_train), precise=pr)
                 ops.layernorm_fwd(h1, P.w(ln.ln1w), P.w(ln.ln1b), lm.layer_norm_eps, Ml, H, y_f32=y1,
-                                  y_bf16=None if pr else y1b, y_split3=y1b if pr else None,
+                                  y_bf16=(buf(f"lm_y1b{sfx}", (Mlp, H), bf) if pt else None) if pr else y1b,
+                                  y_split3=y1b if pr else None,
                                   mean=buf(f"lm_m1{sfx}", (Mlp,)), rstd=buf(f"lm_r1{sfx}", (Mlp,)),
                                   y_q=q8l[0], y_scale=q8l[1])
                 ops.pycall(lambda: self._prof_begin("ffn1"))
-                self._linear(y1b, ln.iw, act, Mlp, FF, H, ops.EPI_BF16_GELU, Ml, bias=P.w(ln.ib), out2=u, precise=pr,
+                # (the epilogue addresses gelu' with the row stride of its main output: in the split form a [rows, 3 FF] buffer
+                #  whose first third is written)
+                u_out = buf(f"lm_u{sfx}_3", (Mlp, W3 * FF), bf) if (pt and u is not None) else u
+                self._linear(y1b, ln.iw, act, Mlp, FF, H, ops.EPI_BF16_GELU, Ml, bias=P.w(ln.ib), out2=u_out, precise=pr,
                              split3=pr, ldo=W3 * FF, prequant=q8l[0] is not None)
+                if pt:
+                    self._keep_hi(act, buf(f"lm_act{sfx}", (Mlp, FF), bf), FF)
+                    if u is not None:
+                        self._keep_hi(u_out, u, FF)
                 fl_l = 2.0 * Ml * FF * H * W3
                 ops.pycall(lambda: self._prof_end("ffn1", fl_l))
                 self._linear(act, ln.fw, h2, Mlp, H, FF, ops.EPI_F32_RES, Ml, bias=P.w(ln.fb), res=y1,
                              drop=self._drop(pdh, 16 * i + 4, lm_train), precise=pr)
                 ops.layernorm_fwd(h2, P.w(ln.ln2w), P.w(ln.ln2b), lm.layer_norm_eps, Ml, H, y_f32=y[i + 1],
-                                  y_bf16=None if pr else yb[i + 1], y_split3=yb[i + 1] if pr else None,
+                                  y_bf16=(ybs[i + 1] if pt else None) if pr else yb[i + 1], y_split3=yb[i + 1] if pr else None,
                                   mean=buf(f"lm_m2{sfx}", (Mlp,)), rstd=buf(f"lm_r2{sfx}", (Mlp,)),
                                   y_q=q8l[0], y_scale=q8l[1])
             text_src = y[nl]
@@ -926,7 +948,7 @@ class VaultEngine:
             ops.rows_add(ws["img_embeds"], mt[ws.get("img_type", 1)], x[0], B * NP, H, NP, S, T)
         else:
             self._patch_embed_forward(ws, x, mt, pix, pr, W3, Kp, Mpp, buf, bf)
-        ws["lm_y"], ws["lm_yb"] = (y if spec.lm is not None else None), (yb if spec.lm is not None else None)
+        ws["lm_y"], ws["lm_yb"] = (y if spec.lm is not None else None), ((ybs if pt else yb) if spec.lm is not None else None)
         return self._forward_encoder(ws, x, need_hidden, loss_scale, pr, W3, labels, km, train, buf, bf)
 
     def _patch_embed_forward(self, ws, x, mt, pix, pr, W3, Kp, Mpp, buf, bf):
@@ -939,6 +961,8 @@ class VaultEngine:
         if ws["ragged"]:
             # padded batch of differently sized images: selected patch slots only, per-image resized position table
             ops.im2col_sel(pix, apatch, ws["sel"], B, NP, v.num_channels, ws["HP"], ws["WP"], v.patch_size, split3=pr)
+            if pr and ws["train"]:
+                ops.im2col_sel(pix, buf("apatch", (Mpp, Kp), bf), ws["sel"], B, NP, v.num_channels, ws["HP"], ws["WP"], v.patch_size)
             ops.image_sel_consts(P.w("embeddings.patch_embeddings.projection.bias"), P.w("embeddings.position_embeddings"),
                                  mt[ws.get("img_type", 1)], P.w("embeddings.cls_token"), addtab, x[0], NP, H, B, S, T)
         else:
@@ -947,6 +971,8 @@ class VaultEngine:
                     raise ValueError("pixel_patches carry bf16 pixels: the precise (split-bf16) mode needs pixel_values")
             else:
                 ops.im2col(pix, apatch, B, v.num_channels, v.image_size, v.patch_size, split3=pr)
+                if pr and ws["train"]:    # the weight gradient's operand
+                    ops.im2col(pix, buf("apatch", (Mpp, Kp), bf), B, v.num_channels, v.image_size, v.patch_size)
             ops.image_consts(P.w("embeddings.patch_embeddings.projection.bias"), P.w("embeddings.position_embeddings"),
                              mt[ws.get("img_type", 1)], P.w("embeddings.cls_token"), addtab, x[0], NP, H, B, S, T)
         ops.gemm(apatch, P.wb3(wpn, H, Kp) if pr else P.wb(wpn, shape=(H, Kp)), x[0], Mpp, H, W3 * Kp, W3 * Kp, W3 * Kp,
@@ -961,7 +987,8 @@ class VaultEngine:
         B, T, S, M, Mp, H, FF, heads, NP = (ws[k] for k in ("B", "T", "S", "M", "Mp", "H", "FF", "heads", "NP"))
         nv = v.num_hidden_layers
         # ------------------------------ ViLT encoder ------------------------------
-        if (train and not pr and self.LM_WGRAD_BATCHED and Mp <= self.WGRAD_BATCH_MAX_ROWS and H % 128 == 0
+        pt = pr and train
+        if (train and self.LM_WGRAD_BATCHED and Mp <= self.WGRAD_BATCH_MAX_ROWS and H % 128 == 0
                 and FF % 128 == 0):
             # the ViLT layers' weight gradients are deferred and batched like the LM's
             for base, width in (("n1", H), ("ctx", H), ("n2", H), ("act", FF)):
@@ -984,21 +1011,28 @@ class VaultEngine:
                 continue
             ws["vilt_stage"] = False
             q8 = self._fp8_scratch(Mp, H) if (self.fp8_forward and not pr and Mp % 256 == 0) else (None, None)
-            ops.layernorm_fwd(x[i], P.w(ln.ln1w), P.w(ln.ln1b), v.layer_norm_eps, M, H, y_bf16=None if pr else n1,
-                              y_split3=n1 if pr else None, mean=buf(f"m1{sfx}", (Mp,)), rstd=buf(f"r1{sfx}", (Mp,)),
+            ops.layernorm_fwd(x[i], P.w(ln.ln1w), P.w(ln.ln1b), v.layer_norm_eps, M, H,
+                              y_bf16=(buf(f"n1{sfx}", (Mp, H), bf) if pt else None) if pr else n1, y_split3=n1 if pr else None, mean=buf(f"m1{sfx}", (Mp,)), rstd=buf(f"r1{sfx}", (Mp,)),
                               y_q=q8[0], y_scale=q8[1])
             self._linear(n1, ln.qw, qkv, Mp, 3 * H, H, ops.EPI_BF16, M, bias=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)),
                          precise=pr, prequant=q8[0] is not None)
             ops.attention_fwd(qkv, km, None if pr else ctx, lse, B, S, H, heads, ctx_split3=ctx if pr else None)
+            if pt:
+                self._keep_hi(ctx, buf(f"ctx{sfx}", (Mp, H), bf), H)
             self._linear(ctx, ln.ow, xm, Mp, H, H, ops.EPI_F32_RES, M, bias=P.w(ln.ob), res=x[i], precise=pr)
-            ops.layernorm_fwd(xm, P.w(ln.ln2w), P.w(ln.ln2b), v.layer_norm_eps, M, H, y_bf16=None if pr else n2,
-                              y_split3=n2 if pr else None, mean=buf(f"m2{sfx}", (Mp,)), rstd=buf(f"r2{sfx}", (Mp,)),
+            ops.layernorm_fwd(xm, P.w(ln.ln2w), P.w(ln.ln2b), v.layer_norm_eps, M, H,
+                              y_bf16=(buf(f"n2{sfx}", (Mp, H), bf) if pt else None) if pr else n2, y_split3=n2 if pr else None, mean=buf(f"m2{sfx}", (Mp,)), rstd=buf(f"r2{sfx}", (Mp,)),
                               y_q=q8[0], y_scale=q8[1])
             ops.pycall(lambda: self._prof_begin("ffn1"))
             g8 = None if pr else self._plan_gelu8(ws, n2, act, u, ln, Mp, M)
             g8kw = dict(cfg=g8, aux_u8=True) if g8 is not None else {}
-            self._linear(n2, ln.iw, act, Mp, FF, H, ops.EPI_BF16_GELU, M, bias=P.w(ln.ib), out2=u, precise=pr,
+            u_out = buf(f"u{sfx}_3", (Mp, W3 * FF), bf) if (pt and u is not None) else u      # (row stride of the main output)
+            self._linear(n2, ln.iw, act, Mp, FF, H, ops.EPI_BF16_GELU, M, bias=P.w(ln.ib), out2=u_out, precise=pr,
                          split3=pr, ldo=W3 * FF, prequant=q8[0] is not None, **g8kw)
+            if pt:
+                self._keep_hi(act, buf(f"act{sfx}", (Mp, FF), bf), FF)
+                if u is not None:
+                    self._keep_hi(u_out, u, FF)
             fl_v = 2.0 * M * FF * H * W3
             ops.pycall(lambda: self._prof_end("ffn1", fl_v))
             self._linear(act, ln.fw, x[i + 1], Mp, H, FF, ops.EPI_F32_RES, M, bias=P.w(ln.fb), res=xm, precise=pr)
@@ -1016,7 +1050,7 @@ class VaultEngine:
             Bp = _pad(B)
             ws["Bp"] = Bp
             h0b = buf("h0b_3" if pr else "h0b", (Bp, W3 * H), bf)
-            ops.layernorm_fwd(xl, lw, lb, v.layer_norm_eps, B, H, y_bf16=None if pr else h0b,
+            ops.layernorm_fwd(xl, lw, lb, v.layer_norm_eps, B, H, y_bf16=(buf("h0b", (Bp, H), bf) if pt else None) if pr else h0b,
                               y_split3=h0b if pr else None, xmap=(1, S, 0), mean=buf("f_mean", (Bp,)),
                               rstd=buf("f_rstd", (Bp,)))
             pre = buf("pool_pre", (Bp, H))

@@ -320,7 +320,8 @@ class TrainStep:
                  adam_beta2: float = 0.999, adam_epsilon: float = 1e-8, weight_decay: float = 0.0,
                  correct_bias: bool = False, warmup_ratio: float = 0.1, total_steps: int = 1000,
                  process_group=None, bucket_mb: float = 64.0, constant_lr: bool = False, use_tape: bool = True,
-                 assume_full_pixel_mask: bool = False, wire: Optional[str] = None, sparse_embedding: Optional[bool] = None):
+                 assume_full_pixel_mask: bool = False, wire: Optional[str] = None, sparse_embedding: Optional[bool] = None,
+                 precise_forward: bool = False):
         self.engine = engine
         self.lr, self.b1, self.b2, self.eps, self.wd = learning_rate, adam_beta1, adam_beta2, adam_epsilon, weight_decay
         self.correct_bias = correct_bias
@@ -330,6 +331,9 @@ class TrainStep:
         self.step_idx = 0
         self.loss: Optional[torch.Tensor] = None
         self.use_tape = use_tape
+        # split-bf16 ("bf16x3") forward GEMMs: logits / loss of the training step at fp32 class (inside the 1e-3 of the reference),
+        # bf16 backward as in the fast mode; ~3x the forward GEMM time
+        self.precise_forward = bool(precise_forward)
         self._tape = None
         self._tape_key = None
         self._tape_ws = None
@@ -394,7 +398,7 @@ class TrainStep:
             # what the recorded launches bake in besides the buffers of the (B, T, geometry) workspace: whether token
             # types were given, the launch stream, the GEMM scheduling mode and the forward number format
             key = ws["key"] + (ws["tt"] is None, torch.cuda.current_stream().cuda_stream, ops.GEMM_SCHED,
-                               bool(eng.fp8_forward), labels.dtype.is_floating_point, bool(ws.get("patches_in")))
+                               bool(eng.fp8_forward), labels.dtype.is_floating_point, bool(ws.get("patches_in")), self.precise_forward)
             if self.reducer:
                 # the token ids of every rank name the rows of the word-embedding table this step touches: their
                 # all-gather + union start now on the communication stream (inputs_embeds: no row is touched)
@@ -406,7 +410,7 @@ class TrainStep:
                 eng.drop_seed = (eng.drop_seed + 1) & 0xFFFFFFFF
                 tape = ops.start_tape() if self.use_tape else None
                 try:
-                    out = eng.forward_staged(ws, need_hidden=False, loss_scale=1.0 / B)
+                    out = eng.forward_staged(ws, need_hidden=False, loss_scale=1.0 / B, precise=self.precise_forward)
                     # gradients are zero here: the fused optimizer clears them after use (they start at 0)
                     eng._backward(1.0 / B, None, None, None, self.reducer.on_stage if self.reducer else None)
                 finally:
