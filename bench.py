@@ -316,6 +316,25 @@ def main():
         exchange = {"wire": stepper.wire, "sparse_word_embedding": stepper.reducer.sparse is not None,
                     "bytes_sent_per_rank_and_step": int(stepper.reducer.wire_bytes),
                     "dense_f32_all_reduce_would_send": int(dense), "rccl_world_size": torch.distributed.get_world_size()}
+        if world > 1 or os.environ.get("VAULT_FORCE_DP") == "1":
+            # the OTHER wire format on the same ranks, a short loop (the reducer reads its format at every launch: no
+            # re-recording): informational - `value` above is the configured format's
+            other = "bf16" if stepper.wire == "fp32" else "fp32"
+            stepper.reducer.wire = other
+            for _ in range(3):
+                stepper(batch, labels)
+            sync_all()
+            t0 = time.perf_counter()
+            n_o = max(4, args.steps // 2)
+            for _ in range(n_o):
+                stepper(batch, labels)
+            sync_all()
+            t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            exchange["other_wire"] = {"wire": other, "ms_per_step": round(float(t.item()) / n_o * 1e3, 3),
+                                      "value": round(B * world * n_o / float(t.item()), 2),
+                                      "bytes_sent_per_rank_and_step": int(stepper.reducer.wire_bytes)}
+            stepper.reducer.wire = stepper.wire
 
     # ---- second loop: the same K steps with the input copies inside the loop (ref: tmsc_utils/trainer.py:183-202,353
     #      batch_to_device): a fresh host batch per step from pinned memory, copied on a side stream into one of two
