@@ -503,12 +503,15 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
         // fold the 16 lanes (rows) of each column group (DPP: no LDS traffic, no index registers)
 #pragma unroll
         for (int e = 0; e < 8 + NV1; ++e) csum[e] = w8_row16_sum(csum[e]);
-        if (el15 == 0) {
+        // lane e of a row takes column e's sum: ONE atomic instruction per wave (two 128-byte lines of 32 sums each)
+        // instead of 16 with four active lanes - an eighth of the requests that queue up on one address when the
+        // blocks of a round finish together (small M: no stagger between the rounds)
+        float sel = csum[0];
 #pragma unroll
-          for (int e = 0; e < 8 + NV1; ++e) {
-            const uint32_t co = (uint32_t)nc * 4u + (e < 8 ? (uint32_t)e * 4u : 2u * c1 + (uint32_t)(e - 8) * 4u);
-            asm volatile("global_atomic_add_f32 %0, %1, %2\n\ts_nop 1" ::"v"(co), "v"(csum[e]), "s"(p.colsum) : "memory");
-          }
+        for (int e = 1; e < 8 + NV1; ++e) sel = (el15 == e) ? csum[e] : sel;
+        if (el15 < 8 + NV1) {
+          const uint32_t co = (uint32_t)nc * 4u + (el15 < 8 ? (uint32_t)el15 * 4u : 2u * c1 + (uint32_t)(el15 - 8) * 4u);
+          asm volatile("global_atomic_add_f32 %0, %1, %2\n\ts_nop 1" ::"v"(co), "v"(sel), "s"(p.colsum) : "memory");
         }
       }
     } else {
