@@ -34,7 +34,8 @@ int vault_abi_version(void);
  * 256x256 / 256x192 tiles (M % 256 == 0, N % 256 / 192 == 0; its residual epilogue needs `res`, without one
  * the launcher takes the double-buffered kernel), 5 / 6 (ABI 4) = 8-wave kernel with 256x256 / 256x192 tiles whose
  * epilogue stores the accumulators straight from registers (a_mode = b_mode = 0 only, K >= 128, no split-K, no split3,
- * no dropout, epi 0 / 1 / 2 / 3; M x ldo x 4 B < 4 GiB): the automatic choice for the bf16-output Linears with K <= 1024.
+ * no dropout, epi 0 / 1 / 2 / 3; M x ldo x 4 B < 4 GiB): the automatic choice for the bf16-output Linears with K <= 1024;
+ * 7 = 64x128 tiles, four stages (a_mode 0, epi 0..4, no split-K): the automatic choice while (M/64) x (N/128) <= 256 blocks.
  * Threading: one host thread per device; the ring kernel's dynamic scheduler (persist bit 0) keeps per-device ticket
  * counters that assume its launches are serialised on ONE stream per device. */
 typedef struct vault_gemm_args {
@@ -64,7 +65,7 @@ typedef struct vault_gemm_args {
                   call would take and pass that cfg explicitly to both calls. */
 } vault_gemm_args;
 int vault_gemm(const vault_gemm_args* args, void* stream);
-/* the kernel / tile configuration vault_gemm would run these arguments on (the resolved `cfg`, 0..6), or -EINVAL */
+/* the kernel / tile configuration vault_gemm would run these arguments on (the resolved `cfg`, 0..7), or -EINVAL */
 int vault_gemm_plan(const vault_gemm_args* args);
 
 /* ---- MXFP8 forward GEMM (BASELINE config "fp8 MFMA forward, bf16 backward") -------------------------------------

@@ -43,7 +43,7 @@ def _rand(*shape, scale=1.0, seed=0):
     return (torch.randn(*shape, generator=g) * scale).cuda()
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 7])
 @pytest.mark.parametrize("shape", [(512, 768, 768), (256, 2304, 768), (768, 768, 3072), (256, 256, 64), (512, 256, 192), (256, 512, 320)])
 def test_forward_nt_bias(cfg, shape):
     M, N, K = shape
@@ -61,7 +61,7 @@ def test_forward_nt_bias(cfg, shape):
     assert out[m_valid:].abs().max().item() == 0.0  # masked rows untouched
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 7])
 def test_forward_gelu_and_residual(cfg):
     M, N, K = 512, 1024, 256
     A = _rand(M, K, seed=4).bfloat16()
@@ -84,7 +84,7 @@ def test_forward_gelu_and_residual(cfg):
     assert (o32 - (z + res)).abs().max().item() <= 2e-4 * z.abs().max().item()
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 7])
 def test_dgrad_nn_and_dgelu(cfg):
     # dX[M,Kin] = dY[M,Nout] . W[Nout,Kin]  (A mode 0, B mode 1)
     M, Nout, Kin = 512, 768, 1024
@@ -219,7 +219,7 @@ def test_phase_kernel_repeatability_and_large_k(mode):
     assert (outs[0] - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 7])
 def test_fused_bias_gradient_colsum(cfg):
     """bf16 epilogues can accumulate the column sums of what they store (rows < m_valid): the bias
     gradient of the Linear whose dY this GEMM produces."""
@@ -497,3 +497,25 @@ def test_8wave_kernel_8bit_gelu_prime_round_trip(cfg, shape):
     assert _gemm(A, W, act8, M, N, K, K, K, N, 0, 0, EPI_GELU, cfg=3, bias=bias, out2=u8, aux_u8=1, plan_only=True) < 0
     with pytest.raises(RuntimeError):
         _gemm(A, W, act8, M, N, K, K, K, N, 0, 0, EPI_BF16, cfg=cfg, bias=bias, aux_u8=1)
+
+
+def test_small_launches_take_64_row_tiles():
+    """Launches of at most 256 blocks of 64 x 128 resolve to cfg 7 (the LM stack at per-GPU batch <= 64, both stacks at batch 8),
+    one more block and they stay on 128 x 128; same results as the 128 x 128 form (same K order: bit-identical)."""
+    for (M, N, K, want) in [(2560, 768, 3072, 7), (2560, 768, 768, 7), (2816, 768, 3072, 0), (512, 3072, 768, 7), (768, 3072, 768, 0),
+                            (512, 2304, 768, 7)]:
+        A = _rand(M, K, seed=1).bfloat16()
+        W = _rand(N, K, scale=0.05, seed=2).bfloat16()
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        got = _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_BF16, plan_only=True)
+        assert (got == 7) == (want == 7), (M, N, K, got)
+        ref = torch.zeros_like(out)
+        _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_BF16)
+        _gemm(A, W, ref, M, N, K, K, K, N, 0, 0, EPI_BF16, cfg=0)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+    # not for weight gradients, split-K or a_mode 1
+    dY = _rand(512, 768, seed=3).bfloat16(); X = _rand(512, 768, seed=4).bfloat16()
+    dW = torch.zeros(768, 768, device="cuda")
+    assert _gemm(dY, X, dW, 768, 768, 512, 768, 768, 768, 1, 1, EPI_ATOMIC, plan_only=True) != 7
+    assert _gemm(dY, X, dW, 768, 768, 512, 768, 768, 768, 1, 1, EPI_ATOMIC, cfg=7, plan_only=True) < 0

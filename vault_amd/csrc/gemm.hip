@@ -291,6 +291,9 @@ int launch_modes(const GemmParams& p, int cfg, hipStream_t st) {
     }
     case 1: return launch_cfg<256, 128, 4, 2, A_MODE, B_MODE, EPI>(p, st);
     case 2: return launch_cfg<256, 256, 2, 4, A_MODE, B_MODE, EPI>(p, st);
+    case 7:   // 64 x 128 tiles, four stages: twice the blocks of cfg 0 for the launches that leave half of the CUs idle
+      if constexpr (A_MODE == 0 && EPI != EPI_F32_ATOMIC) return launch_cfg<64, 128, 2, 2, A_MODE, B_MODE, EPI, 4>(p, st);
+      return VAULT_EINVAL;
     default: return VAULT_EINVAL;
   }
 }
@@ -346,6 +349,13 @@ int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) 
     const long c192 = (long)(p.M / 256) * ((p.N + 191) / 192), c256 = (long)(p.M / 256) * ((p.N + 255) / 256);
     small = c192 < 128 || (p.N >= 3072 && c256 <= 256);
     if (small) cfg = 0;
+    // ... and 64 x 128 tiles (four stages) while those still fit one block per CU: a block's K loop is bound by its CU's
+    // L2 -> LDS rate (~20 B/clk), i.e. by the bytes a K tile stages - 24 instead of 32 KiB - and twice the CUs work
+    // (tools/small_tile_bench.py, M = 2560, N = 768: FFN-in dgrad 34.1 -> 23.9 us, QKV dgrad 27.5 -> 18.9, FFN-out forward
+    // 34.1 -> 24.3, attention-out forward 12.8 -> 9.6, its dgrad 11.5 -> 8.4; the same ratios down to M = 512; from 257 blocks
+    // on the second round costs more: M = 3072 32.5 -> 41.0)
+    static const bool use64 = [] { const char* e = getenv("VAULT_GEMM_64"); return !(e && e[0] == '0'); }();   // development A/B switch
+    if (small && use64 && p.splits <= 1 && (long)(p.M / 64) * (p.N / 128) <= 256) cfg = 7;
   }
   static const bool use8w = [] { const char* e = getenv("VAULT_GEMM8W"); return !(e && e[0] == '0'); }();   // development A/B switch
   // (also in data-parallel steps - persist bit 0 -: its static tile walk under an RCCL kernel that holds 8-64 CUs costs what the
@@ -368,7 +378,8 @@ int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) 
   } else if (p.aux_u8) {
     return -VAULT_EINVAL;       // the 8-bit gelu' exists in the 8-wave kernel's tile order only
   }
-  if (cfg < 0 || cfg > 6) return -VAULT_EINVAL;
+  if (cfg < 0 || cfg > 7) return -VAULT_EINVAL;
+  if (cfg == 7 && (a_mode != 0 || epi == EPI_F32_ATOMIC || p.splits > 1 || p.batch > 1)) return -VAULT_EINVAL;
   return cfg;
 }
 
