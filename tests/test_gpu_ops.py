@@ -202,3 +202,41 @@ def test_attention_fwd_bwd_many_items(B, S, heads):
             first = dqkv.clone()
         else:
             assert torch.equal(dqkv, first)
+
+
+@pytest.mark.parametrize("rows,H,tt_kind", [(2560, 768, "zeros"), (333, 256, "mixed"), (40, 768, "ones"), (1000, 512, "int32")])
+def test_scatter_add_embedding_gradients(rows, H, tt_kind):
+    """Embedding-table gradients (ref: the autograd backward of nn.Embedding in HF modeling_roberta.py:86-120 /
+    modeling_vilt.py:249-262): word rows by id, positions by row % period, token types by an index that is the same for
+    (nearly) every row - the kernel sums rows that repeat the first index of their block in registers; masked rows add
+    nothing; the tables ACCUMULATE."""
+    g = torch.Generator(device="cpu").manual_seed(rows)
+    d = torch.randn(rows, H, generator=g).cuda()
+    V, period = 500, 40
+    ids = torch.randint(0, V, (rows,), generator=g).cuda()
+    ids[: rows // 3] = 7                                           # long runs of one id, too
+    if tt_kind == "zeros":
+        tt = torch.zeros(rows, dtype=torch.int64, device="cuda")
+    elif tt_kind == "ones":
+        tt = torch.ones(rows, dtype=torch.int64, device="cuda")
+    elif tt_kind == "int32":
+        tt = (torch.arange(rows, device="cuda") % 2).to(torch.int32)
+    else:
+        tt = (torch.rand(rows, generator=g) < 0.2).long().cuda()
+    mask = (torch.rand(rows, generator=g) < 0.8).float().cuda()
+    for rowmask in (None, mask):
+        word = torch.full((V, H), 0.5, device="cuda"); pos = torch.full((period, H), -0.25, device="cuda")
+        typ = torch.full((2, H), 1.0, device="cuda")
+        ops.scatter_add(d, [(word, ids), (pos, "mod"), (typ, tt)], rows, H, period=period, rowmask=rowmask)
+        dm = d if rowmask is None else d * rowmask[:, None]
+        rw = torch.full((V, H), 0.5, device="cuda").index_add_(0, ids, dm)
+        rp = torch.full((period, H), -0.25, device="cuda").index_add_(0, torch.arange(rows, device="cuda") % period, dm)
+        rt = torch.full((2, H), 1.0, device="cuda").index_add_(0, tt.long(), dm)
+        torch.cuda.synchronize()
+        for got, ref in ((word, rw), (pos, rp), (typ, rt)):
+            assert (got - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    # a fixed destination row and an absent table
+    typ = torch.zeros(2, H, device="cuda")
+    ops.scatter_add(d, [None, None, (typ, 1)], rows, H)
+    torch.cuda.synchronize()
+    assert (typ[1] - d.sum(0)).abs().max().item() <= 1e-4 * d.sum(0).abs().max().item() and float(typ[0].abs().max()) == 0.0

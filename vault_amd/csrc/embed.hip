@@ -8,6 +8,7 @@
 // (HF:models/vilt/modeling_vilt.py:237-269), ViltPatchEmbeddings' unfold (modeling_vilt.py:290-300) and
 // the bookkeeping of ViltEmbeddings.visual_embed / forward for full pixel masks (modeling_vilt.py:92-219).
 #include <algorithm>
+#include <cstdlib>
 #include "common.h"
 #include "../../include/vault_hip.h"
 
@@ -82,7 +83,9 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(const float* __restric
                                                           const float* __restrict__ rowmask, int rows_per_block) {
   const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
   // a thread owns the columns c, c + 256, ... of the block's rows; four rows per trip so that their loads (index, mask,
-  // gradient) are in flight together (the one-row-at-a-time form was latency-bound: 87 us for 31 MB)
+  // gradient) are in flight together, and the loads of trip t + 1 are issued BEFORE the atomics of trip t: VMEM operations
+  // retire in order, so a trip's loads issued behind the previous trip's atomics would wait for those to complete in the
+  // memory-side atomic units first (a chain of 8 round trips per block: 87 us for a 31 MB pass whatever the row count)
   constexpr int MAXC = 6;   // H <= 1536
   const int nc = (H + 255 - (int)threadIdx.x) / 256;
   float fsum[3][MAXC];
@@ -90,49 +93,79 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(const float* __restric
   for (int k = 0; k < 3; ++k)
 #pragma unroll
     for (int q = 0; q < MAXC; ++q) fsum[k][q] = 0.f;
-  for (int rb = r0; rb < r1; rb += 4) {
+  // Rows of an INDEXED table that carry the index of the block's first row are summed in registers too and added once per
+  // block: a token-type table has one or two rows, i.e. every token of the batch lands on the same H addresses; word /
+  // position indices rarely repeat the first row's, those keep their atomics.
+  long long ix0[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    ix0[k] = -1;
+    if (g.tab[k] != nullptr && g.idx[k] != nullptr && r0 < rows)
+      ix0[k] = g.is64[k] ? reinterpret_cast<const long long*>(g.idx[k])[r0] : (long long)reinterpret_cast<const int*>(g.idx[k])[r0];
+  }
+  struct Trip {
     float v[4][MAXC];
     long long ix[4][3];
     bool on[4];
+  };
+  auto load_trip = [&](int rb, Trip& t) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int row = rb + u;
-      on[u] = row < r1 && (rowmask == nullptr || rowmask[row] != 0.f);
+      t.on[u] = row < r1 && (rowmask == nullptr || rowmask[min(row, r1 - 1)] != 0.f);
       const int rr = min(row, r1 - 1);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        ix[u][k] = 0;
+        t.ix[u][k] = 0;
         if (g.tab[k] != nullptr && g.idx[k] != nullptr)
-          ix[u][k] = g.is64[k] ? reinterpret_cast<const long long*>(g.idx[k])[rr]
-                               : (long long)reinterpret_cast<const int*>(g.idx[k])[rr];
+          t.ix[u][k] = g.is64[k] ? reinterpret_cast<const long long*>(g.idx[k])[rr]
+                                 : (long long)reinterpret_cast<const int*>(g.idx[k])[rr];
         else if (g.fixed[k] == -2)
-          ix[u][k] = rr % g.period;
+          t.ix[u][k] = rr % g.period;
       }
 #pragma unroll
-      for (int q = 0; q < MAXC; ++q) v[u][q] = (q < nc) ? d[(size_t)rr * H + threadIdx.x + 256 * q] : 0.f;
+      for (int q = 0; q < MAXC; ++q) t.v[u][q] = (q < nc) ? d[(size_t)rr * H + threadIdx.x + 256 * q] : 0.f;
     }
+  };
+  auto add_trip = [&](const Trip& t) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (!on[u]) continue;
+      if (!t.on[u]) continue;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         if (g.tab[k] == nullptr) continue;
-        const bool indexed = g.idx[k] != nullptr || g.fixed[k] == -2;
+        const bool indexed = (g.idx[k] != nullptr && t.ix[u][k] != ix0[k]) || g.fixed[k] == -2;   // (uniform over the block)
 #pragma unroll
         for (int q = 0; q < MAXC; ++q) {
           if (q >= nc) continue;
-          if (indexed) atomicAdd(g.tab[k] + (size_t)ix[u][k] * H + threadIdx.x + 256 * q, v[u][q]);
-          else fsum[k][q] += v[u][q];
+          if (indexed) atomicAdd(g.tab[k] + (size_t)t.ix[u][k] * H + threadIdx.x + 256 * q, t.v[u][q]);
+          else fsum[k][q] += t.v[u][q];
         }
       }
     }
+  };
+  if (r0 < r1) {
+    Trip a, b;
+    load_trip(r0, a);
+    for (int rb = r0; rb < r1; rb += 8) {
+      if (rb + 4 < r1) load_trip(rb + 4, b);
+      add_trip(a);
+      if (rb + 4 >= r1) break;
+      if (rb + 8 < r1) load_trip(rb + 8, a);
+      add_trip(b);
+    }
   }
 #pragma unroll
-  for (int k = 0; k < 3; ++k)
-    if (g.tab[k] != nullptr && g.idx[k] == nullptr && g.fixed[k] >= 0)
+  for (int k = 0; k < 3; ++k) {
+    if (g.tab[k] == nullptr) continue;
+    long long dst = -1;
+    if (g.idx[k] == nullptr && g.fixed[k] >= 0) dst = g.fixed[k];
+    else if (g.idx[k] != nullptr) dst = ix0[k];
+    if (dst < 0) continue;
 #pragma unroll
-      for (int q = 0; q < MAXC; ++q)
-        if (q < nc) atomicAdd(g.tab[k] + (size_t)g.fixed[k] * H + threadIdx.x + 256 * q, fsum[k][q]);
+    for (int q = 0; q < MAXC; ++q)
+      if (q < nc && fsum[k][q] != 0.f) atomicAdd(g.tab[k] + (size_t)dst * H + threadIdx.x + 256 * q, fsum[k][q]);
+  }
 }
 
 // pixel [B][C][IMG][IMG] f32 -> A [B*P (padded)][C*ps*ps] bf16, k = c*ps*ps + py*ps + px, patches row-major
@@ -274,7 +307,10 @@ extern "C" int vault_scatter_add(const vault_gather_args* a, void* stream) {
     g.tab[k] = const_cast<float*>(a->tab[k]); g.idx[k] = a->idx[k]; g.is64[k] = a->is64[k]; g.fixed[k] = a->fixed[k];
   }
   g.period = a->period > 0 ? a->period : 1;
-  const int rpb = 32;
+  // rows per block: a block is a chain of trips (loads -> atomics), so few rows per block while the launch is small
+  // (tools/scatter_bench.py, 3 tables, H = 768: 2560 rows 87 us at 32 rows per block, 33 us at 8; 10240 rows 90 / 80 / 89 us
+  // at 32 / 16 / 8 - there the float atomics themselves, ~0.2 T/s, are the bound)
+  const int rpb = a->rows >= 5120 ? 16 : 8;
   hipLaunchKernelGGL(scatter_add_kernel, dim3((a->rows + rpb - 1) / rpb), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), a->src, g, a->rows, a->H, a->rowmask, rpb);
   return (int)hipGetLastError();
