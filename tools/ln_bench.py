@@ -28,4 +28,8 @@ for rows in [int(a) for a in sys.argv[1:]] or [2560, 10240, 11840, 47360]:
     t_full = timeit(lambda: ops.layernorm_bwd(x, mean, rstd, g, rows, H, dy_bf16=dy, dres=dres, dx_f32=dx, dgamma=dg, dbeta=db))
     t_nog = timeit(lambda: ops.layernorm_bwd(x, mean, rstd, g, rows, H, dy_bf16=dy, dres=dres, dx_f32=dx))
     byts = rows * H * 14
-    print(f"rows {rows:6d}: with dgamma/dbeta {t_full:7.1f} us ({byts / t_full / 1e6:6.2f} TB/s)   without {t_nog:7.1f} us ({byts / t_nog / 1e6:6.2f} TB/s)")
+    dxb = torch.empty(rows, H, device="cuda", dtype=torch.bfloat16); dbias = torch.zeros(H, device="cuda")
+    t_3 = timeit(lambda: ops.layernorm_bwd(x, mean, rstd, g, rows, H, dy_bf16=dy, dres=dres, dx_f32=dx, dx_bf16=dxb, dgamma=dg, dbeta=db, dbias=dbias))
+    t_3n = timeit(lambda: ops.layernorm_bwd(x, mean, rstd, g, rows, H, dy_bf16=dy, dres=dres, dx_f32=dx, dx_bf16=dxb))
+    print(f"rows {rows:6d}: with dgamma/dbeta {t_full:7.1f} us ({byts / t_full / 1e6:6.2f} TB/s)   without {t_nog:7.1f} us ({byts / t_nog / 1e6:6.2f} TB/s)"
+          f"   + bf16 copy and its column sums {t_3:7.1f} us, without the three sums {t_3n:7.1f} us")

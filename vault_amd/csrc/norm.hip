@@ -130,7 +130,9 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void ln_bwd_kernel(const bf
                                                      float* __restrict__ dbeta, float* __restrict__ dbias,
                                                      int rows_per_block, uint32_t drop_thresh, uint32_t drop_seed, uint32_t drop_stream,
                                                      float drop_scale, int drop_on_dy, const bf16* __restrict__ dres_bf16) {
-  __shared__ float red[4][VPT * 256];
+  constexpr int NB = WAVES >= 8 ? 8 : 4;      // waves that fold into the scratch per round
+  constexpr int HH = VPT * 256;               // = H
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [NB][3][HH]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x4 gw[VPT], ag[VPT], ab[VPT], ac[VPT];
 #pragma unroll
@@ -207,31 +209,37 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void ln_bwd_kernel(const bf
     }
   }
   if (dgamma == nullptr && dbias == nullptr) return;
-  // cross-wave reduction, one quantity at a time through a [4][H] buffer (12 KiB at H = 768) that the waves add
-  // into four at a time (LDS float atomics run ~a lane per clock here: 30 us for this - plain read-add-write
-  // rounds instead), then one global atomic per column and block.  The global atomics of all blocks land on the
-  // same H addresses at the end of the kernel and serialise in the L2: with 1024 blocks that tail cost 14-22 us
-  // per launch whatever the row count (tools/ln_bench.py), hence 16-wave blocks, one per CU (<= 256 blocks)
+  // cross-wave reduction of the three column sums together through a [NB][3][H] scratch (72 KiB at H = 768) that the
+  // waves add into NB at a time (LDS float atomics run ~a lane per clock here: 30 us for this - plain read-add-write
+  // rounds instead; one quantity at a time through a [4][H] scratch took 12 rounds + 3 passes of atomics: 4-7 us of
+  // every launch at small row counts), then one global atomic per column and block.  The global atomics of all blocks
+  // land on the same H addresses at the end of the kernel and serialise in the L2: with 1024 blocks that tail cost
+  // 14-22 us per launch whatever the row count (tools/ln_bench.py), hence 16-wave blocks, one per CU (<= 256 blocks)
+  float* const dsts[3] = {dgamma, dbeta, dbias};
+  for (int r = 0; r < WAVES / NB; ++r) {
+    if ((wave / NB) == r) {
+      float* rw = red + (wave % NB) * (3 * HH);
 #pragma unroll
-  for (int qn = 0; qn < 3; ++qn) {
-    float* dst = qn == 0 ? dgamma : (qn == 1 ? dbeta : dbias);
-    if (dst == nullptr) continue;     // uniform
-    for (int r = 0; r < WAVES / 4; ++r) {
-      if ((wave >> 2) == r) {
-        float* rw = red[wave & 3];
+      for (int qn = 0; qn < 3; ++qn) {
+        if (dsts[qn] == nullptr) continue;     // uniform
 #pragma unroll
-        for (int j = 0; j < VPT; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = qn == 0 ? ag[j][e] : (qn == 1 ? ab[j][e] : ac[j][e]);
-            const int idx = (lane + 64 * j) * 4 + e;
-            rw[idx] = (r == 0) ? v : rw[idx] + v;
-          }
+        for (int j = 0; j < VPT; ++j) {
+          const f32x4 v = qn == 0 ? ag[j] : (qn == 1 ? ab[j] : ac[j]);
+          f32x4* q4 = reinterpret_cast<f32x4*>(rw + qn * HH + (lane + 64 * j) * 4);
+          *q4 = (r == 0) ? v : (*q4 + v);
+        }
       }
-      __syncthreads();
     }
-    for (int c = threadIdx.x; c < H; c += WAVES * 64) atomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
     __syncthreads();
+  }
+  for (int c = threadIdx.x; c < 3 * HH; c += WAVES * 64) {
+    const int qn = c / HH;
+    float* dst = dsts[qn];
+    if (dst == nullptr) continue;
+    float t = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) t += red[b * (3 * HH) + c];
+    atomicAdd(dst + (c - qn * HH), t);
   }
 }
 
@@ -295,13 +303,30 @@ extern "C" int vault_layernorm_bwd(const vault_ln_bwd_args* a, void* stream) {
   int rpb = (a->rows + maxb - 1) / maxb;
   rpb = ((rpb + waves - 1) / waves) * waves;
   dim3 grid((a->rows + rpb - 1) / rpb), block(waves * 64);
+  int lds_bytes = 0;
 #define LN_BWD(V)                                                                                              \
-  if (waves == 16) LN_BWD_W(V, 16); else LN_BWD_W(V, 4)
+  if (waves == 16) LN_BWD_W(V, 16) else LN_BWD_W(V, 4)
 #define LN_BWD_W(V, W)                                                                                              \
-  hipLaunchKernelGGL((ln_bwd_kernel<V, W>), grid, block, 0, st, reinterpret_cast<const bf16*>(a->dy_bf16), a->dy_f32, \
+  {                                                                                                                 \
+  {                                                                                                                 \
+    constexpr int LDS = (W >= 8 ? 8 : 4) * 3 * V * 256 * 4;                                                         \
+    if (LDS > 64 * 1024) {                                                                                          \
+      static bool done[64] = {};                                                                                    \
+      int dev = 0;                                                                                                  \
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VAULT_EINVAL;                            \
+      if (!done[dev]) {                                                                                             \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<V, W>),                                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return VAULT_EINVAL; \
+        done[dev] = true;                                                                                           \
+      }                                                                                                             \
+    }                                                                                                               \
+    lds_bytes = LDS;                                                                                                \
+  }                                                                                                                 \
+  hipLaunchKernelGGL((ln_bwd_kernel<V, W>), grid, block, lds_bytes, st, reinterpret_cast<const bf16*>(a->dy_bf16), a->dy_f32, \
                      dym, a->x, xm, a->mean, a->rstd, a->gamma, a->rows, a->H, a->dres, a->dx_f32,               \
                      reinterpret_cast<bf16*>(a->dx_bf16), dxm, a->dgamma, a->dbeta, a->dbias, rpb, a->drop_thresh,          \
-                     a->drop_seed, a->drop_stream, a->drop_scale, a->drop_on_dy, reinterpret_cast<const bf16*>(a->dres_bf16))
+                     a->drop_seed, a->drop_stream, a->drop_scale, a->drop_on_dy, reinterpret_cast<const bf16*>(a->dres_bf16)); \
+  }
   switch (a->H / 256) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;
