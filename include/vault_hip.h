@@ -118,6 +118,10 @@ int vault_layernorm_bwd(const vault_ln_bwd_args* args, void* stream);
 
 /* out[n] += sum_{r < rows} in_bf16[r][n]   (bias gradients); N % 256 == 0 */
 int vault_colsum(const void* in_bf16, int ld, int rows, int N, float* out, void* stream);
+/* ABI 7: the same for `batch` matrices at element stride batch_in, into `batch` vectors at float stride batch_out (the QKV bias
+ * gradients of a group of layers in one launch) */
+int vault_colsum_batched(const void* in_bf16, int ld, int rows, int N, float* out, int batch, long long batch_in,
+                         long long batch_out, void* stream);
 
 
 /* ---- attention ------------------------------------------------------------------------------

@@ -240,3 +240,24 @@ def test_scatter_add_embedding_gradients(rows, H, tt_kind):
     ops.scatter_add(d, [None, None, (typ, 1)], rows, H)
     torch.cuda.synchronize()
     assert (typ[1] - d.sum(0)).abs().max().item() <= 1e-4 * d.sum(0).abs().max().item() and float(typ[0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rows,ld,N,batch", [(2560, 2304, 2304, 6), (11840, 2304, 768, 6), (300, 768, 256, 1), (47360, 2304, 768, 2)])
+def test_colsum_batched_bias_gradients_of_a_group_of_layers(rows, ld, N, batch):
+    """The QKV bias gradients of `batch` layers in one launch (db = sum over token rows of dY, ref: autograd of nn.Linear's
+    bias, HF modeling_vilt.py:303-313): matrix z of a stack sums into vector z at a uniform stride of the flat gradient
+    buffer, accumulating; rows beyond `rows` and columns beyond N are not read."""
+    pad = ((rows + 255) // 256) * 256
+    x = torch.randn(batch, pad, ld, device="cuda").bfloat16()
+    stride_o = 4096
+    out = torch.full((batch * stride_o,), 0.25, device="cuda")
+    ops.colsum_batched(x[0], ld, rows, N, out, batch, x.stride(0), stride_o)
+    ref = x[:, :rows, :N].float().sum(1)
+    torch.cuda.synchronize()
+    got = out.view(batch, stride_o)
+    assert (got[:, :N] - 0.25 - ref).abs().max().item() <= 2e-5 * rows ** 0.5 * ref.abs().max().item() + 1e-3
+    assert float((got[:, N:] - 0.25).abs().max()) == 0.0
+    single = torch.zeros(N, device="cuda")
+    ops.colsum(x[batch - 1], ld, rows, N, single)
+    torch.cuda.synchronize()
+    assert (single - ref[batch - 1]).abs().max().item() <= 2e-5 * rows ** 0.5 * ref.abs().max().item() + 1e-3

@@ -61,7 +61,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     lib.vault_abi_version.restype = ctypes.c_int
-    assert lib.vault_abi_version() == 6
+    assert lib.vault_abi_version() == 7
 
 
 def test_ctypes_structures_match_the_c_header(tmp_path):

@@ -44,4 +44,4 @@ extern "C" int vault_gemm_mxfp8(const vault_gemm_args* a, const void* a_scale, c
   return vault_gemm_mx8_launch(params_of(a), a_scale, b_scale, a->epi, reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" int vault_abi_version(void) { return 6; }
+extern "C" int vault_abi_version(void) { return 7; }

@@ -247,8 +247,10 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void ln_bwd_kernel(const bf
 // atomics of all row blocks land on the same N addresses (thousands of adds per address serialise in the memory-side
 // atomic units: 3072 four-wave blocks took 30 us for 73 MB, the adds alone ~25 of them), so few, wide blocks
 __global__ __launch_bounds__(1024) void colsum_kernel(const bf16* __restrict__ in, int ld, int rows, int rows_per_block,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, long long batch_in, long long batch_out) {
   __shared__ float red[16][256];
+  in += (size_t)blockIdx.z * batch_in;       // batched form: matrix z of a stack, sums into vector z (uniform strides)
+  out += (size_t)blockIdx.z * batch_out;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c0 = blockIdx.x * 256 + lane * 4;
   const int r0 = blockIdx.y * rows_per_block;
@@ -346,6 +348,21 @@ extern "C" int vault_colsum(const void* in_bf16, int ld, int rows, int N, float*
   rpb = ((rpb + 15) / 16) * 16;
   dim3 grid(N / 256, (rows + rpb - 1) / rpb);
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const bf16*>(in_bf16), ld, rows, rpb, out);
+                     reinterpret_cast<const bf16*>(in_bf16), ld, rows, rpb, out, 0ll, 0ll);
+  return (int)hipGetLastError();
+}
+
+// `batch` matrices at element stride batch_in, sums into `batch` vectors at float stride batch_out: the QKV bias gradients
+// of a group of layers in one launch, next to the group's batched weight gradients (at small batches one matrix is a
+// 4 us read behind a 10 us launch + reduction tail)
+extern "C" int vault_colsum_batched(const void* in_bf16, int ld, int rows, int N, float* out, int batch, long long batch_in,
+                                    long long batch_out, void* stream) {
+  if (!in_bf16 || !out || N % 256 || rows <= 0 || batch <= 0 || batch > 65535 || (batch_in & 3)) return VAULT_EINVAL;
+  const int row_blocks = std::max(16, 256 / batch);
+  int rpb = (rows + row_blocks - 1) / row_blocks;
+  rpb = ((rpb + 15) / 16) * 16;
+  dim3 grid(N / 256, (rows + rpb - 1) / rpb, batch);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const bf16*>(in_bf16), ld, rows, rpb, out, batch_in, batch_out);
   return (int)hipGetLastError();
 }

@@ -515,6 +515,18 @@ class VaultEngine:
             fl = 2.0 * m_valid * Nout * Kin * G
             ops.pycall(lambda: self._prof_end("wgrad", fl, st))
 
+    def _qkv_bias_grads_batched(self, dqkv_all, layers, i0, hi, ld, rows, N):
+        """QKV bias gradients of layers i0 .. hi - 1 (column sums over the token rows of the first N columns of their dqkv) in
+        ONE launch, issued with the group's batched weight gradients: at small batches a single layer's pass is a 4 us read
+        behind a 10 us launch + reduction tail, and next to the weight gradients it is off the backward chain."""
+        P = self.params
+        offs = [P.offsets[l_.qb][0] for l_ in layers[i0:hi]]
+        stride_o = (offs[1] - offs[0]) if len(offs) > 1 else 0
+        if any(offs[k + 1] - offs[k] != stride_o for k in range(len(offs) - 1)):
+            raise RuntimeError("batched bias gradients need identically laid out layers")
+        gqb = P.gr(layers[i0].qb, n_elems=ld, shape=(ld,))
+        ops.colsum_batched(dqkv_all[i0], ld, rows, N, gqb, hi - i0, dqkv_all.stride(0), stride_o)
+
     def _plan_gelu8(self, ws, n2, act, u, ln, Mp, M):
         """Kernel configuration (5 / 6) on which BOTH the FFN-in forward and the gelu'-product data gradient of this ViLT
         workspace run with the 8-bit tile-native gelu' (vault_gemm aux_u8: an opaque image only the same kernel and shape reads
@@ -1325,7 +1337,8 @@ class VaultEngine:
                 gb = ops.layer_bwd_args(
                     ws[f"stage_vilt{i}"], dy_bf16=dyA, dx_f32=dx[cur] if (not gbf or i == 0) else None, dx_bf16=dyN, dU=dU, dN=dN,
                     dctx=dctx, dqkv=dqkv, dmid_bf16=dyB, do_wgrad=0 if vbatch else 1, **stream_f32,
-                    g_wqkv=P.gr(ln.qw, n_elems=3 * H * H, shape=(3 * H, H)), g_bqkv=P.gr(ln.qb, n_elems=3 * H, shape=(3 * H,)),
+                    g_wqkv=P.gr(ln.qw, n_elems=3 * H * H, shape=(3 * H, H)),
+                    g_bqkv=None if vbatch else P.gr(ln.qb, n_elems=3 * H, shape=(3 * H,)),      # (batched: with the group's launches)
                     g_wo=P.gr(ln.ow), g_bo=P.gr(ln.ob), g_wi=P.gr(ln.iw), g_bi=P.gr(ln.ib), g_wf=P.gr(ln.fw),
                     g_ln1w=P.gr(ln.ln1w), g_ln1b=P.gr(ln.ln1b), g_ln2w=P.gr(ln.ln2w), g_ln2b=P.gr(ln.ln2b),
                     g_bf_below=P.gr(self.vl[i - 1].fb) if i > 0 else None)
@@ -1336,6 +1349,7 @@ class VaultEngine:
                 elif i % vgroup == 0:
                     hi = min(nv, i + vgroup)
                     def launch(i=i, hi=hi):
+                        self._qkv_bias_grads_batched(dqkv_all, self.vl, i, hi, 3 * H, M, 3 * H)
                         for dY_all, X_all, wsel, Nout, Kin in ((dxbA_all, ws["act_all"], "fw", H, FF), (dU_all, ws["n2_all"], "iw", FF, H),
                                                                (dxbB_all, ws["ctx_all"], "ow", H, H), (dqkv_all, ws["n1_all"], "qw", 3 * H, H)):
                             self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.vl[i:hi]], i, Mp, Nout, Kin, M)
@@ -1376,10 +1390,7 @@ class VaultEngine:
             self._dgrad(dqkv, ln.qw, dN, Mp, H, 3 * H, ops.EPI_BF16, M)
             if not vbatch:
                 self._wgrad(dqkv, g("n1"), ln.qw, ln.qb, Mp, 3 * H, H, M)
-            elif short:
-                ops.colsum(dqkv, 3 * H, M, H, gqb[:H])
-            else:
-                ops.colsum(dqkv, 3 * H, M, 3 * H, gqb)
+            # (vbatch: the query third - or, without the shortcut, all of it - with the group's batched launches below)
             nxt = cur ^ 1
             if gbf:
                 ops.layernorm_bwd(x[i], g("m1"), g("r1"), P.w(ln.ln1w), M, H, dy_bf16=dN, dres_bf16=dyB,
@@ -1394,7 +1405,8 @@ class VaultEngine:
                 note(f"vilt{i}")
             elif i % vgroup == 0:
                 hi = min(nv, i + vgroup)
-                def launch(i=i, hi=hi):
+                def launch(i=i, hi=hi, short=short):
+                    self._qkv_bias_grads_batched(dqkv_all, self.vl, i, hi, 3 * H, M, H if short else 3 * H)
                     for dY_all, X_all, wsel, Nout, Kin in ((dxbA_all, ws["act_all"], "fw", H, FF), (dU_all, ws["n2_all"], "iw", FF, H),
                                                            (dxbB_all, ws["ctx_all"], "ow", H, H), (dqkv_all, ws["n1_all"], "qw", 3 * H, H)):
                         self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.vl[i:hi]], i, Mp, Nout, Kin, M)
@@ -1492,7 +1504,8 @@ class VaultEngine:
                 gb = ops.layer_bwd_args(
                     a, dy_bf16=dyb, dy_f32=dyf, dx_f32=dh1, dx_bf16=ldN, dU=ldU, dN=ldN, dctx=ldctx, dqkv=ldqkv,
                     dmid_bf16=dhb, dh1_bf16=dh1b, dmid_f32=dh, do_wgrad=0 if batched else 1,
-                    g_wqkv=P.gr(ln.qw, n_elems=3 * H * H, shape=(3 * H, H)), g_bqkv=P.gr(ln.qb, n_elems=3 * H, shape=(3 * H,)),
+                    g_wqkv=P.gr(ln.qw, n_elems=3 * H * H, shape=(3 * H, H)),
+                    g_bqkv=None if batched else P.gr(ln.qb, n_elems=3 * H, shape=(3 * H,)),
                     g_wo=P.gr(ln.ow), g_bo=P.gr(ln.ob), g_wi=P.gr(ln.iw), g_bi=P.gr(ln.ib), g_wf=P.gr(ln.fw), g_bf=P.gr(ln.fb),
                     g_ln1w=P.gr(ln.ln1w), g_ln1b=P.gr(ln.ln1b), g_ln2w=P.gr(ln.ln2w), g_ln2b=P.gr(ln.ln2b))
                 ws[f"stage_lm_bwd{i}"] = gb
@@ -1509,6 +1522,7 @@ class VaultEngine:
                         embed_done = True
                         note("lm_embed")
                     def launch(i=i, hi=hi):
+                        self._qkv_bias_grads_batched(ldqkv_all, self.ll, i, hi, 3 * H, Ml, 3 * H)
                         for dY_all, X_all, wsel, Nout, Kin in ((dhb_all, ws["lm_act_all"], "fw", H, FF), (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
                                                                (dh1b_all, ws["lm_ctx_all"], "ow", H, H), (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H)):
                             self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.ll[i:hi]], i, Mlp, Nout, Kin, Ml)
@@ -1538,8 +1552,7 @@ class VaultEngine:
             self._dgrad(ldqkv, ln.qw, ldN, Mlp, H, 3 * H, ops.EPI_BF16, Ml)
             if not batched:
                 self._wgrad(ldqkv, yb[i], ln.qw, ln.qb, Mlp, 3 * H, H, Ml)
-            else:
-                ops.colsum(ldqkv, 3 * H, Ml, 3 * H, P.gr(ln.qb, n_elems=3 * H, shape=(3 * H,)))
+            # (batched: the QKV bias gradient with the group's launches below)
             dyb, dyf = ldN, dh1   # consumed by the next iteration's LN2 backward before being overwritten
             if not batched:
                 note(f"lm{i}")
@@ -1551,6 +1564,7 @@ class VaultEngine:
                     embed_done = True
                     note("lm_embed")
                 def launch(i=i, hi=hi):
+                    self._qkv_bias_grads_batched(ldqkv_all, self.ll, i, hi, 3 * H, Ml, 3 * H)
                     for dY_all, X_all, wsel, Nout, Kin in ((dhb_all, ws["lm_act_all"], "fw", H, FF), (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
                                                            (dh1b_all, ws["lm_ctx_all"], "ow", H, H), (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H)):
                         self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.ll[i:hi]], i, Mlp, Nout, Kin, Ml)

@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VAULT_HIP_LIB: development override (A/B of two builds of the SAME HIP library on one box); still no fallback
 LIB_PATH = os.environ.get("VAULT_HIP_LIB") or os.path.join(_HERE, "libvault_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

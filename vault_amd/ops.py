@@ -205,6 +205,11 @@ def layernorm_bwd(x, mean, rstd, gamma, rows, H, *, dy_bf16=None, dy_f32=None, d
     _invoke("vault_layernorm_bwd", C.byref(a), _stream(), struct=a, drop=drop)
 
 
+def colsum_batched(x_bf16, ld, rows, N, out, batch, batch_in, batch_out):
+    _invoke("vault_colsum_batched", C.c_void_p(_p(x_bf16)), C.c_int(ld), C.c_int(rows), C.c_int(N), C.c_void_p(_p(out)),
+            C.c_int(batch), C.c_longlong(batch_in), C.c_longlong(batch_out), _stream())
+
+
 def colsum(x_bf16, ld, rows, N, out):
     _invoke("vault_colsum", C.c_void_p(_p(x_bf16)), C.c_int(ld), C.c_int(rows), C.c_int(N), C.c_void_p(_p(out)), _stream())
 
