@@ -1,0 +1,27 @@
+"""The fused AdamW pass over the flat parameter buffer of ViLT-B/32 + BERTweet (development tool)."""
+import sys
+import torch
+sys.path.insert(0, ".")
+from vault_amd import ops
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 246_000_000
+n -= n % 4
+p = torch.randn(n, device="cuda"); g = torch.randn(n, device="cuda") * 1e-3
+m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda"); pb = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
+
+
+def fn():
+    ops.adamw_step(p, g, m, v, pb, n, 2e-5, 0.9, 0.999, 1e-8, 0.01, zero_grad=True)
+
+
+for _ in range(3):
+    fn()
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(10):
+    fn()
+e.record()
+torch.cuda.synchronize()
+t = s.elapsed_time(e) / 10
+print(f"n={n}: {t * 1e3:.1f} us, {34 * n / t / 1e9:.2f} TB/s of 34 B per parameter")
