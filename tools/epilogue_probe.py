@@ -7,6 +7,7 @@ from tests.test_gpu_gemm import _gemm, EPI_BF16, EPI_DGELU
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 SEQ = int(sys.argv[2]) if len(sys.argv) > 2 else 185
+CFG = int(sys.argv[3]) if len(sys.argv) > 3 else 5      # 5: 256-wide tiles, 6: 192-wide
 M = ((B * SEQ + 255) // 256) * 256
 H, FF = 768, 3072
 
@@ -31,10 +32,10 @@ aux = torch.empty(M, FF, dtype=torch.bfloat16, device="cuda")
 csum = torch.zeros(FF, device="cuda")
 flops = 2 * M * FF * H
 for name, fn in [
-    ("plain bf16 epilogue", lambda: _gemm(X, W2t, o_f, M, FF, H, H, H, FF, 0, 0, EPI_BF16, cfg=5)),
-    ("gelu' u8, no colsum", lambda: _gemm(X, W2t, o_f, M, FF, H, H, H, FF, 0, 0, EPI_DGELU, cfg=5, aux=aux, aux_u8=1)),
-    ("gelu' u8 + colsum", lambda: _gemm(X, W2t, o_f, M, FF, H, H, H, FF, 0, 0, EPI_DGELU, cfg=5, aux=aux, colsum=csum, aux_u8=1)),
-    ("gelu' bf16 + colsum", lambda: _gemm(X, W2t, o_f, M, FF, H, H, H, FF, 0, 0, EPI_DGELU, cfg=5, aux=aux, colsum=csum)),
+    ("plain bf16 epilogue", lambda: _gemm(X, W2t, o_f, M, FF, H, H, H, FF, 0, 0, EPI_BF16, cfg=CFG)),
+    ("gelu' u8, no colsum", lambda: _gemm(X, W2t, o_f, M, FF, H, H, H, FF, 0, 0, EPI_DGELU, cfg=CFG, aux=aux, aux_u8=1)),
+    ("gelu' u8 + colsum", lambda: _gemm(X, W2t, o_f, M, FF, H, H, H, FF, 0, 0, EPI_DGELU, cfg=CFG, aux=aux, colsum=csum, aux_u8=1)),
+    ("gelu' bf16 + colsum", lambda: _gemm(X, W2t, o_f, M, FF, H, H, H, FF, 0, 0, EPI_DGELU, cfg=CFG, aux=aux, colsum=csum)),
 ]:
     t = timeit(fn)
-    print(f"M={M} {name:24s} {t*1e6:8.1f} us {flops/t/1e12:7.1f} TF/s")
+    print(f"M={M} cfg{CFG} {name:24s} {t*1e6:8.1f} us {flops/t/1e12:7.1f} TF/s")
