@@ -17,6 +17,9 @@
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
+#ifndef ATTN_WL
+#define ATTN_WL 1         // single-pass backward: whole-line output stores (0: the half-line form, development A/B)
+#endif
 #ifndef ATTN_ABLATE
 #define ATTN_ABLATE 0     // development (resident backward kernels): 1 = memory traffic only, 2 = arithmetic only (every block on item 0..heads-1)
 #endif
@@ -643,6 +646,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
 #ifndef ATTN_ST_NT
 #define ATTN_ST_NT 0      // development: 1 = non-temporal output stores
 #endif
+#if ATTN_WL && defined(ATTN_LOADS_FIRST) && ATTN_LOADS_FIRST
+#error "ATTN_LOADS_FIRST counts the half-line form's stores: build it with -DATTN_WL=0"
+#endif
 #ifndef ATTN_LOADS_FIRST
 #define ATTN_LOADS_FIRST 0   // development: 1 = the next items' loads are issued in front of the dK / dV stores
 #endif
@@ -721,8 +727,27 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16*
   }
   const uint32_t off_frag = (uint32_t)min(wave * 16 + l15, S - 1) * (uint32_t)(ld * 2) + (uint32_t)g * 16u;   // own key row, d = 8 g (+ 32 s)
   const uint32_t off_out = (uint32_t)(wave * 16 + l15) * (uint32_t)(ld * 2) + (uint32_t)g * 16u;             // own row, d = 8 g (+ 32 hf)
-  // (measured with wrong addresses, 8 lanes per 128-byte row: whole-line stores would take another 5-8 % off the kernel;
-  //  they need a transposition of the output tiles through LDS, which has 8 KiB to spare here)
+#if ATTN_WL
+  // Whole-line stores: a lane holds the 16-byte chunks g (hf = 0) and 4 + g (hf = 1) of its row's 128-byte head slice, so a
+  // store of one hf writes 16 half lines.  Lanes l15 and l15 ^ 8 swap one chunk each (DPP row_ror:8): instruction A then
+  // writes rows 0-7 of the tile as whole lines (lanes l15 < 8: chunk g, lanes l15 >= 8: chunk 4 + g of row l15 - 8),
+  // instruction B rows 8-15.  (Measured beforehand with the addresses alone: 5-8 % of the kernel.)
+  const int row_a = wave * 16 + (l15 & 7);                                                                    // B: + 8
+  const uint32_t off_wl = (uint32_t)row_a * (uint32_t)(ld * 2) + (uint32_t)(l15 >> 3) * 64u + (uint32_t)g * 16u;
+  const uint32_t off_wl_b = 8u * (uint32_t)(ld * 2);
+  const int S_st = (ATTN_ABLATE == 5 ? -S : S);
+  const bool wave_rows_b = __builtin_amdgcn_readfirstlane((int)(wave * 16 + 8 < S_st)) != 0;   // rows for instruction B too
+  auto wl_pair = [&](const u32x4& x, const u32x4& y, u32x4& a, u32x4& b) {     // x: chunk g, y: chunk 4 + g of the own row
+    const bool lo8 = l15 < 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t xr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[k], 0x128, 0xF, 0xF, true);   // row_ror:8
+      const uint32_t yr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y[k], 0x128, 0xF, 0xF, true);
+      a[k] = lo8 ? x[k] : yr;
+      b[k] = lo8 ? xr : y[k];
+    }
+  };
+#endif
   const uint32_t off_stat = (uint32_t)min(tid, S - 1) * 4u;
   auto item_bh = [&](int item, int& b, int& h) {
 #if ATTN_ABLATE == 2 || ATTN_ABLATE == 6
@@ -886,6 +911,31 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16*
     if (more) fetch_kv_frags(item + G);
     if (more2) fetch_q_do(item + 2 * G);
 #endif
+#if ATTN_WL
+    {
+      char* dstk = dqbase + 2 * H;        // (byte offsets: K part at + H elements, V part at + 2 H elements)
+      char* dstv = dqbase + 4 * H;
+      u32x4 wk[2], wv[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {    // tiles (2 hf, 2 hf + 1): d = 32 hf + 8 g + 0..7 of this lane's row
+        const f32x4 ka = dk[2 * hf], kb2 = dk[2 * hf + 1], va = dv[2 * hf], vb2 = dv[2 * hf + 1];
+        wk[hf] = u32x4{pack_bf16x2(ka[0] * scale, ka[1] * scale), pack_bf16x2(ka[2] * scale, ka[3] * scale),
+                       pack_bf16x2(kb2[0] * scale, kb2[1] * scale), pack_bf16x2(kb2[2] * scale, kb2[3] * scale)};
+        wv[hf] = u32x4{pack_bf16x2(va[0], va[1]), pack_bf16x2(va[2], va[3]), pack_bf16x2(vb2[0], vb2[1]), pack_bf16x2(vb2[2], vb2[3])};
+      }
+      u32x4 ka_, kb_, va_, vb_;
+      wl_pair(wk[0], wk[1], ka_, kb_);
+      wl_pair(wv[0], wv[1], va_, vb_);
+      if (row_a < S_st) {
+        ATTN_STORE16(dstk + off_wl, ka_);
+        ATTN_STORE16(dstv + off_wl, va_);
+      }
+      if (row_a + 8 < S_st) {
+        ATTN_STORE16(dstk + (off_wl + off_wl_b), kb_);
+        ATTN_STORE16(dstv + (off_wl + off_wl_b), vb_);
+      }
+    }
+#else
     if (wave * 16 + l15 < (ATTN_ABLATE == 5 ? -S : S)) {
       char* dstk = dqbase + 2 * H;        // (byte offsets: K part at + H elements, V part at + 2 H elements)
       char* dstv = dqbase + 4 * H;
@@ -899,6 +949,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16*
         ATTN_STORE16(dstv + (off_out + 64u * hf), wv);
       }
     }
+#endif
     // requests of the following items, issued here so that they are in flight for a whole item: the K / V fragments of the
     // next item first (4 loads), then the Q / dO / O chunks + statistics of the item after next (8 loads)
 #if !ATTN_LOADS_FIRST
@@ -919,6 +970,20 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16*
         for (int dt = 0; dt < 4; ++dt)
           o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Ks, T, dt >> 1, dt & 1, g, l15), dsB, o[dt], 0, 0, 0);
       }
+#if ATTN_WL
+      {
+        u32x4 wq[2], qa_, qb_;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const f32x4 qa = o[2 * hf], qb2 = o[2 * hf + 1];
+          wq[hf] = u32x4{pack_bf16x2(qa[0] * scale, qa[1] * scale), pack_bf16x2(qa[2] * scale, qa[3] * scale),
+                         pack_bf16x2(qb2[0] * scale, qb2[1] * scale), pack_bf16x2(qb2[2] * scale, qb2[3] * scale)};
+        }
+        wl_pair(wq[0], wq[1], qa_, qb_);
+        if (row_a < S_st) ATTN_STORE16(dqbase + off_wl, qa_);
+        if (row_a + 8 < S_st) ATTN_STORE16(dqbase + (off_wl + off_wl_b), qb_);
+      }
+#else
       if (wave * 16 + l15 < (ATTN_ABLATE == 5 ? -S : S)) {
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -928,6 +993,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16*
           ATTN_STORE16(dqbase + (off_out + 64u * hf), w);
         }
       }
+#endif
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with K and dS^T
     if (more) {
@@ -940,11 +1006,23 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16*
         if (wave_rows) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
 #else
+#if ATTN_WL   // (dQ stores: instruction A if the tile has rows, instruction B if it has more than 8)
+      if (more2) {
+        if (wave_rows_b) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (wave_rows) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        if (wave_rows_b) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (wave_rows) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+#else
       if (more2) {
         if (wave_rows) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       } else {
         if (wave_rows) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+#endif
 #endif
       dma_k(item + G);
     }

@@ -316,6 +316,13 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
       constexpr int PDM = 2;                                        // 8-bit aux: prefetch distance in row tiles
       constexpr int SU = (EPI == EPI_BF16_GELU) ? 2 : 1;            // stores per unit (the 8-bit form: + one per mt)
       constexpr int NV1 = (NTW == 4) ? 8 : 4;                       // values of unit 1
+      // Whole-line stores (256-wide tiles): the two units of a row tile are the two 64-byte
+      // halves of the wave's 128-byte row segments.  Stored unit by unit, an instruction writes 16 half lines; with the
+      // halves of rows 0-7 / 8-15 exchanged between lanes l15 and l15 ^ 8 (DPP row_ror:8) an instruction writes 8 whole
+      // lines.  Built and measured on one box (tools/gemm_bench.py, M = 47360): gelu'-product dgrad 261.5 -> 250-257 us; the
+      // GELU forward got slower (285 -> 288-295: unit 0 stays in registers under unit 1's GELU arithmetic) and the plain
+      // bf16 epilogue did not move (QKV 172 -> 172-176) - so only the 8-bit gelu'-product form stores this way
+      constexpr bool WL = (NTW == 4) && EPI == EPI_BF16_DGELU_U8;
       const int nc = n0 + wc * 16 * NTW + 8 * eg;
       const uint32_t c1 = (NTW == 4) ? 64u : (uint32_t)(64 - 8 * eg);   // byte offset of unit 1 behind unit 0 (bf16)
       // (bias: bq, loaded under the item's last K tile - always a valid pointer: the launcher substitutes zeros)
@@ -330,6 +337,8 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
       const uint32_t off0 = (uint32_t)(((size_t)(mw + el15) * p.ldo + nc) * 2);
 #endif
       const uint32_t step = (uint32_t)p.ldo * 32u;
+      // WL: rows (l15 & 7) [+ 8 for the second instruction], byte half (l15 >> 3) of the 128-byte segment
+      const uint32_t offw = (uint32_t)(((size_t)(mw + (el15 & 7)) * p.ldo + nc) * 2) + (uint32_t)(el15 >> 3) * 64u;
       const char* outp = reinterpret_cast<const char*>(p.out);
       const char* out2p = reinterpret_cast<const char*>(p.out2);
       const char* auxp = reinterpret_cast<const char*>(p.aux);
@@ -344,6 +353,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
         const char* const u8_ = u8p;
         const uint32_t v8_ = voff8;
         uint32_t q8a = 0u, q8b = 0u;      // 8-bit gelu' of unit 0, held until unit 1 completes the slot
+        u32x4 wv0 = {0u, 0u, 0u, 0u};     // WL: unit 0 of the row tile, held until unit 1 is packed
         u32x4 a8q[(HAS_AUX && U8) ? PDM : 1];
         u32x4 a8 = {0u, 0u, 0u, 0u};
         auto aux8_load = [&](int mt) {
@@ -468,6 +478,31 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
           }
           const u32x4 wv = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
                             pack_bf16x2(v[6], v[7])};
+          if constexpr (WL) {
+            if (j == 0) {
+              wv0 = wv;
+            } else {
+              // lanes l15 < 8 keep unit 0 of their row for instruction A and take unit 0 of row l15 + 8 for instruction B;
+              // lanes l15 >= 8 take unit 1 of row l15 - 8 for A and keep their own unit 1 for B
+              const bool lo8 = el15 < 8;
+              u32x4 da, db;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const uint32_t xr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wv0[k], 0x128, 0xF, 0xF, true);   // row_ror:8
+                const uint32_t yr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wv[k], 0x128, 0xF, 0xF, true);
+                da[k] = lo8 ? wv0[k] : yr;
+                db[k] = lo8 ? xr : wv[k];
+              }
+              const int ma = mw + mt * 16 + (el15 & 7);
+              const uint32_t oa = offw + (uint32_t)mt * step;
+              if (FULL || ma < p.m_valid)
+                asm volatile("global_store_dwordx4 %0, %1, %2" W8_STORE_MOD "\n\ts_nop 1" ::"v"(oa), "v"(da), "s"(o1_) : "memory");
+              if (FULL || ma + 8 < p.m_valid) {
+                const uint32_t ob = oa + (uint32_t)p.ldo * 16u;
+                asm volatile("global_store_dwordx4 %0, %1, %2" W8_STORE_MOD "\n\ts_nop 1" ::"v"(ob), "v"(db), "s"(o1_) : "memory");
+              }
+            }
+          } else
 #if W8_ABLATE == 1   // development: half of the stores
           if ((FULL || m < p.m_valid) && j == 0) {
 #else
