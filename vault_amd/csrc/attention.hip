@@ -17,6 +17,9 @@
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
+#ifndef ATTN_FWD_WL
+#define ATTN_FWD_WL 1     // forward: permuted d rows (16-byte pieces) + whole-line stores (0: 8-byte pieces, development A/B)
+#endif
 #ifndef ATTN_WL
 #define ATTN_WL 1         // single-pass backward: whole-line output stores (0: the half-line form, development A/B)
 #endif
@@ -158,15 +161,65 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __r
       }
       // O^T[d][q] += V^T[d][key] P^T[key][q]: the transposed-read V fragment is the A operand (row = d), the
       // probabilities (accumulator layout: query on the lane) the B operand.  The result has the query on the
-      // lane and four consecutive d in its registers: 8-byte stores and a lane-local normalisation.
+      // lane (lane-local normalisation); with the d rows of the A operand permuted (frag_tr8) the tiles (2 hf, 2 hf + 1)
+      // hold d = 32 hf + 8 g + 0..7 of the lane's row: 16-byte pieces, written as whole 128-byte lines (below).
       const bf16x8 pf = pack_frag(p2[0], p2[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
+#if ATTN_FWD_WL
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Vs, T, dt >> 1, dt & 1, g, l15), pf, o[dt], 0, 0, 0);
+#else
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Vs, T, dt, g, l15), pf, o[dt], 0, 0, 0);
+#endif
     }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;       // this lane's query row (l15)
+#if ATTN_FWD_WL
+    if (q_l < S && g == 0) lse[(size_t)bh * S + q_l] = mx * scale + __logf(sum);
+    if (ctx3 != nullptr) {   // precise path: [hi | lo | hi] operand of the split-bf16 projection GEMM (16-byte pieces)
+      if (q_l < S) {
+        bf16* dst = ctx3 + (row0 + q_l) * 3 * H + h * 64 + 8 * g;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          uint32_t wh[4], wl[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            bf16 h0, l0, h1, l1;
+            split_bf16(o[2 * hf + (k >> 1)][2 * (k & 1)] * inv, h0, l0);
+            split_bf16(o[2 * hf + (k >> 1)][2 * (k & 1) + 1] * inv, h1, l1);
+            wh[k] = pack_bf16x2((float)h0, (float)h1);
+            wl[k] = pack_bf16x2((float)l0, (float)l1);
+          }
+          const u32x4 vh = {wh[0], wh[1], wh[2], wh[3]}, vl = {wl[0], wl[1], wl[2], wl[3]};
+          *reinterpret_cast<u32x4*>(dst + 32 * hf) = vh;
+          *reinterpret_cast<u32x4*>(dst + H + 32 * hf) = vl;
+          *reinterpret_cast<u32x4*>(dst + 2 * H + 32 * hf) = vh;
+        }
+      }
+    } else {
+      // whole-line stores: lanes l15 and l15 ^ 8 swap one 16-byte chunk each (DPP row_ror:8, see the single-pass backward):
+      // instruction A writes rows 0-7 of the tile, instruction B rows 8-15, 128 contiguous bytes per row
+      u32x4 w[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+        w[hf] = u32x4{pack_bf16x2(o[2 * hf][0] * inv, o[2 * hf][1] * inv), pack_bf16x2(o[2 * hf][2] * inv, o[2 * hf][3] * inv),
+                      pack_bf16x2(o[2 * hf + 1][0] * inv, o[2 * hf + 1][1] * inv), pack_bf16x2(o[2 * hf + 1][2] * inv, o[2 * hf + 1][3] * inv)};
+      const bool lo8 = l15 < 8;
+      u32x4 wa, wb;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t xr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[0][k], 0x128, 0xF, 0xF, true);   // row_ror:8
+        const uint32_t yr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[1][k], 0x128, 0xF, 0xF, true);
+        wa[k] = lo8 ? w[0][k] : yr;
+        wb[k] = lo8 ? xr : w[1][k];
+      }
+      const int ra = qt * 16 + (l15 & 7);
+      bf16* dst = ctx + (row0 + ra) * H + h * 64 + (l15 >> 3) * 32 + 8 * g;
+      if (ra < S) *reinterpret_cast<u32x4*>(dst) = wa;
+      if (ra + 8 < S) *reinterpret_cast<u32x4*>(dst + 8 * (size_t)H) = wb;
+    }
+#else
     if (q_l < S) {
       if (g == 0) lse[(size_t)bh * S + q_l] = mx * scale + __logf(sum);
       if (ctx3 != nullptr) {   // precise path: [hi | lo | hi] operand of the split-bf16 projection GEMM
@@ -191,6 +244,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __r
         }
       }
     }
+#endif
   }
 }
 
