@@ -3,6 +3,7 @@ import sys, torch
 sys.path.insert(0, ".")
 from vault_amd import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+SEQS = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (185, 40)    # 281: padded batches (two-phase backward)
 H, heads = 768, 12
 def t(fn, n=10):
     for _ in range(3): fn()
@@ -10,7 +11,7 @@ def t(fn, n=10):
     s.record()
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / n * 1e3
-for S in (185, 40):
+for S in SEQS:
     M = ((B * S + 255) // 256) * 256
     qkv = (torch.randn(M, 3 * H, device="cuda") * 0.5).bfloat16()
     km = torch.ones(B, S, device="cuda")

@@ -86,6 +86,32 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& lo, const f32x4& hi) {
   return f;
 }
 
+// Output tile of 16 rows x 64 d (one head's 128-byte slice per row) whose accumulators came from frag_tr8 operands: tiles
+// (2 hf, 2 hf + 1) of lane (g, l15) hold d = 32 hf + 8 g + 0..7 of row l15, i.e. the 16-byte chunks g and 4 + g of the row.
+// Lanes l15 and l15 ^ 8 swap one chunk each (DPP row_ror:8) so that the two store instructions write rows 0-7 and rows 8-15
+// of the tile as whole 128-byte lines.  dst: element (row 0, first column of the head); rows >= S are not stored.
+__device__ __forceinline__ void store_tile_lines(bf16* dst, int ld, int tile_row0, int S, const f32x4 (&o)[4], float mul,
+                                                 int g, int l15) {
+  u32x4 w[2];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+    w[hf] = u32x4{pack_bf16x2(o[2 * hf][0] * mul, o[2 * hf][1] * mul), pack_bf16x2(o[2 * hf][2] * mul, o[2 * hf][3] * mul),
+                  pack_bf16x2(o[2 * hf + 1][0] * mul, o[2 * hf + 1][1] * mul), pack_bf16x2(o[2 * hf + 1][2] * mul, o[2 * hf + 1][3] * mul)};
+  const bool lo8 = l15 < 8;
+  u32x4 wa, wb;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t xr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[0][k], 0x128, 0xF, 0xF, true);   // row_ror:8
+    const uint32_t yr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[1][k], 0x128, 0xF, 0xF, true);
+    wa[k] = lo8 ? w[0][k] : yr;
+    wb[k] = lo8 ? xr : w[1][k];
+  }
+  const int ra = tile_row0 + (l15 & 7);
+  bf16* d = dst + (size_t)ra * ld + (l15 >> 3) * 32 + 8 * g;
+  if (ra < S) *reinterpret_cast<u32x4*>(d) = wa;
+  if (ra + 8 < S) *reinterpret_cast<u32x4*>(d + 8 * (size_t)ld) = wb;
+}
+
 struct AttnDrop {
   uint32_t thresh, seed, stream;
   float scale;
@@ -337,20 +363,13 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __r
           ds2[hh][r] = pv * (dpv - dl) * scale;
         }
       }
-      // dQ^T[d][q] += K^T[d][key] dS^T[key][q] (query stays on the lane: 8-byte stores)
+      // dQ^T[d][q] += K^T[d][key] dS^T[key][q] (query stays on the lane; d rows permuted: 16-byte chunks, whole-line stores)
       const bf16x8 dsf = pack_frag(ds2[0], ds2[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(img0, T, dt, g, l15), dsf, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(img0, T, dt >> 1, dt & 1, g, l15), dsf, o[dt], 0, 0, 0);
     }
-    if (q_l < S) {
-      bf16* dst = dqbase + (size_t)q_l * ld + 4 * g;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const uint2 w = {pack_bf16x2(o[dt][0], o[dt][1]), pack_bf16x2(o[dt][2], o[dt][3])};
-        *reinterpret_cast<uint2*>(dst + dt * 16) = w;
-      }
-    }
+    store_tile_lines(dqbase, ld, qt * 16, S, o, 1.0f, g, l15);
   }
   __syncthreads();
   // ---------------- phase B: dK, dV ----------------
@@ -407,21 +426,12 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __r
       // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]  (key on the lane)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(img1, T, dt, g, l15), pf, dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(img0, T, dt, g, l15), dsf, dk[dt], 0, 0, 0);
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(img1, T, dt >> 1, dt & 1, g, l15), pf, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(img0, T, dt >> 1, dt & 1, g, l15), dsf, dk[dt], 0, 0, 0);
       }
     }
-    if (k_l < S) {
-      bf16* dstk = dqbase + H + (size_t)k_l * ld + 4 * g;
-      bf16* dstv = dqbase + 2 * H + (size_t)k_l * ld + 4 * g;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const uint2 wk = {pack_bf16x2(dk[dt][0], dk[dt][1]), pack_bf16x2(dk[dt][2], dk[dt][3])};
-        const uint2 wv = {pack_bf16x2(dv[dt][0], dv[dt][1]), pack_bf16x2(dv[dt][2], dv[dt][3])};
-        *reinterpret_cast<uint2*>(dstk + dt * 16) = wk;
-        *reinterpret_cast<uint2*>(dstv + dt * 16) = wv;
-      }
-    }
+    store_tile_lines(dqbase + H, ld, kt * 16, S, dk, 1.0f, g, l15);
+    store_tile_lines(dqbase + 2 * H, ld, kt * 16, S, dv, 1.0f, g, l15);
   }
 }
 
