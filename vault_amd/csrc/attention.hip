@@ -17,6 +17,15 @@
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
+// Waves of the one-workgroup-per-CU kernels for 192 < S <= 320 (80 KiB K / V image; 320 * 8 chunks / (64 waves) must be whole).
+// tools/attn_bench.py 64 281, same box: backward 252.6 us with 4 waves, 153.4 with 8, 134.3 with 10 (18 query / key tiles per
+// item: 4 waves walk them in 5 rounds); the forward is fastest with 4 (106.8 us; 116.6 with 8, 158 with 10).
+#ifndef ATTN_LONG_WAVES_FWD
+#define ATTN_LONG_WAVES_FWD 4
+#endif
+#ifndef ATTN_LONG_WAVES_BWD
+#define ATTN_LONG_WAVES_BWD 10
+#endif
 #ifndef ATTN_FWD_WL
 #define ATTN_FWD_WL 1     // forward: permuted d rows (16-byte pieces) + whole-line stores (0: 8-byte pieces, development A/B)
 #endif
@@ -1124,7 +1133,7 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
   } else if (a->S <= 192) {
     if (drop) FWD_V(6, 12, 6, true); else FWD_V(6, 12, 6, false);
   } else {   // long sequences of padded, larger images: K/V image 80 KiB -> one block per CU
-    auto kern = attn_fwd_kernel<10, 4, 1>;
+    auto kern = attn_fwd_kernel<10, ATTN_LONG_WAVES_FWD, 1>;
     static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];
     if (!attr_done) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1132,7 +1141,7 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
       if (e != hipSuccess) return (int)e;
       attr_done = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), attn_lds_bytes<10>(), st, reinterpret_cast<const bf16*>(a->qkv),
+    hipLaunchKernelGGL(kern, grid, dim3(ATTN_LONG_WAVES_FWD * 64), attn_lds_bytes<10>(), st, reinterpret_cast<const bf16*>(a->qkv),
                        a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
                        reinterpret_cast<bf16*>(a->ctx_split3));
   }
@@ -1209,7 +1218,7 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
       if (drop) RES_V(true) else RES_V(false)
     }
   } else {
-    auto kern = attn_bwd_kernel<10, 4, 1>;
+    auto kern = attn_bwd_kernel<10, ATTN_LONG_WAVES_BWD, 1>;
     static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];
     if (!attr_done) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1217,7 +1226,7 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
       if (e != hipSuccess) return (int)e;
       attr_done = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), attn_lds_bytes<10>(), st, reinterpret_cast<const bf16*>(a->qkv),
+    hipLaunchKernelGGL(kern, grid, dim3(ATTN_LONG_WAVES_BWD * 64), attn_lds_bytes<10>(), st, reinterpret_cast<const bf16*>(a->qkv),
                        a->keymask, reinterpret_cast<const bf16*>(a->ctx), reinterpret_cast<const bf16*>(a->dctx), a->lse,
                        reinterpret_cast<bf16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
   }
