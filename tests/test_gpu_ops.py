@@ -91,7 +91,8 @@ def _attn_ref(qkv, keymask, B, S, H, heads):
 
 # (S = 70 / 129 / 65: waves of the single-pass backward whose 16-row tile lies entirely behind the sequence - they issue no
 #  stores, the other branch of its counted waits; S = 192 / 64: no padding rows at all; S = 17: a single tile)
-@pytest.mark.parametrize("S,heads", [(185, 12), (40, 12), (185, 4), (33, 2), (70, 3), (129, 5), (192, 2), (65, 1), (64, 2), (17, 1)])
+@pytest.mark.parametrize("S,heads", [(185, 12), (40, 12), (185, 4), (33, 2), (70, 3), (129, 5), (192, 2), (65, 1), (64, 2), (17, 1),
+                                     (193, 2), (281, 3), (288, 1), (289, 2), (320, 1)])     # 72 KiB and 80 KiB K / V images (padded image batches)
 def test_attention_fwd_bwd(S, heads):
     B, H = 3, heads * 64
     M = B * S

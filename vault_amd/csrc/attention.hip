@@ -20,6 +20,17 @@ constexpr float LOG2E = 1.4426950408889634f;
 // Waves of the one-workgroup-per-CU kernels for 192 < S <= 320 (80 KiB K / V image; 320 * 8 chunks / (64 waves) must be whole).
 // tools/attn_bench.py 64 281, same box: backward 252.6 us with 4 waves, 153.4 with 8, 134.3 with 10 (18 query / key tiles per
 // item: 4 waves walk them in 5 rounds); the forward is fastest with 4 (106.8 us; 116.6 with 8, 158 with 10).
+// 192 < S <= 288: waves per workgroup / launch-bounds waves per SIMD (2304 chunks / (64 waves) must be whole)
+// (tools/attn_bench.py 64 281, same box: forward 73.5 us with 4 waves, 78 with 6, 50.2 with 12; backward 157 us with 6 waves,
+//  133 with 9, 121 with 12 - against 106.8 / 134.3 us for the 320-row kernels below, one block per CU)
+#ifndef ATTN_L9_FWD_W
+#define ATTN_L9_FWD_W 12
+#define ATTN_L9_FWD_WPE 6     // (two 12-wave blocks per CU: 46.9 against 50.3 us with one)
+#endif
+#ifndef ATTN_L9_BWD_W
+#define ATTN_L9_BWD_W 12
+#define ATTN_L9_BWD_WPE 3
+#endif
 #ifndef ATTN_LONG_WAVES_FWD
 #define ATTN_LONG_WAVES_FWD 4
 #endif
@@ -1132,6 +1143,18 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
     if (drop) FWD_V(2, 4, 3, true); else FWD_V(2, 4, 3, false);
   } else if (a->S <= 192) {
     if (drop) FWD_V(6, 12, 6, true); else FWD_V(6, 12, 6, false);
+  } else if (a->S <= 288) {   // padded batches up to the HF processor's 384 x 640 canvas (281 tokens): 72 KiB K / V image, two blocks per CU
+    auto kern = attn_fwd_kernel<9, ATTN_L9_FWD_W, ATTN_L9_FWD_WPE>;
+    static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         attn_lds_bytes<9>());
+      if (e != hipSuccess) return (int)e;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(ATTN_L9_FWD_W * 64), attn_lds_bytes<9>(), st, reinterpret_cast<const bf16*>(a->qkv),
+                       a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
+                       reinterpret_cast<bf16*>(a->ctx_split3));
   } else {   // long sequences of padded, larger images: K/V image 80 KiB -> one block per CU
     auto kern = attn_fwd_kernel<10, ATTN_LONG_WAVES_FWD, 1>;
     static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];
@@ -1217,6 +1240,18 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
     } else {
       if (drop) RES_V(true) else RES_V(false)
     }
+  } else if (a->S <= 288) {
+    auto kern = attn_bwd_kernel<9, ATTN_L9_BWD_W, ATTN_L9_BWD_WPE>;
+    static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         attn_lds_bytes<9>());
+      if (e != hipSuccess) return (int)e;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(ATTN_L9_BWD_W * 64), attn_lds_bytes<9>(), st, reinterpret_cast<const bf16*>(a->qkv),
+                       a->keymask, reinterpret_cast<const bf16*>(a->ctx), reinterpret_cast<const bf16*>(a->dctx), a->lse,
+                       reinterpret_cast<bf16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
   } else {
     auto kern = attn_bwd_kernel<10, ATTN_LONG_WAVES_BWD, 1>;
     static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];
