@@ -124,6 +124,54 @@ def measure_parity(eng, spec, args, dev):
     return name, out
 
 
+def measure_fp16(spec, args, dev, batch, labels, B, steps: int = 10, warmup: int = 3):
+    """The fp16 operand build (libvault_hip_f16.so, VaultEngine(half="fp16")) on this box: (1) TRAIN-mode forward on the
+    reference golden batch - the logits / loss a training step computes - against the reference's numbers; (2) the training
+    throughput of that mode at the bench batch (same steps as the headline loop: tape, fused AdamW dividing the gradient
+    scale out)."""
+    name = "full_bert_base_frozen_b2" if args.lm == "bert-base-uncased" else "full_bertweet_b2"
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    e16 = VaultEngine(spec, dev, seed=0, freeze_lm=args.freeze_lm, classifier_dropout=0.0, half="fp16")
+    import copy
+    spec0 = copy.deepcopy(spec)
+    spec0.lm.hidden_dropout_prob = 0.0
+    spec0.lm.attention_probs_dropout_prob = 0.0
+    e16.spec = spec0
+    bn = synthetic_batch(spec, int(g["meta_batch"]), seed=int(g["meta_data_seed"]), n_classes=3)
+    db = {k: torch.from_numpy(v).to(dev) for k, v in bn.items()}
+    o = e16.forward(db, train=True, labels=db["labels"], need_hidden=False)
+    torch.cuda.synchronize(dev)
+    res = {"what": "IEEE fp16 MFMA operands (v_mfma_f32_16x16x32_f16, the bf16 instruction's rate), fp32 accumulate / residual / "
+                   "statistics / master weights; 16-bit gradients under a static 2^12 scale divided out inside the fused AdamW; "
+                   "conversions saturate at 65504 (VaultEngine(half='fp16'), bench.py --half fp16)",
+           "golden": f"tests/golden/{name}.npz (reference-generated, B = 2), TRAIN-mode forward, dropout off",
+           "max_abs_dlogits": round(float(np.abs(o["logits"].cpu().numpy() - g["logits"]).max()), 6),
+           "dloss": round(abs(float(o["loss"]) - float(g["loss"])), 6), "north_star_tolerance": 1e-3}
+    e16.spec = spec
+    e16.classifier_dropout = 0.1
+    e16._ws.clear()
+    st = TrainStep(e16, learning_rate=2e-5, warmup_ratio=0.1, total_steps=100, assume_full_pixel_mask=True)
+    stage = e16.input_buffers(B, batch["input_ids"].shape[1], True)
+    b16 = dict(batch)
+    for k in ("input_ids", "pixel_values"):
+        stage[k].copy_(batch[k])
+        b16[k] = stage[k]
+    stage["labels"].copy_(labels)
+    for _ in range(warmup):
+        st(b16, stage["labels"])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st(b16, stage["labels"])
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    res.update(train_samples_per_s=round(B * steps / dt, 2), ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
+               final_loss=round(float(st.loss.item()), 5))
+    del st, e16, stage, b16
+    torch.cuda.empty_cache()
+    return res
+
+
 CONFIGS = {   # BASELINE.json `configs` (1 is the CPU plumbing case: a test, not a bench line)
     2: dict(batch=64, what="config 2: bf16 fine-tune, batch 64, 1 GPU"),
     3: dict(batch=64, what="config 3: bf16 fine-tune, global batch 64 x ranks (512 at DP = 8)"),
@@ -132,12 +180,31 @@ CONFIGS = {   # BASELINE.json `configs` (1 is the CPU plumbing case: a test, not
 }
 
 
+def count_gpus_sysfs() -> int:
+    """GPUs of this node WITHOUT touching the HIP runtime: KFD topology nodes with SIMDs (CPU nodes have simd_count 0),
+    capped by the visibility variables.  The launcher parent forks the ranks: it must not have initialised a runtime."""
+    import glob
+    n = 0
+    for p in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(l.split()[:2] for l in open(p) if len(l.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
+
+
 def _self_launch(n: int, argv):
-    """`--gpus N` outside a torchrun environment: this process has made no GPU call (counting devices does not
-    initialise the runtime) - it starts N fresh ranks through torch.distributed.run and exits with their code."""
+    """`--gpus N` outside a torchrun environment: this process has made no GPU call (the devices are counted from sysfs) -
+    it starts N fresh ranks through torch.distributed.run and exits with their code."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()
+    have = count_gpus_sysfs()
     if have < n:
         print(f"bench.py: --gpus {n} needs {n} devices, this node shows {have}: refusing to measure fewer ranks than asked for",
               file=sys.stderr)
@@ -215,6 +282,10 @@ def main():
     ap.add_argument("--fp8-forward", action="store_true",
                     help="BASELINE config 5: MXFP8 forward Linear GEMMs (block-scaled fp8 MFMA), bf16 backward")
     ap.add_argument("--lm", default="bertweet", choices=["bertweet", "bert-base-uncased"])
+    ap.add_argument("--half", default="bf16", choices=["bf16", "fp16"],
+                    help="16-bit operand format of the timed steps (default bf16: BASELINE's; fp16 = libvault_hip_f16.so, the "
+                         "format whose training step is inside the 1e-3 tolerance - also measured beside the bf16 line, "
+                         "`parity.fp16_operands`)")
     ap.add_argument("--no-parity", action="store_true", help="skip the golden-batch parity measurement and the precise-mode timing")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second timed loop with pipelined host->device input copies")
     args = ap.parse_args()
@@ -250,7 +321,8 @@ def main():
 
     lm = LMSpec.bertweet_base() if args.lm == "bertweet" else LMSpec.bert_base_uncased()
     spec = VaultSpec(vilt=ViltSpec(), lm=lm, n_classes=3)
-    eng = VaultEngine(spec, dev, seed=0, freeze_lm=args.freeze_lm, classifier_dropout=0.1, fp8_forward=args.fp8_forward)
+    eng = VaultEngine(spec, dev, seed=0, freeze_lm=args.freeze_lm, classifier_dropout=0.1, fp8_forward=args.fp8_forward,
+                      half=args.half)
     total = args.steps + args.warmup
     stepper = TrainStep(eng, learning_rate=2e-5, warmup_ratio=0.1, total_steps=max(total, 10), process_group=pg,
                        assume_full_pixel_mask=True,   # synthetic 384x384 images, all-ones masks: no per-step mask check
@@ -261,7 +333,7 @@ def main():
     if rank == 0 and not args.no_parity:
         gname, par = measure_parity(eng, spec, args, dev)
         parity = {"golden": f"tests/golden/{gname}.npz (reference-generated, B = 2, eval mode)",
-                  "mode": ("mxfp8 forward GEMMs" if args.fp8_forward else "bf16 MFMA operands, fp32 accumulate (the timed mode)"),
+                  "mode": ("mxfp8 forward GEMMs" if args.fp8_forward else f"{args.half} MFMA operands, fp32 accumulate (the timed mode)"),
                   "max_abs_dlogits": round(par["fast"]["max_abs_dlogits"], 6), "dloss": round(par["fast"]["dloss"], 6),
                   "north_star_tolerance": 1e-3,
                   "precise_mode": {"what": "split-bf16 (bf16x3) forward GEMMs: fp32-class products on the bf16 MFMA path - as an inference "
@@ -294,14 +366,22 @@ def main():
     for _ in range(args.warmup):
         stepper(batch, labels)
     sync_all()
+    step_ev = []          # one event pair per timed step on the launch stream: the median beside the mean
     t0 = time.perf_counter()
     for k in range(args.steps):
         eng.profile_events = evs if (k % 4 == 0) else None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
         stepper(batch, labels)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        step_ev.append((e0, e1))
     sync_all()
     dt = time.perf_counter() - t0
     eng.profile_events = None
     loss = float(stepper.loss.item())
+    step_ms = sorted(a.elapsed_time(b) for a, b in step_ev)
+    ms_median = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
 
     ms_by_rank = [round(dt / args.steps * 1e3, 3)]
     if world > 1:
@@ -396,7 +476,7 @@ def main():
 
         # the resize kernel writes the patch-embedding GEMM's bf16 operand itself (no f32 pixel tensor, no unfold pass)
         Kp = spec.vilt.num_channels * spec.vilt.patch_size ** 2
-        devp = [torch.empty(B * spec.vilt.num_patches, Kp, dtype=torch.bfloat16, device=dev) for _ in range(nb)]
+        devp = [torch.empty(B * spec.vilt.num_patches, Kp, dtype=eng.hdt, device=dev) for _ in range(nb)]
 
         def prefetch_u8(k):
             with torch.cuda.stream(copy_stream):
@@ -467,6 +547,15 @@ def main():
             precise_fwd["precise_forward_train_samples_per_s"] = round(B * 5 / (time.perf_counter() - t0), 1)
             del pstep
 
+    # ---- the fp16 operand build beside the bf16 line (same box, same batch, same steps): TRAIN-mode logits / loss on the
+    #      reference golden and the training throughput of that mode
+    fp16_line = None
+    if rank == 0 and world == 1 and not args.no_parity and not args.fp8_forward and args.half == "bf16":
+        try:
+            fp16_line = measure_fp16(spec, args, dev, batch, labels, B)
+        except Exception as e:  # pragma: no cover
+            fp16_line = {"error": repr(e)}
+
     # ---- the other BASELINE configurations, each a short loop on its own engine (rank 0 prints them in `other_configs`):
     #      per-GPU batch 64 (config 2 on one GPU, config 3's per-GPU shape on N), and on one GPU the frozen-LM and fp8-forward ones
     others = None
@@ -522,8 +611,10 @@ def main():
         out = {
             "metric": "train samples/sec (img+text pairs) ViLT-B32+BERTweet, bs256, 1/2/4/8 MI355X",
             "value": round(sps, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "mxfp8 forward GEMMs / bf16 backward" if args.fp8_forward else "bf16",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_per_step_median": round(ms_median, 3),
+            "ms_per_step_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)],
+            "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "mxfp8 forward GEMMs / bf16 backward" if args.fp8_forward else args.half,
             "data": "synthetic",
             "config": {"workload": f"ViLT-B32 + {args.lm} fine-tune step (fwd+bwd+AdamW), per-GPU batch {B}, "
                                    f"40 text tokens + 384x384 image (185-token fused sequence), "
@@ -541,6 +632,10 @@ def main():
         if others is not None:
             out["other_configs"] = others
         if parity is not None:
+            if fp16_line is not None:
+                if "train_samples_per_s" in fp16_line:
+                    fp16_line["ratio_to_the_bf16_line"] = round(fp16_line["train_samples_per_s"] / sps, 4)
+                parity["fp16_operands"] = fp16_line
             if precise_fwd is not None:
                 parity["precise_mode"].update(precise_fwd)
             out["parity"] = parity

@@ -9,7 +9,15 @@
  *   - `stream` is a hipStream_t passed as void*; work is enqueued on it, never synchronised;
  *   - return 0 on success, 22 (EINVAL) on a shape/alignment violation detected before launch,
  *     otherwise a hipError_t value;
- *   - "bf16" = 16-bit brain float, "f32" = IEEE binary32; row-major everywhere.
+ *   - "f32" = IEEE binary32; row-major everywhere;
+ *   - "bf16" in a name or comment = the library's 16-bit OPERAND type.  The same sources are built twice
+ *     (vault_amd/build.py): libvault_hip.so computes on bf16 operands (v_mfma_f32_16x16x32_bf16),
+ *     libvault_hip_f16.so on IEEE fp16 operands (v_mfma_f32_16x16x32_f16, same matrix rate; f32 -> f16 conversions
+ *     saturate at +-65504 instead of overflowing to infinity).  Both export this one ABI, name for name;
+ *     vault_operand_format() says which build a loaded library is.  A caller that wants the reference's fp32
+ *     logits / loss within 1e-3 through a 24-layer stack binds the fp16 build and multiplies the loss gradient by a
+ *     power of two (vault_head_loss_args.grad_scale) that the optimizer divides out again (vault_adamw_step
+ *     grad_scale); bf16 needs no such scale and is 4e-3 from the reference (ABI 8).
  */
 #ifndef VAULT_HIP_H
 #define VAULT_HIP_H
@@ -19,6 +27,8 @@ extern "C" {
 #endif
 
 int vault_abi_version(void);
+/* 0 = bf16 operands (libvault_hip.so), 1 = IEEE fp16 operands (libvault_hip_f16.so).  ABI 8. */
+int vault_operand_format(void);
 
 /* ---- GEMM -------------------------------------------------------------------------------
  * C[M,N] = A.B with bf16 operands / f32 accumulation and a fused epilogue.  Replaces every
@@ -195,6 +205,11 @@ int vault_image_pos_sel_fwd(float* x, const float* pos_emb, const int* sel, cons
 int vault_image_sel_bwd(const float* dx, float* dpos, float* dmtype1, float* dcls, float* dconv_bias, void* dyp_bf16,
                         const int* sel, const int* hw, int B, int L, int S, int T, int H, int gw, int G, void* stream);
 int vault_axpy_f32(float* dst, const float* src, float a, long long n, void* stream);
+/* ABI 8: x *= a over n floats (n % 4 == 0, x 16-byte aligned).  The fp16 build's caller multiplies the loss gradient by a
+ * power of two so that the 16-bit data gradients stay inside fp16's exponent range; the flat f32 gradient buffer then
+ * holds scaled sums, and this pass (exact for a power of two) removes the scale where no fused optimizer does it
+ * (p.grad of the autograd bridge; ref: loss.backward() at vault/tmsc_utils/trainer.py:365). */
+int vault_scale_f32(float* x, float a, long long n, void* stream);
 /* ABI 4: externally supplied image embeddings (HF ViltEmbeddings.forward with `image_embeds`, modeling_vilt.py:190-207;
  * reached from the reference through TomViltForTMSC, ref: vault/models/tomvilt/model.py:281-287): only the modality type
  * is added.  out[map(r)] = src[r] + vec with map(r) = (r / rpg) * gstride + goff + r % rpg (the image rows of the fused

@@ -72,25 +72,54 @@ _EMULATE_GELU8 = False
 _INJECT_DGRAD = None
 
 
+# the 16-bit operand type being emulated (the HIP library exists for both: csrc/common.h `h16`) and, for fp16, the static
+# power-of-two scale the HIP backward's gradients carry while they are 16-bit tensors (engine.VaultEngine.grad_scale)
+_EMU_DTYPE = torch.bfloat16
+_EMU_GSCALE = 1.0
+
+
 class emulate_bf16:
     """``with emulate_bf16():`` - run the oracle with bf16-rounded matmul operands; ``backward=True``: gradients in the
     HIP backward's number format too (``gelu8``: the ViLT FFN keeps gelu' on the 8-bit grid)."""
+    dtype, gscale = torch.bfloat16, 1.0
 
     def __init__(self, backward: bool = False, gelu8: bool = False):
         self.backward, self.gelu8 = backward, gelu8
 
     def __enter__(self):
-        global _EMULATE_BF16, _EMULATE_BWD, _EMULATE_GELU8
-        self._old = (_EMULATE_BF16, _EMULATE_BWD, _EMULATE_GELU8)
+        global _EMULATE_BF16, _EMULATE_BWD, _EMULATE_GELU8, _EMU_DTYPE, _EMU_GSCALE
+        self._old = (_EMULATE_BF16, _EMULATE_BWD, _EMULATE_GELU8, _EMU_DTYPE, _EMU_GSCALE)
         _EMULATE_BF16, _EMULATE_BWD, _EMULATE_GELU8 = True, self.backward, self.gelu8
+        _EMU_DTYPE, _EMU_GSCALE = self.dtype, float(self.gscale)
 
     def __exit__(self, *a):
-        global _EMULATE_BF16, _EMULATE_BWD, _EMULATE_GELU8
-        _EMULATE_BF16, _EMULATE_BWD, _EMULATE_GELU8 = self._old
+        global _EMULATE_BF16, _EMULATE_BWD, _EMULATE_GELU8, _EMU_DTYPE, _EMU_GSCALE
+        _EMULATE_BF16, _EMULATE_BWD, _EMULATE_GELU8, _EMU_DTYPE, _EMU_GSCALE = self._old
+
+
+class emulate_fp16(emulate_bf16):
+    """The same emulation for the fp16 build of the HIP library (libvault_hip_f16.so): IEEE half operands, conversions
+    saturating at +-65504, and - ``backward=True`` - 16-bit gradient tensors rounded under the static power-of-two gradient
+    scale ``grad_scale`` (a tensor the HIP backward stores as fp16(S g) is emulated as fp16(S g) / S)."""
+    dtype = torch.float16
+
+    def __init__(self, backward: bool = False, gelu8: bool = False, grad_scale: float = 4096.0):
+        super().__init__(backward, gelu8)
+        self.gscale = grad_scale
 
 
 def _rb(x):
+    """Round a forward value to the emulated operand type."""
+    if _EMU_DTYPE is torch.float16:
+        return x.clamp(-65504.0, 65504.0).half().float()
     return x.bfloat16().float()
+
+
+def _rg(g):
+    """Round a gradient tensor the way the HIP backward stores it (under the gradient scale in the fp16 build)."""
+    if _EMU_DTYPE is torch.float16:
+        return (g * _EMU_GSCALE).clamp(-65504.0, 65504.0).half().float() / _EMU_GSCALE
+    return g.bfloat16().float()
 
 
 class _RoundST(torch.autograd.Function):
@@ -114,7 +143,7 @@ class _RoundGrad(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return _rb(g)
+        return _rg(g)
 
 
 class _LinearEmu(torch.autograd.Function):
@@ -131,10 +160,10 @@ class _LinearEmu(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         xr, wr = ctx.saved_tensors
-        gr = _rb(gy)
+        gr = _rg(gy)
         dx = torch.matmul(gr, wr) * ctx.scale_dx
         if ctx.round_dx:
-            dx = _rb(dx)
+            dx = _rg(dx)
         dw = torch.matmul(gr.reshape(-1, gr.shape[-1]).t(), xr.reshape(-1, xr.shape[-1]))
         db = gy.reshape(-1, gy.shape[-1]).sum(0) if ctx.has_b else None
         return dx, dw, db, None, None
@@ -158,7 +187,7 @@ class _GeluEmu(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (gp,) = ctx.saved_tensors
-        return _rb(g * gp), None
+        return _rg(g * gp), None
 
 
 class _AttnEmu(torch.autograd.Function):
@@ -182,20 +211,20 @@ class _AttnEmu(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go):
         q, k, v, p, o = ctx.saved_tensors
-        go = _rb(go)
+        go = _rg(go)
         dp = torch.matmul(go, v.transpose(-1, -2))
         dsum = (go * o).sum(-1, keepdim=True)
-        ds = _rb(p * (dp - dsum))
+        ds = _rg(p * (dp - dsum))
         dq = torch.matmul(ds, k) * ctx.scale
         dk = torch.matmul(ds.transpose(-1, -2), q) * ctx.scale
         dv = torch.matmul(_rb(p).transpose(-1, -2), go)
-        return _rb(dq), _rb(dk), _rb(dv), None, None
+        return _rg(dq), _rg(dk), _rg(dv), None, None
 
 
 def _r(x):
     if _EMULATE_BWD:
         return _RoundST.apply(x)
-    return x.bfloat16().float() if _EMULATE_BF16 else x
+    return _rb(x) if _EMULATE_BF16 else x
 
 
 def _lin(x, w, b=None, round_dx=True, name=""):

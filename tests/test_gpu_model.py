@@ -50,13 +50,14 @@ def _grad_errors(eng, P):
     return (tot_e / tot_r) ** 0.5, sorted(per, reverse=True)
 
 
-def _emulated_backward(spec, state, bn, gelu8=False, inject=None):
-    """Oracle loss + gradients in the HIP path's own number format, forward AND backward (oracle.emulate_bf16(backward=True));
-    ``inject`` = (weight-name substring, factor): the mutation check's scaled data gradient."""
+def _emulated_backward(spec, state, bn, gelu8=False, inject=None, half="bf16"):
+    """Oracle loss + gradients in the HIP path's own number format, forward AND backward (oracle.emulate_bf16(backward=True),
+    or emulate_fp16 for the fp16 operand build); ``inject`` = (weight-name substring, factor): the mutation check's scaled
+    data gradient."""
     P = O.to_torch_state(state, requires_grad=True)
     O._INJECT_DGRAD = inject
     try:
-        with O.emulate_bf16(backward=True, gelu8=gelu8):
+        with (O.emulate_bf16 if half == "bf16" else O.emulate_fp16)(backward=True, gelu8=gelu8):
             loss, ref = O.vault_loss(P, spec, O.torch_batch(bn))
             loss.backward()
     finally:
@@ -82,7 +83,7 @@ def _param_class(n):
 
 
 def _assert_same_format_gradients(spec, state, bn, tag, glob_bound, class_bounds, gelu8=None,
-                                  mutate="encoder.layer.1.attention.attention.qkv"):
+                                  mutate="encoder.layer.1.attention.attention.qkv", half="bf16", mutate_bound=None):
     """The backward pinned to its own number format.  A fresh HIP forward + backward of `bn` with every label set to class 0
     (per-sample gradients then add up instead of cancelling: a relative bound means something) against the oracle emulating
     the HIP number format forward AND backward (oracle.emulate_bf16(backward=True)): global relative L2 <= glob_bound and per
@@ -90,20 +91,20 @@ def _assert_same_format_gradients(spec, state, bn, tag, glob_bound, class_bounds
     an oracle whose `mutate` dgrad is scaled by 1.01 breaks the LayerNorm-class bound (that dgrad feeds the LayerNorm below it)."""
     bn = dict(bn)
     bn["labels"] = np.zeros_like(bn["labels"])
-    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half=half)
     db = _dev(bn)
     eng.forward(db, train=True, labels=db["labels"], need_hidden=False)
     eng.zero_grad()
     eng.backward()
     torch.cuda.synchronize()
     if gelu8 is None:
-        gelu8 = eng.last.get("gelu8_cfg") is not None
-    Pe, _ = _emulated_backward(spec, state, bn, gelu8)
+        gelu8 = eng.last.get("gelu8_active") is not None
+    Pe, _ = _emulated_backward(spec, state, bn, gelu8, half=half)
     glob, per = _grad_errors(eng, Pe)
     worst = {}
     for e, n in per:
         worst.setdefault(_param_class(n), (e, n))
-    print(f"{tag}: gradients vs the bf16-emulating oracle (forward + backward): global rel L2 {glob:.2e}; worst per class: "
+    print(f"{tag}: gradients vs the {half}-emulating oracle (forward + backward): global rel L2 {glob:.2e}; worst per class: "
           + "; ".join(f"{c}: {n} {e:.2e}" for c, (e, n) in worst.items()))
     assert glob < glob_bound, glob
     for c, (e, n) in worst.items():
@@ -111,11 +112,13 @@ def _assert_same_format_gradients(spec, state, bn, tag, glob_bound, class_bounds
     if mutate is None:
         del eng
         return
-    Pm, _ = _emulated_backward(spec, state, bn, gelu8, inject=(mutate, 1.01))
+    Pm, _ = _emulated_backward(spec, state, bn, gelu8, inject=(mutate, 1.01), half=half)
     globm, perm = _grad_errors(eng, Pm)
     wm = max((e, n) for e, n in perm if _param_class(n) == "layernorm")
     print(f"{tag}: with a 1 % error injected into the {mutate} data gradient: global {globm:.2e}, worst LayerNorm parameter {wm[1]} {wm[0]:.2e}")
     assert wm[0] > class_bounds["layernorm"], wm
+    if mutate_bound is not None:      # (deep models: the injected error must also break the GLOBAL bound)
+        assert globm > mutate_bound, (globm, mutate_bound)
     del eng
 
 
@@ -724,6 +727,39 @@ def test_precise_forward_training_step_meets_the_1e3_bar_with_bf16_level_gradien
             mine = eng.params.gr(k[6:]).cpu().numpy().reshape(g[k].shape)
             rel = np.linalg.norm(mine - g[k]) / (np.linalg.norm(g[k]) + 1e-12)
             assert rel < 8e-2, (k, rel)
+
+
+def test_precise_step_after_a_fast_step_on_the_same_workspace():
+    """The gelu' format is a property of the FORWARD that wrote it: a fast-mode train step leaves the 8-bit
+    tile image plan in the workspace, a precise-forward step on the same (B, T) workspace writes plain 16-bit gelu' - its
+    backward must read what its own forward stored.  Full width, B = 48 (8,880 token rows: the per-kernel path with the 8-bit
+    gelu'), 2 + 2 layers: gradients of (fast step, then precise step) on one engine equal those of a fresh engine's precise step."""
+    spec = _nodrop(VaultSpec(vilt=ViltSpec(num_hidden_layers=2), lm=LMSpec.bertweet_base(), n_classes=3))
+    spec.lm.num_hidden_layers = 2
+    state = build_state(spec, 3)
+    bn = synthetic_batch(spec, 48, seed=548, n_classes=3)
+    db = _dev(bn)
+
+    def precise_step(eng):
+        out = eng.forward(db, train=True, labels=db["labels"], need_hidden=False, precise=True)
+        eng.zero_grad()
+        eng.backward()
+        torch.cuda.synchronize()
+        return out["logits"].clone(), eng.params.g[:eng.params.n_train].clone()
+
+    a = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    a.forward(db, train=True, labels=db["labels"], need_hidden=False)
+    a.zero_grad()
+    a.backward()
+    assert a.last.get("gelu8_active") in (5, 6)          # the fast step used the 8-bit image ...
+    la, ga = precise_step(a)
+    assert a.last.get("gelu8_active") is None            # ... the precise step did not
+    b = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    lb, gb = precise_step(b)
+    assert torch.equal(la, lb)
+    rel = float((ga - gb).norm() / gb.norm())
+    print(f"precise step after a fast step vs a fresh precise step: gradient rel diff {rel:.2e}")
+    assert rel < 1e-5                                    # (float-atomic summation order only)
 
 
 @pytest.mark.parametrize("kind,seed", [("roberta", 11), ("bert", 12)])

@@ -541,3 +541,10 @@ def test_8bit_gelu_prime_follows_the_kernel_choice():
     small.forward({k: torch.from_numpy(v).cuda() for k, v in sb.items() if k != "labels"}, train=True,
                   labels=torch.from_numpy(sb["labels"]).cuda())
     assert small.last.get("gelu8_cfg") is None
+
+
+def test_bench_refuses_two_ranks_on_the_one_gpu_box():
+    """On the 1-GPU box: `python bench.py --gpus 2` exits 2 with the refusal text (devices counted from sysfs in the launcher)."""
+    from .test_host import _bench_refusal
+    have = _bench_refusal()
+    assert have >= 1

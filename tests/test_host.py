@@ -49,10 +49,13 @@ def test_synthetic_batch_contract():
     assert "token_type_ids" not in b                                   # BERTweet tokenizer returns none
 
 
-def test_library_exports_every_declared_symbol():
-    path = os.path.join(ROOT, "vault_amd", "libvault_hip.so")
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
+def test_library_exports_every_declared_symbol(fmt):
+    """Both builds of the library (bf16 / IEEE fp16 operand type, the same sources: vault_amd/build.py) export the one ABI of
+    include/vault_hip.h, and each says which build it is."""
+    from vault_amd import build
+    path = build.VARIANTS[fmt][0]
     if not os.path.exists(path):
-        from vault_amd import build
         build.build()
     lib = ctypes.CDLL(path)   # torch (imported above) is already in the process
     hdr = open(os.path.join(ROOT, "include", "vault_hip.h")).read()
@@ -61,7 +64,9 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     lib.vault_abi_version.restype = ctypes.c_int
-    assert lib.vault_abi_version() == 7
+    assert lib.vault_abi_version() == 8
+    lib.vault_operand_format.restype = ctypes.c_int
+    assert lib.vault_operand_format() == ("bf16", "fp16").index(fmt)
 
 
 def test_ctypes_structures_match_the_c_header(tmp_path):
@@ -424,3 +429,36 @@ def test_embedding_surgery_api_and_vault_alias_package():
     with pytest.raises(NotImplementedError, match="head_mask"):
         m._collect_batch([torch.zeros(1, 40, dtype=torch.long), None, None, torch.zeros(1, 3, 192, 192), None,
                           torch.ones(2, 4)], {})
+
+
+def _bench_refusal():
+    """`python bench.py --gpus N` with N above the node's device count: the launcher parent counts devices from sysfs (no HIP
+    call in the process that would fork the ranks), prints the refusal and exits 2 - it never measures fewer ranks than asked."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    have = bench.count_gpus_sysfs()
+    n = max(2, have + 1)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert f"--gpus {n} needs {n} devices, this node shows {have}" in r.stderr and "refusing" in r.stderr
+    assert r.stdout.strip() == ""            # no JSON line: nothing was measured
+    return have
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    _bench_refusal()
+
+
+def test_sysfs_device_count_honours_visibility_variables(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    have = bench.count_gpus_sysfs()
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.count_gpus_sysfs() == 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    assert bench.count_gpus_sysfs() == min(have, 1)
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0,1,2")
+    assert bench.count_gpus_sysfs() == min(have, 1)

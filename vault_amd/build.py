@@ -1,4 +1,5 @@
-"""Build vault_amd/libvault_hip.so (gfx950) and, for tests, the C-ABI smoke objects.
+"""Build vault_amd/libvault_hip.so and libvault_hip_f16.so (gfx950): the same sources compiled for the two 16-bit
+operand types (csrc/common.h `h16`: bf16, and IEEE fp16 with -DVAULT_F16); same exported C ABI in both.
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the .so is kept
 in-tree (git-ignored) and travels to the GPU box with the snapshot.
@@ -15,6 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvault_hip.so")
 OBJ = os.path.join(CSRC, "_obj")
+# (library, object directory, extra compiler flags) per operand format
+VARIANTS = {"bf16": (OUT, OBJ, []),
+            "fp16": (os.path.join(HERE, "libvault_hip_f16.so"), os.path.join(CSRC, "_obj_f16"), ["-DVAULT_F16"])}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17",
          "-Wno-unused-result"]
@@ -24,24 +28,25 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _digest(path: str) -> str:
+def _digest(path: str, extra=()) -> str:
     h = hashlib.sha1()
     for f in sorted(os.listdir(CSRC)) + ["../../include/vault_hip.h"]:
         p = os.path.join(CSRC, f)
         if os.path.isfile(p) and (f.endswith(".h") or os.path.abspath(p) == os.path.abspath(path)):
             h.update(open(p, "rb").read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + list(extra)).encode())
     return h.hexdigest()
 
 
-def _compile(src: str) -> str:
+def _compile(job) -> str:
+    src, objdir, extra = job
     path = os.path.join(CSRC, src)
-    obj = os.path.join(OBJ, src[:-4] + ".o")
+    obj = os.path.join(objdir, src[:-4] + ".o")
     stamp = obj + ".sha1"
-    dg = _digest(path)
+    dg = _digest(path, extra)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dg:
         return obj
-    cmd = [HIPCC, *FLAGS, "-c", path, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *extra, "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -49,19 +54,28 @@ def _compile(src: str) -> str:
     return obj
 
 
-def build(verbose: bool = False) -> str:
-    os.makedirs(OBJ, exist_ok=True)
+def build(verbose: bool = False, formats=("bf16", "fp16")) -> str:
     srcs = _sources()
-    with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        objs = list(ex.map(_compile, srcs))
-    newest = max(os.path.getmtime(o) for o in objs)
-    if not os.path.exists(OUT) or os.path.getmtime(OUT) < newest:
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    if verbose:
-        print("built", OUT, f"{os.path.getsize(OUT) / 1e6:.1f} MB")
+    jobs = []
+    for fmt in formats:
+        _, objdir, extra = VARIANTS[fmt]
+        os.makedirs(objdir, exist_ok=True)
+        jobs += [(s, objdir, extra) for s in srcs]
+    with cf.ThreadPoolExecutor(max_workers=min(7, len(jobs))) as ex:
+        objs = list(ex.map(_compile, jobs))
+    for k, fmt in enumerate(formats):
+        out = VARIANTS[fmt][0]
+        mine = objs[k * len(srcs):(k + 1) * len(srcs)]
+        newest = max(os.path.getmtime(o) for o in mine)
+        if not os.path.exists(out) or os.path.getmtime(out) < newest:
+            # -Bsymbolic: calls between the library's own translation units bind inside the library (both builds export
+            # the same names and may be loaded into one process)
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", out, *mine]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print("built", out, f"{os.path.getsize(out) / 1e6:.1f} MB")
     return OUT
 
 

@@ -51,7 +51,7 @@ __device__ __forceinline__ int swz_row(int row) { return (row >> 1) & 3; }  // 3
 
 // stage a [rows<=S][64] bf16 matrix (row stride ld elements) into a swizzled [SK][128 B] LDS image
 template <int SK, int NT>
-__device__ __forceinline__ void stage_rows(char* dst, const bf16* src, int ld, int S, int tid) {
+__device__ __forceinline__ void stage_rows(char* dst, const h16* src, int ld, int S, int tid) {
   // all global loads are issued before the first LDS write: one memory round trip per call instead of
   // one per 16-byte chunk (a rolled load->store loop waits for every load separately)
   constexpr int N = (SK * 8) / NT;
@@ -71,14 +71,14 @@ __device__ __forceinline__ void stage_rows(char* dst, const bf16* src, int ld, i
 }
 
 // row-read fragment (A or B operand, k = d): rows tile*16 + l15, d = 32s + 8g .. +7
-__device__ __forceinline__ bf16x8 frag_rows(const char* img, int tile, int s, int g, int l15) {
+__device__ __forceinline__ h16x8 frag_rows(const char* img, int tile, int s, int g, int l15) {
   const int fx = swz_row(l15) << 1;
-  return *LDS_PTR(const bf16x8, img + (tile * 16 + l15) * 128 + (((4 * s + g) ^ fx) << 4));
+  return *LDS_PTR(const h16x8, img + (tile * 16 + l15) * 128 + (((4 * s + g) ^ fx) << 4));
 }
 
 // transposed fragment (B operand, k = row index permuted as kappa(g,j) = 32T + 16(j>>2) + 4g + (j&3),
 // col = d = dt*16 + l15) from a row-major [rows][64] image
-__device__ __forceinline__ bf16x8 frag_tr(const char* img, int T, int dt, int g, int l15) {
+__device__ __forceinline__ h16x8 frag_tr(const char* img, int T, int dt, int g, int l15) {
   const int qq = l15 >> 2, pp = l15 & 3;
   const int row = 32 * T + 4 * g + qq;
   const int x = (2 * (g & 1) + (qq >> 1)) & 3;  // == swz_row(row) and == swz_row(row + 16)
@@ -91,7 +91,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* img, int T, int dt, int g,
 // (2 half, 2 half + 1) then holds d = 32 half + 8 g + 0..7 of row l15: one 16-byte store instead of two 8-byte ones, 64
 // contiguous bytes per row and instruction (the output rows are 128 bytes per head).  Costs a 2-way bank conflict on
 // these reads (two of the four rows of a lane group share a 64-byte half of the swizzled image).
-__device__ __forceinline__ bf16x8 frag_tr8(const char* img, int T, int half, int odd, int g, int l15) {
+__device__ __forceinline__ h16x8 frag_tr8(const char* img, int T, int half, int odd, int g, int l15) {
   const int qq = l15 >> 2, pp = l15 & 3;
   const int row = 32 * T + 4 * g + qq;
   const int x = (2 * (g & 1) + (qq >> 1)) & 3;  // == swz_row(row) and == swz_row(row + 16)
@@ -99,10 +99,10 @@ __device__ __forceinline__ bf16x8 frag_tr8(const char* img, int T, int half, int
   return cat_tr(lds_read_tr16(a), lds_read_tr16(a + 16 * 128));
 }
 
-__device__ __forceinline__ bf16x8 pack_frag(const f32x4& lo, const f32x4& hi) {
-  bf16x8 f;
-  f[0] = (bf16)lo[0]; f[1] = (bf16)lo[1]; f[2] = (bf16)lo[2]; f[3] = (bf16)lo[3];
-  f[4] = (bf16)hi[0]; f[5] = (bf16)hi[1]; f[6] = (bf16)hi[2]; f[7] = (bf16)hi[3];
+__device__ __forceinline__ h16x8 pack_frag(const f32x4& lo, const f32x4& hi) {
+  h16x8 f;
+  f[0] = (h16)lo[0]; f[1] = (h16)lo[1]; f[2] = (h16)lo[2]; f[3] = (h16)lo[3];
+  f[4] = (h16)hi[0]; f[5] = (h16)hi[1]; f[6] = (h16)hi[2]; f[7] = (h16)hi[3];
   return f;
 }
 
@@ -110,13 +110,13 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& lo, const f32x4& hi) {
 // (2 hf, 2 hf + 1) of lane (g, l15) hold d = 32 hf + 8 g + 0..7 of row l15, i.e. the 16-byte chunks g and 4 + g of the row.
 // Lanes l15 and l15 ^ 8 swap one chunk each (DPP row_ror:8) so that the two store instructions write rows 0-7 and rows 8-15
 // of the tile as whole 128-byte lines.  dst: element (row 0, first column of the head); rows >= S are not stored.
-__device__ __forceinline__ void store_tile_lines(bf16* dst, int ld, int tile_row0, int S, const f32x4 (&o)[4], float mul,
+__device__ __forceinline__ void store_tile_lines(h16* dst, int ld, int tile_row0, int S, const f32x4 (&o)[4], float mul,
                                                  int g, int l15) {
   u32x4 w[2];
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf)
-    w[hf] = u32x4{pack_bf16x2(o[2 * hf][0] * mul, o[2 * hf][1] * mul), pack_bf16x2(o[2 * hf][2] * mul, o[2 * hf][3] * mul),
-                  pack_bf16x2(o[2 * hf + 1][0] * mul, o[2 * hf + 1][1] * mul), pack_bf16x2(o[2 * hf + 1][2] * mul, o[2 * hf + 1][3] * mul)};
+    w[hf] = u32x4{pack_h16x2(o[2 * hf][0] * mul, o[2 * hf][1] * mul), pack_h16x2(o[2 * hf][2] * mul, o[2 * hf][3] * mul),
+                  pack_h16x2(o[2 * hf + 1][0] * mul, o[2 * hf + 1][1] * mul), pack_h16x2(o[2 * hf + 1][2] * mul, o[2 * hf + 1][3] * mul)};
   const bool lo8 = l15 < 8;
   u32x4 wa, wb;
 #pragma unroll
@@ -127,7 +127,7 @@ __device__ __forceinline__ void store_tile_lines(bf16* dst, int ld, int tile_row
     wb[k] = lo8 ? xr : w[1][k];
   }
   const int ra = tile_row0 + (l15 & 7);
-  bf16* d = dst + (size_t)ra * ld + (l15 >> 3) * 32 + 8 * g;
+  h16* d = dst + (size_t)ra * ld + (l15 >> 3) * 32 + 8 * g;
   if (ra < S) *reinterpret_cast<u32x4*>(d) = wa;
   if (ra + 8 < S) *reinterpret_cast<u32x4*>(d + 8 * (size_t)ld) = wb;
 }
@@ -138,9 +138,10 @@ struct AttnDrop {
 };
 
 template <int NKT, int NWV, int WPE, bool DROP = true>
-__global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
-                                                       bf16* __restrict__ ctx, float* __restrict__ lse, int S, int H,
-                                                       int heads, float scale, AttnDrop dr, bf16* __restrict__ ctx3) {
+__global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const h16* __restrict__ qkv, const float* __restrict__ keymask,
+                                                       h16* __restrict__ ctx, float* __restrict__ lse, int S, int H,
+                                                       int heads, float scale, AttnDrop dr, h16* __restrict__ ctx3) {
+  H16_SATURATE();
   constexpr int SK = NKT * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __r
   const int h = blockIdx.x, b = blockIdx.y;
   const size_t row0 = (size_t)b * S;
   const int ld = 3 * H;
-  const bf16* qbase = qkv + row0 * ld + h * 64;
+  const h16* qbase = qkv + row0 * ld + h * 64;
   stage_rows<SK, NWV * 64>(Ks, qbase + H, ld, S, tid);
   stage_rows<SK, NWV * 64>(Vs, qbase + 2 * H, ld, S, tid);
   for (int k = tid; k < SK; k += NWV * 64)
@@ -162,9 +163,9 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __r
   const uint32_t bh = (uint32_t)(b * heads + h);
   for (int qt = wave; qt < nqt; qt += NWV) {
     const int qrow = min(qt * 16 + l15, S - 1);
-    bf16x8 qf[2];
-    qf[0] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * ld + 8 * g);
-    qf[1] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * ld + 32 + 8 * g);
+    h16x8 qf[2];
+    qf[0] = *reinterpret_cast<const h16x8*>(qbase + (size_t)qrow * ld + 8 * g);
+    qf[1] = *reinterpret_cast<const h16x8*>(qbase + (size_t)qrow * ld + 32 + 8 * g);
     // pass 1: row maximum only (scores are recomputed in pass 2: the matrix pipe is nearly idle in this
     // kernel, while keeping all 12 score tiles live costs 48 registers and the occupancy that hides LDS latency)
     // (the key-mask bias, 0 or -inf per key = accumulator row, is the MFMA's initial accumulator: no add)
@@ -172,8 +173,8 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __r
 #pragma unroll 3
     for (int kt = 0; kt < 2 * NKT; ++kt) {
       f32x4 a = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, kt, 0, g, l15), qf[0], a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, kt, 1, g, l15), qf[1], a, 0, 0, 0);
+      a = mfma16(frag_rows(Ks, kt, 0, g, l15), qf[0], a);
+      a = mfma16(frag_rows(Ks, kt, 1, g, l15), qf[1], a);
       mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -192,8 +193,8 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __r
       for (int hh = 0; hh < 2; ++hh) {
         const int kt = 2 * T + hh;
         f32x4 a = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, kt, 0, g, l15), qf[0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, kt, 1, g, l15), qf[1], a, 0, 0, 0);
+        a = mfma16(frag_rows(Ks, kt, 0, g, l15), qf[0], a);
+        a = mfma16(frag_rows(Ks, kt, 1, g, l15), qf[1], a);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float pv = __builtin_amdgcn_exp2f(a[r] * sl2 - mxs);
@@ -209,13 +210,13 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __r
       // probabilities (accumulator layout: query on the lane) the B operand.  The result has the query on the
       // lane (lane-local normalisation); with the d rows of the A operand permuted (frag_tr8) the tiles (2 hf, 2 hf + 1)
       // hold d = 32 hf + 8 g + 0..7 of the lane's row: 16-byte pieces, written as whole 128-byte lines (below).
-      const bf16x8 pf = pack_frag(p2[0], p2[1]);
+      const h16x8 pf = pack_frag(p2[0], p2[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
 #if ATTN_FWD_WL
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Vs, T, dt >> 1, dt & 1, g, l15), pf, o[dt], 0, 0, 0);
+        o[dt] = mfma16(frag_tr8(Vs, T, dt >> 1, dt & 1, g, l15), pf, o[dt]);
 #else
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Vs, T, dt, g, l15), pf, o[dt], 0, 0, 0);
+        o[dt] = mfma16(frag_tr(Vs, T, dt, g, l15), pf, o[dt]);
 #endif
     }
     sum += __shfl_xor(sum, 16, 64);
@@ -225,17 +226,17 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __r
     if (q_l < S && g == 0) lse[(size_t)bh * S + q_l] = mx * scale + __logf(sum);
     if (ctx3 != nullptr) {   // precise path: [hi | lo | hi] operand of the split-bf16 projection GEMM (16-byte pieces)
       if (q_l < S) {
-        bf16* dst = ctx3 + (row0 + q_l) * 3 * H + h * 64 + 8 * g;
+        h16* dst = ctx3 + (row0 + q_l) * 3 * H + h * 64 + 8 * g;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           uint32_t wh[4], wl[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            bf16 h0, l0, h1, l1;
+            h16 h0, l0, h1, l1;
             split_bf16(o[2 * hf + (k >> 1)][2 * (k & 1)] * inv, h0, l0);
             split_bf16(o[2 * hf + (k >> 1)][2 * (k & 1) + 1] * inv, h1, l1);
-            wh[k] = pack_bf16x2((float)h0, (float)h1);
-            wl[k] = pack_bf16x2((float)l0, (float)l1);
+            wh[k] = pack_h16x2((float)h0, (float)h1);
+            wl[k] = pack_h16x2((float)l0, (float)l1);
           }
           const u32x4 vh = {wh[0], wh[1], wh[2], wh[3]}, vl = {wl[0], wl[1], wl[2], wl[3]};
           *reinterpret_cast<u32x4*>(dst + 32 * hf) = vh;
@@ -249,8 +250,8 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __r
       u32x4 w[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf)
-        w[hf] = u32x4{pack_bf16x2(o[2 * hf][0] * inv, o[2 * hf][1] * inv), pack_bf16x2(o[2 * hf][2] * inv, o[2 * hf][3] * inv),
-                      pack_bf16x2(o[2 * hf + 1][0] * inv, o[2 * hf + 1][1] * inv), pack_bf16x2(o[2 * hf + 1][2] * inv, o[2 * hf + 1][3] * inv)};
+        w[hf] = u32x4{pack_h16x2(o[2 * hf][0] * inv, o[2 * hf][1] * inv), pack_h16x2(o[2 * hf][2] * inv, o[2 * hf][3] * inv),
+                      pack_h16x2(o[2 * hf + 1][0] * inv, o[2 * hf + 1][1] * inv), pack_h16x2(o[2 * hf + 1][2] * inv, o[2 * hf + 1][3] * inv)};
       const bool lo8 = l15 < 8;
       u32x4 wa, wb;
 #pragma unroll
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __r
         wb[k] = lo8 ? xr : w[1][k];
       }
       const int ra = qt * 16 + (l15 & 7);
-      bf16* dst = ctx + (row0 + ra) * H + h * 64 + (l15 >> 3) * 32 + 8 * g;
+      h16* dst = ctx + (row0 + ra) * H + h * 64 + (l15 >> 3) * 32 + 8 * g;
       if (ra < S) *reinterpret_cast<u32x4*>(dst) = wa;
       if (ra + 8 < S) *reinterpret_cast<u32x4*>(dst + 8 * (size_t)H) = wb;
     }
@@ -269,23 +270,23 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __r
     if (q_l < S) {
       if (g == 0) lse[(size_t)bh * S + q_l] = mx * scale + __logf(sum);
       if (ctx3 != nullptr) {   // precise path: [hi | lo | hi] operand of the split-bf16 projection GEMM
-        bf16* dst = ctx3 + (row0 + q_l) * 3 * H + h * 64 + 4 * g;
+        h16* dst = ctx3 + (row0 + q_l) * 3 * H + h * 64 + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          bf16 hi[4], lo[4];
+          h16 hi[4], lo[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) split_bf16(o[dt][r] * inv, hi[r], lo[r]);
-          const uint2 wh = {pack_bf16x2((float)hi[0], (float)hi[1]), pack_bf16x2((float)hi[2], (float)hi[3])};
-          const uint2 wl = {pack_bf16x2((float)lo[0], (float)lo[1]), pack_bf16x2((float)lo[2], (float)lo[3])};
+          const uint2 wh = {pack_h16x2((float)hi[0], (float)hi[1]), pack_h16x2((float)hi[2], (float)hi[3])};
+          const uint2 wl = {pack_h16x2((float)lo[0], (float)lo[1]), pack_h16x2((float)lo[2], (float)lo[3])};
           *reinterpret_cast<uint2*>(dst + dt * 16) = wh;
           *reinterpret_cast<uint2*>(dst + H + dt * 16) = wl;
           *reinterpret_cast<uint2*>(dst + 2 * H + dt * 16) = wh;
         }
       } else {
-        bf16* dst = ctx + (row0 + q_l) * H + h * 64 + 4 * g;
+        h16* dst = ctx + (row0 + q_l) * H + h * 64 + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const uint2 w = {pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
+          const uint2 w = {pack_h16x2(o[dt][0] * inv, o[dt][1] * inv), pack_h16x2(o[dt][2] * inv, o[dt][3] * inv)};
           *reinterpret_cast<uint2*>(dst + dt * 16) = w;
         }
       }
@@ -298,10 +299,11 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const bf16* __r
 // from Q, K and the forward's log-sum-exp; both phases recompute the score tile in the orientation
 // whose accumulator is directly the next MFMA's A operand.
 template <int NKT, int NWV, int WPE, bool DROP = true>
-__global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
-                                                       const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
-                                                       const float* __restrict__ lse, bf16* __restrict__ dqkv, int S,
+__global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const h16* __restrict__ qkv, const float* __restrict__ keymask,
+                                                       const h16* __restrict__ ctx, const h16* __restrict__ dctx,
+                                                       const float* __restrict__ lse, h16* __restrict__ dqkv, int S,
                                                        int H, int heads, float scale, AttnDrop dr) {
+  H16_SATURATE();
   constexpr int SK = NKT * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* img0 = smem;               // phase A: K     phase B: Q
@@ -314,10 +316,10 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __r
   const int h = blockIdx.x, b = blockIdx.y;
   const size_t row0 = (size_t)b * S;
   const int ld = 3 * H;
-  const bf16* qbase = qkv + row0 * ld + h * 64;
-  const bf16* obase = ctx + row0 * H + h * 64;
-  const bf16* dobase = dctx + row0 * H + h * 64;
-  bf16* dqbase = dqkv + row0 * ld + h * 64;
+  const h16* qbase = qkv + row0 * ld + h * 64;
+  const h16* obase = ctx + row0 * H + h * 64;
+  const h16* dobase = dctx + row0 * H + h * 64;
+  h16* dqbase = dqkv + row0 * ld + h * 64;
   const uint32_t bh = (uint32_t)(b * heads + h);
   const float sl2 = scale * LOG2E;
 
@@ -334,8 +336,8 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __r
       const int d0 = (tid & 3) * 16;
 #pragma unroll
       for (int c = 0; c < 16; c += 8) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(obase + (size_t)q * H + d0 + c);
-        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dobase + (size_t)q * H + d0 + c);
+        const h16x8 a = *reinterpret_cast<const h16x8*>(obase + (size_t)q * H + d0 + c);
+        const h16x8 d = *reinterpret_cast<const h16x8*>(dobase + (size_t)q * H + d0 + c);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)d[e];
       }
@@ -351,11 +353,11 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __r
   for (int qt = wave; qt < nqt; qt += NWV) {
     const int q_l = qt * 16 + l15;
     const int qrow = min(q_l, S - 1);
-    bf16x8 qf[2], df[2];
-    qf[0] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * ld + 8 * g);
-    qf[1] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * ld + 32 + 8 * g);
-    df[0] = *reinterpret_cast<const bf16x8*>(dobase + (size_t)qrow * H + 8 * g);
-    df[1] = *reinterpret_cast<const bf16x8*>(dobase + (size_t)qrow * H + 32 + 8 * g);
+    h16x8 qf[2], df[2];
+    qf[0] = *reinterpret_cast<const h16x8*>(qbase + (size_t)qrow * ld + 8 * g);
+    qf[1] = *reinterpret_cast<const h16x8*>(qbase + (size_t)qrow * ld + 32 + 8 * g);
+    df[0] = *reinterpret_cast<const h16x8*>(dobase + (size_t)qrow * H + 8 * g);
+    df[1] = *reinterpret_cast<const h16x8*>(dobase + (size_t)qrow * H + 32 + 8 * g);
     const float nl = lse_s[min(q_l, SK - 1)], dl = dl_s[min(q_l, SK - 1)];
     f32x4 o[4];
 #pragma unroll
@@ -367,10 +369,10 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __r
       for (int hh = 0; hh < 2; ++hh) {
         const int kt = 2 * T + hh;
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(img0, kt, 0, g, l15), qf[0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(img0, kt, 1, g, l15), qf[1], a, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(img1, kt, 0, g, l15), df[0], dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(img1, kt, 1, g, l15), df[1], dp, 0, 0, 0);
+        a = mfma16(frag_rows(img0, kt, 0, g, l15), qf[0], a);
+        a = mfma16(frag_rows(img0, kt, 1, g, l15), qf[1], a);
+        dp = mfma16(frag_rows(img1, kt, 0, g, l15), df[0], dp);
+        dp = mfma16(frag_rows(img1, kt, 1, g, l15), df[1], dp);
         const f32x4 m4 = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -384,10 +386,10 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __r
         }
       }
       // dQ^T[d][q] += K^T[d][key] dS^T[key][q] (query stays on the lane; d rows permuted: 16-byte chunks, whole-line stores)
-      const bf16x8 dsf = pack_frag(ds2[0], ds2[1]);
+      const h16x8 dsf = pack_frag(ds2[0], ds2[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(img0, T, dt >> 1, dt & 1, g, l15), dsf, o[dt], 0, 0, 0);
+        o[dt] = mfma16(frag_tr8(img0, T, dt >> 1, dt & 1, g, l15), dsf, o[dt]);
     }
     store_tile_lines(dqbase, ld, qt * 16, S, o, 1.0f, g, l15);
   }
@@ -400,11 +402,11 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __r
   for (int kt = wave; kt < nkt; kt += NWV) {
     const int k_l = kt * 16 + l15;
     const int krow = min(k_l, S - 1);
-    bf16x8 kf[2], vf[2];
-    kf[0] = *reinterpret_cast<const bf16x8*>(qbase + H + (size_t)krow * ld + 8 * g);
-    kf[1] = *reinterpret_cast<const bf16x8*>(qbase + H + (size_t)krow * ld + 32 + 8 * g);
-    vf[0] = *reinterpret_cast<const bf16x8*>(qbase + 2 * H + (size_t)krow * ld + 8 * g);
-    vf[1] = *reinterpret_cast<const bf16x8*>(qbase + 2 * H + (size_t)krow * ld + 32 + 8 * g);
+    h16x8 kf[2], vf[2];
+    kf[0] = *reinterpret_cast<const h16x8*>(qbase + H + (size_t)krow * ld + 8 * g);
+    kf[1] = *reinterpret_cast<const h16x8*>(qbase + H + (size_t)krow * ld + 32 + 8 * g);
+    vf[0] = *reinterpret_cast<const h16x8*>(qbase + 2 * H + (size_t)krow * ld + 8 * g);
+    vf[1] = *reinterpret_cast<const h16x8*>(qbase + 2 * H + (size_t)krow * ld + 32 + 8 * g);
     const float mk = mb[min(k_l, SK - 1)];
     f32x4 dk[4], dv[4];
 #pragma unroll
@@ -419,10 +421,10 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __r
       for (int hh = 0; hh < 2; ++hh) {
         const int qt = 2 * T + hh;
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(img0, qt, 0, g, l15), kf[0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(img0, qt, 1, g, l15), kf[1], a, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(img1, qt, 0, g, l15), vf[0], dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(img1, qt, 1, g, l15), vf[1], dp, 0, 0, 0);
+        a = mfma16(frag_rows(img0, qt, 0, g, l15), kf[0], a);
+        a = mfma16(frag_rows(img0, qt, 1, g, l15), kf[1], a);
+        dp = mfma16(frag_rows(img1, qt, 0, g, l15), vf[0], dp);
+        dp = mfma16(frag_rows(img1, qt, 1, g, l15), vf[1], dp);
         const f32x4 nl4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * g);
         const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dl_s + qt * 16 + 4 * g);
 #pragma unroll
@@ -441,13 +443,13 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __r
           p2[hh][r] = pv;
         }
       }
-      const bf16x8 pf = pack_frag(p2[0], p2[1]);
-      const bf16x8 dsf = pack_frag(ds2[0], ds2[1]);
+      const h16x8 pf = pack_frag(p2[0], p2[1]);
+      const h16x8 dsf = pack_frag(ds2[0], ds2[1]);
       // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]  (key on the lane)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(img1, T, dt >> 1, dt & 1, g, l15), pf, dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(img0, T, dt >> 1, dt & 1, g, l15), dsf, dk[dt], 0, 0, 0);
+        dv[dt] = mfma16(frag_tr8(img1, T, dt >> 1, dt & 1, g, l15), pf, dv[dt]);
+        dk[dt] = mfma16(frag_tr8(img0, T, dt >> 1, dt & 1, g, l15), dsf, dk[dt]);
       }
     }
     store_tile_lines(dqbase + H, ld, kt * 16, S, dk, 1.0f, g, l15);
@@ -469,10 +471,11 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const bf16* __r
 // round trips in front of the transposed-fragment MFMAs, which the compiler neither hoists (register cap 168 at
 // three waves per SIMD) nor overlaps within one wave.
 template <int NKT, int NWV, bool DROP = true>
-__global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
-                                                         const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
-                                                         const float* __restrict__ lse, bf16* __restrict__ dqkv, int S,
+__global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const h16* __restrict__ qkv, const float* __restrict__ keymask,
+                                                         const h16* __restrict__ ctx, const h16* __restrict__ dctx,
+                                                         const float* __restrict__ lse, h16* __restrict__ dqkv, int S,
                                                          int H, int heads, int items, float scale, AttnDrop dr) {
+  H16_SATURATE();
   constexpr int SK = NKT * 32;
   constexpr int NT = NWV * 64;
   constexpr int NC = (SK * 8) / NT;   // 16-byte chunks per thread and matrix
@@ -500,15 +503,15 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
 #endif
     const int b = item / heads, h = item - b * heads;
     const size_t row0 = (size_t)b * S;
-    const bf16* qb = qkv + row0 * ld + h * 64;
-    const bf16* ob = ctx + row0 * H + h * 64;
-    const bf16* db = dctx + row0 * H + h * 64;
+    const h16* qb = qkv + row0 * ld + h * 64;
+    const h16* ob = ctx + row0 * H + h * 64;
+    const h16* db = dctx + row0 * H + h * 64;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = tid + i * NT, row = c >> 3, pos = c & 7;
       rq[i] = rk[i] = rv[i] = rd[i] = ro[i] = u32x4{0u, 0u, 0u, 0u};
       if (row < S) {
-        const bf16* r = qb + (size_t)row * ld + pos * 8;
+        const h16* r = qb + (size_t)row * ld + pos * 8;
         rq[i] = *reinterpret_cast<const u32x4*>(r);
         rk[i] = *reinterpret_cast<const u32x4*>(r + H);
         rv[i] = *reinterpret_cast<const u32x4*>(r + 2 * H);
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        const float2 a = unpack_bf16x2(ro[i][w]), d = unpack_bf16x2(rd[i][w]);
+        const float2 a = unpack_h16x2(ro[i][w]), d = unpack_h16x2(rd[i][w]);
         s += a.x * d.x + a.y * d.y;
       }
       s += __shfl_xor(s, 1, 64);
@@ -555,13 +558,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
     const int b = item / heads, h = item - b * heads;
 #endif
     const uint32_t bh = (uint32_t)item;
-    bf16* dqbase = dqkv + (size_t)b * S * ld + h * 64;
+    h16* dqbase = dqkv + (size_t)b * S * ld + h * 64;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (no vmcnt wait: the previous item's stores stay in flight)
     if (item + (int)gridDim.x < items) fetch(item + gridDim.x);
 
     // ---------------- dQ: wave = TPW query tiles at once (they share every K / V fragment read) ----------------
     {
-      bf16x8 qf[TPW][2], df[TPW][2];
+      h16x8 qf[TPW][2], df[TPW][2];
       float nl[TPW], dl[TPW];
       f32x4 o[TPW][4];
 #pragma unroll
@@ -579,16 +582,16 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const int kt = 2 * T + hh;
-          const bf16x8 k0 = frag_rows(Ks, kt, 0, g, l15), k1 = frag_rows(Ks, kt, 1, g, l15);
-          const bf16x8 v0 = frag_rows(Vs, kt, 0, g, l15), v1 = frag_rows(Vs, kt, 1, g, l15);
+          const h16x8 k0 = frag_rows(Ks, kt, 0, g, l15), k1 = frag_rows(Ks, kt, 1, g, l15);
+          const h16x8 v0 = frag_rows(Vs, kt, 0, g, l15), v1 = frag_rows(Vs, kt, 1, g, l15);
           const f32x4 m4 = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
 #pragma unroll
           for (int j = 0; j < TPW; ++j) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[j][0], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[j][1], a, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, df[j][0], dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, df[j][1], dp, 0, 0, 0);
+            a = mfma16(k0, qf[j][0], a);
+            a = mfma16(k1, qf[j][1], a);
+            dp = mfma16(v0, df[j][0], dp);
+            dp = mfma16(v1, df[j][1], dp);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float pv = __builtin_amdgcn_exp2f((a[r] + m4[r]) * sl2 + nl[j]);
@@ -602,24 +605,24 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
             }
           }
         }
-        bf16x8 dsf[TPW];
+        h16x8 dsf[TPW];
 #pragma unroll
         for (int j = 0; j < TPW; ++j) dsf[j] = pack_frag(ds2[j][0], ds2[j][1]);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const bf16x8 kt_ = frag_tr(Ks, T, dt, g, l15);
+          const h16x8 kt_ = frag_tr(Ks, T, dt, g, l15);
 #pragma unroll
-          for (int j = 0; j < TPW; ++j) o[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsf[j], o[j][dt], 0, 0, 0);
+          for (int j = 0; j < TPW; ++j) o[j][dt] = mfma16(kt_, dsf[j], o[j][dt]);
         }
       }
 #pragma unroll
       for (int j = 0; j < TPW; ++j) {
         const int q_l = (wave * TPW + j) * 16 + l15;
         if (q_l < S) {
-          bf16* dst = dqbase + (size_t)q_l * ld + 4 * g;
+          h16* dst = dqbase + (size_t)q_l * ld + 4 * g;
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
-            const uint2 w = {pack_bf16x2(o[j][dt][0], o[j][dt][1]), pack_bf16x2(o[j][dt][2], o[j][dt][3])};
+            const uint2 w = {pack_h16x2(o[j][dt][0], o[j][dt][1]), pack_h16x2(o[j][dt][2], o[j][dt][3])};
             *reinterpret_cast<uint2*>(dst + dt * 16) = w;
           }
         }
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
     }
     // ---------------- dK, dV: wave = TPW key tiles at once (they share every Q / dO fragment read) ----------------
     {
-      bf16x8 kf[TPW][2], vf[TPW][2];
+      h16x8 kf[TPW][2], vf[TPW][2];
       float mk[TPW];
       f32x4 dk[TPW][4], dv[TPW][4];
 #pragma unroll
@@ -648,17 +651,17 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const int qt = 2 * T + hh;
-          const bf16x8 q0 = frag_rows(Qs, qt, 0, g, l15), q1 = frag_rows(Qs, qt, 1, g, l15);
-          const bf16x8 d0 = frag_rows(Ds, qt, 0, g, l15), d1 = frag_rows(Ds, qt, 1, g, l15);
+          const h16x8 q0 = frag_rows(Qs, qt, 0, g, l15), q1 = frag_rows(Qs, qt, 1, g, l15);
+          const h16x8 d0 = frag_rows(Ds, qt, 0, g, l15), d1 = frag_rows(Ds, qt, 1, g, l15);
           const f32x4 nl4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * g);
           const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dl_s + qt * 16 + 4 * g);
 #pragma unroll
           for (int j = 0; j < TPW; ++j) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, kf[j][0], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, kf[j][1], a, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf[j][0], dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf[j][1], dp, 0, 0, 0);
+            a = mfma16(q0, kf[j][0], a);
+            a = mfma16(q1, kf[j][1], a);
+            dp = mfma16(d0, vf[j][0], dp);
+            dp = mfma16(d1, vf[j][1], dp);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float pv = __builtin_amdgcn_exp2f((a[r] + mk[j]) * sl2 + nl4[r]);
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
             }
           }
         }
-        bf16x8 pf[TPW], dsf[TPW];
+        h16x8 pf[TPW], dsf[TPW];
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
           pf[j] = pack_frag(p2[j][0], p2[j][1]);
@@ -685,11 +688,11 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const bf16x8 dt_ = frag_tr(Ds, T, dt, g, l15), qt_ = frag_tr(Qs, T, dt, g, l15);
+          const h16x8 dt_ = frag_tr(Ds, T, dt, g, l15), qt_ = frag_tr(Qs, T, dt, g, l15);
 #pragma unroll
           for (int j = 0; j < TPW; ++j) {
-            dv[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt_, pf[j], dv[j][dt], 0, 0, 0);
-            dk[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsf[j], dk[j][dt], 0, 0, 0);
+            dv[j][dt] = mfma16(dt_, pf[j], dv[j][dt]);
+            dk[j][dt] = mfma16(qt_, dsf[j], dk[j][dt]);
           }
         }
       }
@@ -697,12 +700,12 @@ __global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const bf16* _
       for (int j = 0; j < TPW; ++j) {
         const int k_l = (wave * TPW + j) * 16 + l15;
         if (k_l < S) {
-          bf16* dstk = dqbase + H + (size_t)k_l * ld + 4 * g;
-          bf16* dstv = dqbase + 2 * H + (size_t)k_l * ld + 4 * g;
+          h16* dstk = dqbase + H + (size_t)k_l * ld + 4 * g;
+          h16* dstv = dqbase + 2 * H + (size_t)k_l * ld + 4 * g;
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
-            const uint2 wk = {pack_bf16x2(dk[j][dt][0], dk[j][dt][1]), pack_bf16x2(dk[j][dt][2], dk[j][dt][3])};
-            const uint2 wv = {pack_bf16x2(dv[j][dt][0], dv[j][dt][1]), pack_bf16x2(dv[j][dt][2], dv[j][dt][3])};
+            const uint2 wk = {pack_h16x2(dk[j][dt][0], dk[j][dt][1]), pack_h16x2(dk[j][dt][2], dk[j][dt][3])};
+            const uint2 wv = {pack_h16x2(dv[j][dt][0], dv[j][dt][1]), pack_h16x2(dv[j][dt][2], dv[j][dt][3])};
             *reinterpret_cast<uint2*>(dstk + dt * 16) = wk;
             *reinterpret_cast<uint2*>(dstv + dt * 16) = wv;
           }
@@ -770,10 +773,11 @@ __device__ __forceinline__ const char* attn_uniform(const void* p) {
 }
 
 template <int NKT, int NWV, bool DROP = true, int WPE = 1>
-__global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16* __restrict__ qkv, const float* __restrict__ keymask,
-                                                         const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
-                                                         const float* __restrict__ lse, bf16* __restrict__ dqkv, int S,
+__global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* __restrict__ qkv, const float* __restrict__ keymask,
+                                                         const h16* __restrict__ ctx, const h16* __restrict__ dctx,
+                                                         const float* __restrict__ lse, h16* __restrict__ dqkv, int S,
                                                          int H, int heads, int items, float scale, AttnDrop dr) {
+  H16_SATURATE();
   constexpr int SK = NKT * 32;
   constexpr int DS_LD = ds_ld<SK>();
   constexpr int NT = NWV * 64;
@@ -891,7 +895,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16*
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        const float2 a = unpack_bf16x2(ro[i][w]), d = unpack_bf16x2(rd[i][w]);
+        const float2 a = unpack_h16x2(ro[i][w]), d = unpack_h16x2(rd[i][w]);
         s += a.x * d.x + a.y * d.y;
       }
       s += __shfl_xor(s, 1, 64);
@@ -917,8 +921,8 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16*
   if (item + G < items) fetch_q_do(item + G);
   for (; item < items; item += G) {
     asm volatile("" : "+v"(rkf[0]), "+v"(rkf[1]), "+v"(rvf[0]), "+v"(rvf[1]));   // (landed: waited for in front of the DMA / above)
-    const bf16x8 kf0 = __builtin_bit_cast(bf16x8, rkf[0]), kf1 = __builtin_bit_cast(bf16x8, rkf[1]);
-    const bf16x8 vf0 = __builtin_bit_cast(bf16x8, rvf[0]), vf1 = __builtin_bit_cast(bf16x8, rvf[1]);
+    const h16x8 kf0 = __builtin_bit_cast(h16x8, rkf[0]), kf1 = __builtin_bit_cast(h16x8, rkf[1]);
+    const h16x8 vf0 = __builtin_bit_cast(h16x8, rvf[0]), vf1 = __builtin_bit_cast(h16x8, rvf[1]);
     int b, h;
     item_bh(item, b, h);
 #if ATTN_ABLATE == 2
@@ -947,15 +951,15 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16*
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const int qt = 2 * T + hh;
-          const bf16x8 q0 = frag_rows(Qs, qt, 0, g, l15), q1 = frag_rows(Qs, qt, 1, g, l15);
-          const bf16x8 d0 = frag_rows(Ds, qt, 0, g, l15), d1 = frag_rows(Ds, qt, 1, g, l15);
+          const h16x8 q0 = frag_rows(Qs, qt, 0, g, l15), q1 = frag_rows(Qs, qt, 1, g, l15);
+          const h16x8 d0 = frag_rows(Ds, qt, 0, g, l15), d1 = frag_rows(Ds, qt, 1, g, l15);
           const f32x4 nl4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * g);
           const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dl_s + qt * 16 + 4 * g);
           f32x4 a = {mk, mk, mk, mk}, dp = {0.f, 0.f, 0.f, 0.f};     // (the key mask is the initial accumulator)
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, kf0, a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, kf1, a, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf0, dp, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf1, dp, 0, 0, 0);
+          a = mfma16(q0, kf0, a);
+          a = mfma16(q1, kf1, a);
+          dp = mfma16(d0, vf0, dp);
+          dp = mfma16(d1, vf1, dp);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(a[r], sl2, nl4[r]));
@@ -973,16 +977,16 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16*
             p2[hh][r] = pv;
           }
         }
-        const bf16x8 pf = pack_frag(p2[0], p2[1]);
-        const bf16x8 dsf = pack_frag(ds2[0], ds2[1]);
+        const h16x8 pf = pack_frag(p2[0], p2[1]);
+        const h16x8 dsf = pack_frag(ds2[0], ds2[1]);
         // dS^T[key = this lane's][queries 32 T + 16 hh + 4 g + 0..3]: two 8-byte stores
         const u32x4 dsw = __builtin_bit_cast(u32x4, dsf);
         *reinterpret_cast<uint2*>(dsrow + T * 64) = uint2{dsw[0], dsw[1]};
         *reinterpret_cast<uint2*>(dsrow + T * 64 + 32) = uint2{dsw[2], dsw[3]};
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Ds, T, dt >> 1, dt & 1, g, l15), pf, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Qs, T, dt >> 1, dt & 1, g, l15), dsf, dk[dt], 0, 0, 0);
+          dv[dt] = mfma16(frag_tr8(Ds, T, dt >> 1, dt & 1, g, l15), pf, dv[dt]);
+          dk[dt] = mfma16(frag_tr8(Qs, T, dt >> 1, dt & 1, g, l15), dsf, dk[dt]);
         }
       }
     }
@@ -1003,9 +1007,9 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16*
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {    // tiles (2 hf, 2 hf + 1): d = 32 hf + 8 g + 0..7 of this lane's row
         const f32x4 ka = dk[2 * hf], kb2 = dk[2 * hf + 1], va = dv[2 * hf], vb2 = dv[2 * hf + 1];
-        wk[hf] = u32x4{pack_bf16x2(ka[0] * scale, ka[1] * scale), pack_bf16x2(ka[2] * scale, ka[3] * scale),
-                       pack_bf16x2(kb2[0] * scale, kb2[1] * scale), pack_bf16x2(kb2[2] * scale, kb2[3] * scale)};
-        wv[hf] = u32x4{pack_bf16x2(va[0], va[1]), pack_bf16x2(va[2], va[3]), pack_bf16x2(vb2[0], vb2[1]), pack_bf16x2(vb2[2], vb2[3])};
+        wk[hf] = u32x4{pack_h16x2(ka[0] * scale, ka[1] * scale), pack_h16x2(ka[2] * scale, ka[3] * scale),
+                       pack_h16x2(kb2[0] * scale, kb2[1] * scale), pack_h16x2(kb2[2] * scale, kb2[3] * scale)};
+        wv[hf] = u32x4{pack_h16x2(va[0], va[1]), pack_h16x2(va[2], va[3]), pack_h16x2(vb2[0], vb2[1]), pack_h16x2(vb2[2], vb2[3])};
       }
       u32x4 ka_, kb_, va_, vb_;
       wl_pair(wk[0], wk[1], ka_, kb_);
@@ -1026,9 +1030,9 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16*
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {    // tiles (2 hf, 2 hf + 1): d = 32 hf + 8 g + 0..7 of this lane's row
         const f32x4 ka = dk[2 * hf], kb2 = dk[2 * hf + 1], va = dv[2 * hf], vb2 = dv[2 * hf + 1];
-        const u32x4 wk = {pack_bf16x2(ka[0] * scale, ka[1] * scale), pack_bf16x2(ka[2] * scale, ka[3] * scale),
-                          pack_bf16x2(kb2[0] * scale, kb2[1] * scale), pack_bf16x2(kb2[2] * scale, kb2[3] * scale)};
-        const u32x4 wv = {pack_bf16x2(va[0], va[1]), pack_bf16x2(va[2], va[3]), pack_bf16x2(vb2[0], vb2[1]), pack_bf16x2(vb2[2], vb2[3])};
+        const u32x4 wk = {pack_h16x2(ka[0] * scale, ka[1] * scale), pack_h16x2(ka[2] * scale, ka[3] * scale),
+                          pack_h16x2(kb2[0] * scale, kb2[1] * scale), pack_h16x2(kb2[2] * scale, kb2[3] * scale)};
+        const u32x4 wv = {pack_h16x2(va[0], va[1]), pack_h16x2(va[2], va[3]), pack_h16x2(vb2[0], vb2[1]), pack_h16x2(vb2[2], vb2[3])};
         ATTN_STORE16(dstk + (off_out + 64u * hf), wk);
         ATTN_STORE16(dstv + (off_out + 64u * hf), wv);
       }
@@ -1049,10 +1053,10 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16*
 #pragma unroll
       for (int T = 0; T < ((ATTN_ABLATE == 1 || ATTN_ABLATE == 3) ? 0 : NKT); ++T) {
         const char* a = dsb + T * 32 * DS_LD;
-        const bf16x8 dsB = cat_tr(lds_read_tr16(a), lds_read_tr16(a + 16 * DS_LD));
+        const h16x8 dsB = cat_tr(lds_read_tr16(a), lds_read_tr16(a + 16 * DS_LD));
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
-          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Ks, T, dt >> 1, dt & 1, g, l15), dsB, o[dt], 0, 0, 0);
+          o[dt] = mfma16(frag_tr8(Ks, T, dt >> 1, dt & 1, g, l15), dsB, o[dt]);
       }
 #if ATTN_WL
       {
@@ -1060,8 +1064,8 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16*
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const f32x4 qa = o[2 * hf], qb2 = o[2 * hf + 1];
-          wq[hf] = u32x4{pack_bf16x2(qa[0] * scale, qa[1] * scale), pack_bf16x2(qa[2] * scale, qa[3] * scale),
-                         pack_bf16x2(qb2[0] * scale, qb2[1] * scale), pack_bf16x2(qb2[2] * scale, qb2[3] * scale)};
+          wq[hf] = u32x4{pack_h16x2(qa[0] * scale, qa[1] * scale), pack_h16x2(qa[2] * scale, qa[3] * scale),
+                         pack_h16x2(qb2[0] * scale, qb2[1] * scale), pack_h16x2(qb2[2] * scale, qb2[3] * scale)};
         }
         wl_pair(wq[0], wq[1], qa_, qb_);
         if (row_a < S_st) ATTN_STORE16(dqbase + off_wl, qa_);
@@ -1072,8 +1076,8 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const bf16*
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const f32x4 qa = o[2 * hf], qb2 = o[2 * hf + 1];
-          const u32x4 w = {pack_bf16x2(qa[0] * scale, qa[1] * scale), pack_bf16x2(qa[2] * scale, qa[3] * scale),
-                           pack_bf16x2(qb2[0] * scale, qb2[1] * scale), pack_bf16x2(qb2[2] * scale, qb2[3] * scale)};
+          const u32x4 w = {pack_h16x2(qa[0] * scale, qa[1] * scale), pack_h16x2(qa[2] * scale, qa[3] * scale),
+                           pack_h16x2(qb2[0] * scale, qb2[1] * scale), pack_h16x2(qb2[2] * scale, qb2[3] * scale)};
           ATTN_STORE16(dqbase + (off_out + 64u * hf), w);
         }
       }
@@ -1134,8 +1138,8 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
   const float scale = 0.125f;  // 1/sqrt(64)
 #define FWD_V(NK, NW, WP, DR)                                                                                          \
     hipLaunchKernelGGL((attn_fwd_kernel<NK, NW, WP, DR>), grid, dim3(NW * 64), attn_lds_bytes<NK>(), st,                \
-                       reinterpret_cast<const bf16*>(a->qkv), a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, \
-                       a->H, a->heads, scale, dr, reinterpret_cast<bf16*>(a->ctx_split3))
+                       reinterpret_cast<const h16*>(a->qkv), a->keymask, reinterpret_cast<h16*>(a->ctx), a->lse, a->S, \
+                       a->H, a->heads, scale, dr, reinterpret_cast<h16*>(a->ctx_split3))
   // (dropout is a template switch: a per-element run-time test splits the loop body into basic blocks that the
   //  instruction scheduler cannot move MFMAs and LDS reads across)
   const bool drop = a->drop_thresh != 0u;
@@ -1152,9 +1156,9 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
       if (e != hipSuccess) return (int)e;
       attr_done = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(ATTN_L9_FWD_W * 64), attn_lds_bytes<9>(), st, reinterpret_cast<const bf16*>(a->qkv),
-                       a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
-                       reinterpret_cast<bf16*>(a->ctx_split3));
+    hipLaunchKernelGGL(kern, grid, dim3(ATTN_L9_FWD_W * 64), attn_lds_bytes<9>(), st, reinterpret_cast<const h16*>(a->qkv),
+                       a->keymask, reinterpret_cast<h16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
+                       reinterpret_cast<h16*>(a->ctx_split3));
   } else {   // long sequences of padded, larger images: K/V image 80 KiB -> one block per CU
     auto kern = attn_fwd_kernel<10, ATTN_LONG_WAVES_FWD, 1>;
     static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];
@@ -1164,9 +1168,9 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
       if (e != hipSuccess) return (int)e;
       attr_done = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(ATTN_LONG_WAVES_FWD * 64), attn_lds_bytes<10>(), st, reinterpret_cast<const bf16*>(a->qkv),
-                       a->keymask, reinterpret_cast<bf16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
-                       reinterpret_cast<bf16*>(a->ctx_split3));
+    hipLaunchKernelGGL(kern, grid, dim3(ATTN_LONG_WAVES_FWD * 64), attn_lds_bytes<10>(), st, reinterpret_cast<const h16*>(a->qkv),
+                       a->keymask, reinterpret_cast<h16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
+                       reinterpret_cast<h16*>(a->ctx_split3));
   }
 #undef FWD_V
   return (int)hipGetLastError();
@@ -1183,9 +1187,9 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
   const float scale = 0.125f;
   const bool drop = a->drop_thresh != 0u;
 #define OLD_V(NK, DR)                                                                                                         \
-    hipLaunchKernelGGL((attn_bwd_kernel<NK, 4, 3, DR>), grid, dim3(256), attn_lds_bytes<NK>(), st, reinterpret_cast<const bf16*>(a->qkv), \
-                       a->keymask, reinterpret_cast<const bf16*>(a->ctx), reinterpret_cast<const bf16*>(a->dctx), a->lse,     \
-                       reinterpret_cast<bf16*>(a->dqkv), a->S, a->H, a->heads, scale, dr)
+    hipLaunchKernelGGL((attn_bwd_kernel<NK, 4, 3, DR>), grid, dim3(256), attn_lds_bytes<NK>(), st, reinterpret_cast<const h16*>(a->qkv), \
+                       a->keymask, reinterpret_cast<const h16*>(a->ctx), reinterpret_cast<const h16*>(a->dctx), a->lse,     \
+                       reinterpret_cast<h16*>(a->dqkv), a->S, a->H, a->heads, scale, dr)
 #define RES_V(DR)                                                                                                             \
     {                                                                                                                         \
       auto kern = attn_bwd_res_kernel<6, 12, DR>;   /* 98.3 KiB of LDS: one 12-wave workgroup per CU, persistent */           \
@@ -1197,8 +1201,8 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
         attr_done = true;                                                                                                     \
       }                                                                                                                       \
       hipLaunchKernelGGL(kern, dim3(items < 256 ? items : 256), dim3(768), attn_res_lds_bytes<6>(), st,                       \
-                         reinterpret_cast<const bf16*>(a->qkv), a->keymask, reinterpret_cast<const bf16*>(a->ctx),            \
-                         reinterpret_cast<const bf16*>(a->dctx), a->lse, reinterpret_cast<bf16*>(a->dqkv), a->S, a->H,        \
+                         reinterpret_cast<const h16*>(a->qkv), a->keymask, reinterpret_cast<const h16*>(a->ctx),            \
+                         reinterpret_cast<const h16*>(a->dctx), a->lse, reinterpret_cast<h16*>(a->dqkv), a->S, a->H,        \
                          a->heads, items, scale, dr);                                                                         \
     }
 #define ONE_V(DR)                                                                                                             \
@@ -1212,8 +1216,8 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
         attr_done = true;                                                                                                     \
       }                                                                                                                       \
       hipLaunchKernelGGL(kern, dim3(items < 256 ? items : 256), dim3(768), attn_one_lds_bytes<6>(), st,                       \
-                         reinterpret_cast<const bf16*>(a->qkv), a->keymask, reinterpret_cast<const bf16*>(a->ctx),            \
-                         reinterpret_cast<const bf16*>(a->dctx), a->lse, reinterpret_cast<bf16*>(a->dqkv), a->S, a->H,        \
+                         reinterpret_cast<const h16*>(a->qkv), a->keymask, reinterpret_cast<const h16*>(a->ctx),            \
+                         reinterpret_cast<const h16*>(a->dctx), a->lse, reinterpret_cast<h16*>(a->dqkv), a->S, a->H,        \
                          a->heads, items, scale, dr);                                                                         \
     }
   static const bool one_pass_s = [] { const char* e = getenv("VAULT_ATTN_BWD_S"); return !(e && e[0] == '0'); }();   // development A/B switch
@@ -1223,12 +1227,12 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
     const int items = a->B * a->heads;
     const int grid = items < 768 ? items : 768;
     if (drop) hipLaunchKernelGGL((attn_bwd_one_kernel<2, 4, true, 3>), dim3(grid), dim3(256), attn_one_lds_bytes<2>(), st,
-                                 reinterpret_cast<const bf16*>(a->qkv), a->keymask, reinterpret_cast<const bf16*>(a->ctx),
-                                 reinterpret_cast<const bf16*>(a->dctx), a->lse, reinterpret_cast<bf16*>(a->dqkv), a->S, a->H,
+                                 reinterpret_cast<const h16*>(a->qkv), a->keymask, reinterpret_cast<const h16*>(a->ctx),
+                                 reinterpret_cast<const h16*>(a->dctx), a->lse, reinterpret_cast<h16*>(a->dqkv), a->S, a->H,
                                  a->heads, items, scale, dr);
     else hipLaunchKernelGGL((attn_bwd_one_kernel<2, 4, false, 3>), dim3(grid), dim3(256), attn_one_lds_bytes<2>(), st,
-                            reinterpret_cast<const bf16*>(a->qkv), a->keymask, reinterpret_cast<const bf16*>(a->ctx),
-                            reinterpret_cast<const bf16*>(a->dctx), a->lse, reinterpret_cast<bf16*>(a->dqkv), a->S, a->H,
+                            reinterpret_cast<const h16*>(a->qkv), a->keymask, reinterpret_cast<const h16*>(a->ctx),
+                            reinterpret_cast<const h16*>(a->dctx), a->lse, reinterpret_cast<h16*>(a->dqkv), a->S, a->H,
                             a->heads, items, scale, dr);
   } else if (a->S <= 64) {
     if (drop) OLD_V(2, true); else OLD_V(2, false);
@@ -1249,9 +1253,9 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
       if (e != hipSuccess) return (int)e;
       attr_done = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(ATTN_L9_BWD_W * 64), attn_lds_bytes<9>(), st, reinterpret_cast<const bf16*>(a->qkv),
-                       a->keymask, reinterpret_cast<const bf16*>(a->ctx), reinterpret_cast<const bf16*>(a->dctx), a->lse,
-                       reinterpret_cast<bf16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
+    hipLaunchKernelGGL(kern, grid, dim3(ATTN_L9_BWD_W * 64), attn_lds_bytes<9>(), st, reinterpret_cast<const h16*>(a->qkv),
+                       a->keymask, reinterpret_cast<const h16*>(a->ctx), reinterpret_cast<const h16*>(a->dctx), a->lse,
+                       reinterpret_cast<h16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
   } else {
     auto kern = attn_bwd_kernel<10, ATTN_LONG_WAVES_BWD, 1>;
     static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];
@@ -1261,9 +1265,9 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
       if (e != hipSuccess) return (int)e;
       attr_done = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(ATTN_LONG_WAVES_BWD * 64), attn_lds_bytes<10>(), st, reinterpret_cast<const bf16*>(a->qkv),
-                       a->keymask, reinterpret_cast<const bf16*>(a->ctx), reinterpret_cast<const bf16*>(a->dctx), a->lse,
-                       reinterpret_cast<bf16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
+    hipLaunchKernelGGL(kern, grid, dim3(ATTN_LONG_WAVES_BWD * 64), attn_lds_bytes<10>(), st, reinterpret_cast<const h16*>(a->qkv),
+                       a->keymask, reinterpret_cast<const h16*>(a->ctx), reinterpret_cast<const h16*>(a->dctx), a->lse,
+                       reinterpret_cast<h16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
   }
 #undef OLD_V
 #undef RES_V

@@ -7,15 +7,15 @@ int vault_gemm_mx8_launch(const GemmParams& p, const void* a_scale, const void* 
 
 static GemmParams params_of(const vault_gemm_args* a) {
   GemmParams p{};
-  p.A = reinterpret_cast<const __bf16*>(a->A);
-  p.B = reinterpret_cast<const __bf16*>(a->B);
+  p.A = reinterpret_cast<const h16*>(a->A);
+  p.B = reinterpret_cast<const h16*>(a->B);
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.lda = a->lda; p.ldb = a->ldb; p.ldo = a->ldo;
   p.m_valid = a->m_valid > 0 ? a->m_valid : a->M;
   p.splits = a->splits; p.accumulate = a->accumulate;
   p.out = a->out; p.out2 = a->out2;
   p.bias = a->bias; p.res = a->res;
-  p.aux = reinterpret_cast<const __bf16*>(a->aux);
+  p.aux = reinterpret_cast<const h16*>(a->aux);
   p.addtab = a->addtab; p.colsum = a->colsum; p.split3 = a->split3; p.rpg = a->rpg; p.gstride = a->gstride; p.goff = a->goff;
   p.drop_thresh = a->drop_thresh; p.drop_seed = a->drop_seed; p.drop_stream = a->drop_stream;
   p.drop_scale = a->drop_scale;
@@ -44,4 +44,9 @@ extern "C" int vault_gemm_mxfp8(const vault_gemm_args* a, const void* a_scale, c
   return vault_gemm_mx8_launch(params_of(a), a_scale, b_scale, a->epi, reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" int vault_abi_version(void) { return 7; }
+extern "C" int vault_abi_version(void) { return 8; }
+#ifdef VAULT_F16
+extern "C" int vault_operand_format(void) { return 1; }
+#else
+extern "C" int vault_operand_format(void) { return 0; }
+#endif

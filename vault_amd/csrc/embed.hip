@@ -169,8 +169,9 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(const float* __restric
 }
 
 // pixel [B][C][IMG][IMG] f32 -> A [B*P (padded)][C*ps*ps] bf16, k = c*ps*ps + py*ps + px, patches row-major
-__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ pix, bf16* __restrict__ out, int B, int Cn,
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ pix, h16* __restrict__ out, int B, int Cn,
                                                      int IMG, int ps, long long total_chunks, int split3) {
+  H16_SATURATE();
   // one block per output row (patch): the row -> (sample, patch row, patch column) split is scalar work, the
   // per-chunk index math stays in 32 bits (64-bit divisions per 16-byte chunk made this kernel VALU-bound)
   const int grid = IMG / ps;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ p
     const int b = row / (grid * grid), p = row - b * grid * grid;
     const int pr = p / grid, pc = p - pr * grid;
     const float* base = pix + ((size_t)b * Cn * IMG + (size_t)pr * ps) * IMG + pc * ps;
-    bf16* orow = out + (size_t)row * (split3 ? 3 * Kp : Kp);
+    h16* orow = out + (size_t)row * (split3 ? 3 * Kp : Kp);
     for (int kc = threadIdx.x; kc < Kp / 8; kc += 256) {
       const int k = kc * 8;
       const int c = k / pp, rem = k - c * pp;
@@ -190,19 +191,19 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ p
       const f32x4 d = *reinterpret_cast<const f32x4*>(s + 4);
       if (split3) {
         const float xs[8] = {a[0], a[1], a[2], a[3], d[0], d[1], d[2], d[3]};
-        bf16 hi[8], lo[8];
+        h16 hi[8], lo[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) split_bf16(xs[e], hi[e], lo[e]);
-        u32x4 wh = {pack_bf16x2((float)hi[0], (float)hi[1]), pack_bf16x2((float)hi[2], (float)hi[3]),
-                    pack_bf16x2((float)hi[4], (float)hi[5]), pack_bf16x2((float)hi[6], (float)hi[7])};
-        u32x4 wl = {pack_bf16x2((float)lo[0], (float)lo[1]), pack_bf16x2((float)lo[2], (float)lo[3]),
-                    pack_bf16x2((float)lo[4], (float)lo[5]), pack_bf16x2((float)lo[6], (float)lo[7])};
+        u32x4 wh = {pack_h16x2((float)hi[0], (float)hi[1]), pack_h16x2((float)hi[2], (float)hi[3]),
+                    pack_h16x2((float)hi[4], (float)hi[5]), pack_h16x2((float)hi[6], (float)hi[7])};
+        u32x4 wl = {pack_h16x2((float)lo[0], (float)lo[1]), pack_h16x2((float)lo[2], (float)lo[3]),
+                    pack_h16x2((float)lo[4], (float)lo[5]), pack_h16x2((float)lo[6], (float)lo[7])};
         *reinterpret_cast<u32x4*>(orow + k) = wh;
         *reinterpret_cast<u32x4*>(orow + Kp + k) = wl;
         *reinterpret_cast<u32x4*>(orow + 2 * Kp + k) = wh;
         continue;
       }
-      u32x4 w = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
+      u32x4 w = {pack_h16x2(a[0], a[1]), pack_h16x2(a[2], a[3]), pack_h16x2(d[0], d[1]), pack_h16x2(d[2], d[3])};
       *reinterpret_cast<u32x4*>(orow + k) = w;
     }
   }
@@ -229,8 +230,9 @@ __global__ __launch_bounds__(256) void image_consts_kernel(const float* __restri
 //   dyp[b*P + j-1] = bf16(dx[b, T+j])   (compact operand for the projection wgrad)
 __global__ __launch_bounds__(256) void image_rows_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dpos,
                                                              float* __restrict__ dmtype1, float* __restrict__ dcls,
-                                                             float* __restrict__ dbias, bf16* __restrict__ dyp, int P, int H,
+                                                             float* __restrict__ dbias, h16* __restrict__ dyp, int P, int H,
                                                              int B, int S, int T, int b_per_block) {
+  H16_SATURATE();
   const int j = blockIdx.x;
   const int b0 = blockIdx.y * b_per_block, b1 = min(B, b0 + b_per_block);
   // a thread owns the columns n, n + 256, ... (three at H = 768) of position j: their sample loops run side by side, four
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void image_rows_bwd_kernel(const float* __rest
       for (int k = 0; k < MAXC; ++k)
         if (k < nc) {
           acc[k] += v[q][k];
-          if (j >= 1) dyp[((size_t)(b + q) * P + (j - 1)) * H + threadIdx.x + 256 * k] = (bf16)v[q][k];
+          if (j >= 1) dyp[((size_t)(b + q) * P + (j - 1)) * H + threadIdx.x + 256 * k] = (h16)v[q][k];
         }
   }
   for (; b < b1; ++b)
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void image_rows_bwd_kernel(const float* __rest
       if (k < nc) {
         const float v = dx[((size_t)b * S + T + j) * H + threadIdx.x + 256 * k];
         acc[k] += v;
-        if (j >= 1) dyp[((size_t)b * P + (j - 1)) * H + threadIdx.x + 256 * k] = (bf16)v;
+        if (j >= 1) dyp[((size_t)b * P + (j - 1)) * H + threadIdx.x + 256 * k] = (h16)v;
       }
 #pragma unroll
   for (int k = 0; k < MAXC; ++k)
@@ -277,6 +279,14 @@ __global__ __launch_bounds__(256) void image_rows_bwd_kernel(const float* __rest
 
 __global__ void axpy_kernel(float* __restrict__ dst, const float* __restrict__ src, float a, long long n) {
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256ll) dst[i] += a * src[i];
+}
+
+// x *= a, 16 bytes per lane (the flat gradient buffer under the fp16 build's power-of-two gradient scale: exact)
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, float a, long long n4) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256ll) {
+    f32x4 v = reinterpret_cast<f32x4*>(x)[i];
+    reinterpret_cast<f32x4*>(x)[i] = v * a;
+  }
 }
 
 }  // namespace
@@ -322,7 +332,7 @@ extern "C" int vault_im2col(const float* pix, void* out_bf16, int B, int C, int 
   const long long chunks = rows * (C * ps * ps / 8);
   const int blocks = (int)std::min<long long>(rows, 256 * 64);
   hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pix,
-                     reinterpret_cast<bf16*>(out_bf16), B, C, IMG, ps, chunks, split3);
+                     reinterpret_cast<h16*>(out_bf16), B, C, IMG, ps, chunks, split3);
   return (int)hipGetLastError();
 }
 
@@ -340,7 +350,7 @@ extern "C" int vault_image_rows_bwd(const float* dx, float* dpos, float* dmtype1
   const int bpb = 32;   // samples per block: fewer blocks hammer the shared dmtype1 / dbias / dcls addresses with atomics
   hipLaunchKernelGGL(image_rows_bwd_kernel, dim3(P + 1, (B + bpb - 1) / bpb), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), dx, dpos, dmtype1, dcls, dbias,
-                     reinterpret_cast<bf16*>(dyp_bf16), P, H, B, S, T, bpb);
+                     reinterpret_cast<h16*>(dyp_bf16), P, H, B, S, T, bpb);
   return (int)hipGetLastError();
 }
 
@@ -348,6 +358,13 @@ extern "C" int vault_axpy_f32(float* dst, const float* src, float a, long long n
   if (!dst || !src || n <= 0) return VAULT_EINVAL;
   const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
   hipLaunchKernelGGL(axpy_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dst, src, a, n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int vault_scale_f32(float* x, float a, long long n, void* stream) {
+  if (!x || n <= 0 || (n & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return VAULT_EINVAL;
+  const int blocks = (int)std::min<long long>((n / 4 + 255) / 256, 8192);
+  hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, a, n / 4);
   return (int)hipGetLastError();
 }
 

@@ -15,9 +15,10 @@ namespace {
 
 // pixel [B][C][HP][WP] f32 -> A [B*L (padded)][C*ps*ps] bf16 ; row (b, l) = patch slot sel[b*L + l] of the
 // (HP/ps) x (WP/ps) grid, k = c*ps*ps + py*ps + px
-__global__ __launch_bounds__(256) void im2col_sel_kernel(const float* __restrict__ pix, bf16* __restrict__ out,
+__global__ __launch_bounds__(256) void im2col_sel_kernel(const float* __restrict__ pix, h16* __restrict__ out,
                                                          const int* __restrict__ sel, int B, int L, int Cn, int HP, int WP,
                                                          int ps, long long total_chunks, int split3) {
+  H16_SATURATE();
   const int gw = WP / ps;
   const int Kp = Cn * ps * ps;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total_chunks; i += (long long)gridDim.x * 256ll) {
@@ -34,20 +35,20 @@ __global__ __launch_bounds__(256) void im2col_sel_kernel(const float* __restrict
     const f32x4 d = *reinterpret_cast<const f32x4*>(s + 4);
     if (split3) {
       const float xs[8] = {a[0], a[1], a[2], a[3], d[0], d[1], d[2], d[3]};
-      bf16 hi[8], lo[8];
+      h16 hi[8], lo[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) split_bf16(xs[e], hi[e], lo[e]);
-      u32x4 wh = {pack_bf16x2((float)hi[0], (float)hi[1]), pack_bf16x2((float)hi[2], (float)hi[3]),
-                  pack_bf16x2((float)hi[4], (float)hi[5]), pack_bf16x2((float)hi[6], (float)hi[7])};
-      u32x4 wl = {pack_bf16x2((float)lo[0], (float)lo[1]), pack_bf16x2((float)lo[2], (float)lo[3]),
-                  pack_bf16x2((float)lo[4], (float)lo[5]), pack_bf16x2((float)lo[6], (float)lo[7])};
-      bf16* o = out + row * 3 * Kp + k;
+      u32x4 wh = {pack_h16x2((float)hi[0], (float)hi[1]), pack_h16x2((float)hi[2], (float)hi[3]),
+                  pack_h16x2((float)hi[4], (float)hi[5]), pack_h16x2((float)hi[6], (float)hi[7])};
+      u32x4 wl = {pack_h16x2((float)lo[0], (float)lo[1]), pack_h16x2((float)lo[2], (float)lo[3]),
+                  pack_h16x2((float)lo[4], (float)lo[5]), pack_h16x2((float)lo[6], (float)lo[7])};
+      h16* o = out + row * 3 * Kp + k;
       *reinterpret_cast<u32x4*>(o) = wh;
       *reinterpret_cast<u32x4*>(o + Kp) = wl;
       *reinterpret_cast<u32x4*>(o + 2 * Kp) = wh;
       continue;
     }
-    u32x4 w = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
+    u32x4 w = {pack_h16x2(a[0], a[1]), pack_h16x2(a[2], a[3]), pack_h16x2(d[0], d[1]), pack_h16x2(d[2], d[3])};
     *reinterpret_cast<u32x4*>(out + row * Kp + k) = w;
   }
 }
@@ -123,9 +124,10 @@ __global__ __launch_bounds__(256) void image_pos_sel_fwd_kernel(float* __restric
 // reads their output), so they need no special case.
 __global__ __launch_bounds__(256) void image_sel_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dpos,
                                                             float* __restrict__ dmtype1, float* __restrict__ dcls,
-                                                            float* __restrict__ dbias, bf16* __restrict__ dyp,
+                                                            float* __restrict__ dbias, h16* __restrict__ dyp,
                                                             const int* __restrict__ sel, const int* __restrict__ hw, int L,
                                                             int H, int B, int S, int T, int gw, int G, int b_per_block) {
+  H16_SATURATE();
   const int l = blockIdx.x;   // L -> CLS rows
   const int b0 = blockIdx.y * b_per_block, b1 = min(B, b0 + b_per_block);
   for (int n = threadIdx.x; n < H; n += 256) {
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void image_sel_bwd_kernel(const float* __restr
       } else {
         const float v = dx[((size_t)b * S + T + 1 + l) * H + n];
         acc += v;
-        dyp[((size_t)b * L + l) * H + n] = (bf16)v;
+        dyp[((size_t)b * L + l) * H + n] = (h16)v;
         if (v != 0.f) {
           const Lerp4 q = lerp_of(sel[b * L + l], gw, hw[2 * b], hw[2 * b + 1], G);
 #pragma unroll
@@ -164,7 +166,7 @@ extern "C" int vault_im2col_sel(const float* pix, void* out_bf16, const int* sel
   const long long chunks = rows * (C * ps * ps / 8);
   const int blocks = (int)std::min<long long>((chunks + 255) / 256, 256 * 16);
   hipLaunchKernelGGL(im2col_sel_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pix,
-                     reinterpret_cast<bf16*>(out_bf16), sel, B, L, C, HP, WP, ps, chunks, split3);
+                     reinterpret_cast<h16*>(out_bf16), sel, B, L, C, HP, WP, ps, chunks, split3);
   return (int)hipGetLastError();
 }
 
@@ -190,7 +192,7 @@ extern "C" int vault_image_sel_bwd(const float* dx, float* dpos, float* dmtype1,
   if (!dx || !dpos || !dmtype1 || !dcls || !dbias || !dyp_bf16 || !sel || !hw || B <= 0 || L <= 0) return VAULT_EINVAL;
   const int bpb = 32;   // samples per block: fewer blocks hammer the shared dmtype1 / dbias / dcls addresses with atomics
   hipLaunchKernelGGL(image_sel_bwd_kernel, dim3(L + 1, (B + bpb - 1) / bpb), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), dx, dpos, dmtype1, dcls, dbias, reinterpret_cast<bf16*>(dyp_bf16),
+                     reinterpret_cast<hipStream_t>(stream), dx, dpos, dmtype1, dcls, dbias, reinterpret_cast<h16*>(dyp_bf16),
                      sel, hw, L, H, B, S, T, gw, G, bpb);
   return (int)hipGetLastError();
 }

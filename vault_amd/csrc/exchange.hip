@@ -55,25 +55,26 @@ __global__ __launch_bounds__(256) void rows_move_kernel(float* __restrict__ tabl
 }
 
 // out[i] = bf16( sum_{k < n_src} f32(src[k * chunk + i]) ), k ascending (the same order on every rank)
-__global__ __launch_bounds__(256) void sum_chunks_bf16_kernel(const bf16* __restrict__ src, int n_src, long long chunk8,
-                                                              bf16* __restrict__ out) {
+__global__ __launch_bounds__(256) void sum_chunks_bf16_kernel(const h16* __restrict__ src, int n_src, long long chunk8,
+                                                              h16* __restrict__ out) {
+  H16_SATURATE();
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < chunk8; i += (long long)gridDim.x * 256ll) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < n_src; ++k) {
-      const bf16x8 v = reinterpret_cast<const bf16x8*>(src)[(long long)k * chunk8 + i];
+      const h16x8 v = reinterpret_cast<const h16x8*>(src)[(long long)k * chunk8 + i];
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
     }
-    bf16x8 o;
+    h16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
-    reinterpret_cast<bf16x8*>(out)[i] = o;
+    for (int e = 0; e < 8; ++e) o[e] = (h16)acc[e];
+    reinterpret_cast<h16x8*>(out)[i] = o;
   }
 }
 
-__global__ __launch_bounds__(256) void widen_bf16_kernel(const bf16* __restrict__ x, float* __restrict__ y, long long n4) {
+__global__ __launch_bounds__(256) void widen_bf16_kernel(const h16* __restrict__ x, float* __restrict__ y, long long n4) {
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256ll) {
-    const bf16x4 v = reinterpret_cast<const bf16x4*>(x)[i];
+    const h16x4 v = reinterpret_cast<const h16x4*>(x)[i];
     reinterpret_cast<f32x4*>(y)[i] = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
   }
 }
@@ -108,13 +109,13 @@ extern "C" int vault_rows_scatter_f32(const float* src, const long long* idx, in
 extern "C" int vault_sum_chunks_bf16(const void* src_bf16, int n_src, long long chunk, void* out_bf16, void* stream) {
   if (!src_bf16 || !out_bf16 || n_src <= 0 || chunk <= 0 || (chunk & 7)) return VAULT_EINVAL;
   hipLaunchKernelGGL(sum_chunks_bf16_kernel, dim3(grid_for(chunk / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const bf16*>(src_bf16), n_src, chunk / 8, reinterpret_cast<bf16*>(out_bf16));
+                     reinterpret_cast<const h16*>(src_bf16), n_src, chunk / 8, reinterpret_cast<h16*>(out_bf16));
   return (int)hipGetLastError();
 }
 
 extern "C" int vault_widen_bf16(const void* x_bf16, float* y, long long n, void* stream) {
   if (!x_bf16 || !y || n <= 0 || (n & 3)) return VAULT_EINVAL;
   hipLaunchKernelGGL(widen_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const bf16*>(x_bf16), y, n / 4);
+                     reinterpret_cast<const h16*>(x_bf16), y, n / 4);
   return (int)hipGetLastError();
 }

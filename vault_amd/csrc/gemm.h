@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "common.h"
 
 enum GemmEpi {
   EPI_BF16 = 0,        // out_bf16 = acc (+ bias)
@@ -17,8 +18,8 @@ enum GemmEpi {
 };
 
 struct GemmParams {
-  const __bf16* A;
-  const __bf16* B;
+  const h16* A;
+  const h16* B;
   int M, N, K;      // output M x N, contraction K; M % BM == N % BN == K % 64 == 0 (buffers padded)
   int lda, ldb;     // leading dimensions in elements (see A_MODE / B_MODE in gemm.hip)
   int m_valid;      // rows >= m_valid are never stored
@@ -29,7 +30,7 @@ struct GemmParams {
   void* out2;
   const float* bias;
   const float* res;
-  const __bf16* aux;
+  const h16* aux;
   const float* addtab;
   int split3;       // bf16 epilogues: store [hi | lo | hi] (row stride ldo = 3N) for the split-bf16 precise path
   float* colsum;    // bf16 epilogues: += column sums of the stored values (bias gradient), or null

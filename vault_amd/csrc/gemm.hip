@@ -45,6 +45,7 @@ __device__ __forceinline__ void gemm_glds16_asm(const void* gptr, uint32_t lds) 
 // three tiles in flight divide that by three.
 template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, int EPI, int NS = 2>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p_in) {
+  H16_SATURATE();
   GemmParams p = p_in;
   int split_z = blockIdx.z;
   if constexpr (EPI == EPI_F32_ATOMIC) {
@@ -91,8 +92,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p_in
   const int nk = kt1 - kt0;
 
   // ---- per-lane staging sources
-  const bf16* a_src[NIA];
-  const bf16* b_src[NIB];
+  const h16* a_src[NIA];
+  const h16* b_src[NIB];
   if constexpr (A_MODE == 0) {
     const int r8 = lane >> 3, pos = lane & 7;
     const int c = pos ^ (((r8 >> 1) & 3) << 1);
@@ -210,11 +211,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p_in
     const char* Bs = As + A_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 af[TM], bfr[TN];
+      h16x8 af[TM], bfr[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         if constexpr (A_MODE == 0) {
-          af[i] = *LDS_PTR(const bf16x8, As + a_off[s] + i * 16 * 128);
+          af[i] = *LDS_PTR(const h16x8, As + a_off[s] + i * 16 * 128);
         } else {
           const int cb = (wm0 >> 4) + i;
           const char* base = As + a_off[0] + s * 32 * (BM * 2) + ((cb ^ a_off[1]) << 5);
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p_in
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if constexpr (B_MODE == 0) {
-          bfr[j] = *LDS_PTR(const bf16x8, Bs + b_off[s] + j * 16 * 128);
+          bfr[j] = *LDS_PTR(const h16x8, Bs + b_off[s] + j * 16 * 128);
         } else {
           const int cb = (wn0 >> 4) + j;
           const char* base = Bs + b_off[0] + s * 32 * (BN * 2) + ((cb ^ b_off[1]) << 5);
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p_in
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16(af[i], bfr[j], acc[i][j]);
     }
   }
 

@@ -71,6 +71,7 @@ __device__ __forceinline__ s16x4 tr16_asm(uint32_t lds_addr) {
 // last round's CUs busy)
 template <int A_MODE, int B_MODE, int EPI, int NTQ>
 __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
+  H16_SATURATE();
   constexpr int BNT = NTQ * 64;                     // block tile width
   constexpr int PB = (B_MODE == 0) ? NTQ : 4;       // global_load_lds pieces per wave per B half-tile
   constexpr int W32 = 3 * 4 + 2 * PB;               // pieces of the five youngest half-tiles: 3 A + 2 B
@@ -113,8 +114,8 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     // one or two K ranges only, so the A / B panels of a range are fetched into one or two L2s instead of all
     // eight (weight gradients, 36 tiles x 7 splits: L2 fill 970 -> ~460 MB per launch by this count)
     int lin = gemm_xcd_contiguous(nwork, w);
-    const __bf16* pA = p.A;
-    const __bf16* pB = p.B;
+    const h16* pA = p.A;
+    const h16* pB = p.B;
     if constexpr (EPI == EPI_F32_ATOMIC) {
       if (nbatch > 1) {
         const int per_problem = ntiles * p.splits;
@@ -210,8 +211,8 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   {                                                                                                      \
     if constexpr (A_MODE == 0) {                                                                         \
       const char* base_ = smem + (BUF) * BUFB + (H) * HT;                                                \
-      RA[U][0] = *LDS_PTR(const bf16x8, base_ + a_o0 + (U) * 2048);                                      \
-      RA[U][1] = *LDS_PTR(const bf16x8, base_ + a_o1 + (U) * 2048);                                      \
+      RA[U][0] = *LDS_PTR(const h16x8, base_ + a_o0 + (U) * 2048);                                      \
+      RA[U][1] = *LDS_PTR(const h16x8, base_ + a_o1 + (U) * 2048);                                      \
     } else {                                                                                             \
       LOAD_TR(RA[U], a_tr[U], BUF, H)                                                                    \
     }                                                                                                    \
@@ -220,8 +221,8 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   if constexpr ((U) < NTQ) {                                                                             \
     if constexpr (B_MODE == 0) {                                                                         \
       const char* base_ = smem + (BUF) * BUFB + 2 * HT + (H) * HT;                                       \
-      RB[U][0] = *LDS_PTR(const bf16x8, base_ + b_o0 + (U) * 2048);                                      \
-      RB[U][1] = *LDS_PTR(const bf16x8, base_ + b_o1 + (U) * 2048);                                      \
+      RB[U][0] = *LDS_PTR(const h16x8, base_ + b_o0 + (U) * 2048);                                      \
+      RB[U][1] = *LDS_PTR(const h16x8, base_ + b_o1 + (U) * 2048);                                      \
     } else {                                                                                             \
       LOAD_TR(RB[U], b_tr[U], BUF, H)                                                                    \
     }                                                                                                    \
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   // register file ("+a"): hipcc otherwise allocates out-of-place destinations for this many live
   // accumulators and spills.  `volatile` keeps every cluster inside its phase.
 
-  bf16x8 RA0[4][2], RA1[4][2], RB0[4][2], RB1[4][2];
+  h16x8 RA0[4][2], RA1[4][2], RB0[4][2], RB1[4][2];
 
   // the first two K tiles of the current work item in ring order, one half-tile per call (h8 = 0..7)
   auto stage_first = [&](int h8) {
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   {                                                                                                      \
     if constexpr (A_MODE == 0) {                                                                         \
       const char* base_ = smem + (BUF) * BUFB + (H) * HT;                                                \
-      RA[U][KS] = *LDS_PTR(const bf16x8, base_ + ((KS) ? a_o1 : a_o0) + (U) * 2048);                     \
+      RA[U][KS] = *LDS_PTR(const h16x8, base_ + ((KS) ? a_o1 : a_o0) + (U) * 2048);                     \
     } else {                                                                                             \
       LOAD_TR_H(RA[U], a_tr[U], BUF, H, KS)                                                              \
     }                                                                                                    \
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   if constexpr ((U) < NTQ) {                                                                             \
     if constexpr (B_MODE == 0) {                                                                         \
       const char* base_ = smem + (BUF) * BUFB + 2 * HT + (H) * HT;                                       \
-      RB[U][KS] = *LDS_PTR(const bf16x8, base_ + ((KS) ? b_o1 : b_o0) + (U) * 2048);                     \
+      RB[U][KS] = *LDS_PTR(const h16x8, base_ + ((KS) ? b_o1 : b_o0) + (U) * 2048);                     \
     } else {                                                                                             \
       LOAD_TR_H(RB[U], b_tr[U], BUF, H, KS)                                                              \
     }                                                                                                    \
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   // memory instruction (+ its address arithmetic) between two MFMAs
 #define MMA1(KS, MT, NT, MB, NB, RA, RB)                                                   \
   if constexpr ((NT) < NTQ)                                                                \
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                 \
+    asm volatile(MFMA16_ASM " %0, %1, %2, %0"                                 \
                  : "+a"(acc[(MB) + (MT)][(NB) + (NT)])                                     \
                  : "v"(RA[MT][KS]), "v"(RB[NT][KS]));
 #define GA(KS, MT, MB, NB, RA, RB, INS_A, INS_B)                                           \

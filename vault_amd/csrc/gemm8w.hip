@@ -87,6 +87,7 @@ __device__ __forceinline__ float w8_row16_sum(float t) {
 
 template <int EPI, int NTW>
 __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
+  H16_SATURATE();
   constexpr bool F32OUT = (EPI == EPI_F32_RES);
   constexpr int BN = 64 * NTW;                       // block tile width
   constexpr int B_BYTES = BN * 128;
@@ -176,17 +177,17 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
   const uint32_t b_rd1 = (uint32_t)(W8_A_BYTES + (wc * 16 * NTW + l15) * 128 + (((4 + g) ^ fx) << 4));
 
   f32x4 acc[8][NTW];
-  bf16x8 FA0[8], FA1[8], FB0[NTW], FB1[NTW];
+  h16x8 FA0[8], FA1[8], FB0[NTW], FB1[NTW];
   // MFMAs through inline asm with the accumulator tied in place in the AGPR half of the register file ("+a").
   // Operands swapped: A-operand = weight fragment (rows = n), B-operand = activation fragment (columns = m).
 #define W8_MMA(MT, NT, FA, FB) \
   if constexpr ((NT) < NTW) \
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[MT][NT]) : "v"(FB[NT]), "v"(FA[MT]))
+    asm volatile(MFMA16_ASM " %0, %1, %2, %0" : "+a"(acc[MT][NT]) : "v"(FB[NT]), "v"(FA[MT]))
 #define W8_ROW(MT, FA, FB) W8_MMA(MT, 0, FA, FB); W8_MMA(MT, 1, FA, FB); W8_MMA(MT, 2, FA, FB); W8_MMA(MT, 3, FA, FB)
   // first k-step of a work item: C = 0 instead of a pass that zeroes 32 NTW registers
 #define W8_MMA0(MT, NT, FA, FB) \
   if constexpr ((NT) < NTW) \
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[MT][NT]) : "v"(FB[NT]), "v"(FA[MT]))
+    asm volatile(MFMA16_ASM " %0, %1, %2, 0" : "=a"(acc[MT][NT]) : "v"(FB[NT]), "v"(FA[MT]))
 #define W8_ROW0(MT, FA, FB) W8_MMA0(MT, 0, FA, FB); W8_MMA0(MT, 1, FA, FB); W8_MMA0(MT, 2, FA, FB); W8_MMA0(MT, 3, FA, FB)
 
   f32x4 bq[4];     // bias of the lane's columns (loaded in an item's last K tile, used by its epilogue)
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
       if constexpr (FIRST) { W8_ROW0(mt, FA0, FB0); } else { W8_ROW(mt, FA0, FB0); }
-      FA1[mt] = *LDS_PTR(const bf16x8, st + a_rd1 + mt * 2048);
+      FA1[mt] = *LDS_PTR(const h16x8, st + a_rd1 + mt * 2048);
     }
     // ---- mid: tile t + 1 landed (this wave's share: its pieces are the only staging loads in flight), every fragment
     //      of tile t is in registers; barrier: stage (t + 1) & 1 is readable, stage t & 1 is free
@@ -242,8 +243,8 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
     }
     // ---- k-step 1, with tile t + 2's staging pieces (into the stage just freed) and the first fragments of
     //      tile t + 1 (FA0, FB0: their registers are free) spread between the MFMAs
-#define W8_NEXT_A(MT) if constexpr (!LAST) FA0[MT] = *LDS_PTR(const bf16x8, sn + a_rd0 + (MT) * 2048)
-#define W8_NEXT_B(NT) if constexpr (!LAST && (NT) < NTW) FB0[NT] = *LDS_PTR(const bf16x8, sn + b_rd0 + (NT) * 2048)
+#define W8_NEXT_A(MT) if constexpr (!LAST) FA0[MT] = *LDS_PTR(const h16x8, sn + a_rd0 + (MT) * 2048)
+#define W8_NEXT_B(NT) if constexpr (!LAST && (NT) < NTW) FB0[NT] = *LDS_PTR(const h16x8, sn + b_rd0 + (NT) * 2048)
     W8_ROW(0, FA1, FB1); pieceA(ta, stage, 0); W8_NEXT_B(0); W8_NEXT_B(1);
     W8_ROW(1, FA1, FB1); pieceA(ta, stage, 1); W8_NEXT_B(2); W8_NEXT_B(3);
     W8_ROW(2, FA1, FB1); pieceA(ta, stage, 2); W8_NEXT_A(0); W8_NEXT_A(1);
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
 #undef W8_NEXT_B
     if constexpr (!LAST) {   // (FB1 is free once the last MFMA of the k-step has been issued)
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) FB1[nt] = *LDS_PTR(const bf16x8, sn + b_rd1 + nt * 2048);
+      for (int nt = 0; nt < NTW; ++nt) FB1[nt] = *LDS_PTR(const h16x8, sn + b_rd1 + nt * 2048);
     }
     stage ^= 1;
     ++kt;
@@ -270,11 +271,11 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
       const char* st = smem + stage * STAGE;
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
-        FB0[nt] = *LDS_PTR(const bf16x8, st + b_rd0 + nt * 2048);
-        FB1[nt] = *LDS_PTR(const bf16x8, st + b_rd1 + nt * 2048);
+        FB0[nt] = *LDS_PTR(const h16x8, st + b_rd0 + nt * 2048);
+        FB1[nt] = *LDS_PTR(const h16x8, st + b_rd1 + nt * 2048);
       }
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt) FA0[mt] = *LDS_PTR(const bf16x8, st + a_rd0 + mt * 2048);
+      for (int mt = 0; mt < 8; ++mt) FA0[mt] = *LDS_PTR(const h16x8, st + a_rd0 + mt * 2048);
     }
     kt = 0;
     ktile(std::true_type{}, std::false_type{});
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
         // prefetch queue of the gelu' operand: slot u % PD (PD even: odd slots always hold odd units - with 192-wide
         // tiles those are the 8-byte tails, kept in their own registers: an asm load's destination must be consumed
         // as it is, behind the wait - a copy into a wider register would read it before the data arrives)
-        bf16x8 axq[HAS_AUX ? PD : 1];
+        h16x8 axq[HAS_AUX ? PD : 1];
         u32x2 axh[(HAS_AUX && NTW == 3) ? PD : 1];
         // (loads are never predicated: a guarded asm load merges its destination with the old value - a register copy
         //  hipcc would place before our wait; rows that are not stored read a valid row instead)
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
           const int mt = u >> 1, j = u & 1;
           const int m = mw + mt * 16 + el15;
           const int nv = (j == 0) ? 8 : NV1;
-          bf16x8 ax;
+          h16x8 ax;
           if constexpr (HAS_AUX && U8) {
             if (j == 0) {
               // behind load mt: the loads mt + 1 .. mt + PDM - 1 and the stores of the units since it was issued
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
             if ((u & 1) && NTW == 3) {
               u32x2 h = axh[u % PD];
               asm volatile("" : "+v"(h));
-              ax = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], 0u, 0u});
+              ax = __builtin_bit_cast(h16x8, u32x4{h[0], h[1], 0u, 0u});
             } else {
               ax = axq[u % PD];
               asm volatile("" : "+v"(ax));
@@ -444,8 +445,8 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
               if (j == 0) { q8a = d0; q8b = d1; }
               else w2 = u32x4{q8a, q8b, d0, d1};
             } else {
-              w2 = u32x4{pack_bf16x2(gp[0], gp[1]), pack_bf16x2(gp[2], gp[3]), pack_bf16x2(gp[4], gp[5]),
-                         pack_bf16x2(gp[6], gp[7])};
+              w2 = u32x4{pack_h16x2(gp[0], gp[1]), pack_h16x2(gp[2], gp[3]), pack_h16x2(gp[4], gp[5]),
+                         pack_h16x2(gp[6], gp[7])};
               gp4[0] = gp[0]; gp4[1] = gp[1]; gp4[2] = gp[2]; gp4[3] = gp[3];
             }
           } else if constexpr (EPI == EPI_BF16_GELU_INF) {
@@ -476,8 +477,8 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
                 if (e < nv) csum[8 * j + e] += v[e];
             }
           }
-          const u32x4 wv = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                            pack_bf16x2(v[6], v[7])};
+          const u32x4 wv = {pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]),
+                            pack_h16x2(v[6], v[7])};
           if constexpr (WL) {
             if (j == 0) {
               wv0 = wv;
@@ -515,10 +516,10 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
               asm volatile("global_store_dwordx4 %0, %1, %2" W8_STORE_MOD "\n\ts_nop 1" ::"v"(o), "v"(wv), "s"(o1_) : "memory");
             } else {
               if constexpr (EPI == EPI_BF16_GELU) {
-                const u32x2 h2 = {pack_bf16x2(gp4[0], gp4[1]), pack_bf16x2(gp4[2], gp4[3])};
+                const u32x2 h2 = {pack_h16x2(gp4[0], gp4[1]), pack_h16x2(gp4[2], gp4[3])};
                 asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(o), "v"(h2), "s"(o2_) : "memory");
               }
-              const u32x2 h1 = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+              const u32x2 h1 = {pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3])};
               asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(o), "v"(h1), "s"(o1_) : "memory");
             }
           }

@@ -97,7 +97,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
   // ---- per-row operands, queued PD passes ahead
   struct Pre {
     f32x4 f[PRE_F32 ? EL / 4 : 1];
-    bf16x8 h[PRE_B16 ? EL / 8 : 1];
+    h16x8 h[PRE_B16 ? EL / 8 : 1];
   };
   Pre pq[(PRE_F32 || PRE_B16) ? PD : 1];
   // ASYNC: the loads are issued through asm (invisible to hipcc's wait insertion, which would answer the
@@ -129,13 +129,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
           d.f[k] = *reinterpret_cast<const f32x4*>(src + ecol(4 * k));
       }
     } else if constexpr (PRE_B16) {
-      const bf16* src = p.aux + (size_t)m * p.ldo + nc;
+      const h16* src = p.aux + (size_t)m * p.ldo + nc;
 #pragma unroll
       for (int k = 0; k < EL / 8; ++k) {
         if constexpr (ASYNC)
           asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(d.h[k]) : "v"(src), "i"(ecol(8 * k) * 2));
         else
-          d.h[k] = *reinterpret_cast<const bf16x8*>(src + ecol(8 * k));
+          d.h[k] = *reinterpret_cast<const h16x8*>(src + ecol(8 * k));
       }
     }
   };
@@ -284,7 +284,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
           // element instead of re-evaluating erf/exp (both epilogues are VALU-bound otherwise).  The ring
           // kernel instantiates the two forms separately (its launcher looks at out2): half the epilogue code.
           if (EPI == EPI_BF16_GELU && (ASYNC || p.out2 != nullptr)) {
-            bf16* o2 = reinterpret_cast<bf16*>(p.out2) + o;
+            h16* o2 = reinterpret_cast<h16*>(p.out2) + o;
 #pragma unroll
             for (int c = 0; c < EL; c += 8) {
               float gp[8];
@@ -295,8 +295,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
                 gp[e] = d2[0]; gp[e + 1] = d2[1];
                 v[c + e] = y2[0]; v[c + e + 1] = y2[1];
               }
-              u32x4 w = {pack_bf16x2(gp[0], gp[1]), pack_bf16x2(gp[2], gp[3]), pack_bf16x2(gp[4], gp[5]),
-                         pack_bf16x2(gp[6], gp[7])};
+              u32x4 w = {pack_h16x2(gp[0], gp[1]), pack_h16x2(gp[2], gp[3]), pack_h16x2(gp[4], gp[5]),
+                         pack_h16x2(gp[6], gp[7])};
               *reinterpret_cast<u32x4*>(o2 + ecol(c)) = w;
             }
           } else {
@@ -313,17 +313,17 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
         }
 #pragma unroll
         for (int e = 0; e < EL; ++e) csum[q * EL + e] += v[e];
-        bf16* out = reinterpret_cast<bf16*>(p.out) + o;
+        h16* out = reinterpret_cast<h16*>(p.out) + o;
         if (p.split3) {   // precise path: this output is the next GEMM's A operand -> [hi | lo | hi], ldo = 3N
 #pragma unroll
           for (int c = 0; c < EL; c += 8) {
-            bf16 hi[8], lo[8];
+            h16 hi[8], lo[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) split_bf16(v[c + e], hi[e], lo[e]);
-            u32x4 wh = {pack_bf16x2((float)hi[0], (float)hi[1]), pack_bf16x2((float)hi[2], (float)hi[3]),
-                        pack_bf16x2((float)hi[4], (float)hi[5]), pack_bf16x2((float)hi[6], (float)hi[7])};
-            u32x4 wl = {pack_bf16x2((float)lo[0], (float)lo[1]), pack_bf16x2((float)lo[2], (float)lo[3]),
-                        pack_bf16x2((float)lo[4], (float)lo[5]), pack_bf16x2((float)lo[6], (float)lo[7])};
+            u32x4 wh = {pack_h16x2((float)hi[0], (float)hi[1]), pack_h16x2((float)hi[2], (float)hi[3]),
+                        pack_h16x2((float)hi[4], (float)hi[5]), pack_h16x2((float)hi[6], (float)hi[7])};
+            u32x4 wl = {pack_h16x2((float)lo[0], (float)lo[1]), pack_h16x2((float)lo[2], (float)lo[3]),
+                        pack_h16x2((float)lo[4], (float)lo[5]), pack_h16x2((float)lo[6], (float)lo[7])};
             *reinterpret_cast<u32x4*>(out + ecol(c)) = wh;
             *reinterpret_cast<u32x4*>(out + p.N + ecol(c)) = wl;
             *reinterpret_cast<u32x4*>(out + 2 * p.N + ecol(c)) = wh;
@@ -332,8 +332,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
         }
 #pragma unroll
         for (int c = 0; c < EL; c += 8) {
-          u32x4 w = {pack_bf16x2(v[c], v[c + 1]), pack_bf16x2(v[c + 2], v[c + 3]),
-                     pack_bf16x2(v[c + 4], v[c + 5]), pack_bf16x2(v[c + 6], v[c + 7])};
+          u32x4 w = {pack_h16x2(v[c], v[c + 1]), pack_h16x2(v[c + 2], v[c + 3]),
+                     pack_h16x2(v[c + 4], v[c + 5]), pack_h16x2(v[c + 6], v[c + 7])};
           *reinterpret_cast<u32x4*>(out + ecol(c)) = w;
         }
       }

@@ -32,6 +32,7 @@ __device__ __forceinline__ int mx8_key(int row) { return ((row >> 1) & 3) << 1; 
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_mx8_kernel(const GemmParams p, const uint8_t* __restrict__ a_scale,
                                                                const uint8_t* __restrict__ b_scale, int lds_a, int lds_b) {
+  H16_SATURATE();
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM / 16;
   constexpr int TN = BN / WN / 16;
@@ -164,13 +165,13 @@ __device__ __forceinline__ uint32_t cvt4_e4m3(float a, float b, float c, float d
   return (uint32_t)w;
 }
 
-__global__ __launch_bounds__(256) void quant_mx8_kernel(const bf16* __restrict__ src, int64_t rows, int K, int ld,
+__global__ __launch_bounds__(256) void quant_mx8_kernel(const h16* __restrict__ src, int64_t rows, int K, int ld,
                                                         uint8_t* __restrict__ q, uint8_t* __restrict__ scale) {
   const int64_t nchunk = rows * (K / 8);
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nchunk; idx += (int64_t)gridDim.x * 256) {
     const int64_t row = idx / (K / 8);
     const int c8 = (int)(idx - row * (K / 8));
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + row * ld + c8 * 8);
+    const h16x8 v = *reinterpret_cast<const h16x8*>(src + row * ld + c8 * 8);
     float x[8];
     float amax = 0.f;
 #pragma unroll
@@ -204,7 +205,7 @@ extern "C" int vault_quant_mxfp8(const void* src_bf16, long long rows, int K, in
   if (rows <= 0 || K <= 0 || (K & 31) || (ld_src & 7) || ld_src < K) return VAULT_EINVAL;
   const long long nchunk = rows * (K / 8);
   const int blocks = (int)std::min<long long>((nchunk + 255) / 256, 256 * 16);
-  hipLaunchKernelGGL(quant_mx8_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const bf16*>(src_bf16),
+  hipLaunchKernelGGL(quant_mx8_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const h16*>(src_bf16),
                      (int64_t)rows, K, ld_src, reinterpret_cast<uint8_t*>(dst_q), reinterpret_cast<uint8_t*>(dst_scale));
   return (int)hipGetLastError();
 }

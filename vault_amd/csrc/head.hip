@@ -64,9 +64,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ dlogits_in,
                                                        const long long* __restrict__ labels, const float* __restrict__ Wc,
                                                        float* __restrict__ dWc, float* __restrict__ dbc,
-                                                       bf16* __restrict__ dpre, int B, int H, int C, float gscale,
+                                                       h16* __restrict__ dpre, int B, int H, int C, float gscale,
                                                        uint32_t drop_thresh, uint32_t drop_seed, uint32_t drop_stream,
                                                        float drop_scale, const float* __restrict__ targets) {
+  H16_SATURATE();
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         dz += dl[c] * Wc[(size_t)c * H + n];
         atomicAdd(dWc + (size_t)c * H + n, dl[c] * z);
       }
-    dpre[(size_t)b * H + n] = (bf16)(dz * keep * (1.f - t * t));
+    dpre[(size_t)b * H + n] = (h16)(dz * keep * (1.f - t * t));
   }
   if (lane == 0)
     for (int c = 0; c < C; ++c) atomicAdd(dbc + c, dl[c]);
@@ -116,16 +117,18 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 
 // dpre_bf16 = bf16(dpooled * (1 - pooled^2))   (VaultModel path: gradient arrives at pooler_output)
 __global__ void tanh_bwd_kernel(const float* __restrict__ pooled, const float* __restrict__ dpooled,
-                                bf16* __restrict__ dpre, long long n) {
+                                h16* __restrict__ dpre, long long n) {
+  H16_SATURATE();
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256ll) {
     const float t = pooled[i];
-    dpre[i] = (bf16)(dpooled[i] * (1.f - t * t));
+    dpre[i] = (h16)(dpooled[i] * (1.f - t * t));
   }
 }
 
 // y_bf16 = gelu(x)   /   dx = dy * gelu'(x)      (MLP task heads: Linear - LayerNorm - GELU - Linear on the pooled output)
-__global__ void gelu_fwd_kernel(const float* __restrict__ x, bf16* __restrict__ y, long long n) {
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256ll) y[i] = (bf16)gelu_f(x[i]);
+__global__ void gelu_fwd_kernel(const float* __restrict__ x, h16* __restrict__ y, long long n) {
+  H16_SATURATE();
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256ll) y[i] = (h16)gelu_f(x[i]);
 }
 __global__ void gelu_fwd_f32_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256ll) y[i] = gelu_f(x[i]);
@@ -142,7 +145,7 @@ extern "C" int vault_gelu_fwd(const float* x, void* y_bf16, long long n, void* s
   if (!x || !y_bf16 || n <= 0) return VAULT_EINVAL;
   const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
   hipLaunchKernelGGL(gelu_fwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                     reinterpret_cast<bf16*>(y_bf16), n);
+                     reinterpret_cast<h16*>(y_bf16), n);
   return (int)hipGetLastError();
 }
 
@@ -179,7 +182,7 @@ extern "C" int vault_head_bwd(const vault_head_args* a, void* stream) {
   if (a->dlogits == nullptr && a->loss_kind == 0 && (a->labels == nullptr || a->logits == nullptr)) return VAULT_EINVAL;
   hipLaunchKernelGGL(head_bwd_kernel, dim3((a->B + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      a->pooled, a->logits, a->dlogits, reinterpret_cast<const long long*>(a->labels), a->Wc, a->dWc,
-                     a->dbc, reinterpret_cast<bf16*>(a->dpre_bf16), a->B, a->H, a->C, a->grad_scale, a->drop_thresh,
+                     a->dbc, reinterpret_cast<h16*>(a->dpre_bf16), a->B, a->H, a->C, a->grad_scale, a->drop_thresh,
                      a->drop_seed, a->drop_stream, a->drop_scale, a->loss_kind == 1 ? a->targets : nullptr);
   return (int)hipGetLastError();
 }
@@ -188,6 +191,6 @@ extern "C" int vault_tanh_bwd(const float* pooled, const float* dpooled, void* d
   if (!pooled || !dpooled || !dpre_bf16 || n <= 0) return VAULT_EINVAL;
   const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
   hipLaunchKernelGGL(tanh_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pooled, dpooled,
-                     reinterpret_cast<bf16*>(dpre_bf16), n);
+                     reinterpret_cast<h16*>(dpre_bf16), n);
   return (int)hipGetLastError();
 }

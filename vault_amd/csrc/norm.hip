@@ -23,12 +23,13 @@ template <int VPT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, RowMap xmap,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, int rows, int H,
-                                                     bf16* __restrict__ y_bf16, float* __restrict__ y_f32, RowMap ymap,
+                                                     h16* __restrict__ y_bf16, float* __restrict__ y_f32, RowMap ymap,
                                                      const float* __restrict__ post_add,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
                                                      uint32_t drop_thresh, uint32_t drop_seed, uint32_t drop_stream,
-                                                     float drop_scale, bf16* __restrict__ y_split3,
+                                                     float drop_scale, h16* __restrict__ y_split3,
                                                      uint8_t* __restrict__ y_q, uint8_t* __restrict__ y_scale) {
+  H16_SATURATE();
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
     if (y_f32) *reinterpret_cast<f32x4*>(y_f32 + orow * H + c) = o;
     if (y_bf16) {
-      uint2 w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+      uint2 w = {pack_h16x2(o[0], o[1]), pack_h16x2(o[2], o[3])};
       *reinterpret_cast<uint2*>(y_bf16 + orow * H + c) = w;
     }
     if (y_q) {
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       float b[4];
       float amax = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { b[e] = (float)(bf16)o[e]; amax = fmaxf(amax, fabsf(b[e])); }
+      for (int e = 0; e < 4; ++e) { b[e] = (float)(h16)o[e]; amax = fmaxf(amax, fabsf(b[e])); }
       amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
       amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
       amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
@@ -104,12 +105,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       if ((lane & 7) == 0) y_scale[orow * (H / 32) + (c >> 5)] = (uint8_t)e8;
     }
     if (y_split3) {   // [hi | lo | hi] A-operand layout of the split-bf16 (precise) GEMM path
-      bf16 hi[4], lo[4];
+      h16 hi[4], lo[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) split_bf16(o[e], hi[e], lo[e]);
-      const uint2 wh = {pack_bf16x2((float)hi[0], (float)hi[1]), pack_bf16x2((float)hi[2], (float)hi[3])};
-      const uint2 wl = {pack_bf16x2((float)lo[0], (float)lo[1]), pack_bf16x2((float)lo[2], (float)lo[3])};
-      bf16* d = y_split3 + orow * 3 * H + c;
+      const uint2 wh = {pack_h16x2((float)hi[0], (float)hi[1]), pack_h16x2((float)hi[2], (float)hi[3])};
+      const uint2 wl = {pack_h16x2((float)lo[0], (float)lo[1]), pack_h16x2((float)lo[2], (float)lo[3])};
+      h16* d = y_split3 + orow * 3 * H + c;
       *reinterpret_cast<uint2*>(d) = wh;
       *reinterpret_cast<uint2*>(d + H) = wl;
       *reinterpret_cast<uint2*>(d + 2 * H) = wh;
@@ -121,15 +122,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // null).  Outputs dx_f32 = dx + dres (optional) and a bf16 copy (optionally dropout-masked for the
 // branch that sits behind a dropout in forward).  dgamma / dbeta: per-block partials + float atomics.
 template <int VPT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void ln_bwd_kernel(const bf16* __restrict__ dy_bf16, const float* __restrict__ dy_f32,
+__global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void ln_bwd_kernel(const h16* __restrict__ dy_bf16, const float* __restrict__ dy_f32,
                                                      RowMap dymap, const float* __restrict__ x, RowMap xmap,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, int rows, int H,
                                                      const float* __restrict__ dres, float* __restrict__ dx_f32,
-                                                     bf16* __restrict__ dx_bf16, RowMap dxmap, float* __restrict__ dgamma,
+                                                     h16* __restrict__ dx_bf16, RowMap dxmap, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, float* __restrict__ dbias,
                                                      int rows_per_block, uint32_t drop_thresh, uint32_t drop_seed, uint32_t drop_stream,
-                                                     float drop_scale, int drop_on_dy, const bf16* __restrict__ dres_bf16) {
+                                                     float drop_scale, int drop_on_dy, const h16* __restrict__ dres_bf16) {
+  H16_SATURATE();
   constexpr int NB = WAVES >= 8 ? 8 : 4;      // waves that fold into the scratch per round
   constexpr int HH = VPT * 256;               // = H
   extern __shared__ __attribute__((aligned(16))) float red[];   // [NB][3][HH]
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void ln_bwd_kernel(const bf
       if (dy_f32) d = *reinterpret_cast<const f32x4*>(dy_f32 + dr + c);
       if (dy_bf16) {
         const uint2 w = *reinterpret_cast<const uint2*>(dy_bf16 + dr + c);
-        const float2 a = unpack_bf16x2(w.x), b = unpack_bf16x2(w.y);
+        const float2 a = unpack_h16x2(w.x), b = unpack_h16x2(w.y);
         d[0] += a.x; d[1] += a.y; d[2] += b.x; d[3] += b.y;
       }
       if (drop_on_dy && drop_thresh != 0u) {   // y = dropout(LN(x)): mask the incoming gradient
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void ln_bwd_kernel(const bf
       }
       if (dres_bf16) {   // residual-gradient stream kept in bf16 (the same tensor is the next Linear's dY operand)
         const uint2 w = *reinterpret_cast<const uint2*>(dres_bf16 + orow + c);
-        const float2 a = unpack_bf16x2(w.x), b = unpack_bf16x2(w.y);
+        const float2 a = unpack_h16x2(w.x), b = unpack_h16x2(w.y);
         o[0] += a.x; o[1] += a.y; o[2] += b.x; o[3] += b.y;
       }
       if (dx_f32) *reinterpret_cast<f32x4*>(dx_f32 + orow + c) = o;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void ln_bwd_kernel(const bf
           for (int e = 0; e < 4; ++e)
             o[e] = dropout_keep(drop_seed, drop_stream, (uint32_t)(orow + c + e), drop_thresh) ? o[e] * drop_scale : 0.f;
         }
-        uint2 w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        uint2 w = {pack_h16x2(o[0], o[1]), pack_h16x2(o[2], o[3])};
         *reinterpret_cast<uint2*>(dx_bf16 + orow + c) = w;
 #pragma unroll
         for (int e = 0; e < 4; ++e) ac[j][e] += o[e];   // column sums of the bf16 branch (a Linear's bias gradient)
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void ln_bwd_kernel(const bf
 // out[n] += sum over rows < rows of in[row][n]  (bias gradients); N % 256 == 0.  16-wave blocks, 256 row blocks: the float
 // atomics of all row blocks land on the same N addresses (thousands of adds per address serialise in the memory-side
 // atomic units: 3072 four-wave blocks took 30 us for 73 MB, the adds alone ~25 of them), so few, wide blocks
-__global__ __launch_bounds__(1024) void colsum_kernel(const bf16* __restrict__ in, int ld, int rows, int rows_per_block,
+__global__ __launch_bounds__(1024) void colsum_kernel(const h16* __restrict__ in, int ld, int rows, int rows_per_block,
                                                       float* __restrict__ out, long long batch_in, long long batch_out) {
   __shared__ float red[16][256];
   in += (size_t)blockIdx.z * batch_in;       // batched form: matrix z of a stack, sums into vector z (uniform strides)
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const bf16* __restrict__ i
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   for (int r = r0 + wave; r < r1; r += 16) {
     const uint2 w = *reinterpret_cast<const uint2*>(in + (size_t)r * ld + c0);
-    const float2 x = unpack_bf16x2(w.x), y = unpack_bf16x2(w.y);
+    const float2 x = unpack_h16x2(w.x), y = unpack_h16x2(w.y);
     a0 += x.x; a1 += x.y; a2 += y.x; a3 += y.y;
   }
   red[wave][lane * 4] = a0; red[wave][lane * 4 + 1] = a1; red[wave][lane * 4 + 2] = a2; red[wave][lane * 4 + 3] = a3;
@@ -281,8 +283,8 @@ extern "C" int vault_layernorm_fwd(const vault_ln_fwd_args* a, void* stream) {
   dim3 grid((a->rows + 3) / 4), block(256);
 #define LN_FWD(V)                                                                                          \
   hipLaunchKernelGGL(ln_fwd_kernel<V>, grid, block, 0, st, a->x, xm, a->gamma, a->beta, a->eps, a->rows,   \
-                     a->H, reinterpret_cast<bf16*>(a->y_bf16), a->y_f32, ym, a->post_add, a->mean, a->rstd, \
-                     a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale, reinterpret_cast<bf16*>(a->y_split3), \
+                     a->H, reinterpret_cast<h16*>(a->y_bf16), a->y_f32, ym, a->post_add, a->mean, a->rstd, \
+                     a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale, reinterpret_cast<h16*>(a->y_split3), \
                      reinterpret_cast<uint8_t*>(a->y_q), reinterpret_cast<uint8_t*>(a->y_scale))
   switch (a->H / 256) {
     case 1: LN_FWD(1); break;
@@ -324,10 +326,10 @@ extern "C" int vault_layernorm_bwd(const vault_ln_bwd_args* a, void* stream) {
     }                                                                                                               \
     lds_bytes = LDS;                                                                                                \
   }                                                                                                                 \
-  hipLaunchKernelGGL((ln_bwd_kernel<V, W>), grid, block, lds_bytes, st, reinterpret_cast<const bf16*>(a->dy_bf16), a->dy_f32, \
+  hipLaunchKernelGGL((ln_bwd_kernel<V, W>), grid, block, lds_bytes, st, reinterpret_cast<const h16*>(a->dy_bf16), a->dy_f32, \
                      dym, a->x, xm, a->mean, a->rstd, a->gamma, a->rows, a->H, a->dres, a->dx_f32,               \
-                     reinterpret_cast<bf16*>(a->dx_bf16), dxm, a->dgamma, a->dbeta, a->dbias, rpb, a->drop_thresh,          \
-                     a->drop_seed, a->drop_stream, a->drop_scale, a->drop_on_dy, reinterpret_cast<const bf16*>(a->dres_bf16)); \
+                     reinterpret_cast<h16*>(a->dx_bf16), dxm, a->dgamma, a->dbeta, a->dbias, rpb, a->drop_thresh,          \
+                     a->drop_seed, a->drop_stream, a->drop_scale, a->drop_on_dy, reinterpret_cast<const h16*>(a->dres_bf16)); \
   }
   switch (a->H / 256) {
     case 1: LN_BWD(1); break;
@@ -348,7 +350,7 @@ extern "C" int vault_colsum(const void* in_bf16, int ld, int rows, int N, float*
   rpb = ((rpb + 15) / 16) * 16;
   dim3 grid(N / 256, (rows + rpb - 1) / rpb);
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const bf16*>(in_bf16), ld, rows, rpb, out, 0ll, 0ll);
+                     reinterpret_cast<const h16*>(in_bf16), ld, rows, rpb, out, 0ll, 0ll);
   return (int)hipGetLastError();
 }
 
@@ -363,6 +365,6 @@ extern "C" int vault_colsum_batched(const void* in_bf16, int ld, int rows, int N
   rpb = ((rpb + 15) / 16) * 16;
   dim3 grid(N / 256, (rows + rpb - 1) / rpb, batch);
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const bf16*>(in_bf16), ld, rows, rpb, out, batch_in, batch_out);
+                     reinterpret_cast<const h16*>(in_bf16), ld, rows, rpb, out, batch_in, batch_out);
   return (int)hipGetLastError();
 }

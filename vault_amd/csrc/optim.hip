@@ -9,9 +9,10 @@
 namespace {
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, bf16* __restrict__ pb, long long n4,
+                                                    float* __restrict__ v, h16* __restrict__ pb, long long n4,
                                                     float step_size, float lr_wd, float b1, float b2, float eps,
                                                     float gscale, int zero_grad) {
+  H16_SATURATE();
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256ll) {
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
     f32x4 gv = reinterpret_cast<f32x4*>(g)[i];
@@ -30,34 +31,36 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     reinterpret_cast<f32x4*>(v)[i] = vv;
     if (zero_grad) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (pb) {
-      uint2 w = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+      uint2 w = {pack_h16x2(pv[0], pv[1]), pack_h16x2(pv[2], pv[3])};
       reinterpret_cast<uint2*>(pb)[i] = w;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, long long n4) {
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, h16* __restrict__ y, long long n4) {
+  H16_SATURATE();
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256ll) {
     const f32x4 a = reinterpret_cast<const f32x4*>(x)[i];
-    uint2 w = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
+    uint2 w = {pack_h16x2(a[0], a[1]), pack_h16x2(a[2], a[3])};
     reinterpret_cast<uint2*>(y)[i] = w;
   }
 }
 
 // out[r][3K]: layout 0 (activation/A operand) = [hi | lo | hi], layout 1 (weight/B operand) = [hi | hi | lo]
-__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, bf16* __restrict__ out, long long rows,
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, h16* __restrict__ out, long long rows,
                                                      int K, int layout) {
+  H16_SATURATE();
   const long long total = rows * (long long)(K / 4);
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256ll) {
     const long long r = i / (K / 4);
     const int c = (int)(i - r * (K / 4)) * 4;
     const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * K + c);
-    bf16 hi[4], lo[4];
+    h16 hi[4], lo[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) split_bf16(a[e], hi[e], lo[e]);
-    bf16* o = out + r * 3 * K + c;
-    const uint2 wh = {pack_bf16x2((float)hi[0], (float)hi[1]), pack_bf16x2((float)hi[2], (float)hi[3])};
-    const uint2 wl = {pack_bf16x2((float)lo[0], (float)lo[1]), pack_bf16x2((float)lo[2], (float)lo[3])};
+    h16* o = out + r * 3 * K + c;
+    const uint2 wh = {pack_h16x2((float)hi[0], (float)hi[1]), pack_h16x2((float)hi[2], (float)hi[3])};
+    const uint2 wl = {pack_h16x2((float)lo[0], (float)lo[1]), pack_h16x2((float)lo[2], (float)lo[3])};
     *reinterpret_cast<uint2*>(o) = wh;
     *reinterpret_cast<uint2*>(o + K) = layout == 0 ? wl : wh;
     *reinterpret_cast<uint2*>(o + 2 * K) = layout == 0 ? wh : wl;
@@ -71,7 +74,7 @@ extern "C" int vault_split3_bf16(const float* x, void* out_bf16, long long rows,
   const long long total = rows * (K / 4);
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipLaunchKernelGGL(split3_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                     reinterpret_cast<bf16*>(out_bf16), rows, K, layout);
+                     reinterpret_cast<h16*>(out_bf16), rows, K, layout);
   return (int)hipGetLastError();
 }
 
@@ -82,7 +85,7 @@ extern "C" int vault_adamw_step(float* p, float* g, float* m, float* v, void* p_
   const long long n4 = n / 4;
   const int blocks = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v,
-                     reinterpret_cast<bf16*>(p_bf16), n4, lr * bias_corr_factor, lr * weight_decay, beta1, beta2, eps,
+                     reinterpret_cast<h16*>(p_bf16), n4, lr * bias_corr_factor, lr * weight_decay, beta1, beta2, eps,
                      grad_scale, zero_grad);
   return (int)hipGetLastError();
 }
@@ -92,7 +95,7 @@ extern "C" int vault_cast_bf16(const float* x, void* y_bf16, long long n, void* 
   const long long n4 = n / 4;
   const int blocks = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                     reinterpret_cast<bf16*>(y_bf16), n4);
+                     reinterpret_cast<h16*>(y_bf16), n4);
   return (int)hipGetLastError();
 }
 
@@ -100,18 +103,18 @@ extern "C" int vault_cast_bf16(const float* x, void* y_bf16, long long n, void* 
 // (the layers of a stack in the flat bf16 parameter buffer).  The data-gradient GEMMs dX = dY . W then read W^T as a
 // forward-form operand ([N = in][K = out], K contiguous): the register-direct GEMM (gemm8w.hip) takes no k-strided
 // weights.  64 x 64 tiles through LDS (padded rows), 16-byte global accesses on both sides.
-__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int rows,
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const h16* __restrict__ src, h16* __restrict__ dst, int rows,
                                                              int cols, long long stride_src, long long stride_dst) {
-  __shared__ bf16 tile[64][72];
+  __shared__ h16 tile[64][72];
   const int tiles_c = cols >> 6;
   const int tr = blockIdx.x / tiles_c, tc = blockIdx.x - tr * tiles_c;
-  const bf16* s = src + (size_t)blockIdx.y * stride_src + (size_t)(tr * 64) * cols + tc * 64;
-  bf16* d = dst + (size_t)blockIdx.y * stride_dst + (size_t)(tc * 64) * rows + tr * 64;
+  const h16* s = src + (size_t)blockIdx.y * stride_src + (size_t)(tr * 64) * cols + tc * 64;
+  h16* d = dst + (size_t)blockIdx.y * stride_dst + (size_t)(tc * 64) * rows + tr * 64;
   const int t = threadIdx.x;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int r = (t >> 3) + 32 * k, c8 = (t & 7) * 8;
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(s + (size_t)r * cols + c8);
+    const h16x8 v = *reinterpret_cast<const h16x8*>(s + (size_t)r * cols + c8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) tile[r][c8 + e] = v[e];
   }
@@ -119,10 +122,10 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restr
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int c = (t >> 3) + 32 * k, r8 = (t & 7) * 8;   // output row c (a source column), 8 consecutive source rows
-    bf16x8 v;
+    h16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = tile[r8 + e][c];
-    *reinterpret_cast<bf16x8*>(d + (size_t)c * rows + r8) = v;
+    *reinterpret_cast<h16x8*>(d + (size_t)c * rows + r8) = v;
   }
 }
 
@@ -132,7 +135,7 @@ extern "C" int vault_transpose_bf16(const void* src, void* dst, int rows, int co
       (stride_src & 7) || (stride_dst & 7))
     return VAULT_EINVAL;
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3((rows >> 6) * (cols >> 6), batch), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16*>(src),
-                     reinterpret_cast<bf16*>(dst), rows, cols, stride_src, stride_dst);
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const h16*>(src),
+                     reinterpret_cast<h16*>(dst), rows, cols, stride_src, stride_dst);
   return (int)hipGetLastError();
 }

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void resize_v_norm_pad_kernel(const uint8_t* _
                                                                 const vault_image_desc* __restrict__ desc,
                                                                 const float* __restrict__ lut, float* __restrict__ out,
                                                                 long long* __restrict__ mask, float* __restrict__ mask_f32,
-                                                                int H, int W, bf16* __restrict__ unfold, int ps) {
+                                                                int H, int W, h16* __restrict__ unfold, int ps) {
+  H16_SATURATE();
   __shared__ float slut[3 * 256];
   for (int i = threadIdx.x; i < 3 * 256; i += 256) slut[i] = lut[i];
   __syncthreads();
@@ -140,10 +141,10 @@ __global__ __launch_bounds__(256) void resize_v_norm_pad_kernel(const uint8_t* _
   if (unfold) {   // four consecutive x of one patch row: four consecutive k of the unfold row, per channel
     const int gw = W / ps, py = y / ps, px = x / ps;
     const size_t row = ((size_t)b * (H / ps) + py) * gw + px;
-    bf16* u = unfold + row * (size_t)(3 * ps * ps) + (size_t)(y - py * ps) * ps + (x - px * ps);
+    h16* u = unfold + row * (size_t)(3 * ps * ps) + (size_t)(y - py * ps) * ps + (x - px * ps);
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-      *reinterpret_cast<uint2*>(u + (size_t)c * ps * ps) = uint2{pack_bf16x2(v[c][0], v[c][1]), pack_bf16x2(v[c][2], v[c][3])};
+      *reinterpret_cast<uint2*>(u + (size_t)c * ps * ps) = uint2{pack_h16x2(v[c][0], v[c][1]), pack_h16x2(v[c][2], v[c][3])};
   }
   const size_t mo = (size_t)b * plane + (size_t)y * W + x;
   if (mask) {
@@ -170,6 +171,6 @@ extern "C" int vault_image_preprocess(const vault_preprocess_args* a, void* stre
                        a->plan, a->desc);
   hipLaunchKernelGGL(resize_v_norm_pad_kernel, dim3((a->W / 4 + 255) / 256, a->H, a->B), dim3(256), 0, st, a->tmp, a->plan, a->desc,
                      a->lut, a->pixel_values, reinterpret_cast<long long*>(a->pixel_mask), a->pixel_mask_f32, a->H, a->W,
-                     reinterpret_cast<bf16*>(a->patch_unfold_bf16), a->ps);
+                     reinterpret_cast<h16*>(a->patch_unfold_bf16), a->ps);
   return (int)hipGetLastError();
 }

@@ -32,10 +32,23 @@ def _pad(n: int, m: int = 256) -> int:
     return ((n + m - 1) // m) * m
 
 
+def _in_format(method):
+    """Run a method with its object's 16-bit operand format current (ops.operand_format): every launch inside goes to the
+    library built for that format."""
+    import functools
+
+    @functools.wraps(method)
+    def run(self, *a, **kw):
+        with ops.operand_format(self.half):
+            return method(self, *a, **kw)
+    return run
+
+
 class ParamStore:
     def __init__(self, spec: VaultSpec, device, state: Optional[Dict[str, np.ndarray]] = None, seed: int = 0,
-                 freeze_lm: bool = False, with_grads: bool = True):
+                 freeze_lm: bool = False, with_grads: bool = True, half: str = "bf16"):
         self.spec, self.device, self.freeze_lm = spec, device, freeze_lm
+        self.half, self.hdt = half, ops.HALF_DTYPE[half]      # operand format of the shadow copies (bf16 | fp16)
         entries = {n: s for n, s, _ in param_entries(spec)}
         order = self._flat_order(spec)
         assert set(order) == set(entries), "flat order must cover the parameter inventory"
@@ -65,8 +78,9 @@ class ParamStore:
         for n, (o, shp) in self.offsets.items():
             host[o:o + int(np.prod(shp))] = np.asarray(state[n], np.float32).reshape(-1)
         self.p = torch.from_numpy(host).to(device)
-        self.pb = torch.zeros(self.n_total + self.slack, dtype=torch.bfloat16, device=device)
-        ops.cast_bf16(self.p, self.pb, self.n_total)
+        self.pb = torch.zeros(self.n_total + self.slack, dtype=self.hdt, device=device)
+        with ops.operand_format(half):
+            ops.cast_bf16(self.p, self.pb, self.n_total)
         # transposed bf16 shadow W^T [in][out] of the Linears whose data gradient runs as a forward-form GEMM on the
         # register-direct kernel (attention-out and FFN-out of every trained encoder layer): {weight name: tensor}
         self.pbT: Dict[str, torch.Tensor] = {}
@@ -140,6 +154,7 @@ class ParamStore:
         return o
 
     # ---- transposed weight shadow -----------------------------------------------------------
+    @_in_format
     def enable_transposed(self, groups):
         """``groups``: lists of weight names of identical shape lying at a uniform stride in the flat buffer (the layers
         of a stack); one stacked [L, in, out] bf16 tensor per group, refreshed by :meth:`refresh_transposed`."""
@@ -150,17 +165,19 @@ class ParamStore:
             stride = (offs[1] - offs[0]) if len(offs) > 1 else 0
             if rows % 64 or cols % 64 or stride % 8 or any(offs[k + 1] - offs[k] != stride for k in range(len(offs) - 1)):
                 continue
-            t = torch.zeros((len(names), cols, rows), dtype=torch.bfloat16, device=self.device)
+            t = torch.zeros((len(names), cols, rows), dtype=self.hdt, device=self.device)
             for k, n in enumerate(names):
                 self.pbT[n] = t[k]
             self._pbT_groups.append((offs[0], rows, cols, len(names), stride, t))
         self.refresh_transposed()
 
+    @_in_format
     def refresh_transposed(self):
         """Re-derive the transposed shadow from the bf16 shadow (after every change of the parameters)."""
         for o, rows, cols, L, stride, t in self._pbT_groups:
             ops.transpose_bf16(self.pb[o:], t, rows, cols, L, stride, rows * cols)
 
+    @_in_format
     def refresh_shadows(self):
         """fp32 master -> bf16 shadow -> transposed shadow (after the master changed outside the fused optimizer)."""
         ops.cast_bf16(self.p, self.pb, self.n_total)
@@ -185,9 +202,10 @@ class ParamStore:
         return self._view(self.g, name, **kw)
 
     # ---- split-bf16 (precise inference) weight shadow: [N][hi | hi | lo] per 2-D weight --------
+    @_in_format
     def ensure_split3(self):
         if getattr(self, "pb3", None) is None:
-            self.pb3 = torch.zeros(3 * self.n_total, dtype=torch.bfloat16, device=self.device)
+            self.pb3 = torch.zeros(3 * self.n_total, dtype=self.hdt, device=self.device)
             self._pb3_fresh = False
         if self._pb3_fresh:
             return
@@ -213,6 +231,7 @@ class ParamStore:
         host = self.p.detach().cpu().numpy()
         return {n: host[o:o + int(np.prod(s))].reshape(s).copy() for n, (o, s) in self.offsets.items()}
 
+    @_in_format
     def load_numpy(self, state: Dict[str, np.ndarray]):
         host = self.p.detach().cpu().numpy().copy()
         for n, v in state.items():
@@ -264,8 +283,26 @@ class VaultEngine:
                                    # 22 GB of per-layer dY operands at that size; 7.9 GB at B = 256)
 
     def __init__(self, spec: VaultSpec, device="cuda:0", state=None, seed: int = 0, freeze_lm: bool = False,
-                 with_grads: bool = True, classifier_dropout: float = 0.1, fp8_forward: bool = False):
+                 with_grads: bool = True, classifier_dropout: float = 0.1, fp8_forward: bool = False,
+                 half: str = "bf16", grad_scale_pow2: Optional[float] = None):
         self.spec, self.device = spec, torch.device(device)
+        # 16-bit operand format of every GEMM / attention operand, saved activation and data gradient: "bf16" (default,
+        # BASELINE's format) or "fp16" - the same kernels compiled for IEEE half operands (libvault_hip_f16.so), same
+        # matrix rate, 11 instead of 8 significant bits: logits / loss of the full-size stack inside 1e-3 of the fp32
+        # reference (ref: vault/models/vault/model.py:557-570 runs fp32) at the bf16 mode's speed.  fp16's narrow
+        # exponent range is handled the classic way: the backward runs on gradients multiplied by the static power of
+        # two `grad_scale` (exact in every format; default 2^12: |dlogits| <= 1 becomes 4096, elements down to 1.5e-8
+        # stay normal numbers), the flat gradient buffer holds SCALED gradients while a backward runs, the fused
+        # optimizer divides the scale out (TrainStep), the autograd bridge un-scales after each backward (backward());
+        # conversions saturate at +-65504 (csrc/common.h H16_SATURATE) instead of producing infinities.
+        if half not in ops.HALF_DTYPE:
+            raise ValueError("half must be 'bf16' or 'fp16'")
+        self.half, self.hdt = half, ops.HALF_DTYPE[half]
+        if fp8_forward and half != "bf16":
+            raise ValueError("the fp8-forward mode quantises bf16 operands: half must be 'bf16'")
+        self.grad_scale = float(grad_scale_pow2) if grad_scale_pow2 is not None else (4096.0 if half == "fp16" else 1.0)
+        if self.grad_scale <= 0 or math.frexp(self.grad_scale)[0] != 0.5:
+            raise ValueError("grad_scale_pow2 must be a power of two")
         # BASELINE config "fp8 MFMA forward, bf16 backward": the forward Linear layers of both encoder stacks run on
         # MXFP8 operands (QKV and FFN-in: activations quantised in front of the GEMM, weights from the bf16 shadow once
         # per forward);
@@ -279,7 +316,7 @@ class VaultEngine:
         if spec.vilt.hidden_size // spec.vilt.num_attention_heads != 64:
             raise ValueError("head dimension must be 64")
         with torch.cuda.device(self.device):
-            self.params = ParamStore(spec, self.device, state, seed, self.freeze_lm, with_grads)
+            self.params = ParamStore(spec, self.device, state, seed, self.freeze_lm, with_grads, half=half)
         if os.environ.get("VAULT_LM_WGRAD_BATCHED") == "0":   # development override (same-box A/B)
             self.LM_WGRAD_BATCHED = False
         if os.environ.get("VAULT_WGRAD_BATCH_RING") == "0":   # development override (same-box A/B)
@@ -725,15 +762,15 @@ class VaultEngine:
         H, FF, heads = v.hidden_size, v.intermediate_size, v.num_attention_heads
         NP, Kp = v.num_patches, v.num_channels * v.patch_size * v.patch_size
         pp = batch["pixel_patches"]
-        if pp.dtype != torch.bfloat16 or pp.numel() != B * NP * Kp:
-            raise ValueError(f"pixel_patches must be bf16 [{B} * {NP}, {Kp}] (square {v.image_size} x {v.image_size} canvases)")
+        if pp.dtype != self.hdt or pp.numel() != B * NP * Kp:
+            raise ValueError(f"pixel_patches must be {self.half} [{B} * {NP}, {Kp}] (square {v.image_size} x {v.image_size} canvases)")
         S = T + 1 + NP
         ws = self.workspace(B, T, train, (0, 0, 0), ws_tag)
         ws.update(S=S, M=B * S, Mp=_pad(B * S), H=H, FF=FF, heads=heads, NP=NP, train=train, Ml=B * T, Mlp=_pad(B * T),
                   ragged=False, HP=v.image_size, WP=v.image_size)
         buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
         self._stage_text(ws, ids, temb, B, T, H)
-        ap = buf("apatch", (_pad(B * NP), Kp), torch.bfloat16)
+        ap = buf("apatch", (_pad(B * NP), Kp), self.hdt)
         ap[:B * NP].copy_(pp.reshape(B * NP, Kp))          # (onto itself when the caller wrote into input_buffers()["pixel_patches"])
         ws["img_embeds"] = None
         km = buf("keymask", (B, S))
@@ -804,7 +841,7 @@ class VaultEngine:
         return {"input_ids": buf("in_ids", (B, T), torch.int64),
                 "pixel_values": buf("in_pix", (B, v.num_channels, v.image_size, v.image_size)),
                 # (alternative image input: the bf16 patch unfold, _stage_pixel_patches - the patch-embedding GEMM's own operand)
-                "pixel_patches": buf("apatch", (_pad(B * v.num_patches), Kp), torch.bfloat16)[:B * v.num_patches],
+                "pixel_patches": buf("apatch", (_pad(B * v.num_patches), Kp), self.hdt)[:B * v.num_patches],
                 "labels": buf("in_labels", (B,), torch.int64)}
 
     def _forward(self, batch, train, labels, need_hidden, loss_scale, precise=False, ws_tag=0, image_type_idx=1,
@@ -821,6 +858,7 @@ class VaultEngine:
             self.params.ensure_split3()
         return self.forward_staged(ws, need_hidden, loss_scale, precise)
 
+    @_in_format
     def forward_staged(self, ws: dict, need_hidden: bool = True, loss_scale: Optional[float] = None,
                        precise: bool = False):
         """Forward over the staged inputs of ``ws`` (every launch goes through ops.* and can be taped)."""
@@ -830,7 +868,7 @@ class VaultEngine:
         B, T, S, M, Mp, H, FF, heads, NP = (ws[k] for k in ("B", "T", "S", "M", "Mp", "H", "FF", "heads", "NP"))
         ids, tt, amf, pix, labels, km = ws["ids"], ws["tt"], ws["amf"], ws["pix"], ws["labels"], ws["keymask"]
         buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
-        bf = torch.bfloat16
+        bf = self.hdt
         ws["drop_seed"] = self.drop_seed
         pr = precise
         W3 = 3 if pr else 1   # operand width multiplier of the split-bf16 path
@@ -1037,6 +1075,7 @@ class VaultEngine:
                               y_q=q8[0], y_scale=q8[1])
             ops.pycall(lambda: self._prof_begin("ffn1"))
             g8 = None if pr else self._plan_gelu8(ws, n2, act, u, ln, Mp, M)
+            ws["gelu8_active"] = g8     # what THIS forward stored in `u` (8-bit tile image or plain 16-bit): backward reads this
             g8kw = dict(cfg=g8, aux_u8=True) if g8 is not None else {}
             u_out = buf(f"u{sfx}_3", (Mp, W3 * FF), bf) if (pt and u is not None) else u      # (row stride of the main output)
             self._linear(n2, ln.iw, act, Mp, FF, H, ops.EPI_BF16_GELU, M, bias=P.w(ln.ib), out2=u_out, precise=pr,
@@ -1101,7 +1140,7 @@ class VaultEngine:
         Hin, Hm = spec.mlp_dims
         L = spec.n_classes
         Lp, Bp = _pad(L), _pad(B)
-        bf = torch.bfloat16
+        bf = self.hdt
         buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
         xb = buf("mlp_xb", (Bp, Hin), bf)
         ops.cast_bf16(x_f32, xb, B * Hin)
@@ -1117,17 +1156,20 @@ class VaultEngine:
                  ops.EPI_F32_RES, m_valid=B, bias=P.w("classifier.3.bias", n_elems=Lp, shape=(Lp,)))
         return lg[:B, :L]
 
-    def _mlp_backward(self, ws: dict, dlogits: torch.Tensor, B: int) -> torch.Tensor:
-        """Parameter gradients of the MLP head (+=) and d/dx [Bp, H_in] f32 of the last :meth:`_mlp_forward` on ``ws``."""
+    def _mlp_backward(self, ws: dict, dlogits: torch.Tensor, B: int, scale: float = 1.0) -> torch.Tensor:
+        """Parameter gradients of the MLP head (+=) and d/dx [Bp, H_in] f32 of the last :meth:`_mlp_forward` on ``ws``.
+        ``scale``: the gradient scale of the operand format, applied to ``dlogits`` (every result is scaled by it)."""
         spec, P = self.spec, self.params
         Hin, Hm = spec.mlp_dims
         L = spec.n_classes
         Lp, Bp = _pad(L), _pad(B)
-        bf = torch.bfloat16
+        bf = self.hdt
         buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
         dl32 = buf("mlp_dlogits", (Bp, Lp))
         ops.pycall(dl32.zero_)
         dl32[:B, :L].copy_(dlogits.reshape(B, L))
+        if scale != 1.0:
+            ops.scale(dl32.view(-1), scale, Bp * Lp)
         dlb = buf("mlp_dlogits_b", (Bp, Lp), bf)
         ops.cast_bf16(dl32, dlb, Bp * Lp)
         # output projection: weight-gradient rows >= L are never written (m_valid); its bias gradient is the column sum
@@ -1149,6 +1191,7 @@ class VaultEngine:
         return dx
 
     # ---- MLM head (HF ViltMLMHead): dense(H, H) - GELU - LayerNorm - decoder tied to ViLT's word embeddings + bias --------
+    @_in_format
     def mlm_head_forward(self, x_f32: torch.Tensor) -> torch.Tensor:
         """x [R, H] f32 (text rows of last_hidden_state) -> logits [R, V]."""
         with torch.cuda.device(self.device):
@@ -1158,7 +1201,7 @@ class VaultEngine:
             R = x_f32.shape[0]
             Rp, Vp = _pad(R), _pad(V)
             ws = self._ws.setdefault(("mlm_head", R), {})
-            bf = torch.bfloat16
+            bf = self.hdt
             buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
             xin = buf("x", (Rp, H))
             xin[:R].copy_(x_f32)
@@ -1178,19 +1221,22 @@ class VaultEngine:
                      bias=P.w("mlm_score.bias", n_elems=Vp, shape=(Vp,)))
             return lg[:R, :V]
 
+    @_in_format
     def mlm_head_backward(self, dlogits: torch.Tensor) -> torch.Tensor:
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), self._grads_scaled():
             spec, P = self.spec, self.params
             v = spec.vilt
             H, V = v.hidden_size, v.vocab_size
             R = dlogits.shape[0]
             Rp, Vp = _pad(R), _pad(V)
             ws = self._ws[("mlm_head", R)]
-            bf = torch.bfloat16
+            bf = self.hdt
             buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
             dl32 = buf("dlogits", (Rp, Vp))
             dl32.zero_()
             dl32[:R, :V].copy_(dlogits.reshape(R, V))
+            if self.grad_scale != 1.0:
+                ops.scale(dl32.view(-1), self.grad_scale, Rp * Vp)
             dlb = buf("dlogits_b", (Rp, Vp), bf)
             ops.cast_bf16(dl32, dlb, Rp * Vp)
             wn = "embeddings.text_embeddings.word_embeddings.weight"
@@ -1209,8 +1255,11 @@ class VaultEngine:
             dx = buf("dx", (Rp, H))
             ops.gemm(dh1b, P.wb("mlm_score.transform.dense.weight", shape=(H, H)), dx, Rp, H, H, H, H, H, 0, 1,
                      ops.EPI_F32_RES, m_valid=R)
+            if self.grad_scale != 1.0:
+                ops.scale(dx.view(-1), 1.0 / self.grad_scale, dx.numel())
             return dx[:R]
 
+    @_in_format
     def mlp_head_forward(self, x_f32: torch.Tensor, train: bool = True) -> torch.Tensor:
         """The MLP head on an external input [B, H_in] (concatenated pooled outputs of several encoder passes)."""
         with torch.cuda.device(self.device):
@@ -1220,12 +1269,17 @@ class VaultEngine:
             xin[:B].copy_(x_f32)
             return self._mlp_forward(ws, xin, B)
 
+    @_in_format
     def mlp_head_backward(self, dlogits: torch.Tensor) -> torch.Tensor:
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), self._grads_scaled():
             B = dlogits.shape[0]
-            return self._mlp_backward(self._ws[("mlp_head", B)], dlogits.contiguous().float(), B)[:B]
+            dx = self._mlp_backward(self._ws[("mlp_head", B)], dlogits.contiguous().float(), B, scale=self.grad_scale)
+            if self.grad_scale != 1.0:
+                ops.scale(dx.view(-1), 1.0 / self.grad_scale, dx.numel())
+            return dx[:B]
 
     # ---- backward ---------------------------------------------------------------------------
+    @_in_format
     def zero_grad(self):
         if self.params.g is not None:
             self.params.g.zero_()
@@ -1240,9 +1294,46 @@ class VaultEngine:
         ``after_layer(tag)`` is called after each stage so a DP driver can start all-reducing the
         gradient range that just became final.
         """
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), self._grads_scaled():
             self._backward(grad_scale, dlogits, dpooled, dhidden, after_layer, ws)
+            if self.grad_scale != 1.0:      # gradients handed back to the caller's autograd graph
+                w_ = self.last if ws is None else ws
+                for k in ("d_inputs_embeds", "d_image_embeds"):
+                    t = w_.get(k)
+                    if t is not None:
+                        with ops.operand_format(self.half):
+                            ops.scale(t, 1.0 / self.grad_scale, t.numel())
 
+    def _grads_scaled(self):
+        """Context for a backward outside the fused train step when the operand format carries a gradient scale (fp16): the
+        flat gradient buffer may hold earlier, un-scaled contributions (gradient accumulation, several encoder passes): it
+        is multiplied by the scale before and by its inverse after the backward - exact, a power of two."""
+        eng = self
+
+        class _Ctx:
+            def __enter__(self_c):
+                if eng.grad_scale != 1.0 and eng.params.g is not None:
+                    with ops.operand_format(eng.half):
+                        ops.scale(eng.params.g, eng.grad_scale, eng.params.n_train)
+
+            def __exit__(self_c, *exc):
+                if eng.grad_scale != 1.0 and eng.params.g is not None:
+                    with ops.operand_format(eng.half):
+                        ops.scale(eng.params.g, 1.0 / eng.grad_scale, eng.params.n_train)
+                return False
+        return _Ctx()
+
+    def _scaled_in(self, ws, name, t):
+        """An externally supplied output gradient (f32) times the gradient scale, in a workspace buffer (identity at 1)."""
+        t = t.contiguous()
+        if self.grad_scale == 1.0:
+            return t
+        b = self._buf(ws, name, tuple(t.shape), torch.float32)
+        b.copy_(t)
+        ops.scale(b.view(-1), self.grad_scale, b.numel()) if b.numel() % 4 == 0 else b.mul_(self.grad_scale)
+        return b
+
+    @_in_format
     def _backward(self, grad_scale, dlogits, dpooled, dhidden, after_layer, ws=None):
         ws = self.last if ws is None else ws
         if ws is None or not ws.get("train"):
@@ -1251,7 +1342,7 @@ class VaultEngine:
         v = spec.vilt
         B, T, S, M, Mp, H, FF, heads, NP = (ws[k] for k in ("B", "T", "S", "M", "Mp", "H", "FF", "heads", "NP"))
         Ml, Mlp = ws["Ml"], ws["Mlp"]
-        bf = torch.bfloat16
+        bf = self.hdt
         buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
         self.drop_seed = ws["drop_seed"]
         x = ws["x"]
@@ -1287,15 +1378,17 @@ class VaultEngine:
             if spec.n_classes > 0 and spec.head == "mlp" and dpooled is None:
                 if dlogits is None:
                     raise ValueError("the MLP head has no built-in loss: pass dlogits (the autograd bridge does)")
-                ops.tanh_bwd(ws["pooled"], self._mlp_backward(ws, dlogits, B), dpre, B * H)
+                ops.tanh_bwd(ws["pooled"], self._mlp_backward(ws, dlogits, B, scale=self.grad_scale), dpre, B * H)
             elif spec.n_classes > 0 and dpooled is None:
                 hd = self._drop(self.classifier_dropout, 9001, True)
-                gs = (1.0 / B) if grad_scale is None else grad_scale
+                gs = ((1.0 / B) if grad_scale is None else grad_scale) * self.grad_scale
+                if dlogits is not None:
+                    dlogits = self._scaled_in(ws, "dlogits_scaled", dlogits)
                 ops.head_bwd(ws["pooled"], ws["logits"], ws.get("labels"), P.w("classifier.1.weight"),
                              P.gr("classifier.1.weight"), P.gr("classifier.1.bias"), dpre, B, H, spec.n_classes, gs,
                              dlogits=dlogits, drop=hd)
             else:
-                ops.tanh_bwd(ws["pooled"], dpooled.contiguous(), dpre, B * H)
+                ops.tanh_bwd(ws["pooled"], self._scaled_in(ws, "dpooled_scaled", dpooled), dpre, B * H)
             self._wgrad(dpre, ws["h0b"], "pooler.dense.weight", "pooler.dense.bias", Bp, H, H, B)
             dh0 = buf("dh0", (Bp, H), bf)
             self._dgrad(dpre, "pooler.dense.weight", dh0, Bp, H, H, ops.EPI_BF16, B)
@@ -1306,7 +1399,7 @@ class VaultEngine:
         if dhidden is not None:
             # gradient w.r.t. last_hidden_state (all rows): LN backward over all rows, added on top
             ops.layernorm_bwd(x[nv], ws["f_mean_all"], ws["f_rstd_all"], P.w("layernorm.weight"), M, H,
-                              dy_f32=dhidden.contiguous().view(M, H), dres=None if gbf else dx[0],
+                              dy_f32=self._scaled_in(ws, "dhidden_scaled", dhidden).view(M, H), dres=None if gbf else dx[0],
                               dres_bf16=dxb_top if gbf else None,        # (in place: every element is read, then written, by one lane)
                               dx_f32=None if gbf else dx[0], dx_bf16=dxb_top,
                               dgamma=P.gr("layernorm.weight"), dbeta=P.gr("layernorm.bias"),
@@ -1360,7 +1453,7 @@ class VaultEngine:
             # FFN
             # (bias gradients are column sums of dY: fused into the kernel that PRODUCES dY - the LayerNorm
             #  backward for the residual-stream gradient, the GEMM epilogue for dU)
-            g8 = ws.get("gelu8_cfg")
+            g8 = ws.get("gelu8_active")
             g8kw = dict(cfg=g8, aux_u8=True) if g8 is not None else {}
             self._dgrad(dyA, ln.fw, dU, Mp, FF, H, ops.EPI_BF16_DGELU, M, aux=g("u"), colsum=P.gr(ln.ib), **g8kw)
             if not vbatch:

@@ -7,8 +7,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VAULT_HIP_LIB: development override (A/B of two builds of the SAME HIP library on one box); still no fallback
 LIB_PATH = os.environ.get("VAULT_HIP_LIB") or os.path.join(_HERE, "libvault_hip.so")
-ABI_VERSION = 7
-_lib = None
+# the same sources compiled for the IEEE fp16 operand type (csrc/common.h `h16`, build.py VARIANTS): same exported ABI
+LIB_PATH_F16 = os.environ.get("VAULT_HIP_LIB_F16") or os.path.join(_HERE, "libvault_hip_f16.so")
+ABI_VERSION = 8
+FORMATS = ("bf16", "fp16")
+_libs = {}
 
 
 class GemmArgs(C.Structure):
@@ -28,24 +31,31 @@ class GemmArgs(C.Structure):
     ]
 
 
-def load() -> C.CDLL:
-    """Load the HIP library; raise (never fall back) when it is absent or has the wrong ABI."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(fmt: str = "bf16") -> C.CDLL:
+    """Load the HIP library of the 16-bit operand format ``fmt``; raise (never fall back) when it is absent or has the
+    wrong ABI."""
+    lib = _libs.get(fmt)
+    if lib is not None:
+        return lib
+    if fmt not in FORMATS:
+        raise ValueError(f"operand format must be one of {FORMATS}")
     # torch ships its own libamdhip64: it must be in the process before our library is, or the
     # kernels would launch through a second, uninitialised HIP runtime
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATH if fmt == "bf16" else LIB_PATH_F16
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: build it with `python -m vault_amd.build` "
+            f"{path} not found: build it with `python -m vault_amd.build` "
             "(the VAuLT hot path has no CPU/PyTorch fallback)")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)           # (RTLD_LOCAL: the two builds export the same names)
     lib.vault_abi_version.restype = C.c_int
     v = lib.vault_abi_version()
     if v != ABI_VERSION:
-        raise RuntimeError(f"libvault_hip.so ABI {v} != expected {ABI_VERSION}: rebuild")
-    _lib = lib
+        raise RuntimeError(f"{os.path.basename(path)} ABI {v} != expected {ABI_VERSION}: rebuild")
+    lib.vault_operand_format.restype = C.c_int
+    if lib.vault_operand_format() != FORMATS.index(fmt):
+        raise RuntimeError(f"{os.path.basename(path)} was not built for {fmt} operands: rebuild")
+    _libs[fmt] = lib
     return lib
 
 

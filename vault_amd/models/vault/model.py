@@ -231,6 +231,11 @@ class VaultMixin(nn.Module):
     #: forward Linear layers fed by a LayerNorm (QKV, FFN-in) on MXFP8 operands, backward in bf16 (BASELINE config
     #: "fp8 MFMA forward, bf16 backward"): faster, outside the 1e-3 parity bar
     fp8_forward = False
+    #: 16-bit operand format of the HIP engine, read when the model is moved to a GPU: "bf16" (default) or "fp16" - IEEE
+    #: half operands at the same matrix rate, logits / loss inside 1e-3 of the fp32 reference in training and inference
+    #: (bf16: 4e-3), gradients carried under a static power-of-two scale that is divided out before ``p.grad`` is
+    #: published (engine.VaultEngine).  Environment override: VAULT_HALF.
+    half_format = "bf16"
 
     def __init__(self, vilt_config, bert_config=None, freeze_lm: bool = False, vilt_dropout_prob: float = 0.0,
                  use_vilt_position_embeddings: bool = False, add_pooling_layer: bool = True, *, _n_classes: int = 0,
@@ -288,8 +293,10 @@ class VaultMixin(nn.Module):
 
     def _bind(self, device):
         state = {n: p.detach().float().cpu().numpy() for n, p in self._params_by_name.items()}
+        import os
         self._engine = VaultEngine(self.spec, device, state=state, freeze_lm=self.freeze_lm,
-                                   classifier_dropout=self.vilt_dropout_prob if (self._n_classes and self._head_dropout) else 0.0)
+                                   classifier_dropout=self.vilt_dropout_prob if (self._n_classes and self._head_dropout) else 0.0,
+                                   half=os.environ.get("VAULT_HALF") or self.half_format)
         P = self._engine.params
         for n, p in self._params_by_name.items():
             p.data = P.w(n)

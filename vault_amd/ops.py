@@ -48,6 +48,48 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+# ---- 16-bit operand format -------------------------------------------------------------------------------------
+# Every wrapper below launches through the library of the CURRENT format ("bf16": libvault_hip.so, "fp16":
+# libvault_hip_f16.so - the same kernels compiled for the other operand type, csrc/common.h).  An engine makes its own
+# format current around its entry points (``with ops.operand_format(fmt):``); a recorded tape holds the function
+# pointers of the library it was recorded on.  One host thread per device (include/vault_hip.h): a plain module global.
+_FMT = "bf16"
+HALF_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+class operand_format:
+    """Context manager: the launches inside run on the library of ``fmt``."""
+
+    def __init__(self, fmt: str):
+        if fmt not in HALF_DTYPE:
+            raise ValueError("operand format must be 'bf16' or 'fp16'")
+        self.fmt = fmt
+
+    def __enter__(self):
+        global _FMT
+        self.prev, _FMT = _FMT, self.fmt
+        return self
+
+    def __exit__(self, *exc):
+        global _FMT
+        _FMT = self.prev
+        return False
+
+
+def current_format() -> str:
+    return _FMT
+
+
+def _h(t: Optional[torch.Tensor]):
+    """Pointer of a 16-bit operand tensor; its dtype must be the current library's (a bf16 tensor handed to the fp16
+    kernels, or the reverse, would be read as garbage without any error from the device)."""
+    if t is None:
+        return None
+    if t.dtype != HALF_DTYPE[_FMT] and t.dtype in (torch.bfloat16, torch.float16):
+        raise TypeError(f"{t.dtype} operand in a launch on the {_FMT} library")
+    return t.data_ptr()
+
+
 class Tape:
     """A recorded sequence of C-ABI calls (function pointer + prepared ctypes arguments) and host
     callbacks.  Every buffer of the engine is persistent, so a train step is the SAME call list with the
@@ -100,7 +142,7 @@ def pycall(fn):
 
 
 def _invoke(name: str, *args, struct=None, drop=None):
-    fn = getattr(L.load(), name)
+    fn = getattr(L.load(_FMT), name)
     if _TAPE is not None:
         _TAPE.calls.append((fn, args))
         if struct is not None and drop is not None and drop.thresh:
@@ -139,8 +181,8 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_va
          colsum=None, split3=False, batch=0, batch_a=0, batch_b=0, batch_o=0, aux_u8=False, plan_only=False):
     a = L.GemmArgs()
     a.aux_u8 = 1 if aux_u8 else 0
-    a.A, a.B, a.out, a.out2 = _p(A), _p(B), _p(out), _p(out2)
-    a.bias, a.res, a.aux, a.addtab = _p(bias), _p(res), _p(aux), _p(addtab)
+    a.A, a.B, a.out, a.out2 = _h(A), _h(B), _h(out), _h(out2)
+    a.bias, a.res, a.aux, a.addtab = _p(bias), _p(res), _h(aux), _p(addtab)
     a.colsum = _p(colsum)
     a.split3 = 1 if split3 else 0
     a.M, a.N, a.K, a.lda, a.ldb, a.ldo, a.m_valid = M, N, K, lda, ldb, ldo, m_valid
@@ -150,7 +192,7 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_va
     a.batch, a.batch_a, a.batch_b, a.batch_o = batch, batch_a, batch_b, batch_o   # batched weight gradients (ABI 3)
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
     if plan_only:      # the kernel configuration these arguments would run on (vault_gemm_plan): >= 0, or -EINVAL
-        return int(L.load().vault_gemm_plan(C.byref(a)))
+        return int(L.load(_FMT).vault_gemm_plan(C.byref(a)))
     _invoke("vault_gemm", C.byref(a), _stream(), struct=a, drop=drop)
 
 
@@ -177,12 +219,12 @@ def layernorm_fwd(x, gamma, beta, eps, rows, H, *, y_bf16=None, y_f32=None, mean
                   xmap=(0, 0, 0), ymap=(0, 0, 0), drop: Drop = NO_DROP, y_split3=None, y_q=None, y_scale=None):
     a = LnFwdArgs()
     a.x, a.gamma, a.beta, a.post_add = _p(x), _p(gamma), _p(beta), _p(post_add)
-    a.y_bf16, a.y_f32, a.mean, a.rstd = _p(y_bf16), _p(y_f32), _p(mean), _p(rstd)
+    a.y_bf16, a.y_f32, a.mean, a.rstd = _h(y_bf16), _p(y_f32), _p(mean), _p(rstd)
     a.rows, a.H, a.eps = rows, H, eps
     a.x_rpg, a.x_gstride, a.x_goff = xmap
     a.y_rpg, a.y_gstride, a.y_goff = ymap
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
-    a.y_split3 = _p(y_split3)
+    a.y_split3 = _h(y_split3)
     a.y_q, a.y_scale = _p(y_q), _p(y_scale)
     _invoke("vault_layernorm_fwd", C.byref(a), _stream(), struct=a, drop=drop)
 
@@ -191,10 +233,10 @@ def layernorm_bwd(x, mean, rstd, gamma, rows, H, *, dy_bf16=None, dy_f32=None, d
                   dgamma=None, dbeta=None, dymap=(0, 0, 0), xmap=(0, 0, 0), dxmap=(0, 0, 0), drop: Drop = NO_DROP,
                   drop_on_dy: bool = False, dbias=None, dres_bf16=None):
     a = LnBwdArgs()
-    a.dres_bf16 = _p(dres_bf16)
-    a.dy_bf16, a.dy_f32, a.x, a.mean, a.rstd, a.gamma, a.dres = (_p(dy_bf16), _p(dy_f32), _p(x), _p(mean),
+    a.dres_bf16 = _h(dres_bf16)
+    a.dy_bf16, a.dy_f32, a.x, a.mean, a.rstd, a.gamma, a.dres = (_h(dy_bf16), _p(dy_f32), _p(x), _p(mean),
                                                                   _p(rstd), _p(gamma), _p(dres))
-    a.dx_f32, a.dx_bf16, a.dgamma, a.dbeta = _p(dx_f32), _p(dx_bf16), _p(dgamma), _p(dbeta)
+    a.dx_f32, a.dx_bf16, a.dgamma, a.dbeta = _p(dx_f32), _h(dx_bf16), _p(dgamma), _p(dbeta)
     a.rows, a.H = rows, H
     a.dy_rpg, a.dy_gstride, a.dy_goff = dymap
     a.x_rpg, a.x_gstride, a.x_goff = xmap
@@ -216,8 +258,8 @@ def colsum(x_bf16, ld, rows, N, out):
 
 def _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, dctx=None, dqkv=None, drop: Drop = NO_DROP, ctx_split3=None):
     a = AttnArgs()
-    a.ctx_split3 = _p(ctx_split3)
-    a.qkv, a.keymask, a.ctx, a.lse, a.dctx, a.dqkv = _p(qkv), _p(keymask), _p(ctx), _p(lse), _p(dctx), _p(dqkv)
+    a.ctx_split3 = _h(ctx_split3)
+    a.qkv, a.keymask, a.ctx, a.lse, a.dctx, a.dqkv = _h(qkv), _p(keymask), _h(ctx), _p(lse), _h(dctx), _h(dqkv)
     a.B, a.S, a.H, a.heads = B, S, H, heads
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
     return a
@@ -329,6 +371,11 @@ def axpy(dst, src, a, n):
     _invoke("vault_axpy_f32", C.c_void_p(_p(dst)), C.c_void_p(_p(src)), C.c_float(a), C.c_longlong(n), _stream())
 
 
+def scale(x, a, n):
+    """x *= a (n floats, multiple of 4)."""
+    _invoke("vault_scale_f32", C.c_void_p(_p(x)), C.c_float(a), C.c_longlong(n), _stream())
+
+
 def _head_args(pre, Wc, bc, labels, pooled, logits, loss_sum, B, H, Cc, loss_scale=1.0, grad_scale=1.0, dlogits=None,
                dWc=None, dbc=None, dpre=None, drop: Drop = NO_DROP):
     a = HeadArgs()
@@ -375,13 +422,13 @@ def gelu_bwd(x, dy, dx, n):
 def adamw_step(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay, bias_corr_factor=1.0, grad_scale=1.0,
                zero_grad=True):
     _invoke("vault_adamw_step", C.c_void_p(_p(p)), C.c_void_p(_p(g)), C.c_void_p(_p(m)), C.c_void_p(_p(v)),
-            C.c_void_p(_p(p_bf16)), C.c_longlong(n), C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps),
+            C.c_void_p(_h(p_bf16)), C.c_longlong(n), C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps),
             C.c_float(weight_decay), C.c_float(bias_corr_factor), C.c_float(grad_scale),
             C.c_int(1 if zero_grad else 0), _stream())
 
 
 def cast_bf16(x, y_bf16, n):
-    _invoke("vault_cast_bf16", C.c_void_p(_p(x)), C.c_void_p(_p(y_bf16)), C.c_longlong(n), _stream())
+    _invoke("vault_cast_bf16", C.c_void_p(_p(x)), C.c_void_p(_h(y_bf16)), C.c_longlong(n), _stream())
 
 
 # ---- data-parallel gradient exchange (csrc/exchange.hip) ----
@@ -416,7 +463,7 @@ def split3_bf16(x_f32, out_bf16, rows, K, layout):
 
 def transpose_bf16(src, dst, rows, cols, batch=1, stride_src=0, stride_dst=0):
     """dst[b][c][r] = src[b][r][c] (bf16; rows, cols multiples of 64): transposed weight shadow for the data gradients."""
-    _invoke("vault_transpose_bf16", C.c_void_p(_p(src)), C.c_void_p(_p(dst)), C.c_int(rows), C.c_int(cols), C.c_int(batch),
+    _invoke("vault_transpose_bf16", C.c_void_p(_h(src)), C.c_void_p(_h(dst)), C.c_int(rows), C.c_int(cols), C.c_int(batch),
             C.c_longlong(stride_src), C.c_longlong(stride_dst), _stream())
 
 
@@ -491,7 +538,7 @@ def stage_args(struct_type, /, **kw):
 
 
 def workspace_bytes(H, FF, heads, lm_layers, vilt_layers, IMG, ps, Cn, n_classes, B, T, train) -> int:
-    fn = L.load().vault_workspace_bytes
+    fn = L.load(_FMT).vault_workspace_bytes
     fn.restype = C.c_longlong
     d = ModelDims(H, FF, heads, lm_layers, vilt_layers, IMG, ps, Cn, n_classes)
     return int(fn(C.byref(d), C.c_int(B), C.c_int(T), C.c_int(1 if train else 0)))
@@ -517,7 +564,7 @@ def layer_bwd_args(fwd: LayerArgs, **kw) -> LayerBwdArgs:
 def layer_call(name: str, args, seeded: bool = False):
     """vault_{vilt,lm}_layer_{fwd,bwd}: one layer per C call.  ``seeded``: the struct carries a dropout seed the tape
     re-keys between replays (for the backward form: its forward struct)."""
-    fn = getattr(L.load(), name)
+    fn = getattr(L.load(_FMT), name)
     call = (C.byref(args), _stream())
     if _TAPE is not None:
         _TAPE.calls.append((fn, call))

@@ -194,9 +194,9 @@ class DeviceImageProcessor:
                 pv = out["pixel_values"] if out is not None else torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
             else:
                 ps = int(patch_size)
-                if H % ps or W % ps or ps % 4 or patch_out.dtype != torch.bfloat16 or not patch_out.is_contiguous() or \
+                if H % ps or W % ps or ps % 4 or patch_out.dtype not in (torch.bfloat16, torch.float16) or not patch_out.is_contiguous() or \
                         patch_out.numel() < B * (H // ps) * (W // ps) * 3 * ps * ps:
-                    raise ValueError(f"patch_out must be contiguous bf16 with >= {B * (H // ps) * (W // ps)} rows of {3 * ps * ps}")
+                    raise ValueError(f"patch_out must be contiguous bf16 / fp16 with >= {B * (H // ps) * (W // ps)} rows of {3 * ps * ps}")
             pm = out["pixel_mask"] if out is not None else torch.empty(B, H, W, dtype=self.mask_dtype, device=dev)
             if (pv is not None and (tuple(pv.shape) != (B, 3, H, W) or pv.dtype != torch.float32)) or tuple(pm.shape) != (B, H, W) or pm.dtype != self.mask_dtype:
                 raise ValueError(f"out tensors must be pixel_values [{B},3,{H},{W}] float32 and pixel_mask [{B},{H},{W}] {self.mask_dtype}")
@@ -213,7 +213,9 @@ class DeviceImageProcessor:
                 a.pixel_mask_f32 = pm.data_ptr()
             a.B, a.H, a.W, a.max_h_in, a.max_w_out = B, H, W, max_h_in, max_w_out
             a.max_w_in, a.src_bytes = max(w for _, w in sizes), src_bytes
-            L.check(L.load().vault_image_preprocess(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            # (the unfold is written in patch_out's own 16-bit format: by the library built for it)
+            fmt = "fp16" if (patch_out is not None and patch_out.dtype == torch.float16) else "bf16"
+            L.check(L.load(fmt).vault_image_preprocess(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                     "vault_image_preprocess")
             # (src is freed on this stream after the launches; plan / descriptors / intermediate belong to the cached plan: a
             #  batch of other sizes on ANOTHER stream must not start before this one has passed them)

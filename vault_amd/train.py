@@ -80,12 +80,21 @@ class SparseTable:
         self.hi = self.lo + self.rows * self.H
 
 
+def _on_bf16_library(fn):
+    """The wire format of the exchange is bf16 whatever the engine's operand format (f32 range: no gradient scale to
+    respect): these kernels always run on libvault_hip.so."""
+    def run(*a):
+        with ops.operand_format("bf16"):
+            return fn(*a)
+    return staticmethod(run)
+
+
 class ExchangeKernels:
     """Pack / unpack kernels of the exchange on DEVICE tensors (csrc/exchange.hip).  The reducer takes them as an object so
     that its bucket logic can be driven with host tensors over gloo in the CPU tests (which bring their own stand-ins)."""
-    narrow = staticmethod(ops.cast_bf16)              # (src_f32, dst_bf16, n)
-    widen = staticmethod(ops.widen_bf16)              # (src_bf16, dst_f32, n)
-    sum_chunks = staticmethod(ops.sum_chunks_bf16)    # (src_bf16, n_src, chunk, out_bf16)
+    narrow = _on_bf16_library(ops.cast_bf16)              # (src_f32, dst_bf16, n)
+    widen = _on_bf16_library(ops.widen_bf16)              # (src_bf16, dst_f32, n)
+    sum_chunks = _on_bf16_library(ops.sum_chunks_bf16)    # (src_bf16, n_src, chunk, out_bf16)
     rows_union = staticmethod(ops.rows_union)         # (keys, n_keys, V, flags, uniq, count)
     rows_gather = staticmethod(ops.rows_gather)       # (table, idx, n_rows, H, out)
     rows_scatter = staticmethod(ops.rows_scatter)     # (src, idx, n_rows, H, table)
@@ -391,14 +400,15 @@ class TrainStep:
         tape (ops.Tape); later calls copy the batch into the persistent input buffers and replay it."""
         eng = self.engine
         B, T = batch["input_ids"].shape
-        with torch.cuda.device(eng.device):
+        with torch.cuda.device(eng.device), ops.operand_format(eng.half):
             # staging decides the image geometry (square all-valid canvas, or a padded batch of differently sized
             # images: host-side patch selection); every geometry has its own workspace, hence its own tape
             ws = eng.stage_inputs(batch, True, labels, validate=not self.assume_full_pixel_mask)
             # what the recorded launches bake in besides the buffers of the (B, T, geometry) workspace: whether token
             # types were given, the launch stream, the GEMM scheduling mode and the forward number format
             key = ws["key"] + (ws["tt"] is None, torch.cuda.current_stream().cuda_stream, ops.GEMM_SCHED,
-                               bool(eng.fp8_forward), labels.dtype.is_floating_point, bool(ws.get("patches_in")), self.precise_forward)
+                               bool(eng.fp8_forward), labels.dtype.is_floating_point, bool(ws.get("patches_in")), self.precise_forward,
+                               eng.half, eng.grad_scale)
             if self.reducer:
                 # the token ids of every rank name the rows of the word-embedding table this step touches: their
                 # all-gather + union start now on the communication stream (inputs_embeds: no row is touched)
@@ -443,11 +453,13 @@ class TrainStep:
         bc = 1.0
         if self.correct_bias:
             bc = math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
-        with torch.cuda.device(eng.device):
+        with torch.cuda.device(eng.device), ops.operand_format(eng.half):
             if hi > lo:
+                # (the gradients carry the operand format's power-of-two scale - fp16: engine.grad_scale - and the sum
+                #  over the ranks: both are divided out here)
                 ops.adamw_step(P.p[lo:hi], P.g[lo:hi], P.m[lo:hi], P.v[lo:hi], P.pb[lo:hi], hi - lo, self.current_lr(),
-                               self.b1, self.b2, self.eps, self.wd, bias_corr_factor=bc, grad_scale=1.0 / self.world,
-                               zero_grad=True)
+                               self.b1, self.b2, self.eps, self.wd, bias_corr_factor=bc,
+                               grad_scale=1.0 / (self.world * eng.grad_scale), zero_grad=True)
         if advance:
             with torch.cuda.device(eng.device):
                 P.refresh_transposed()   # W^T shadow of the data-gradient GEMMs, from the bf16 shadow just written
