@@ -552,7 +552,7 @@ def main():
     fp16_line = None
     if rank == 0 and world == 1 and not args.no_parity and not args.fp8_forward and args.half == "bf16":
         try:
-            fp16_line = measure_fp16(spec, args, dev, batch, labels, B)
+            fp16_line = measure_fp16(spec, args, dev, batch, labels, B, steps=args.steps, warmup=args.warmup)
         except Exception as e:  # pragma: no cover
             fp16_line = {"error": repr(e)}
 

@@ -258,7 +258,9 @@ int vault_cast_bf16(const float* x, void* y_bf16, long long n, void* stream);
  * serve the build's own data-parallel step, between the RCCL collectives that vault_amd/train.py issues.
  *   vault_rows_union      sorted list of the distinct values of keys[0..n_keys) that lie in [0, V) (the token ids of ALL
  *                         ranks after an all-gather: the rows of an embedding table any rank touched) -> uniq[0..*count);
- *                         flags_zeroed: V zero ints of scratch, left zeroed.  Same list on every rank.
+ *                         flags_zeroed: V zero ints of scratch, left zeroed.  Same list on every rank.  `count` points at
+ *                         TWO ints (ABI 8): count[0] = length of the list, count[1] = number of keys outside [0, V) other
+ *                         than the padding value -1 (must be 0: such a row would be left out of the exchange).
  *   vault_rows_gather_f32 out[j][0..H) = table[idx[j]][0..H)     (compact image of the touched gradient rows)
  *   vault_rows_scatter_f32 table[idx[j]][0..H) = src[j][0..H)    (the all-reduced rows back into the dense gradient)
  *   vault_sum_chunks_bf16 out[i] = bf16(sum_k f32(src[k * chunk + i])), k = 0..n_src-1 in that order (f32 accumulation of

@@ -69,6 +69,7 @@ def _emulated_backward(spec, state, bn, gelu8=False, inject=None, half="bf16"):
 # the measured values)
 SAME_FORMAT_CLASS_BOUNDS = {"layernorm": 6e-3, "attention q/k": 1.5e-2, "other": 1e-2}
 SAME_FORMAT_DEEP_BOUNDS = {"layernorm": 1.3e-2, "attention q/k": 3e-2, "other": 1.8e-2}     # 12 + 12 layers (see the tests)
+SAME_FORMAT_B48_BOUNDS = {"layernorm": 2.8e-3, "attention q/k": 9.5e-3, "other": 1.5e-2}     # 12 + 12 layers at B = 48: measured + 50 %
 
 
 def _param_class(n):
@@ -862,8 +863,11 @@ def test_full_size_batch_48_forward_backward_vs_oracle():
     assert (tot_err / tot_ref) ** 0.5 < 2.5e-2                         # global relative L2 (1.0 % at B = 2)
     # same number format (8-bit gelu' grid in the ViLT FFN, bf16 gradient stream, bf16 dY / saved operands): the tight bound
     del eng
-    # (at B = 48 the per-sample rounding noise averages out: measured 1.5e-3 globally, inside the 5e-3 of the shallow models)
-    _assert_same_format_gradients(spec, state, bn, "full size B=48", 5e-3, SAME_FORMAT_DEEP_BOUNDS, gelu8=True, mutate=None)
+    # (at B = 48 the per-sample rounding noise averages out: measured 1.5e-3 globally / 1.8e-3, 6.2e-3, 1.0e-2 per class - the
+    #  bounds are measured + 50 %, and they notice a 1 % error injected into ONE data-gradient GEMM of layer 9: the upper
+    #  weight-gradient group (layers 6-11), the 8-bit gelu' path and the 16-bit gradient stream are what carries it down)
+    _assert_same_format_gradients(spec, state, bn, "full size B=48", 2.3e-3, SAME_FORMAT_B48_BOUNDS, gelu8=True,
+                                  mutate="encoder.layer.9.attention.attention.qkv")
 
 
 @pytest.mark.parametrize("B", [2, 48])

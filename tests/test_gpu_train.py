@@ -238,7 +238,21 @@ def test_train_step_on_padded_image_batches_mixed_with_square_ones():
 
 
 
-def _dp_worker(rank, world, port, out_path, kind, nsteps, use_tape, wire, sparse):
+def _dp_spec(kind):
+    """``kind``: "roberta" / "bert" = the tiny test model; "full-width" = hidden 768, FFN 3072, BERTweet's 64,001-row
+    vocabulary, 2 + 2 layers (80 M parameters: several default-size buckets, the real row-sparse table)."""
+    if kind == "full-width":
+        from vault_amd.spec import LMSpec, ViltSpec
+        spec = VaultSpec(vilt=ViltSpec(num_hidden_layers=2), lm=LMSpec.bertweet_base(), n_classes=3)
+        spec.lm.num_hidden_layers = 2
+    else:
+        spec = VaultSpec.tiny(3, kind)
+    spec.lm.hidden_dropout_prob = 0.0
+    spec.lm.attention_probs_dropout_prob = 0.0
+    return spec
+
+
+def _dp_worker(rank, world, port, out_path, kind, nsteps, use_tape, wire, sparse, bucket_mb=0.25, half="bf16"):
     """One data-parallel rank (both ranks share cuda:0; gloo carries the device tensors): its half of every batch."""
     import os
     import torch.distributed as dist
@@ -246,12 +260,11 @@ def _dp_worker(rank, world, port, out_path, kind, nsteps, use_tape, wire, sparse
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
-        spec = VaultSpec.tiny(3, kind)
-        spec.lm.hidden_dropout_prob = 0.0
-        spec.lm.attention_probs_dropout_prob = 0.0
-        eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0), classifier_dropout=0.0)
-        step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10, use_tape=use_tape, bucket_mb=0.25,
-                         wire=wire, sparse_embedding=sparse)
+        spec = _dp_spec(kind)
+        eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0), classifier_dropout=0.0, half=half)
+        kw = {} if bucket_mb is None else dict(bucket_mb=bucket_mb)          # None: TrainStep's default (64 MB)
+        step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10, use_tape=use_tape,
+                         wire=wire, sparse_embedding=sparse, **kw)
         assert step.world == world and step.reducer is not None and ops.GEMM_SCHED == 3
         assert (step.reducer.sparse is not None) == sparse and step.reducer.wire == wire
         losses, wire_bytes = [], []
@@ -262,7 +275,9 @@ def _dp_worker(rank, world, port, out_path, kind, nsteps, use_tape, wire, sparse
             losses.append(float(step(db, torch.from_numpy(bn["labels"][lo:hi]).cuda())))
             wire_bytes.append(step.reducer.wire_bytes)
         torch.cuda.synchronize()
-        torch.save({"p": eng.params.p.cpu(), "losses": losses, "wire_bytes": wire_bytes, "n_train": eng.params.n_train},
+        torch.save({"p": eng.params.p.cpu(), "losses": losses, "wire_bytes": wire_bytes, "n_train": eng.params.n_train,
+                    "launched": len(step.reducer.launched) if step.reducer.launched else None,
+                    "bucket_elems": step.reducer.bucket_elems, "union_waits": step.reducer.union_waits},
                    f"{out_path}.{rank}")
     finally:
         dist.destroy_process_group()
@@ -326,13 +341,14 @@ def test_exchange_kernels_match_their_host_restatements():
     keys = torch.randint(0, V, (n,), generator=g, dtype=torch.int64)
     keys[::7] = 1
     keys[5], keys[6] = -3, V + 2                                 # outside the table: ignored
-    flags_h, uniq_h, cnt_h = torch.zeros(V, dtype=torch.int32), torch.zeros(n, dtype=torch.int64), torch.zeros(1, dtype=torch.int32)
+    flags_h, uniq_h, cnt_h = torch.zeros(V, dtype=torch.int32), torch.zeros(n, dtype=torch.int64), torch.zeros(2, dtype=torch.int32)
     HK.rows_union(keys, n, V, flags_h, uniq_h, cnt_h)
     flags_d = torch.zeros(V, dtype=torch.int32, device="cuda"); uniq_d = torch.zeros(n, dtype=torch.int64, device="cuda")
-    cnt_d = torch.zeros(1, dtype=torch.int32, device="cuda")
+    cnt_d = torch.zeros(2, dtype=torch.int32, device="cuda")
     for _ in range(2):                                           # (the scratch flags are left zeroed: second call equal)
         DK.rows_union(keys.cuda(), n, V, flags_d, uniq_d, cnt_d)
-        U = int(cnt_d.item())
+        U = int(cnt_d[0].item())
+        assert int(cnt_d[1].item()) == int(cnt_h[1]) == 2           # the two ids outside the table are counted (-1 would not be)
         assert U == int(cnt_h[0]) and torch.equal(uniq_d[:U].cpu(), uniq_h[:U]) and int(flags_d.abs().sum()) == 0
     table = torch.randn(V, H, generator=g)
     td = table.cuda()
@@ -548,3 +564,43 @@ def test_bench_refuses_two_ranks_on_the_one_gpu_box():
     from .test_host import _bench_refusal
     have = _bench_refusal()
     assert have >= 1
+
+
+@pytest.mark.parametrize("wire,half", [("fp32", "bf16"), ("bf16", "bf16"), ("fp32", "fp16")])
+def test_data_parallel_full_width_default_buckets(tmp_path, wire, half):
+    """The data-parallel step at FULL WIDTH with the DEFAULT bucket size: hidden 768, FFN 3072, the 64,001 x 768 word-embedding
+    table exchanged row-sparse, 2 + 2 layers (80 M gradient elements = five 64 MB buckets launched from inside backward, the
+    split optimizer pass over the already reduced upper range), two ranks on the one GPU over gloo, both wire formats and the
+    fp16 operand build (scaled gradients on the wire, divided out in the optimizer): replicas bit-identical, parameters where
+    ONE process stepping the global batch lands."""
+    import torch.multiprocessing as mp
+    nsteps, world = 2, 2
+    out = str(tmp_path / "dpfw")
+    port = 29700 + (1 if wire == "bf16" else 0) + (2 if half == "fp16" else 0)
+    mp.spawn(_dp_worker, args=(world, port, out, "full-width", nsteps, True, wire, True, None, half), nprocs=world, join=True)
+    rs = [torch.load(out + f".{r}") for r in range(world)]
+    assert torch.equal(rs[0]["p"], rs[1]["p"])                                   # replicas stay bit-identical
+    assert rs[0]["bucket_elems"] == 64 * 1024 * 1024 // 4                        # the default bucket size was in force
+    dense_fp32 = 2 * 4 * rs[0]["n_train"] * (world - 1) // world
+    print(f"full width, {wire} wire, {half} operands: bytes per step and rank {rs[0]['wire_bytes']} (dense f32 all-reduce: "
+          f"{dense_fp32}); host waits for the row union: {rs[0]['union_waits']}")
+    # the word-embedding table is 61 % of this model's gradient; 2 ranks x 4 x 40 token ids touch <= 320 of its 64,001 rows
+    assert max(rs[0]["wire_bytes"]) < (0.45 if wire == "fp32" else 0.25) * dense_fp32
+    spec = _dp_spec("full-width")
+    eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0), classifier_dropout=0.0, half=half)
+    step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10, use_tape=False)
+    ref_losses = []
+    for i in range(nsteps):
+        bn = synthetic_batch(spec, 8, seed=90 + i, n_classes=3)
+        db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
+        ref_losses.append(float(step(db, torch.from_numpy(bn["labels"]).cuda())))
+    torch.cuda.synchronize()
+    for i, c in enumerate(ref_losses):
+        mean_local = sum(r["losses"][i] for r in rs) / world
+        assert abs(mean_local - c) < 5e-4, (mean_local, c)
+    d = (rs[0]["p"] - eng.params.p.cpu()).abs()
+    print(f"  against one process on the global batch: mean |dp| {float(d.mean()):.2e}, share above 2e-5: {float((d > 2e-5).float().mean()):.4f}")
+    if wire == "fp32":
+        assert float(d.mean()) < 2e-6 and float((d > 1e-5).float().mean()) < 0.03
+    else:
+        assert float(d.mean()) < 4e-6 and float((d > 2e-5).float().mean()) < 0.03

@@ -252,9 +252,11 @@ class HostKernels:
 
     @staticmethod
     def rows_union(keys, n, V, flags, uniq, count):
-        u = torch.unique(keys[:n][(keys[:n] >= 0) & (keys[:n] < V)])
+        k = keys[:n]
+        u = torch.unique(k[(k >= 0) & (k < V)])
         uniq[:u.numel()].copy_(u)
         count[0] = u.numel()
+        count[1] = int((((k < 0) | (k >= V)) & (k != -1)).sum())
 
     @staticmethod
     def rows_gather(table, idx, n_rows, H, out):
@@ -367,13 +369,57 @@ def _dp_worker(rank, world, port, q):
             else:
                 ok[f"sparse table {wire} x{rep}"] = float((g5 - dense).abs().max()) <= 2.0 ** -7 * float(dense.abs().max())
             ok[f"sparse table {wire} x{rep}: bytes"] = r5.wire_bytes < (4 if wire == "fp32" else 2) * n
-        # a step without token ids (inputs_embeds): the table's gradient is zero everywhere, nothing is exchanged for it
+        # a SHORT batch on one rank (fewer token ids than the count agreed on in the first step): padded with -1, same result
         g5.zero_()
-        r5.begin_step(None)
+        g5[1000:] = torch.arange(n - 1000, dtype=torch.float32) * (rank + 1)
+        short = ids[:2] if rank == 1 else ids
+        tab[short] = torch.arange(H, dtype=torch.float32) + 10.0 * (rank + 1)
+        dense = g5.clone()
+        dist.all_reduce(dense)
+        r5.begin_step(short)
         for tag in ["head", "vilt_embed", "lm0", "lm_embed"]:
             r5.on_stage(tag)
         r5.finish()
-        ok[f"sparse table {wire}: no ids"] = float(g5.abs().max()) == 0.0
+        ok[f"sparse table {wire}: short batch"] = (bool(torch.equal(g5, dense)) if wire == "fp32" else
+                                                   float((g5 - dense).abs().max()) <= 2.0 ** -7 * float(dense.abs().max()))
+        # more ids than agreed on, or a switch to inputs_embeds: the rank that sees it raises (before any collective)
+        for bad_keys in (torch.cat([ids, ids]), None):
+            try:
+                r5.begin_step(bad_keys)
+                ok[f"sparse table {wire}: raises {bad_keys is None}"] = False
+            except RuntimeError:
+                ok[f"sparse table {wire}: raises {bad_keys is None}"] = True
+        # a token id outside the table: its row would be left out of the union - raised when the table is exchanged, and
+        # the reducer is usable again afterwards (finish() resets before it raises)
+        r5.begin_step(torch.tensor([3, V + 5, 1, 0], dtype=torch.int64))
+        try:
+            for tag in ["head", "vilt_embed", "lm0", "lm_embed"]:
+                r5.on_stage(tag)
+            ok[f"sparse table {wire}: out-of-range id"] = False
+        except RuntimeError as e:
+            ok[f"sparse table {wire}: out-of-range id"] = "outside the table" in str(e)
+        try:
+            r5.finish()
+        except RuntimeError:
+            pass
+        ok[f"sparse table {wire}: reset after error"] = (r5.hi, r5.bottom, r5.launched) == (n, 0, [])
+        # a reducer whose steps carry no token ids on ANY rank (inputs_embeds): the table's gradient is zero everywhere,
+        # nothing is exchanged for it
+        g6 = torch.zeros(n)
+        r6 = BucketReducer(g6, lo5, "lm_embed", bucket_elems=2500, dist=dist, wire=wire, sparse=sp, kernels=HostKernels)
+        r6.begin_step(None)
+        for tag in ["head", "vilt_embed", "lm0", "lm_embed"]:
+            r6.on_stage(tag)
+        r6.finish()
+        ok[f"sparse table {wire}: no ids"] = float(g6.abs().max()) == 0.0
+    # ranks that disagree on the token count of the first step: every rank raises instead of hanging in the all-gather
+    g7 = torch.zeros(n)
+    r7 = BucketReducer(g7, lo5, "lm_embed", bucket_elems=2500, dist=dist, sparse=sp, kernels=HostKernels)
+    try:
+        r7.begin_step(torch.zeros(4 + rank, dtype=torch.int64))
+        ok["first-step mismatch raises"] = False
+    except RuntimeError as e:
+        ok["first-step mismatch raises"] = "disagree" in str(e)
     q.put((rank, all(ok.values()), [k for k, v in ok.items() if not v], launched))
     dist.destroy_process_group()
 

@@ -9,11 +9,15 @@
 
 namespace {
 
+// keys equal to -1 are padding (a rank with fewer tokens than its declared capacity); any other key outside [0, V) is an
+// error of the caller that would leave a touched row out of the union (each rank would keep its own local gradient for
+// it: silently diverging replicas) - counted in *bad, the host raises
 __global__ __launch_bounds__(256) void mark_rows_kernel(const long long* __restrict__ keys, long long n, int V,
-                                                        int* __restrict__ flags) {
+                                                        int* __restrict__ flags, int* __restrict__ bad) {
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256ll) {
     const long long k = keys[i];
     if (k >= 0 && k < V) flags[k] = 1;    // (benign race: every writer stores the same value)
+    else if (k != -1) atomicAdd(bad, 1);
   }
 }
 
@@ -87,7 +91,9 @@ extern "C" int vault_rows_union(const long long* keys, long long n_keys, int V, 
                                 int* count, void* stream) {
   if (!keys || !flags_zeroed || !uniq || !count || n_keys <= 0 || V <= 0) return VAULT_EINVAL;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(mark_rows_kernel, dim3(grid_for(n_keys)), dim3(256), 0, s, keys, n_keys, V, flags_zeroed);
+  hipError_t e = hipMemsetAsync(count + 1, 0, sizeof(int), s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(mark_rows_kernel, dim3(grid_for(n_keys)), dim3(256), 0, s, keys, n_keys, V, flags_zeroed, count + 1);
   hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), 0, s, flags_zeroed, V, uniq, count);
   return (int)hipGetLastError();
 }

@@ -140,6 +140,9 @@ class BucketReducer:
         self._scratch: Dict[str, torch.Tensor] = {}
         self._union_ready = None
         self._n_keys = 0
+        self._key_capacity = None   # per-rank key count agreed on in the first step (begin_step)
+        self._keys_given = None
+        self.union_waits = 0        # steps in which the host had to WAIT for the union (diagnostics: expected 0)
 
     # ---- plumbing -------------------------------------------------------------------------------------------
     def _buf(self, name: str, n: int, dtype) -> torch.Tensor:
@@ -220,21 +223,49 @@ class BucketReducer:
     def begin_step(self, keys: Optional[torch.Tensor]):
         """Start of a step: ``keys`` = this rank's token ids (int64, any shape; None: this step touches no row of the table,
         on EVERY rank alike).  Their all-gather and the union run on the communication stream at once; the host reads the
-        union's size only when the table's gradient is final (``_exchange_table``)."""
+        union's size only when the table's gradient is final (``_exchange_table``).
+
+        The all-gather needs the SAME key count on every rank and every rank to agree on ids-or-none: the first step
+        exchanges (count, has-keys) between the ranks and raises on a mismatch (one host synchronisation, once); the count
+        of that step is the capacity afterwards - a later, smaller batch is padded with -1 (ignored by the union), a larger
+        one or a switch between ids and ``inputs_embeds`` raises on the rank that sees it."""
         self.wire_bytes = 0
         self._union_ready, self._n_keys = None, 0
-        if self.sparse is None or keys is None:
+        if self.sparse is None:
             return
+        n_local = 0 if keys is None else int(keys.numel())
+        if self._key_capacity is None:
+            hdr = torch.tensor([n_local, 0 if keys is None else 1], dtype=torch.int64, device=self.g.device)
+            allh = [torch.zeros_like(hdr) for _ in range(self.world)]
+            self.dist.all_gather(allh, hdr, group=self.group)
+            rows = [tuple(int(v) for v in h.cpu()) for h in allh]
+            if any(r != rows[0] for r in rows):
+                raise RuntimeError(f"row-sparse embedding exchange: the ranks disagree on (token count, ids given): {rows} - "
+                                   "every rank must step the same per-rank batch shape (or pass sparse_embedding=False)")
+            self._key_capacity, self._keys_given = n_local, keys is not None
+        if (keys is not None) != self._keys_given:
+            raise RuntimeError("row-sparse embedding exchange: this rank switched between token ids and inputs_embeds "
+                               "(the other ranks cannot know: construct the TrainStep with sparse_embedding=False)")
+        if keys is None:
+            return
+        if n_local > self._key_capacity:
+            raise RuntimeError(f"row-sparse embedding exchange: {n_local} token ids exceed the {self._key_capacity} per rank "
+                               "agreed on in the first step")
         keys = keys.reshape(-1)
-        n = keys.numel()
+        n = self._key_capacity
+        if n_local < n:                                        # a short (last) batch: pad with -1, ignored by the union
+            padded = self._buf("keys_local", n, torch.int64)
+            padded[:n_local].copy_(keys)
+            padded[n_local:].fill_(-1)
+            keys = padded
         W, V = self.world, self.sparse.rows
         allk = self._buf("keys", n * W, torch.int64)
         flags = self._buf("flags", V, torch.int32)
         uniq = self._buf("uniq", min(V, n * W), torch.int64)
-        cnt = self._buf("count", 1, torch.int32)
+        cnt = self._buf("count", 2, torch.int32)               # [distinct rows, keys outside the table]
         host = self._scratch.get("count_host")
         if host is None:
-            host = torch.zeros(1, dtype=torch.int32)
+            host = torch.zeros(2, dtype=torch.int32)
             if self.comm_stream is not None:
                 host = host.pin_memory()
             self._scratch["count_host"] = host
@@ -252,9 +283,15 @@ class BucketReducer:
         sp = self.sparse
         if self._n_keys == 0:
             return                                            # no row touched on any rank: the gradient is zero everywhere
-        if self._union_ready is not None:
-            self._union_ready.synchronize()                   # (enqueued at the start of the step: long done)
-        U = int(self._scratch["count_host"][0])
+        if self._union_ready is not None and not self._union_ready.query():
+            # (enqueued at the start of the step: normally long done - the host only blocks, and counts it, when the
+            #  first collective of the step was slow)
+            self.union_waits += 1
+            self._union_ready.synchronize()
+        U, bad = int(self._scratch["count_host"][0]), int(self._scratch["count_host"][1])
+        if bad:
+            raise RuntimeError(f"row-sparse embedding exchange: {bad} token ids lie outside the table's {sp.rows} rows - their "
+                               "gradient rows would be left un-reduced (replicas would diverge)")
         if U == 0:
             return
         table = self.g[sp.lo:sp.hi]
@@ -318,10 +355,11 @@ class BucketReducer:
     def finish(self):
         self._wait(self.done)
         self.done.clear()
-        if self.hi != self.bottom:
-            raise RuntimeError("gradient range [%d, %d) was never reduced" % (self.bottom, self.hi))
-        self.hi, self.bottom, self.min_seen = self.n, 0, self.n
+        missing = (self.bottom, self.hi) if self.hi != self.bottom else None
+        self.hi, self.bottom, self.min_seen = self.n, 0, self.n      # (reset first: the reducer stays usable after the error)
         self.launched.clear()
+        if missing is not None:
+            raise RuntimeError("gradient range [%d, %d) was never reduced" % missing)
 
 
 class TrainStep:
