@@ -78,6 +78,31 @@ int vault_gemm(const vault_gemm_args* args, void* stream);
 /* the kernel / tile configuration vault_gemm would run these arguments on (the resolved `cfg`, 0..7), or -EINVAL */
 int vault_gemm_plan(const vault_gemm_args* args);
 
+/* ---- grouped weight gradients (ABI 8) ---------------------------------------------------------------------------
+ * dW_k,l[n_out x n_in] (+)= dY_k,l[tokens x n_out]^T . X_k,l[tokens x n_in] for up to three KINDS k of Linear (FFN-out,
+ * FFN-in, attention-out, QKV: autograd of HF:models/vilt/modeling_vilt.py:303-414 under ref: vault/tmsc_utils/trainer.py:365)
+ * and the layers l of a stack in ONE launch.  Every 256 x 256 output tile costs the same whatever its kind (the contraction
+ * runs over the tokens), so a launch is sized by ITEMS, not by kinds: a segment names a run [first, first + count) of its
+ * kind's tiles in (layer-major, tile-minor) order, and e.g. the 216 FFN-out tiles of six layers + 40 attention-out tiles
+ * fill the 256 CUs exactly once, where one launch per kind fills 84 % of them.  n_out, n_in multiples of 256, tokens a
+ * multiple of 64 (zero rows beyond the valid ones contribute nothing); `splits` > 1 cuts the contraction of EVERY item
+ * (partial sums by float atomics); accumulate = 0 with splits = 1 stores instead of adding (dW known to be zero / dead).
+ * layer l of a kind: dy + l * batch_dy, x + l * batch_x (16-bit elements), dw + l * batch_dw (floats). */
+typedef struct vault_wgrad_seg {
+  const void* dy; const void* x; float* dw;
+  int n_out, n_in, ld_dy, ld_x, ld_dw;
+  int batch;       /* layers of this kind */
+  int first, count;
+  long long batch_dy, batch_x, batch_dw;
+} vault_wgrad_seg;
+typedef struct vault_wgrad_grouped_args {
+  int nseg;
+  vault_wgrad_seg seg[3];
+  int tokens, splits, accumulate;
+  int persist;     /* as vault_gemm_args.persist */
+} vault_wgrad_grouped_args;
+int vault_wgrad_grouped(const vault_wgrad_grouped_args* args, void* stream);
+
 /* ---- MXFP8 forward GEMM (BASELINE config "fp8 MFMA forward, bf16 backward") -------------------------------------
  * OCP microscaling format: e4m3 elements [rows][K] (K contiguous) + one E8M0 scale byte per 32 consecutive k,
  * [rows][K/32].  vault_quant_mxfp8 converts a bf16 operand (activations of the forward pass, bf16 weight shadow):

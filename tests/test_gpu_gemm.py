@@ -519,3 +519,43 @@ def test_small_launches_take_64_row_tiles():
     dW = torch.zeros(768, 768, device="cuda")
     assert _gemm(dY, X, dW, 768, 768, 512, 768, 768, 768, 1, 1, EPI_ATOMIC, plan_only=True) != 7
     assert _gemm(dY, X, dW, 768, 768, 512, 768, 768, 768, 1, 1, EPI_ATOMIC, cfg=7, plan_only=True) < 0
+
+
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
+@pytest.mark.parametrize("splits,accumulate", [(1, 0), (1, 1), (3, 1)])
+def test_grouped_weight_gradients_against_matmul(half, splits, accumulate):
+    """vault_wgrad_grouped: three kinds of weight gradient (different n_out / n_in, two layers each, layers at a stride) cut
+    into segments that start and end in the middle of a layer, in two launches that together cover every tile exactly once:
+    dW = dY^T X against a float matmul of the same 16-bit operands; tiles outside a launch's segments stay untouched."""
+    from vault_amd import ops
+    dt = ops.HALF_DTYPE[half]
+    tokens, G = 448, 2                       # 7 K tiles: the 3-way split is ragged (3 + 3 + 1)
+    kinds = [(512, 768), (768, 256), (256, 256)]        # (n_out, n_in): 6, 3, 1 tiles per layer
+    dys = [(_rand(G, tokens, no, seed=10 + k) * 0.5).to(dt) for k, (no, ni) in enumerate(kinds)]
+    xs = [(_rand(G, tokens, ni, seed=20 + k) * 0.5).to(dt) for k, (no, ni) in enumerate(kinds)]
+    # dW of a kind's layers at a stride larger than the matrix (the flat gradient buffer's layout)
+    pads = [no * ni + 1024 for no, ni in kinds]
+    base = 0.25 if accumulate else 0.0
+    dws = [torch.full((G, pads[k]), base, device="cuda") for k in range(3)]
+    tiles = [(no // 256) * (ni // 256) * G for no, ni in kinds]          # 12, 6, 2 items
+    # launch 1: kind 0 items 0..8, kind 1 items 0..1; launch 2: kind 0 items 9..11, kind 1 items 2..5, kind 2 all
+    plan = [[(0, 0, 9), (1, 0, 2)], [(0, 9, 3), (1, 2, 4), (2, 0, 2)]]
+    with ops.operand_format(half):
+        for segs in plan:
+            args = [dict(dy=dys[k][0], x=xs[k][0], dw=dws[k][0], n_out=kinds[k][0], n_in=kinds[k][1], batch=G, first=f, count=c,
+                         batch_dy=dys[k].stride(0), batch_x=xs[k].stride(0), batch_dw=pads[k]) for k, f, c in segs]
+            ops.wgrad_grouped(args, tokens, splits=splits, accumulate=accumulate)
+    torch.cuda.synchronize()
+    assert sum(c for segs in plan for _, _, c in segs) == sum(tiles)
+    for k, (no, ni) in enumerate(kinds):
+        for l in range(G):
+            ref = dys[k][l].float().t() @ xs[k][l].float() + base
+            got = dws[k][l, :no * ni].view(no, ni)
+            err = float((got - ref).abs().max())
+            assert err <= 2e-3 * float(ref.abs().max()), (k, l, err)
+            assert float((dws[k][l, no * ni:] - base).abs().max()) == 0.0        # the padding behind the matrix is untouched
+    # a segment that reaches beyond its kind's tiles is refused
+    with pytest.raises(RuntimeError):
+        with ops.operand_format(half):
+            ops.wgrad_grouped([dict(dy=dys[2][0], x=xs[2][0], dw=dws[2][0], n_out=256, n_in=256, batch=G, first=1, count=2,
+                                    batch_dy=dys[2].stride(0), batch_x=xs[2].stride(0), batch_dw=pads[2])], tokens)

@@ -84,6 +84,7 @@ def test_ctypes_structures_match_the_c_header(tmp_path):
              "vault_lm_embed_args": ops.LmEmbedArgs, "vault_text_embed_args": ops.TextEmbedArgs,
              "vault_patch_embed_args": ops.PatchEmbedArgs, "vault_head_loss_args": ops.HeadLossArgs,
              "vault_model_dims": ops.ModelDims, "vault_image_desc": preprocess.ImageDesc,
+             "vault_wgrad_seg": ops.WgradSeg, "vault_wgrad_grouped_args": ops.WgradGroupedArgs,
              "vault_preprocess_args": preprocess.PreprocessArgs}
     hdr = os.path.join(ROOT, "include", "vault_hip.h")
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{hdr}"', 'int main(void) {']

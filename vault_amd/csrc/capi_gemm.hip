@@ -44,6 +44,28 @@ extern "C" int vault_gemm_mxfp8(const vault_gemm_args* a, const void* a_scale, c
   return vault_gemm_mx8_launch(params_of(a), a_scale, b_scale, a->epi, reinterpret_cast<hipStream_t>(stream));
 }
 
+extern "C" int vault_wgrad_grouped(const vault_wgrad_grouped_args* a, void* stream) {
+  if (a == nullptr || a->nseg < 1 || a->nseg > 3 || a->tokens <= 0 || (a->tokens & 63)) return VAULT_EINVAL;
+  GemmParams p{};
+  p.K = a->tokens;
+  p.splits = a->splits > 0 ? a->splits : 1;
+  p.accumulate = a->accumulate;
+  p.persist = a->persist;
+  p.nseg = a->nseg;
+  for (int k = 0; k < a->nseg; ++k) {
+    const vault_wgrad_seg& g = a->seg[k];
+    if (g.n_out <= 0 || g.n_in <= 0 || (g.n_out & 255) || (g.n_in & 255) || g.batch < 1) return VAULT_EINVAL;
+    GemmParams::Seg& t = p.seg[k];
+    t.A = reinterpret_cast<const h16*>(g.dy); t.B = reinterpret_cast<const h16*>(g.x); t.out = g.dw;
+    t.tiles_n = g.n_in / 256; t.tiles = (g.n_out / 256) * t.tiles_n;
+    t.lda = g.ld_dy; t.ldb = g.ld_x; t.ldo = g.ld_dw;
+    t.first = g.first; t.count = g.count;
+    if (g.first < 0 || g.count < 1 || g.first + g.count > t.tiles * g.batch) return VAULT_EINVAL;
+    t.batch_a = g.batch_dy; t.batch_b = g.batch_x; t.batch_o = g.batch_dw;
+  }
+  return vault_gemm256_grouped_launch(p, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int vault_abi_version(void) { return 8; }
 #ifdef VAULT_F16
 extern "C" int vault_operand_format(void) { return 1; }

@@ -48,6 +48,20 @@ struct GemmParams {
   int batch;
   long long batch_a, batch_b, batch_o;
   int aux_u8;       // 8-wave kernel only: gelu' (out2 of EPI_BF16_GELU, aux of EPI_BF16_DGELU) is the 8-bit tile-native form
+  // Grouped weight gradients (ring kernel, (1,1) operand modes, EPI_F32_ATOMIC): ONE launch over up to three segments of
+  // DIFFERENT weight-gradient kinds that share the contraction (the tokens) and therefore the cost per 256 x 256 tile: the
+  // work list is their concatenation, so a launch can be sized to exactly one round of the 256 CUs (e.g. the 216 FFN-out
+  // tiles of six layers + 40 attention-out tiles) instead of one partial round per kind.  nseg == 0: a plain launch.
+  int nseg;
+  struct Seg {
+    const h16* A;                     // dY of the kind's first problem, [tokens][lda]
+    const h16* B;                     // X of the kind's first problem, [tokens][ldb]
+    float* out;                       // dW of the kind's first problem, [M][ldo]
+    int tiles_n, tiles;               // 256-wide tiles per row of tiles / per problem
+    int lda, ldb, ldo;
+    int first, count;                 // items [first, first + count) of the kind's (problem-major, tile-minor) numbering
+    long long batch_a, batch_b, batch_o;   // element strides between the kind's problems (layers)
+  } seg[3];
 };
 
 #ifdef __HIPCC__
@@ -76,3 +90,4 @@ __device__ __forceinline__ void gemm_tile_of_block(int nwg, int id, int tiles_m,
 #endif
 
 int vault_gemm_launch(const GemmParams& p, int a_mode, int b_mode, int epi, int cfg, hipStream_t st);
+int vault_gemm256_grouped_launch(const GemmParams& p, hipStream_t st);

@@ -93,7 +93,14 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   // (batched weight gradients, EPI_F32_ATOMIC: `batch` problems of one shape, problem-major in the work list - the
   //  XCD-contiguous renumbering then gives an XCD whole problems, so a problem's panels fill ONE L2)
   const int nbatch = (EPI == EPI_F32_ATOMIC && p.batch > 1) ? p.batch : 1;
-  const int nwork = ntiles * p.splits * nbatch;
+  // grouped weight gradients (GemmParams::seg): the list is the concatenation of the segments' items, z-major as below
+  bool grouped = false;
+  int seg_total = 0;
+  if constexpr (EPI == EPI_F32_ATOMIC && A_MODE == 1 && B_MODE == 1) {
+    grouped = p.nseg > 0;
+    seg_total = p.seg[0].count + (p.nseg > 1 ? p.seg[1].count : 0) + (p.nseg > 2 ? p.seg[2].count : 0);
+  }
+  const int nwork = grouped ? seg_total * p.splits : ntiles * p.splits * nbatch;
   const int nk_total = p.K >> 6;
   const int per = (nk_total + p.splits - 1) / p.splits;
 
@@ -101,6 +108,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   //      per wave per half-tile
   int m0, n0, nk;
   float* out_cur = reinterpret_cast<float*>(p.out);   // EPI_F32_ATOMIC: this work item's problem (batched launches)
+  int ldo_cur = p.ldo, mvalid_cur = p.m_valid;        // ... and its output geometry (grouped launches)
   const char* a_base;
   const char* b_base;
   uint32_t a_off[4], b_off[4];
@@ -109,7 +117,63 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   else { a_half = 128u; a_step = 64u * p.lda * 2u; }
   if constexpr (B_MODE == 0) { b_half = (uint32_t)(NTQ * 16) * p.ldb * 2u; b_step = 128u; }
   else { b_half = (uint32_t)(NTQ * 16) * 2u; b_step = 64u * p.ldb * 2u; }
+  // per-lane staging offsets of the four 1-KiB pieces per half-tile (they depend on the leading dimensions: recomputed
+  // per work item in grouped launches, from an opaque copy of the lane id so that nothing extra stays live)
+  auto lane_offsets = [&](int lda_, int ldb_) {
+    const int ln_ = lane_id_volatile();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = wave * 4 + i;
+      const int r8 = ln_ >> 3, r = 8 * j + r8;
+      const int c = (ln_ & 7) ^ (((r8 >> 1) & 3) << 1);
+      const int krow = 4 * j + (ln_ >> 4), pos16 = ln_ & 15;
+      const int hk = (krow & 3) | (((krow >> 3) & 1) << 2);
+      const int cb = (pos16 >> 1) ^ hk;
+      if constexpr (A_MODE == 0) a_off[i] = (uint32_t)(((r >> 6) * 128 + (r & 63)) * lda_ + c * 8) * 2u;
+      else a_off[i] = (uint32_t)(krow * lda_ + (cb >> 2) * 128 + (cb & 3) * 16 + (pos16 & 1) * 8) * 2u;
+      if constexpr (B_MODE == 0) {
+        // half-tile image: 2 wave-columns x NTQ*16 rows of 128 B; piece jb = wave*PB + i covers rows 8jb..8jb+7
+        const int jb = wave * PB + (i < PB ? i : PB - 1), rb = 8 * jb + r8;
+        const int wcol = rb / (NTQ * 16), within = rb - wcol * (NTQ * 16);
+        b_off[i] = (uint32_t)((wcol * (NTQ * 32) + within) * ldb_ + c * 8) * 2u;
+      } else {
+        // [64 k][8 col-blocks of 16] image, blocks wc*4 + nt; nt >= NTQ slots are never read: clamp their source
+        const int ntc = min(cb & 3, NTQ - 1);
+        b_off[i] = (uint32_t)(krow * ldb_ + (cb >> 2) * (NTQ * 32) + ntc * 16 + (pos16 & 1) * 8) * 2u;
+      }
+    }
+  };
   auto setup = [&](int w) {
+    if constexpr (EPI == EPI_F32_ATOMIC && A_MODE == 1 && B_MODE == 1) {
+      if (grouped) {
+        const int lin = gemm_xcd_contiguous(nwork, w);
+        const int z = lin / seg_total;
+        int r = lin - z * seg_total;
+        // segment of list position r (uniform selects: no dynamic indexing of the kernel argument)
+        const int c0 = p.seg[0].count, c1 = (p.nseg > 1) ? p.seg[1].count : 0;
+        const int si = (r < c0) ? 0 : ((r < c0 + c1) ? 1 : 2);
+        r -= (si == 0) ? 0 : (si == 1 ? c0 : c0 + c1);
+#define SEGF(F) ((si == 0) ? p.seg[0].F : ((si == 1) ? p.seg[1].F : p.seg[2].F))
+        const int idx = SEGF(first) + r, tiles_k = SEGF(tiles), tn_k = SEGF(tiles_n);
+        const int bz = idx / tiles_k, tl = idx - bz * tiles_k;
+        const int lda_ = SEGF(lda), ldb_ = SEGF(ldb);
+        const h16* pA = SEGF(A) + (size_t)bz * SEGF(batch_a);
+        const h16* pB = SEGF(B) + (size_t)bz * SEGF(batch_b);
+        out_cur = SEGF(out) + (size_t)bz * SEGF(batch_o);
+        ldo_cur = SEGF(ldo);
+        mvalid_cur = (tiles_k / tn_k) << 8;            // every row of the kind's dW exists
+#undef SEGF
+        const int tile_m = tl / tn_k, tile_n = tl - tile_m * tn_k;
+        m0 = tile_m << 8; n0 = tile_n << 8;
+        const int kt0 = z * per;
+        nk = min(nk_total, kt0 + per) - kt0;
+        a_step = 64u * (uint32_t)lda_ * 2u; b_step = 64u * (uint32_t)ldb_ * 2u;
+        lane_offsets(lda_, ldb_);
+        a_base = reinterpret_cast<const char*>(pA + (size_t)kt0 * 64 * lda_ + m0);
+        b_base = reinterpret_cast<const char*>(pB + (size_t)kt0 * 64 * ldb_ + n0);
+        return;
+      }
+    }
     // the XCD-contiguous renumbering runs over the WHOLE work list (z-major): with split-K an XCD then works on
     // one or two K ranges only, so the A / B panels of a range are fetched into one or two L2s instead of all
     // eight (weight gradients, 36 tiles x 7 splits: L2 fill 970 -> ~460 MB per launch by this count)
@@ -151,27 +215,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   const bool dyn = (p.persist & 1) != 0;   // dynamic hand-out of work items (else: block b walks b, b + grid, ...)
   unsigned int* const tickets = g_ring_tickets[(p.persist >> 8) & 1];   // bit 8: launch parity (set by the launcher)
   if (dyn && blockIdx.x == 0 && tid < 8) g_ring_tickets[((p.persist >> 8) & 1) ^ 1][tid] = 0u;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = wave * 4 + i;
-    const int r8 = lane >> 3, r = 8 * j + r8;
-    const int c = (lane & 7) ^ (((r8 >> 1) & 3) << 1);
-    const int krow = 4 * j + (lane >> 4), pos16 = lane & 15;
-    const int hk = (krow & 3) | (((krow >> 3) & 1) << 2);
-    const int cb = (pos16 >> 1) ^ hk;
-    if constexpr (A_MODE == 0) a_off[i] = (uint32_t)(((r >> 6) * 128 + (r & 63)) * p.lda + c * 8) * 2u;
-    else a_off[i] = (uint32_t)(krow * p.lda + (cb >> 2) * 128 + (cb & 3) * 16 + (pos16 & 1) * 8) * 2u;
-    if constexpr (B_MODE == 0) {
-      // half-tile image: 2 wave-columns x NTQ*16 rows of 128 B; piece jb = wave*PB + i covers rows 8jb..8jb+7
-      const int jb = wave * PB + (i < PB ? i : PB - 1), rb = 8 * jb + r8;
-      const int wcol = rb / (NTQ * 16), within = rb - wcol * (NTQ * 16);
-      b_off[i] = (uint32_t)((wcol * (NTQ * 32) + within) * p.ldb + c * 8) * 2u;
-    } else {
-      // [64 k][8 col-blocks of 16] image, blocks wc*4 + nt; nt >= NTQ slots are never read: clamp their source
-      const int ntc = min(cb & 3, NTQ - 1);
-      b_off[i] = (uint32_t)(krow * p.ldb + (cb >> 2) * (NTQ * 32) + ntc * 16 + (pos16 & 1) * 8) * 2u;
-    }
-  }
+  if (!grouped) lane_offsets(p.lda, p.ldb);
 
   // one 1-KiB piece (i = 0..3) of a half-tile; a half-tile is 4 pieces per wave
   // The per-lane offset passes through an opaque move at every use: hipcc otherwise hoists its 64-bit
@@ -398,6 +442,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
 
     const int em0 = m0, en0 = n0;
     float* const eout = out_cur;
+    const int eldo = ldo_cur, emvalid = mvalid_cur;
     // ---- next work item: own XCD's ticket, else steal; broadcast through LDS
     int* sched_lds = reinterpret_cast<int*>(smem + 2 * BUFB + SCRATCH_BYTES);
     if (!dyn) {
@@ -454,6 +499,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     if constexpr (EPI == EPI_F32_ATOMIC) {
       GemmParams pe = p;
       pe.out = eout;   // (the tile being written belongs to the previous work item's problem)
+      pe.ldo = eldo; pe.m_valid = emvalid;
       gemm_epilogue<8, TN, EPI, 2, 2, true>(acc, pe, smem + 2 * BUFB, em0, en0, wr * 128, wc * (NTQ * 32), wave, lane,
                                             [&](int step) { if (more) stage_first(step); }, more ? 4 : 0);
     } else {
@@ -461,7 +507,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
                                             [&](int step) { if (more) stage_first(step); }, more ? 4 : 0);
     }
     if (!more) break;
-    behind_stores = (em0 + 256 <= p.m_valid);
+    behind_stores = (em0 + 256 <= emvalid);
     w = wnext;
   }
 #undef HALF_A
@@ -559,6 +605,50 @@ int dispatch256(const GemmParams& p, int a_mode, int b_mode, int epi, hipStream_
 }
 
 }  // namespace
+
+// Grouped weight gradients (GemmParams::seg): validated here, launched on the (1,1) atomic-epilogue instantiation.
+int vault_gemm256_grouped_launch(const GemmParams& p, hipStream_t st) {
+  if (p.nseg < 1 || p.nseg > 3 || (p.K & 63) || p.splits < 1) return VAULT_EINVAL;
+  GemmParams q = p;
+  int total = 0;
+  for (int k = 0; k < p.nseg; ++k) {
+    const GemmParams::Seg& g = p.seg[k];
+    if (!g.A || !g.B || !g.out || g.tiles_n < 1 || g.tiles < g.tiles_n || g.tiles % g.tiles_n || g.count < 1 || g.first < 0 ||
+        (g.lda & 7) || (g.ldb & 7) || (g.ldo & 3) || (g.batch_a & 7) || (g.batch_b & 7) || (g.batch_o & 3) ||
+        g.lda < (g.tiles / g.tiles_n) * 256 || g.ldb < g.tiles_n * 256 || g.ldo < g.tiles_n * 256)
+      return VAULT_EINVAL;
+    total += g.count;
+  }
+  for (int k = p.nseg; k < 3; ++k) q.seg[k] = GemmParams::Seg{};
+  // plain-launch fields the kernel still reads
+  q.A = p.seg[0].A; q.B = p.seg[0].B; q.out = p.seg[0].out;
+  q.M = 256; q.N = 256; q.lda = p.seg[0].lda; q.ldb = p.seg[0].ldb; q.ldo = p.seg[0].ldo; q.m_valid = 256;
+  q.batch = 0; q.gn = 1;
+  constexpr int LDS = 2 * BUFB + 4 * 16 * (64 + 4) * 4 + 16;
+  auto kern = gemm256_kernel<1, 1, EPI_F32_ATOMIC, 4>;
+  static bool attr_done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VAULT_EINVAL;
+  if (!attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_done[dev] = true;
+  }
+  const int nk_total = p.K >> 6;
+  const int per = (nk_total + p.splits - 1) / p.splits;
+  q.splits = (nk_total + per - 1) / per;
+  const int nwork = total * q.splits;
+  int persist = p.persist & 0xff, parity = 0;
+  if (persist & 1) {
+    RingSched& rs = ring_sched(dev);
+    if (!rs.bound) { rs.bound = true; rs.stream = st; }
+    if (rs.stream == st) parity = (int)(rs.seq++ & 1u);
+    else persist &= ~1;
+  }
+  q.persist = persist | (parity << 8);
+  hipLaunchKernelGGL(kern, dim3(std::min(nwork, 256)), dim3(256), LDS, st, q);
+  return (int)hipGetLastError();
+}
 
 int vault_gemm256_launch(const GemmParams& p, int a_mode, int b_mode, int epi, int ntq, hipStream_t st) {
   return ntq == 3 ? dispatch256<3>(p, a_mode, b_mode, epi, st) : dispatch256<4>(p, a_mode, b_mode, epi, st);

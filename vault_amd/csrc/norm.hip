@@ -118,6 +118,48 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
+// Cross-wave reduction of the three per-lane column sums (d gamma, d beta, the next Linear's bias gradient) of a block and
+// one global float atomic per column and block.
+template <int VPT, int WAVES>
+__device__ __forceinline__ void ln_bwd_fold(const f32x4 (&ag)[VPT], const f32x4 (&ab)[VPT], const f32x4 (&ac)[VPT], float* red,
+                                            float* dgamma, float* dbeta, float* dbias, int lane, int wave) {
+  constexpr int NB = WAVES >= 8 ? 8 : 4;      // waves that fold into the scratch per round
+  constexpr int HH = VPT * 256;               // = H
+  if (dgamma == nullptr && dbias == nullptr) return;
+  // cross-wave reduction of the three column sums together through a [NB][3][H] scratch (72 KiB at H = 768) that the
+  // waves add into NB at a time (LDS float atomics run ~a lane per clock here: 30 us for this - plain read-add-write
+  // rounds instead; one quantity at a time through a [4][H] scratch took 12 rounds + 3 passes of atomics: 4-7 us of
+  // every launch at small row counts), then one global atomic per column and block.  The global atomics of all blocks
+  // land on the same H addresses at the end of the kernel and serialise in the L2: with 1024 blocks that tail cost
+  // 14-22 us per launch whatever the row count (tools/ln_bench.py), hence 16-wave blocks, one per CU (<= 256 blocks)
+  float* const dsts[3] = {dgamma, dbeta, dbias};
+  for (int r = 0; r < WAVES / NB; ++r) {
+    if ((wave / NB) == r) {
+      float* rw = red + (wave % NB) * (3 * HH);
+#pragma unroll
+      for (int qn = 0; qn < 3; ++qn) {
+        if (dsts[qn] == nullptr) continue;     // uniform
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+          const f32x4 v = qn == 0 ? ag[j] : (qn == 1 ? ab[j] : ac[j]);
+          f32x4* q4 = reinterpret_cast<f32x4*>(rw + qn * HH + (lane + 64 * j) * 4);
+          *q4 = (r == 0) ? v : (*q4 + v);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < 3 * HH; c += WAVES * 64) {
+    const int qn = c / HH;
+    float* dst = dsts[qn];
+    if (dst == nullptr) continue;
+    float t = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) t += red[b * (3 * HH) + c];
+    atomicAdd(dst + (c - qn * HH), t);
+  }
+}
+
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ; dy = dy_bf16 + dy_f32 (either may be
 // null).  Outputs dx_f32 = dx + dres (optional) and a bf16 copy (optionally dropout-masked for the
 // branch that sits behind a dropout in forward).  dgamma / dbeta: per-block partials + float atomics.
@@ -210,39 +252,106 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void ln_bwd_kernel(const h1
       }
     }
   }
-  if (dgamma == nullptr && dbias == nullptr) return;
-  // cross-wave reduction of the three column sums together through a [NB][3][H] scratch (72 KiB at H = 768) that the
-  // waves add into NB at a time (LDS float atomics run ~a lane per clock here: 30 us for this - plain read-add-write
-  // rounds instead; one quantity at a time through a [4][H] scratch took 12 rounds + 3 passes of atomics: 4-7 us of
-  // every launch at small row counts), then one global atomic per column and block.  The global atomics of all blocks
-  // land on the same H addresses at the end of the kernel and serialise in the L2: with 1024 blocks that tail cost
-  // 14-22 us per launch whatever the row count (tools/ln_bench.py), hence 16-wave blocks, one per CU (<= 256 blocks)
-  float* const dsts[3] = {dgamma, dbeta, dbias};
-  for (int r = 0; r < WAVES / NB; ++r) {
-    if ((wave / NB) == r) {
-      float* rw = red + (wave % NB) * (3 * HH);
+  ln_bwd_fold<VPT, WAVES>(ag, ab, ac, red, dgamma, dbeta, dbias, lane, wave);
+}
+
+// The same backward for the case that makes up the pre-LN ViLT stack's 24 launches per step - 16-bit incoming gradient
+// (dy_bf16), 16-bit residual-gradient stream in (dres_bf16) and out (dx_bf16), identity row maps, no dropout, no f32
+// stream - as straight-line code: the general kernel's run-time switches cut its row loop into ~40 basic blocks, which
+// keeps hipcc from issuing a row's loads together (4.3-4.9 TB/s).  Here a wave requests the nine loads of its NEXT row
+// (x: VPT x 16 B, dy / dres: VPT x 8 B per lane) before it touches the current one.  7.5 KB per row: read 6 KB, write 1.5 KB.
+template <int VPT>
+__global__ __launch_bounds__(512, 1) void ln_bwd_stream_kernel(const h16* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, int rows, int H,
+                                                                const h16* __restrict__ dres, h16* __restrict__ dx,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                float* __restrict__ dbias, int rows_per_block) {
+  H16_SATURATE();
+  constexpr int WAVES = 8;        // two per SIMD, 256 registers each: two rows of loads in flight per wave beside the current row
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [8][3][H]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 gw[VPT], ag[VPT], ab[VPT], ac[VPT];
 #pragma unroll
-      for (int qn = 0; qn < 3; ++qn) {
-        if (dsts[qn] == nullptr) continue;     // uniform
+  for (int j = 0; j < VPT; ++j) {
+    gw[j] = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * j) * 4);
+    ag[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ab[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ac[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  struct RowRegs {
+    f32x4 x[VPT];
+    uint2 d[VPT], r[VPT];
+    float mu, rs;
+  };
+  auto request = [&](RowRegs& q, int row) {
+    const size_t o = (size_t)row * H;
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) {
-          const f32x4 v = qn == 0 ? ag[j] : (qn == 1 ? ab[j] : ac[j]);
-          f32x4* q4 = reinterpret_cast<f32x4*>(rw + qn * HH + (lane + 64 * j) * 4);
-          *q4 = (r == 0) ? v : (*q4 + v);
-        }
+    for (int j = 0; j < VPT; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      q.x[j] = *reinterpret_cast<const f32x4*>(x + o + c);
+      q.d[j] = *reinterpret_cast<const uint2*>(dy + o + c);
+      q.r[j] = *reinterpret_cast<const uint2*>(dres + o + c);
+    }
+    q.mu = mean[row]; q.rs = rstd[row];
+  };
+  auto process = [&](const RowRegs& q, int row) {
+    const float mu = q.mu, rs = q.rs;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const float2 a = unpack_h16x2(q.d[j].x), b = unpack_h16x2(q.d[j].y);
+      const float d[4] = {a.x, a.y, b.x, b.y};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (q.x[j][e] - mu) * rs;
+        const float gy = d[e] * gw[j][e];
+        s1 += gy;
+        s2 += gy * xh;
+        ag[j][e] += d[e] * xh;
+        ab[j][e] += d[e];
       }
     }
-    __syncthreads();
-  }
-  for (int c = threadIdx.x; c < 3 * HH; c += WAVES * 64) {
-    const int qn = c / HH;
-    float* dst = dsts[qn];
-    if (dst == nullptr) continue;
-    float t = 0.f;
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+    const size_t o = (size_t)row * H;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) t += red[b * (3 * HH) + c];
-    atomicAdd(dst + (c - qn * HH), t);
+    for (int j = 0; j < VPT; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      const float2 a = unpack_h16x2(q.d[j].x), b = unpack_h16x2(q.d[j].y);
+      const float2 ra = unpack_h16x2(q.r[j].x), rb = unpack_h16x2(q.r[j].y);
+      const float d[4] = {a.x, a.y, b.x, b.y};
+      const float r[4] = {ra.x, ra.y, rb.x, rb.y};
+      float out[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (q.x[j][e] - mu) * rs;
+        out[e] = rs * (d[e] * gw[j][e] - s1 - xh * s2) + r[e];
+        ac[j][e] += out[e];
+      }
+      uint2 w = {pack_h16x2(out[0], out[1]), pack_h16x2(out[2], out[3])};
+      *reinterpret_cast<uint2*>(dx + o + c) = w;
+    }
+  };
+  // software pipeline over the wave's rows (row, row + 8, ...): three register sets rotate, two rows are always requested
+  // ahead of the one being processed
+  RowRegs qa, qb, qc;
+  int row = r0 + wave;
+  if (row < r1) request(qa, row);
+  if (row + WAVES < r1) request(qb, row + WAVES);
+  for (; row < r1; row += 3 * WAVES) {
+    if (row + 2 * WAVES < r1) request(qc, row + 2 * WAVES);
+    process(qa, row);
+    if (row + WAVES >= r1) break;
+    if (row + 3 * WAVES < r1) request(qa, row + 3 * WAVES);
+    process(qb, row + WAVES);
+    if (row + 2 * WAVES >= r1) break;
+    if (row + 4 * WAVES < r1) request(qb, row + 4 * WAVES);
+    process(qc, row + 2 * WAVES);
   }
+  ln_bwd_fold<VPT, WAVES>(ag, ab, ac, red, dgamma, dbeta, dbias, lane, wave);
 }
 
 // out[n] += sum over rows < rows of in[row][n]  (bias gradients); N % 256 == 0.  16-wave blocks, 256 row blocks: the float
@@ -308,6 +417,28 @@ extern "C" int vault_layernorm_bwd(const vault_ln_bwd_args* a, void* stream) {
   rpb = ((rpb + waves - 1) / waves) * waves;
   dim3 grid((a->rows + rpb - 1) / rpb), block(waves * 64);
   int lds_bytes = 0;
+  // the 16-bit gradient stream of the pre-LN stack (engine.GRAD_STREAM_BF16): straight-line kernel with row prefetch
+  static const bool stream_ok = [] { const char* e = getenv("VAULT_LN_STREAM"); return !(e && atoi(e) == 0); }();   // development A/B switch
+  const bool ident = a->dy_rpg == 0 && a->x_rpg == 0 && a->dx_rpg == 0;
+  if (stream_ok && waves == 16 && a->H == 768 && ident && a->dy_bf16 && !a->dy_f32 && !a->dres && a->dres_bf16 && !a->dx_f32 &&
+      a->dx_bf16 && a->drop_thresh == 0 && a->dgamma && a->dbeta) {
+    constexpr int LDS = 8 * 3 * 768 * 4;
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VAULT_EINVAL;
+    if (!done[dev]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_stream_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS) != hipSuccess) return VAULT_EINVAL;
+      done[dev] = true;
+    }
+    int rpb8 = (a->rows + 255) / 256;                 // one 8-wave block per CU
+    rpb8 = ((rpb8 + 7) / 8) * 8;
+    hipLaunchKernelGGL((ln_bwd_stream_kernel<3>), dim3((a->rows + rpb8 - 1) / rpb8), dim3(512), LDS, st,
+                       reinterpret_cast<const h16*>(a->dy_bf16), a->x, a->mean,
+                       a->rstd, a->gamma, a->rows, a->H, reinterpret_cast<const h16*>(a->dres_bf16),
+                       reinterpret_cast<h16*>(a->dx_bf16), a->dgamma, a->dbeta, a->dbias, rpb8);
+    return (int)hipGetLastError();
+  }
 #define LN_BWD(V)                                                                                              \
   if (waves == 16) LN_BWD_W(V, 16) else LN_BWD_W(V, 4)
 #define LN_BWD_W(V, W)                                                                                              \

@@ -321,6 +321,8 @@ class VaultEngine:
             self.LM_WGRAD_BATCHED = False
         if os.environ.get("VAULT_WGRAD_BATCH_RING") == "0":   # development override (same-box A/B)
             self.WGRAD_BATCH_RING = False
+        if os.environ.get("VAULT_WGRAD_GROUPED") in ("0", "1"):   # development override (same-box A/B)
+            self.WGRAD_GROUPED = os.environ["VAULT_WGRAD_GROUPED"] == "1"
         if os.environ.get("VAULT_WGRAD_BATCH_MAX_ROWS"):
             self.WGRAD_BATCH_MAX_ROWS = int(os.environ["VAULT_WGRAD_BATCH_MAX_ROWS"])
         if os.environ.get("VAULT_GELU8") in ("0", "1"):   # development override (same-box A/B)
@@ -343,6 +345,7 @@ class VaultEngine:
         self.last: Optional[dict] = None
         self._wgrad_stream, self._wgrad_pending = None, False
         self._wgrad_side = False
+        self._grads_zero = False
         # optional live kernel timing (bench.py): {site: [(start, end, flops), ...]} of torch.cuda.Event pairs recorded
         # on the launch stream around every launch of a kernel instantiation.  Sites: "wgrad" = the ring kernel's
         # weight-gradient form gemm256_kernel<1,1,EPI_F32_ATOMIC,4> (every _wgrad launch that takes it), "ffn1" =
@@ -545,12 +548,76 @@ class VaultEngine:
         st = torch.cuda.current_stream()
         if cfg == 3:
             ops.pycall(lambda: self._prof_begin("wgrad", st))
+        # un-split launches whose caller vouches for zero gradients (the fused train step: AdamW cleared them) STORE the
+        # tiles instead of adding them with float atomics (memory-side, ~1.3 TB/s against 6 TB/s for stores: 44 -> 10 us
+        # of a 216-tile launch's tail)
+        acc = 0 if (self._grads_zero and splits == 1) else 1
         ops.gemm(dY_all[i0], X_all[i0], gw, Nout, Kin, Mtok_pad, Nout, Kin, Kin, 1, 1, ops.EPI_F32_ATOMIC, cfg=cfg,
-                 splits=splits, accumulate=1, batch=G, batch_a=dY_all.stride(0), batch_b=X_all.stride(0),
+                 splits=splits, accumulate=acc, batch=G, batch_a=dY_all.stride(0), batch_b=X_all.stride(0),
                  batch_o=stride_o)
         if cfg == 3:
             fl = 2.0 * m_valid * Nout * Kin * G
             ops.pycall(lambda: self._prof_end("wgrad", fl, st))
+
+    WGRAD_GROUPED = True           # the four weight-gradient kinds of a group of layers packed into full rounds of 256 tiles
+
+    def _wgrad_group(self, kinds, layers, i0, hi, Mtok_pad, m_valid):
+        """Weight gradients of layers i0 .. hi - 1 of a stack.  ``kinds``: (dY stack, X stack, weight attribute, Nout, Kin) per
+        Linear kind.  Every 256 x 256 tile of every kind costs the same (the contraction runs over the tokens), so the tiles
+        of all kinds are packed into launches of exactly 256 items - one per CU, un-split, stored (or added) once - and one
+        remainder launch whose split count comes from the cost model (vault_wgrad_grouped); one launch per kind leaves 16 %
+        of the CUs idle in the 216-tile FFN launches and splits the attention-out / QKV ones 4 / 3 ways with float atomics.
+        Falls back to one batched launch per kind when a shape is not a multiple of 256 (the tiny test models)."""
+        P = self.params
+        G = hi - i0
+        ok = self.WGRAD_GROUPED and self.WGRAD_BATCH_RING and all(no % 256 == 0 and ki % 256 == 0 for *_, no, ki in kinds)
+        strides = []
+        for dY_all, X_all, wsel, Nout, Kin in kinds:
+            offs = [P.offsets[getattr(l_, wsel)][0] for l_ in layers[i0:hi]]
+            so = (offs[1] - offs[0]) if G > 1 else 0
+            ok = ok and all(offs[k + 1] - offs[k] == so for k in range(G - 1))
+            strides.append(so)
+        if not ok:
+            for dY_all, X_all, wsel, Nout, Kin in kinds:
+                self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in layers[i0:hi]], i0, Mtok_pad, Nout, Kin, m_valid)
+            return
+        nk = Mtok_pad // 64
+        CU = 256
+        # items of every kind in list order, cut into launches of CU items (<= 3 segments each)
+        remaining = []
+        for k, (dY_all, X_all, wsel, Nout, Kin) in enumerate(kinds):
+            remaining.append([k, 0, (Nout // 256) * (Kin // 256) * G])      # kind, first item, items left
+        launches, cur, room = [], [], CU
+        for k, first, left in remaining:
+            while left > 0:
+                take = min(left, room)
+                cur.append((k, first, take))
+                first, left, room = first + take, left - take, room - take
+                if room == 0 or len(cur) == 3:
+                    launches.append(cur)
+                    cur, room = [], CU
+        if cur:
+            launches.append(cur)
+        st = torch.cuda.current_stream()
+        for segs in launches:
+            count = sum(c for _, _, c in segs)
+            if count == CU:
+                splits = 1
+            else:       # remainder: rounds of 256 pieces x (k-steps at 1.67 us + fixed cost per piece: ~10 us stored, ~50 us with float atomics)
+                fixed = lambda sp: 10.0 if (sp == 1 and self._grads_zero) else 50.0   # noqa: E731
+                cost = lambda sp: -(-count * sp // CU) * (1.67 * -(-nk // sp) + fixed(sp))   # noqa: E731
+                splits = min((sp for sp in range(1, 9) if nk // sp >= 2), key=cost)
+            acc = 0 if (self._grads_zero and splits == 1) else 1
+            args = []
+            for k, first, c in segs:
+                dY_all, X_all, wsel, Nout, Kin = kinds[k]
+                gw = P.gr(getattr(layers[i0], wsel), n_elems=Nout * Kin, shape=(Nout, Kin))
+                args.append(dict(dy=dY_all[i0], x=X_all[i0], dw=gw, n_out=Nout, n_in=Kin, batch=G, first=first, count=c,
+                                 batch_dy=dY_all.stride(0), batch_x=X_all.stride(0), batch_dw=strides[k]))
+            ops.pycall(lambda: self._prof_begin("wgrad", st))
+            ops.wgrad_grouped(args, Mtok_pad, splits=splits, accumulate=acc)
+            fl = 2.0 * m_valid * 65536.0 * count
+            ops.pycall(lambda fl=fl: self._prof_end("wgrad", fl, st))
 
     def _qkv_bias_grads_batched(self, dqkv_all, layers, i0, hi, ld, rows, N):
         """QKV bias gradients of layers i0 .. hi - 1 (column sums over the token rows of the first N columns of their dqkv) in
@@ -1334,7 +1401,10 @@ class VaultEngine:
         return b
 
     @_in_format
-    def _backward(self, grad_scale, dlogits, dpooled, dhidden, after_layer, ws=None):
+    def _backward(self, grad_scale, dlogits, dpooled, dhidden, after_layer, ws=None, grads_zero=False):
+        # grads_zero: the caller vouches that the flat gradient buffer is all zero (TrainStep: the fused optimizer cleared
+        # it) - un-split weight-gradient launches may then store instead of accumulate
+        self._grads_zero = bool(grads_zero) and os.environ.get("VAULT_WGRAD_STORE", "1") != "0"
         ws = self.last if ws is None else ws
         if ws is None or not ws.get("train"):
             raise RuntimeError("backward() needs a preceding forward(train=True)")
@@ -1443,9 +1513,9 @@ class VaultEngine:
                     hi = min(nv, i + vgroup)
                     def launch(i=i, hi=hi):
                         self._qkv_bias_grads_batched(dqkv_all, self.vl, i, hi, 3 * H, M, 3 * H)
-                        for dY_all, X_all, wsel, Nout, Kin in ((dxbA_all, ws["act_all"], "fw", H, FF), (dU_all, ws["n2_all"], "iw", FF, H),
-                                                               (dxbB_all, ws["ctx_all"], "ow", H, H), (dqkv_all, ws["n1_all"], "qw", 3 * H, H)):
-                            self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.vl[i:hi]], i, Mp, Nout, Kin, M)
+                        self._wgrad_group(((dxbA_all, ws["act_all"], "fw", H, FF), (dU_all, ws["n2_all"], "iw", FF, H),
+                                           (dxbB_all, ws["ctx_all"], "ow", H, H), (dqkv_all, ws["n1_all"], "qw", 3 * H, H)),
+                                          self.vl, i, hi, Mp, M)
                     self._wgrads_aside(launch, after_layer)
                     for j in reversed(range(i, hi)):
                         note(f"vilt{j}")
@@ -1500,9 +1570,9 @@ class VaultEngine:
                 hi = min(nv, i + vgroup)
                 def launch(i=i, hi=hi, short=short):
                     self._qkv_bias_grads_batched(dqkv_all, self.vl, i, hi, 3 * H, M, H if short else 3 * H)
-                    for dY_all, X_all, wsel, Nout, Kin in ((dxbA_all, ws["act_all"], "fw", H, FF), (dU_all, ws["n2_all"], "iw", FF, H),
-                                                           (dxbB_all, ws["ctx_all"], "ow", H, H), (dqkv_all, ws["n1_all"], "qw", 3 * H, H)):
-                        self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.vl[i:hi]], i, Mp, Nout, Kin, M)
+                    self._wgrad_group(((dxbA_all, ws["act_all"], "fw", H, FF), (dU_all, ws["n2_all"], "iw", FF, H),
+                                       (dxbB_all, ws["ctx_all"], "ow", H, H), (dqkv_all, ws["n1_all"], "qw", 3 * H, H)),
+                                      self.vl, i, hi, Mp, M)
                 self._wgrads_aside(launch, after_layer)
                 for j in reversed(range(i, hi)):
                     note(f"vilt{j}")
@@ -1616,9 +1686,9 @@ class VaultEngine:
                         note("lm_embed")
                     def launch(i=i, hi=hi):
                         self._qkv_bias_grads_batched(ldqkv_all, self.ll, i, hi, 3 * H, Ml, 3 * H)
-                        for dY_all, X_all, wsel, Nout, Kin in ((dhb_all, ws["lm_act_all"], "fw", H, FF), (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
-                                                               (dh1b_all, ws["lm_ctx_all"], "ow", H, H), (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H)):
-                            self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.ll[i:hi]], i, Mlp, Nout, Kin, Ml)
+                        self._wgrad_group(((dhb_all, ws["lm_act_all"], "fw", H, FF), (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
+                                           (dh1b_all, ws["lm_ctx_all"], "ow", H, H), (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H)),
+                                          self.ll, i, hi, Mlp, Ml)
                     self._wgrads_aside(launch, after_layer)
                     for j in reversed(range(i, hi)):
                         note(f"lm{j}")
@@ -1658,9 +1728,9 @@ class VaultEngine:
                     note("lm_embed")
                 def launch(i=i, hi=hi):
                     self._qkv_bias_grads_batched(ldqkv_all, self.ll, i, hi, 3 * H, Ml, 3 * H)
-                    for dY_all, X_all, wsel, Nout, Kin in ((dhb_all, ws["lm_act_all"], "fw", H, FF), (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
-                                                           (dh1b_all, ws["lm_ctx_all"], "ow", H, H), (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H)):
-                        self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in self.ll[i:hi]], i, Mlp, Nout, Kin, Ml)
+                    self._wgrad_group(((dhb_all, ws["lm_act_all"], "fw", H, FF), (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
+                                       (dh1b_all, ws["lm_ctx_all"], "ow", H, H), (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H)),
+                                      self.ll, i, hi, Mlp, Ml)
                 self._wgrads_aside(launch, after_layer)
                 for j in reversed(range(i, hi)):
                     note(f"lm{j}")

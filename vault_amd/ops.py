@@ -196,6 +196,35 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_va
     _invoke("vault_gemm", C.byref(a), _stream(), struct=a, drop=drop)
 
 
+class WgradSeg(C.Structure):
+    """vault_wgrad_seg (include/vault_hip.h)"""
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p),
+                ("n_out", C.c_int), ("n_in", C.c_int), ("ld_dy", C.c_int), ("ld_x", C.c_int), ("ld_dw", C.c_int),
+                ("batch", C.c_int), ("first", C.c_int), ("count", C.c_int),
+                ("batch_dy", C.c_longlong), ("batch_x", C.c_longlong), ("batch_dw", C.c_longlong)]
+
+
+class WgradGroupedArgs(C.Structure):
+    """vault_wgrad_grouped_args"""
+    _fields_ = [("nseg", C.c_int), ("seg", WgradSeg * 3), ("tokens", C.c_int), ("splits", C.c_int), ("accumulate", C.c_int),
+                ("persist", C.c_int)]
+
+
+def wgrad_grouped(segs, tokens, splits=1, accumulate=1):
+    """One launch over up to three segments of weight-gradient tiles (vault_wgrad_grouped).  ``segs``: dicts with dy, x
+    (16-bit [tokens, n] tensors of the kind's FIRST layer), dw (f32 view of its dW), n_out, n_in, batch, first, count,
+    batch_dy, batch_x, batch_dw."""
+    a = WgradGroupedArgs()
+    a.nseg, a.tokens, a.splits, a.accumulate, a.persist = len(segs), tokens, splits, accumulate, GEMM_SCHED
+    for k, g in enumerate(segs):
+        t = a.seg[k]
+        t.dy, t.x, t.dw = _h(g["dy"]), _h(g["x"]), _p(g["dw"])
+        t.n_out, t.n_in, t.ld_dy, t.ld_x, t.ld_dw = g["n_out"], g["n_in"], g["n_out"], g["n_in"], g["n_in"]
+        t.batch, t.first, t.count = g["batch"], g["first"], g["count"]
+        t.batch_dy, t.batch_x, t.batch_dw = g["batch_dy"], g["batch_x"], g["batch_dw"]
+    _invoke("vault_wgrad_grouped", C.byref(a), _stream(), struct=a)
+
+
 def quant_mxfp8(src_bf16, rows, K, ld, dst_q, dst_scale):
     """bf16 [rows][ld >= K] -> MXFP8: e4m3 bytes [rows][K] + E8M0 block scales [rows][K/32] (include/vault_hip.h)."""
     _invoke("vault_quant_mxfp8", C.c_void_p(_p(src_bf16)), C.c_longlong(rows), C.c_int(K), C.c_int(ld),

@@ -460,7 +460,7 @@ class TrainStep:
                 try:
                     out = eng.forward_staged(ws, need_hidden=False, loss_scale=1.0 / B, precise=self.precise_forward)
                     # gradients are zero here: the fused optimizer clears them after use (they start at 0)
-                    eng._backward(1.0 / B, None, None, None, self.reducer.on_stage if self.reducer else None)
+                    eng._backward(1.0 / B, None, None, None, self.reducer.on_stage if self.reducer else None, grads_zero=True)
                 finally:
                     if self.use_tape:
                         ops.stop_tape()
