@@ -561,6 +561,17 @@ class VaultEngine:
 
     WGRAD_GROUPED = True           # the four weight-gradient kinds of a group of layers packed into full rounds of 256 tiles
 
+    def _wgrad_group_size(self, n_layers, after_layer):
+        """Layers per deferred weight-gradient group.  A data-parallel step (``after_layer``: the reducer's stage listener)
+        keeps groups of LM_WGRAD_GROUP layers - the upper group's gradient range goes on the wire under the backward of the
+        layers below it; a single process takes the whole stack (1,296 tiles = five full rounds + 16 tiles, against two
+        remainders of 136: B = 256, same box, 40.2 -> 39.8 ms per step; equal at B = 64).  VAULT_WGRAD_GROUP forces a size."""
+        if os.environ.get("VAULT_WGRAD_GROUP"):
+            g = self.LM_WGRAD_GROUP
+        else:
+            g = self.LM_WGRAD_GROUP if (after_layer is not None or not self.WGRAD_GROUPED) else 0
+        return g if g > 0 else n_layers
+
     def _wgrad_group(self, kinds, layers, i0, hi, Mtok_pad, m_valid):
         """Weight gradients of layers i0 .. hi - 1 of a stack.  ``kinds``: (dY stack, X stack, weight attribute, Nout, Kin) per
         Linear kind.  Every 256 x 256 tile of every kind costs the same (the contraction runs over the tokens), so the tiles
@@ -1435,7 +1446,7 @@ class VaultEngine:
             # A = gradient at the layer output (FFN-out's dY), B = gradient behind the attention block (attn-out's dY)
             dxbA_all = self._stack(ws, "v_dxbA", nv, (Mp, H), bf); dxbB_all = self._stack(ws, "v_dxbB", nv, (Mp, H), bf)
             dU_all = self._stack(ws, "v_dU", nv, (Mp, FF), bf); dqkv_all = self._stack(ws, "v_dqkv", nv, (Mp, 3 * H), bf)
-            vgroup = self.LM_WGRAD_GROUP if self.LM_WGRAD_GROUP > 0 else nv
+            vgroup = self._wgrad_group_size(nv, after_layer)
         dxb_top = dxbA_all[nv - 1] if vbatch else dxb[0]
         gbf = self.GRAD_STREAM_BF16       # the ViLT residual-gradient stream lives in bf16 only (below)
         if not gbf:
@@ -1634,7 +1645,7 @@ class VaultEngine:
             # dY operands of every layer stay alive until their group's batched weight-gradient launches
             dhb_all = self._stack(ws, "lm_dhb", nl, (Mlp, H), bf); dh1b_all = self._stack(ws, "lm_dh1b", nl, (Mlp, H), bf)
             ldU_all = self._stack(ws, "lm_dU", nl, (Mlp, FF), bf); ldqkv_all = self._stack(ws, "lm_dqkv", nl, (Mlp, 3 * H), bf)
-            group = self.LM_WGRAD_GROUP if self.LM_WGRAD_GROUP > 0 else nl
+            group = self._wgrad_group_size(nl, after_layer)
         else:
             dhb = buf("lm_dhb", (Mlp, H), bf); dh1b = buf("lm_dh1b", (Mlp, H), bf)
             ldU = buf("lm_dU", (Mlp, FF), bf); ldqkv = buf("lm_dqkv", (Mlp, 3 * H), bf)
