@@ -45,7 +45,10 @@ int vault_operand_format(void);
  * the launcher takes the double-buffered kernel), 5 / 6 (ABI 4) = 8-wave kernel with 256x256 / 256x192 tiles whose
  * epilogue stores the accumulators straight from registers (a_mode = b_mode = 0 only, K >= 128, no split-K, no split3,
  * no dropout, epi 0 / 1 / 2 / 3; M x ldo x 4 B < 4 GiB): the automatic choice for the bf16-output Linears with K <= 1024;
- * 7 = 64x128 tiles, four stages (a_mode 0, epi 0..4, no split-K): the automatic choice while (M/64) x (N/128) <= 256 blocks.
+ * 7 = 64x128 tiles, four stages (a_mode 0, epi 0..4, no split-K): the automatic choice while (M/64) x (N/128) <= 256 blocks;
+ * 8 (ABI 8) = ring kernel with 256x128 tiles (a_mode 0; epi 3 with `res` and b_mode 0, or epi 0 with b_mode 1; no split-K):
+ * the automatic choice where 256x192 tiles would be one partial round that 256x128 tiles still cover in one (N = 768 at
+ * 32..42 row tiles of 256).
  * Threading: one host thread per device; the ring kernel's dynamic scheduler (persist bit 0) keeps per-device ticket
  * counters that assume its launches are serialised on ONE stream per device. */
 typedef struct vault_gemm_args {
@@ -75,7 +78,7 @@ typedef struct vault_gemm_args {
                   call would take and pass that cfg explicitly to both calls. */
 } vault_gemm_args;
 int vault_gemm(const vault_gemm_args* args, void* stream);
-/* the kernel / tile configuration vault_gemm would run these arguments on (the resolved `cfg`, 0..7), or -EINVAL */
+/* the kernel / tile configuration vault_gemm would run these arguments on (the resolved `cfg`, 0..8), or -EINVAL */
 int vault_gemm_plan(const vault_gemm_args* args);
 
 /* ---- grouped weight gradients (ABI 8) ---------------------------------------------------------------------------

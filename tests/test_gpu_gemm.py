@@ -559,3 +559,31 @@ def test_grouped_weight_gradients_against_matmul(half, splits, accumulate):
         with ops.operand_format(half):
             ops.wgrad_grouped([dict(dy=dys[2][0], x=xs[2][0], dw=dws[2][0], n_out=256, n_in=256, batch=G, first=1, count=2,
                                     batch_dy=dys[2].stride(0), batch_x=xs[2].stride(0), batch_dw=pads[2])], tokens)
+
+
+@pytest.mark.parametrize("K", [64, 192, 768, 3072])
+@pytest.mark.parametrize("rows", [512, 256 * 43])
+def test_ring_kernel_128_wide_tiles(K, rows):
+    """cfg 8 = the ring kernel with 256 x 128 block tiles, the two forms it exists in: residual forward (0,0) and the (0,1)
+    data gradient; one round (12 tiles) and a persistent walk over 43 x 6 = 258 tiles with a partial last row block."""
+    M, N = rows, 768
+    m_valid = M - 35
+    A = _rand(M, K, seed=61).bfloat16()
+    Wnk = _rand(N, K, scale=0.05, seed=62).bfloat16()
+    ref = A.float() @ Wnk.float().t()
+    bias = _rand(N, seed=63)
+    res = _rand(M, N, seed=64)
+    for rep in range(2):
+        o32 = torch.zeros(M, N, device="cuda")
+        _gemm(A, Wnk, o32, M, N, K, K, K, N, 0, 0, EPI_RES, cfg=8, bias=bias, res=res, m_valid=m_valid)
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        _gemm(A, Wnk.t().contiguous(), out, M, N, K, K, N, N, 0, 1, EPI_BF16, cfg=8, m_valid=m_valid)
+        torch.cuda.synchronize()
+        r = ref + bias + res
+        assert (o32[:m_valid] - r[:m_valid]).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-4
+        assert o32[m_valid:].abs().max().item() == 0.0
+        assert (out[:m_valid].float() - ref[:m_valid]).abs().max().item() <= ref.abs().max().item() * 2 ** -7
+        assert out[m_valid:].abs().max().item() == 0.0
+    # not the other forms
+    with pytest.raises(RuntimeError):
+        _gemm(A, Wnk, out, M, N, K, K, K, N, 0, 0, EPI_BF16, cfg=8, bias=bias)

@@ -305,7 +305,7 @@ int vault_gemm256_launch(const GemmParams& p, int a_mode, int b_mode, int epi, i
 bool vault_gemm8w_supports(const GemmParams& p, int a_mode, int b_mode, int epi, int ntw);
 int vault_gemm8w_launch(const GemmParams& p, int epi, int ntw, hipStream_t st);
 
-// argument checks + kernel choice: the resolved cfg (0..6), or -VAULT_EINVAL
+// argument checks + kernel choice: the resolved cfg (0..8), or -VAULT_EINVAL
 int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) {
   if (p.splits < 1) p.splits = 1;
   if (p.A == nullptr || p.B == nullptr || p.out == nullptr) return -VAULT_EINVAL;
@@ -371,6 +371,16 @@ int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) 
     if (ok4 && (!ok3 || eff8((long)(p.M / 256) * (p.N / 256)) >= 0.9 * eff8((long)(p.M / 256) * (p.N / 192)))) cfg = 5;
     else if (ok3) cfg = 6;
   }
+  // 256 x 128 tiles of the ring kernel (cfg 8) where the 192-wide ones are a single partial round that the 128-wide ones
+  // still cover in one: N = 768 at 32..42 row tiles (the LM stack at per-GPU batch 256: 160 -> 240 tiles on 256 CUs;
+  // tools/tile128_bench.py, M = 10240: attention-out 27.9 -> 23.9 us, FFN-out 62.6 -> 51.6, FFN-in dgrad 59.9 -> 48.1, QKV
+  // dgrad 45.5 -> 37.7; one row tile more and the second round costs 45 %)
+  static const bool use128 = [] { const char* e = getenv("VAULT_GEMM_128"); return !(e && e[0] == '0'); }();   // development A/B switch
+  if (auto_cfg && use128 && cfg == 4 && a_mode == 0 && p.splits == 1 && p.batch <= 1 && p.N % 128 == 0 &&
+      ((b_mode == 0 && epi == EPI_F32_RES && p.res != nullptr) || (b_mode == 1 && epi == EPI_BF16 && p.colsum == nullptr))) {
+    const long c192 = (long)(p.M / 256) * (p.N / 192), c128 = (long)(p.M / 256) * (p.N / 128);
+    if (c192 < 256 && c128 <= 256) cfg = 8;
+  }
   // the ring kernel's residual epilogue always loads its residual operand: without one use the simple kernel
   if ((cfg == 3 || cfg == 4) && epi == EPI_F32_RES && p.res == nullptr) cfg = (p.N % 256 == 0) ? 2 : 1;
   if (cfg == 5 || cfg == 6) {   // 8-wave kernel with register-direct epilogue (gemm8w.hip), 256- / 192-wide tiles:
@@ -379,7 +389,10 @@ int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) 
   } else if (p.aux_u8) {
     return -VAULT_EINVAL;       // the 8-bit gelu' exists in the 8-wave kernel's tile order only
   }
-  if (cfg < 0 || cfg > 7) return -VAULT_EINVAL;
+  if (cfg == 8 && (p.M % 256 || p.N % 128 || p.K % 64 || p.splits > 1 || p.batch > 1 || a_mode != 0 ||
+                   !((b_mode == 0 && epi == EPI_F32_RES && p.res != nullptr) || (b_mode == 1 && epi == EPI_BF16))))
+    return -VAULT_EINVAL;
+  if (cfg < 0 || cfg > 8) return -VAULT_EINVAL;
   if (cfg == 7 && (a_mode != 0 || epi == EPI_F32_ATOMIC || p.splits > 1 || p.batch > 1)) return -VAULT_EINVAL;
   return cfg;
 }
@@ -391,6 +404,7 @@ int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, i
   if (cfg == 5 || cfg == 6) return vault_gemm8w_launch(p, epi, cfg == 5 ? 4 : 3, st);
   if (cfg == 3) return vault_gemm256_launch(p, a_mode, b_mode, epi, 4, st);
   if (cfg == 4) return vault_gemm256_launch(p, a_mode, b_mode, epi, 3, st);
+  if (cfg == 8) return vault_gemm256_launch(p, a_mode, b_mode, epi, 2, st);
   const int key = a_mode * 2 + b_mode;
 #define VAULT_DISPATCH(AM, BMD)                                                             \
   switch (epi) {                                                                            \

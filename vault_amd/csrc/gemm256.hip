@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   constexpr int TN = 2 * NTQ;
-  constexpr int SCRATCH_BYTES = 4 * 16 * ((NTQ == 4 ? 64 : 96) + 4) * 4;   // epilogue scratch (gemm_epi.h), then 16 B scheduler word
+  constexpr int SCRATCH_BYTES = 4 * 16 * ((NTQ == 3 ? 96 : 64) + 4) * 4;   // epilogue scratch (gemm_epi.h), then 16 B scheduler word
   constexpr bool F32OUT = (EPI == EPI_F32_RES || EPI == EPI_F32_PATCH);
   // VMEM operations every wave is certain to issue in one 16-row epilogue step of a fully valid tile
   constexpr int SPS = (EPI == EPI_F32_ATOMIC) ? 16 * (TN * 16 / 64) : (F32OUT ? TN : TN / 2);
@@ -547,7 +547,7 @@ template <int A_MODE, int B_MODE, int EPI, int NTQ>
 int launch256(const GemmParams& p, hipStream_t st) {
   constexpr int BNT = NTQ * 64;
   if ((p.M & 255) || (p.N % BNT) || (p.K & 63)) return VAULT_EINVAL;
-  constexpr int LDS = 2 * BUFB + 4 * 16 * ((NTQ == 4 ? 64 : 96) + 4) * 4 + 16;   // ring + epilogue scratch (gemm_epi.h: 16 x LD floats per wave) + scheduler word
+  constexpr int LDS = 2 * BUFB + 4 * 16 * ((NTQ == 3 ? 96 : 64) + 4) * 4 + 16;   // ring + epilogue scratch (gemm_epi.h: 16 x LD floats per wave) + scheduler word
   auto kern = gemm256_kernel<A_MODE, B_MODE, EPI, NTQ>;
   static bool attr_done[64] = {};
   int dev = 0;
@@ -651,5 +651,12 @@ int vault_gemm256_grouped_launch(const GemmParams& p, hipStream_t st) {
 }
 
 int vault_gemm256_launch(const GemmParams& p, int a_mode, int b_mode, int epi, int ntq, hipStream_t st) {
+  if (ntq == 2) {
+    // 256 x 128 tiles (cfg 8): the N = 768 Linears of a 40-row-tile problem (the LM stack at batch 256) are 160 tiles at
+    // 192 columns - 62 % of the CUs, one round - and 240 at 128; residual forward and (0,1) data gradient only
+    if (a_mode == 0 && b_mode == 0 && epi == EPI_F32_RES) return launch256<0, 0, EPI_F32_RES, 2>(p, st);
+    if (a_mode == 0 && b_mode == 1 && epi == EPI_BF16) return launch256<0, 1, EPI_BF16, 2>(p, st);
+    return VAULT_EINVAL;
+  }
   return ntq == 3 ? dispatch256<3>(p, a_mode, b_mode, epi, st) : dispatch256<4>(p, a_mode, b_mode, epi, st);
 }
