@@ -123,6 +123,11 @@ def test_patch_unfold_straight_from_the_resize_kernel():
         torch.cuda.synchronize()
         assert res["pixel_patches"] is po and "pixel_values" not in res and res["canvas"] == (H, W)
         assert torch.equal(po, want) and torch.equal(res["pixel_mask"], ref["pixel_mask"])
+        # the same through the fp16 build of the library: the unfold in IEEE half (the fp16 engine's patch operand)
+        po16 = torch.full((rows, Kp), 7.0, dtype=torch.float16, device="cuda")
+        proc.from_packed(host, sizes, patch_out=po16, patch_size=ps)
+        torch.cuda.synchronize()
+        assert torch.equal(po16, F.unfold(pv, kernel_size=ps, stride=ps).transpose(1, 2).reshape(rows, Kp).half())
     # the tiny model (96 x 96 canvases, 16-pixel patches): same logits and the same training steps from either input form
     spec = VaultSpec.tiny(3, "roberta")
     spec.lm.hidden_dropout_prob = 0.0; spec.lm.attention_probs_dropout_prob = 0.0
@@ -146,3 +151,11 @@ def test_patch_unfold_straight_from_the_resize_kernel():
     assert float(d.mean()) < 2e-6 and float((d > 2e-5).float().mean()) < 0.03      # float-atomic summation order only
     with pytest.raises(ValueError):
         eng.forward(dict(input_ids=ids, attention_mask=am, pixel_patches=po[:-1]), train=False)
+    # what the processor knows about padding travels with the patches: a padded image or another canvas is refused on the host
+    size = spec.vilt.image_size
+    ok = dict(input_ids=ids, attention_mask=am, pixel_patches=po, canvas=(size, size), valid_hw=[(size, size)] * 4)
+    assert torch.equal(eng.forward(ok, train=False)["logits"], outs[0])
+    with pytest.raises(ValueError):
+        eng.forward(dict(ok, valid_hw=[(size, size)] * 3 + [(size, size - 16)]), train=False)
+    with pytest.raises(ValueError):
+        eng.forward(dict(ok, canvas=(size, 2 * size)), train=False)

@@ -840,6 +840,15 @@ class VaultEngine:
         H, FF, heads = v.hidden_size, v.intermediate_size, v.num_attention_heads
         NP, Kp = v.num_patches, v.num_channels * v.patch_size * v.patch_size
         pp = batch["pixel_patches"]
+        # what an image processor that padded knows (DeviceImageProcessor.from_packed returns both): this entry takes square,
+        # fully valid canvases only - a padded image, or another canvas with the same patch count, would be attended to as
+        # real tokens (no device synchronisation: host values)
+        cv, vhw = batch.get("canvas"), batch.get("valid_hw")
+        if cv is not None and tuple(int(c) for c in cv) != (v.image_size, v.image_size):
+            raise ValueError(f"pixel_patches need the square {v.image_size} x {v.image_size} canvas, got {tuple(cv)}: pass pixel_values")
+        if vhw is not None and any((int(h_), int(w_)) != (v.image_size, v.image_size) for h_, w_ in vhw):
+            raise ValueError("pixel_patches need fully valid images (every valid_hw equal to the canvas): pass pixel_values + pixel_mask "
+                             "for padded batches")
         if pp.dtype != self.hdt or pp.numel() != B * NP * Kp:
             raise ValueError(f"pixel_patches must be {self.half} [{B} * {NP}, {Kp}] (square {v.image_size} x {v.image_size} canvases)")
         S = T + 1 + NP
