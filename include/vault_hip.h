@@ -233,7 +233,7 @@ int vault_image_pos_sel_fwd(float* x, const float* pos_emb, const int* sel, cons
 int vault_image_sel_bwd(const float* dx, float* dpos, float* dmtype1, float* dcls, float* dconv_bias, void* dyp_bf16,
                         const int* sel, const int* hw, int B, int L, int S, int T, int H, int gw, int G, void* stream);
 int vault_axpy_f32(float* dst, const float* src, float a, long long n, void* stream);
-/* ABI 8: x *= a over n floats (n % 4 == 0, x 16-byte aligned).  The fp16 build's caller multiplies the loss gradient by a
+/* ABI 8: x *= a over n floats (any n, x 4-byte aligned).  The fp16 build's caller multiplies the loss gradient by a
  * power of two so that the 16-bit data gradients stay inside fp16's exponent range; the flat f32 gradient buffer then
  * holds scaled sums, and this pass (exact for a power of two) removes the scale where no fused optimizer does it
  * (p.grad of the autograd bridge; ref: loss.backward() at vault/tmsc_utils/trainer.py:365). */

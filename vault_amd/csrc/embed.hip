@@ -289,6 +289,10 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, float
   }
 }
 
+__global__ void scale_tail_kernel(float* __restrict__ x, float a, int n) {
+  if ((int)threadIdx.x < n) x[threadIdx.x] *= a;
+}
+
 }  // namespace
 
 extern "C" int vault_position_ids(const int64_t* ids, int* pos, int B, int T, int mode, int pad, void* stream) {
@@ -362,9 +366,18 @@ extern "C" int vault_axpy_f32(float* dst, const float* src, float a, long long n
 }
 
 extern "C" int vault_scale_f32(float* x, float a, long long n, void* stream) {
-  if (!x || n <= 0 || (n & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return VAULT_EINVAL;
-  const int blocks = (int)std::min<long long>((n / 4 + 255) / 256, 8192);
-  hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, a, n / 4);
+  if (!x || n <= 0 || (reinterpret_cast<uintptr_t>(x) & 3)) return VAULT_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // 16-byte pieces over the aligned middle, single floats for a ragged head / tail (small external gradients: [B, 3] logits)
+  long long head = ((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) / 4;
+  if (head > n) head = n;
+  const long long n4 = (n - head) / 4, tail = n - head - 4 * n4;
+  if (n4 > 0) {
+    const int blocks = (int)std::min<long long>((n4 + 255) / 256, 8192);
+    hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, st, x + head, a, n4);
+  }
+  if (head > 0) hipLaunchKernelGGL(scale_tail_kernel, dim3(1), dim3(64), 0, st, x, a, (int)head);
+  if (tail > 0) hipLaunchKernelGGL(scale_tail_kernel, dim3(1), dim3(64), 0, st, x + head + 4 * n4, a, (int)tail);
   return (int)hipGetLastError();
 }
 

@@ -1417,7 +1417,7 @@ class VaultEngine:
             return t
         b = self._buf(ws, name, tuple(t.shape), torch.float32)
         b.copy_(t)
-        ops.scale(b.view(-1), self.grad_scale, b.numel()) if b.numel() % 4 == 0 else b.mul_(self.grad_scale)
+        ops.scale(b.view(-1), self.grad_scale, b.numel())
         return b
 
     @_in_format

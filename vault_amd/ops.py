@@ -401,7 +401,7 @@ def axpy(dst, src, a, n):
 
 
 def scale(x, a, n):
-    """x *= a (n floats, multiple of 4)."""
+    """x *= a over n floats."""
     _invoke("vault_scale_f32", C.c_void_p(_p(x)), C.c_float(a), C.c_longlong(n), _stream())
 
 
