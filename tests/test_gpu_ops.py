@@ -262,3 +262,20 @@ def test_colsum_batched_bias_gradients_of_a_group_of_layers(rows, ld, N, batch):
     ops.colsum(x[batch - 1], ld, rows, N, single)
     torch.cuda.synchronize()
     assert (single - ref[batch - 1]).abs().max().item() <= 2e-5 * rows ** 0.5 * ref.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("n,offset", [(4096, 0), (12, 0), (9, 0), (1027, 1), (3, 2), (1 << 20, 3)])
+def test_scale_is_exact_for_powers_of_two_at_any_length_and_alignment(n, offset):
+    """vault_scale_f32 (the fp16 build's gradient scale in and out of the flat f32 gradient buffer): x * 4096 / 4096 is the
+    identity bit for bit, for 16-byte-aligned middles and ragged heads / tails alike; the neighbours are untouched."""
+    buf = torch.randn(n + offset + 5, device="cuda")
+    x = buf[offset:offset + n]
+    want = x.clone()
+    guard = (buf[:offset].clone(), buf[offset + n:].clone())
+    ops.scale(x, 4096.0, n)
+    torch.cuda.synchronize()
+    assert torch.equal(x, want * 4096.0)
+    ops.scale(x, 1.0 / 4096.0, n)
+    torch.cuda.synchronize()
+    assert torch.equal(x, want)
+    assert torch.equal(buf[:offset], guard[0]) and torch.equal(buf[offset + n:], guard[1])
