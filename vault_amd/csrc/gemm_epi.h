@@ -37,7 +37,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
   constexpr int LD = PW + 4;                         // scratch row stride (floats): LD % 16 == 4 keeps both sides conflict-light
   constexpr int EL = PW / 4;                         // elements per lane per pass
   constexpr int GR = BF16_OUT ? 8 : 4;               // elements per 16-byte global access
-  constexpr int PD = 2 * NP;                         // prefetch distance (passes) = two 16-row steps
+#ifndef VAULT_EPI_PD
+#define VAULT_EPI_PD 2
+#endif
+  constexpr int PD = VAULT_EPI_PD * NP;              // prefetch distance (passes) = two 16-row steps
   constexpr int NPASS = TM * NP;
   static_assert(EL % GR == 0 && TN % NP == 0 && LD % 16 == 4, "epilogue tiling");
 
