@@ -25,3 +25,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _sane_cpu_threads():
+    """The full-size oracle tests raise torch's intra-op thread count to 64; left in place it makes the thousands of tiny
+    CPU ops of the small-model oracle runs that follow crawl (a test took 74 s instead of 1 s on the GPU box's 16-core share).
+    Every test starts at 8 threads; the tests that want more set it themselves."""
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    except Exception:  # pragma: no cover
+        pass
+    yield
