@@ -560,6 +560,7 @@ class VaultEngine:
             ops.pycall(lambda: self._prof_end("wgrad", fl, st))
 
     WGRAD_GROUPED = True           # the four weight-gradient kinds of a group of layers packed into full rounds of 256 tiles
+    WGRAD_SIDE_ITEMS = int(os.environ.get("VAULT_WGRAD_SIDE_ITEMS", "224"))   # items per grouped launch on the second stream (B = 64, same box: 256: 13.50 / 13.59 ms, 224: 13.32 / 13.46, 192: 13.23 / 13.47, 160: 13.63 / 13.53)
 
     def _wgrad_group_size(self, n_layers, after_layer):
         """Layers per deferred weight-gradient group.  A data-parallel step (``after_layer``: the reducer's stage listener)
@@ -593,7 +594,9 @@ class VaultEngine:
                 self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in layers[i0:hi]], i0, Mtok_pad, Nout, Kin, m_valid)
             return
         nk = Mtok_pad // 64
-        CU = 256
+        # items per launch: one per CU; beside a backward chain on another stream (small batches) fewer, so that the chain's
+        # kernels find free CUs while a launch's persistent blocks hold theirs (WGRAD_SIDE_ITEMS)
+        CU = self.WGRAD_SIDE_ITEMS if self._wgrad_side else 256
         # items of every kind in list order, cut into launches of CU items (<= 3 segments each)
         remaining = []
         for k, (dY_all, X_all, wsel, Nout, Kin) in enumerate(kinds):
