@@ -320,3 +320,18 @@ def test_full_size_batch_48_fp16_vs_fp32_oracle():
         assert dl <= NORTH_STAR_TOL and dloss <= NORTH_STAR_TOL
         del eng
     assert res[True] < 3e-3 and res[False] < 1.8e-3, res          # measured 2.0e-3 / 1.1e-3 (bf16 build: 1.1e-2)
+
+
+def test_task_heads_and_module_api_on_fp16_operands(monkeypatch):
+    """The reference's other head classes (retrieval, VQA MLP head, two-image NLVR2, masked LM), `inputs_embeds` /
+    `image_embeds` with gradients handed back to the caller, and gradient accumulation across backward passes - the module-level
+    tests of test_gpu_model.py with every model bound to the fp16 operand build (VAULT_HALF): the separately invoked head
+    backwards scale their incoming gradient, un-scale what they return, and keep the flat gradient buffer consistent."""
+    from . import test_gpu_model as M
+    monkeypatch.setenv("VAULT_HALF", "fp16")
+    M.test_itr_head_model_class_vs_reference_golden()
+    M.test_vqa_head_model_class_vs_reference_golden()
+    M.test_nlvr2_head_model_class_vs_reference_golden()
+    M.test_mlm_head_model_class_vs_reference_golden()
+    M.test_inputs_embeds_and_image_embeds_vs_reference_golden()
+    M.test_model_api_autograd_bridge()
