@@ -317,3 +317,66 @@ def test_embeds_inputs_vs_reference_golden():
     np.testing.assert_allclose(ie.grad.numpy(), g["d_image_embeds"], atol=2e-6, rtol=1e-3)
     assert float(g["grad_norm_word_embeddings"]) == 0.0 and P["bert.embeddings.word_embeddings.weight"].grad is None
     np.testing.assert_allclose(P["embeddings.token_type_embeddings.weight"].grad.numpy(), g["grad_modality_type"], atol=2e-6, rtol=1e-3)
+
+
+def test_number_format_emulations_against_the_reference_golden():
+    """What the two operand formats of the HIP library cost against the reference's fp32 numbers, on the CPU: the oracle with
+    matmul operands rounded to bf16 sits at ~4e-3 on the full-size golden's logits (outside the north star's 1e-3), with IEEE
+    fp16 operands at ~2.5e-4 (inside) - the reason the fp16 build exists.  Forward only (the backward emulations are compared
+    with the HIP kernels in the GPU suite)."""
+    g = np.load(os.path.join(GOLD, "full_bertweet_b2.npz"))
+    spec = CASES["full_bertweet_b2"]()
+    spec.lm.hidden_dropout_prob = 0.0
+    spec.lm.attention_probs_dropout_prob = 0.0
+    torch.set_num_threads(8)
+    bn = synthetic_batch(spec, int(g["meta_batch"]), seed=int(g["meta_data_seed"]), n_classes=3)
+    batch = O.torch_batch(bn)
+    P = O.to_torch_state(build_state(spec, 0))
+    err = {}
+    with torch.no_grad():
+        for name, ctx in (("bf16", O.emulate_bf16()), ("fp16", O.emulate_fp16())):
+            with ctx:
+                loss, out = O.vault_loss(P, spec, batch)
+            err[name] = (float(np.abs(out["logits"].numpy() - g["logits"]).max()), abs(float(loss) - float(g["loss"])))
+    print(err)
+    assert 1e-3 < err["bf16"][0] < 8e-3                      # bf16 operands: the format itself is outside the tolerance
+    assert err["fp16"][0] < 1e-3 and err["fp16"][1] < 1e-3   # fp16 operands: inside, with margin
+    assert err["fp16"][0] < 0.25 * err["bf16"][0]
+
+
+def test_fp16_gradient_emulation_needs_its_scale():
+    """Why the fp16 backward carries a power-of-two gradient scale: tiny model, gradients of the mean loss rounded to fp16 where
+    the HIP backward stores 16-bit tensors - under the engine's 2^12 scale they stay within 2e-3 of fp32, un-scaled (scale 2^-8,
+    as a stand-in for a larger batch / smaller gradients) they fall into fp16's subnormals and lose an order of magnitude."""
+    spec = VaultSpec.tiny(3, "roberta")
+    spec.lm.hidden_dropout_prob = 0.0
+    spec.lm.attention_probs_dropout_prob = 0.0
+    bn = synthetic_batch(spec, 4, seed=3, n_classes=3)
+    bn["labels"] = np.zeros_like(bn["labels"])
+    batch = O.torch_batch(bn)
+    state = build_state(spec, 0)
+
+    def grads(ctx):
+        P = O.to_torch_state(state, requires_grad=True)
+        if ctx is None:
+            loss, _ = O.vault_loss(P, spec, batch)
+            loss.backward()
+        else:
+            with ctx:                      # (the backward pass rounds too: inside the context)
+                loss, _ = O.vault_loss(P, spec, batch)
+                loss.backward()
+        return {k: v.grad.double() for k, v in P.items() if v.grad is not None and ".key.bias" not in k}
+
+    ref = grads(None)
+
+    def rel(a):
+        e = sum(float((a[k] - ref[k]).norm()) ** 2 for k in ref)
+        r = sum(float(ref[k].norm()) ** 2 for k in ref)
+        return (e / r) ** 0.5
+
+    good = rel(grads(O.emulate_fp16(backward=True, grad_scale=4096.0)))
+    bad = rel(grads(O.emulate_fp16(backward=True, grad_scale=2.0 ** -8)))
+    bf = rel(grads(O.emulate_bf16(backward=True)))
+    print(f"gradient error vs fp32: fp16 under 2^12 {good:.2e}, fp16 under 2^-8 {bad:.2e}, bf16 {bf:.2e}")
+    assert good < 2e-3 and good < 0.3 * bf
+    assert bad > 5 * good
