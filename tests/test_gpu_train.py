@@ -604,3 +604,29 @@ def test_data_parallel_full_width_default_buckets(tmp_path, wire, half):
         assert float(d.mean()) < 2e-6 and float((d > 1e-5).float().mean()) < 0.03
     else:
         assert float(d.mean()) < 4e-6 and float((d > 2e-5).float().mean()) < 0.03
+
+
+def test_train_step_after_an_api_backward_starts_from_zero_gradients():
+    """``TrainStep`` stores its un-split weight-gradient tiles (it counts on a zero gradient buffer: the fused AdamW leaves one).
+    Gradients an API-level ``engine.backward()`` left behind are cleared on entry instead of being half overwritten, half
+    accumulated: the step lands where a fresh engine's step lands."""
+    spec = VaultSpec.tiny(3, "roberta")
+    spec.lm.hidden_dropout_prob = 0.0
+    spec.lm.attention_probs_dropout_prob = 0.0
+    bn = synthetic_batch(spec, 4, seed=12, n_classes=3)
+    db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
+    labels = torch.from_numpy(bn["labels"]).cuda()
+    state = build_state(spec, 0)
+    a = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    a.forward(dict(db), train=True, labels=labels)
+    a.backward()                                    # leaves gradients in the flat buffer
+    assert a._g_dirty
+    sa = TrainStep(a, learning_rate=1e-4, warmup_ratio=0.0, total_steps=10, constant_lr=True)
+    la = float(sa(db, labels))
+    b = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    sb = TrainStep(b, learning_rate=1e-4, warmup_ratio=0.0, total_steps=10, constant_lr=True)
+    lb = float(sb(db, labels))
+    torch.cuda.synchronize()
+    assert la == lb and not a._g_dirty
+    d = (a.params.p - b.params.p).abs()
+    assert float(d.mean()) < 2e-6 and float((d > 2e-5).float().mean()) < 0.03      # float-atomic summation order only

@@ -346,6 +346,7 @@ class VaultEngine:
         self._wgrad_stream, self._wgrad_pending = None, False
         self._wgrad_side = False
         self._grads_zero = False
+        self._g_dirty = False      # the flat gradient buffer may hold gradients of an API-level backward (not yet consumed / zeroed)
         # optional live kernel timing (bench.py): {site: [(start, end, flops), ...]} of torch.cuda.Event pairs recorded
         # on the launch stream around every launch of a kernel instantiation.  Sites: "wgrad" = the ring kernel's
         # weight-gradient form gemm256_kernel<1,1,EPI_F32_ATOMIC,4> (every _wgrad launch that takes it), "ffn1" =
@@ -1313,6 +1314,7 @@ class VaultEngine:
 
     @_in_format
     def mlm_head_backward(self, dlogits: torch.Tensor) -> torch.Tensor:
+        self._g_dirty = True
         with torch.cuda.device(self.device), self._grads_scaled():
             spec, P = self.spec, self.params
             v = spec.vilt
@@ -1361,6 +1363,7 @@ class VaultEngine:
 
     @_in_format
     def mlp_head_backward(self, dlogits: torch.Tensor) -> torch.Tensor:
+        self._g_dirty = True
         with torch.cuda.device(self.device), self._grads_scaled():
             B = dlogits.shape[0]
             dx = self._mlp_backward(self._ws[("mlp_head", B)], dlogits.contiguous().float(), B, scale=self.grad_scale)
@@ -1373,6 +1376,7 @@ class VaultEngine:
     def zero_grad(self):
         if self.params.g is not None:
             self.params.g.zero_()
+        self._g_dirty = False
 
     def backward(self, grad_scale: Optional[float] = None, dlogits: Optional[torch.Tensor] = None,
                  dpooled: Optional[torch.Tensor] = None, dhidden: Optional[torch.Tensor] = None,
@@ -1384,6 +1388,7 @@ class VaultEngine:
         ``after_layer(tag)`` is called after each stage so a DP driver can start all-reducing the
         gradient range that just became final.
         """
+        self._g_dirty = True     # (the fused train step stores un-split weight-gradient tiles: it wants zeros, TrainStep checks)
         with torch.cuda.device(self.device), self._grads_scaled():
             self._backward(grad_scale, dlogits, dpooled, dhidden, after_layer, ws)
             if self.grad_scale != 1.0:      # gradients handed back to the caller's autograd graph

@@ -438,6 +438,10 @@ class TrainStep:
         tape (ops.Tape); later calls copy the batch into the persistent input buffers and replay it."""
         eng = self.engine
         B, T = batch["input_ids"].shape
+        if eng._g_dirty:
+            # gradients of an API-level backward (loss.backward() through the module) are still in the flat buffer: the fused step
+            # starts from zeros (it STORES its un-split weight-gradient tiles and lets AdamW clear the buffer afterwards)
+            eng.zero_grad()
         with torch.cuda.device(eng.device), ops.operand_format(eng.half):
             # staging decides the image geometry (square all-valid canvas, or a padded batch of differently sized
             # images: host-side patch selection); every geometry has its own workspace, hence its own tape
