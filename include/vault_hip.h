@@ -76,6 +76,10 @@ typedef struct vault_gemm_args {
                   can read back: q = rne(200 g + 26), step 0.005 over -0.13 .. 1.145 (0, 0.5, 1 exact).  Halves the bytes the
                   FFN-in forward writes for backward and the gelu'-product dgrad reads.  Ask vault_gemm_plan which kernel a
                   call would take and pass that cfg explicitly to both calls. */
+  int out_hm;  /* ABI 8, epi 0 on the 8-wave kernel (cfg 5 / 6) only: R > 0 = write the output HEAD-MAJOR, [N / 64][R][64] instead
+                  of [M][ldo] (R >= M rows per plane): the layout vault_attention_* reads with qkv_hm = R */
+  int a_hm;    /* ABI 8, ring kernel (cfg 3 / 4 / 8), a_mode 0: R > 0 = A is head-major [K / 64][R][64] (lda is ignored): the QKV
+                  data gradient reading the attention backward's dqkv */
 } vault_gemm_args;
 int vault_gemm(const vault_gemm_args* args, void* stream);
 /* the kernel / tile configuration vault_gemm would run these arguments on (the resolved `cfg`, 0..8), or -EINVAL */
@@ -97,6 +101,7 @@ typedef struct vault_wgrad_seg {
   int batch;       /* layers of this kind */
   int first, count;
   long long batch_dy, batch_x, batch_dw;
+  int dy_hm;       /* R > 0: dy is head-major [n_out / 64][R][64] (ld_dy ignored): the QKV kind reading dqkv */
 } vault_wgrad_seg;
 typedef struct vault_wgrad_grouped_args {
   int nseg;
@@ -158,6 +163,10 @@ int vault_layernorm_bwd(const vault_ln_bwd_args* args, void* stream);
 int vault_colsum(const void* in_bf16, int ld, int rows, int N, float* out, void* stream);
 /* ABI 7: the same for `batch` matrices at element stride batch_in, into `batch` vectors at float stride batch_out (the QKV bias
  * gradients of a group of layers in one launch) */
+/* ABI 8: the same column sums over a HEAD-MAJOR tensor [planes][hm_rows][64] (vault_attn_args.qkv_hm): out[64 p + d] += sum over
+ * rows < rows of in[(p * hm_rows + r) * 64 + d] for the first `planes` planes - the query third of the QKV bias gradient. */
+int vault_colsum_hm(const void* in_bf16, int rows, int hm_rows, int planes, float* out, int batch, long long batch_in,
+                    long long batch_out, void* stream);
 int vault_colsum_batched(const void* in_bf16, int ld, int rows, int N, float* out, int batch, long long batch_in,
                          long long batch_out, void* stream);
 
@@ -175,6 +184,11 @@ typedef struct vault_attn_args {
   int B, S, H, heads;
   uint32_t drop_thresh, drop_seed, drop_stream; float drop_scale;
   void* ctx_split3; /* fwd, optional bf16 [B*S][3H] = [hi | lo | hi] instead of ctx (precise path) */
+  int qkv_hm;       /* ABI 8: 0 = qkv / dqkv are [B*S][3H] (q | k | v, head h at columns 64 h); R > 0 = HEAD-MAJOR
+                       [3][heads][R][64] with R >= B*S padded token rows: the S rows of a (batch, head) item are contiguous,
+                       so the attention kernels' loads and - above all - the backward's dq / dk / dv stores stream instead of
+                       touching 128-byte segments at a 6 H byte stride.  Written by vault_gemm with out_hm, read by
+                       vault_gemm a_hm / vault_wgrad_seg.dy_hm / vault_colsum_hm.  S <= 192 in backward, no ctx_split3. */
 } vault_attn_args;
 int vault_attention_fwd(const vault_attn_args* args, void* stream);
 int vault_attention_bwd(const vault_attn_args* args, void* stream);

@@ -16,10 +16,11 @@ EPI_BF16, EPI_GELU, EPI_DGELU, EPI_RES, EPI_PATCH, EPI_ATOMIC = range(6)
 
 def _gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, cfg=-1, m_valid=0, splits=1, bias=None,
           res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, accumulate=0, colsum=None, persist=0, batch=0,
-          batch_a=0, batch_b=0, batch_o=0, aux_u8=0, plan_only=False):
+          batch_a=0, batch_b=0, batch_o=0, aux_u8=0, plan_only=False, out_hm=0, a_hm=0):
     lib = L.load()
     a = L.GemmArgs()
     a.aux_u8 = aux_u8
+    a.out_hm, a.a_hm = out_hm, a_hm
     a.A, a.B, a.out = A.data_ptr(), B.data_ptr(), out.data_ptr()
     a.out2 = out2.data_ptr() if out2 is not None else None
     a.bias = bias.data_ptr() if bias is not None else None
@@ -587,3 +588,69 @@ def test_ring_kernel_128_wide_tiles(K, rows):
     # not the other forms
     with pytest.raises(RuntimeError):
         _gemm(A, Wnk, out, M, N, K, K, K, N, 0, 0, EPI_BF16, cfg=8, bias=bias)
+
+
+def _to_hm(x, R):
+    M, N = x.shape
+    out = torch.zeros(N // 64, R, 64, dtype=x.dtype, device=x.device)
+    out[:, :M] = x.view(M, N // 64, 64).permute(1, 0, 2)
+    return out
+
+
+@pytest.mark.parametrize("cfg", [5, 6])
+@pytest.mark.parametrize("M,m_valid", [(512, 477), (256 * 43, 256 * 43 - 300)])
+def test_8wave_kernel_head_major_output(cfg, M, m_valid):
+    """``out_hm``: the QKV forward's 16-bit output written as [N / 64][R][64] (what the attention kernels read with qkv_hm)
+    equals the row-major output bit for bit; rows >= m_valid and >= M of every plane stay untouched."""
+    N, K, R = 2304, 768, M + 256
+    A = _rand(M, K, seed=71).bfloat16()
+    W = _rand(N, K, scale=0.05, seed=72).bfloat16()
+    bias = _rand(N, seed=73)
+    rm = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    _gemm(A, W, rm, M, N, K, K, K, N, 0, 0, EPI_BF16, cfg=cfg, bias=bias, m_valid=m_valid)
+    hm = torch.full((N // 64, R, 64), 3.0, dtype=torch.bfloat16, device="cuda")
+    _gemm(A, W, hm, M, N, K, K, K, N, 0, 0, EPI_BF16, cfg=cfg, bias=bias, m_valid=m_valid, out_hm=R)
+    torch.cuda.synchronize()
+    assert torch.equal(hm[:, :m_valid].permute(1, 0, 2).reshape(m_valid, N), rm[:m_valid])
+    assert float((hm[:, m_valid:] - 3.0).abs().max()) == 0.0
+    with pytest.raises(RuntimeError):       # not on the other kernels / epilogues
+        _gemm(A, W, hm, M, N, K, K, K, N, 0, 0, EPI_BF16, cfg=3, bias=bias, out_hm=R)
+
+
+@pytest.mark.parametrize("cfg", [3, 4, 8])
+@pytest.mark.parametrize("M", [512, 256 * 43])
+def test_ring_kernel_head_major_a_operand(cfg, M):
+    """``a_hm``: the QKV data gradient reading dqkv as [K / 64][R][64]: same result as from the row-major operand, bit for
+    bit (the same K order), in the (0,1) form of every tile width."""
+    K, N, R = 2304, 768, M + 512
+    dY = _rand(M, K, seed=81).bfloat16()
+    W = _rand(K, N, scale=0.05, seed=82).bfloat16()          # [K][N]: b_mode 1
+    rm = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    _gemm(dY, W, rm, M, N, K, K, N, N, 0, 1, EPI_BF16, cfg=cfg)
+    o = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    _gemm(_to_hm(dY, R), W, o, M, N, K, K, N, N, 0, 1, EPI_BF16, cfg=cfg, a_hm=R)
+    torch.cuda.synchronize()
+    assert torch.equal(o, rm)
+
+
+@pytest.mark.parametrize("splits", [1, 3])
+def test_grouped_weight_gradients_head_major_dy(splits):
+    """The QKV kind of a grouped weight-gradient launch with its dY (dqkv) head-major, beside a row-major kind."""
+    from vault_amd import ops
+    tokens, G, R = 448, 2, 512
+    kinds = [(768, 256), (512, 256)]                       # (n_out, n_in); kind 0's dY is head-major
+    dys = [(_rand(G, tokens, no, seed=90 + k) * 0.5).bfloat16() for k, (no, ni) in enumerate(kinds)]
+    xs = [(_rand(G, tokens, ni, seed=95 + k) * 0.5).bfloat16() for k, (no, ni) in enumerate(kinds)]
+    dy0_hm = torch.stack([_to_hm(dys[0][l], R) for l in range(G)])          # [G][12][R][64]
+    dws = [torch.zeros(G, no * ni, device="cuda") for no, ni in kinds]
+    args = [dict(dy=dy0_hm[0], x=xs[0][0], dw=dws[0][0], n_out=768, n_in=256, batch=G, first=0, count=6, batch_dy=dy0_hm.stride(0),
+                 batch_x=xs[0].stride(0), batch_dw=768 * 256, dy_hm=R),
+            dict(dy=dys[1][0], x=xs[1][0], dw=dws[1][0], n_out=512, n_in=256, batch=G, first=0, count=4, batch_dy=dys[1].stride(0),
+                 batch_x=xs[1].stride(0), batch_dw=512 * 256)]
+    ops.wgrad_grouped(args, tokens, splits=splits, accumulate=1)
+    torch.cuda.synchronize()
+    for k, (no, ni) in enumerate(kinds):
+        for l in range(G):
+            ref = dys[k][l].float().t() @ xs[k][l].float()
+            err = float((dws[k][l].view(no, ni) - ref).abs().max())
+            assert err <= 2e-3 * float(ref.abs().max()), (k, l, err)

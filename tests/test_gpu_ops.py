@@ -279,3 +279,64 @@ def test_scale_is_exact_for_powers_of_two_at_any_length_and_alignment(n, offset)
     torch.cuda.synchronize()
     assert torch.equal(x, want)
     assert torch.equal(buf[:offset], guard[0]) and torch.equal(buf[offset + n:], guard[1])
+
+
+def _to_head_major(x, R):
+    """[M, N] -> [N / 64, R, 64] (R >= M rows per plane, zero padded): the head-major layout of qkv / dqkv."""
+    M, N = x.shape
+    out = torch.zeros(N // 64, R, 64, dtype=x.dtype, device=x.device)
+    out[:, :M] = x.view(M, N // 64, 64).permute(1, 0, 2)
+    return out
+
+
+def _from_head_major(y, M):
+    P, R, _ = y.shape
+    return y[:, :M].permute(1, 0, 2).reshape(M, P * 64)
+
+
+@pytest.mark.parametrize("B,S,heads,drop_p", [(3, 185, 12, 0.0), (50, 185, 12, 0.0), (9, 40, 12, 0.1), (300, 40, 12, 0.0), (5, 129, 5, 0.0),
+                                              (4, 64, 2, 0.0), (2, 17, 1, 0.0)])
+def test_attention_head_major_layout_is_bit_identical(B, S, heads, drop_p):
+    """``qkv_hm``: qkv / dqkv as [3][heads][R][64] (a (batch, head) item's rows contiguous) instead of [tokens][3H]: the same
+    arithmetic on other addresses - context, log-sum-exp and the gradient (brought back to row-major) equal the row-major
+    run bit for bit, also with more items than workgroups and with dropout."""
+    H = heads * 64
+    M = B * S
+    R = ((M + 255) // 256) * 256 + 256
+    qkv = (_rand(M, 3 * H, seed=30) * 1.5).bfloat16()
+    keymask = torch.ones(B, S, device="cuda")
+    keymask[1, 5:min(17, S - 1)] = 0
+    keymask[B - 1, S - min(9, S - 2):] = 0
+    drop = ops.Drop(drop_p, seed=3, stream=2) if drop_p else ops.NO_DROP
+    ctx = torch.zeros(M, H, dtype=torch.bfloat16, device="cuda"); lse = torch.zeros(B, heads, S, device="cuda")
+    ops.attention_fwd(qkv, keymask, ctx, lse, B, S, H, heads, drop=drop)
+    dctx = _rand(M, H, seed=31).bfloat16()
+    dqkv = torch.zeros(M, 3 * H, dtype=torch.bfloat16, device="cuda")
+    ops.attention_bwd(qkv, keymask, ctx, lse, dctx, dqkv, B, S, H, heads, drop=drop)
+    qh = _to_head_major(qkv, R)
+    ctx2 = torch.zeros_like(ctx); lse2 = torch.zeros_like(lse)
+    ops.attention_fwd(qh, keymask, ctx2, lse2, B, S, H, heads, drop=drop, qkv_hm=R)
+    dqh = torch.full((3 * heads, R, 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.attention_bwd(qh, keymask, ctx2, lse2, dctx, dqh, B, S, H, heads, drop=drop, qkv_hm=R)
+    torch.cuda.synchronize()
+    assert torch.equal(ctx, ctx2) and torch.equal(lse, lse2)
+    assert torch.equal(_from_head_major(dqh, M), dqkv)
+    assert float((dqh[:, M:] - 7.0).abs().max()) == 0.0              # rows beyond the tokens are never written
+    # the layouts the kernels do not serve refuse
+    if S <= 64:
+        return
+    with pytest.raises(RuntimeError):
+        ops.attention_fwd(qh, keymask, ctx2, lse2, B, S, H, heads, qkv_hm=M - 1)
+
+
+def test_colsum_head_major():
+    rows, R, planes, batch = 11840, 12032, 12, 3
+    x = torch.randn(batch, 36, R, 64, device="cuda").bfloat16()
+    stride_o = 4096
+    out = torch.full((batch * stride_o,), 0.5, device="cuda")
+    ops.colsum_hm(x[0], rows, R, planes, out, batch, x.stride(0), stride_o)
+    torch.cuda.synchronize()
+    ref = x[:, :planes, :rows].float().sum(2).reshape(batch, planes * 64)
+    got = out.view(batch, stride_o)
+    assert (got[:, :planes * 64] - 0.5 - ref).abs().max().item() <= 2e-5 * rows ** 0.5 * ref.abs().max().item() + 1e-3
+    assert float((got[:, planes * 64:] - 0.5).abs().max()) == 0.0

@@ -20,3 +20,9 @@ for S in SEQS:
     tf = t(lambda: ops.attention_fwd(qkv, km, ctx, lse, B, S, H, heads))
     tb = t(lambda: ops.attention_bwd(qkv, km, ctx, lse, dctx, dqkv, B, S, H, heads))
     print(f"S={S:4d} B={B}: fwd {tf:7.1f} us   bwd {tb:7.1f} us   checksum {dqkv.float().abs().sum().item():.6e}")
+    # the same in the head-major layout of qkv / dqkv ([3][heads][M][64]: vault_attn_args.qkv_hm)
+    qh = qkv.view(M, 3 * heads, 64).permute(1, 0, 2).contiguous()
+    dqh = torch.zeros(3 * heads, M, 64, dtype=torch.bfloat16, device="cuda")
+    tf = t(lambda: ops.attention_fwd(qh, km, ctx, lse, B, S, H, heads, qkv_hm=M))
+    tb = t(lambda: ops.attention_bwd(qh, km, ctx, lse, dctx, dqh, B, S, H, heads, qkv_hm=M))
+    print(f"S={S:4d} B={B}: fwd {tf:7.1f} us   bwd {tb:7.1f} us   checksum {dqh.float().abs().sum().item():.6e}   (head-major qkv / dqkv)")

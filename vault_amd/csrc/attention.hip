@@ -49,6 +49,18 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ int swz_row(int row) { return (row >> 1) & 3; }  // 32-byte block XOR key
 
+// Layout of qkv / dqkv.  Row-major (hm_rows == 0): [tokens][3H], q | k | v, head h at columns 64 h: a (batch, head) item's rows
+// are 128-byte segments at a 6 H byte stride.  Head-major (hm_rows = padded token rows): [3][heads][hm_rows][64] - an item's S
+// rows are contiguous, its stores and loads stream (vault_attn_args.qkv_hm; the QKV GEMM's epilogue writes it, the QKV data /
+// weight gradient GEMMs read it: vault_gemm_args.out_hm / a_hm).
+struct QkvLayout {
+  int ld;        // elements between consecutive token rows
+  int hs;        // elements between consecutive heads
+  int pl;        // elements between q, k and v of one head
+  __device__ __forceinline__ QkvLayout(int H, int heads, int hm_rows)
+      : ld(hm_rows ? 64 : 3 * H), hs(hm_rows ? hm_rows * 64 : 64), pl(hm_rows ? heads * hm_rows * 64 : H) {}
+};
+
 // stage a [rows<=S][64] bf16 matrix (row stride ld elements) into a swizzled [SK][128 B] LDS image
 template <int SK, int NT>
 __device__ __forceinline__ void stage_rows(char* dst, const h16* src, int ld, int S, int tid) {
@@ -140,7 +152,7 @@ struct AttnDrop {
 template <int NKT, int NWV, int WPE, bool DROP = true>
 __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const h16* __restrict__ qkv, const float* __restrict__ keymask,
                                                        h16* __restrict__ ctx, float* __restrict__ lse, int S, int H,
-                                                       int heads, float scale, AttnDrop dr, h16* __restrict__ ctx3) {
+                                                       int heads, float scale, AttnDrop dr, h16* __restrict__ ctx3, int hm_rows) {
   H16_SATURATE();
   constexpr int SK = NKT * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -151,10 +163,11 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const h16* __re
   const int g = lane >> 4, l15 = lane & 15;
   const int h = blockIdx.x, b = blockIdx.y;
   const size_t row0 = (size_t)b * S;
-  const int ld = 3 * H;
-  const h16* qbase = qkv + row0 * ld + h * 64;
-  stage_rows<SK, NWV * 64>(Ks, qbase + H, ld, S, tid);
-  stage_rows<SK, NWV * 64>(Vs, qbase + 2 * H, ld, S, tid);
+  const QkvLayout lay(H, heads, hm_rows);
+  const int ld = lay.ld;
+  const h16* qbase = qkv + row0 * ld + (size_t)h * lay.hs;
+  stage_rows<SK, NWV * 64>(Ks, qbase + lay.pl, ld, S, tid);
+  stage_rows<SK, NWV * 64>(Vs, qbase + 2 * (size_t)lay.pl, ld, S, tid);
   for (int k = tid; k < SK; k += NWV * 64)
     mb[k] = (k < S && (keymask == nullptr || keymask[(size_t)b * S + k] != 0.f)) ? 0.f : -INFINITY;
   __syncthreads();
@@ -776,7 +789,7 @@ template <int NKT, int NWV, bool DROP = true, int WPE = 1>
 __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* __restrict__ qkv, const float* __restrict__ keymask,
                                                          const h16* __restrict__ ctx, const h16* __restrict__ dctx,
                                                          const float* __restrict__ lse, h16* __restrict__ dqkv, int S,
-                                                         int H, int heads, int items, float scale, AttnDrop dr) {
+                                                         int H, int heads, int items, float scale, AttnDrop dr, int hm_rows) {
   H16_SATURATE();
   constexpr int SK = NKT * 32;
   constexpr int DS_LD = ds_ld<SK>();
@@ -794,7 +807,8 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
   float* dl_s = lse_s + SK;        // delta[q]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
-  const int ld = 3 * H;
+  const QkvLayout lay(H, heads, hm_rows);
+  const int ld = lay.ld;
   const float sl2 = scale * LOG2E;
   const uint32_t ks_lds = (uint32_t)(size_t)LDS_PTR(char, Ks);
   const int G = (int)gridDim.x;
@@ -847,7 +861,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
     int b, h;
     item_bh(item, b, h);
     const size_t row0 = (size_t)b * S;
-    const char* qb = attn_uniform(qkv + row0 * ld + h * 64);
+    const char* qb = attn_uniform(qkv + row0 * ld + (size_t)h * lay.hs);
     const char* ob = attn_uniform(ctx + row0 * H + h * 64);
     const char* db = attn_uniform(dctx + row0 * H + h * 64);
 #pragma unroll
@@ -862,8 +876,8 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
   auto fetch_kv_frags = [&](int item) {  // 4 loads per wave, unconditional
     int b, h;
     item_bh(item, b, h);
-    const char* kb = attn_uniform(qkv + (size_t)b * S * ld + h * 64 + H);
-    const char* vb = attn_uniform(qkv + (size_t)b * S * ld + h * 64 + 2 * H);
+    const char* kb = attn_uniform(qkv + (size_t)b * S * ld + (size_t)h * lay.hs + lay.pl);
+    const char* vb = attn_uniform(qkv + (size_t)b * S * ld + (size_t)h * lay.hs + 2 * (size_t)lay.pl);
 #pragma unroll
     for (int s_ = 0; s_ < 2; ++s_) {
       attn_gload16(rkf[s_], kb, off_frag + 64u * s_);
@@ -875,7 +889,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
   auto dma_k = [&](int item) {
     int b, h;
     item_bh(item, b, h);
-    const char* kb = attn_uniform(qkv + (size_t)b * S * ld + h * 64 + H);
+    const char* kb = attn_uniform(qkv + (size_t)b * S * ld + (size_t)h * lay.hs + lay.pl);
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int pc = wave * NC + i, row = pc * 8 + (lane >> 3), slot = lane & 7;
@@ -931,7 +945,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
     b = item / heads; h = item - b * heads;
 #endif
     const uint32_t bh = (uint32_t)item;
-    char* dqbase = reinterpret_cast<char*>(dqkv + (size_t)b * S * ld + h * 64);
+    char* dqbase = reinterpret_cast<char*>(dqkv + (size_t)b * S * ld + (size_t)h * lay.hs);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // Q / dO images + statistics of this item complete
     const bool more = item + G < items, more2 = item + 2 * G < items;
 
@@ -1001,8 +1015,8 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
 #endif
 #if ATTN_WL
     {
-      char* dstk = dqbase + 2 * H;        // (byte offsets: K part at + H elements, V part at + 2 H elements)
-      char* dstv = dqbase + 4 * H;
+      char* dstk = dqbase + 2 * (size_t)lay.pl;        // (byte offsets: K part at + pl elements, V part at + 2 pl elements)
+      char* dstv = dqbase + 4 * (size_t)lay.pl;
       u32x4 wk[2], wv[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {    // tiles (2 hf, 2 hf + 1): d = 32 hf + 8 g + 0..7 of this lane's row
@@ -1025,8 +1039,8 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
     }
 #else
     if (wave * 16 + l15 < (ATTN_ABLATE == 5 ? -S : S)) {
-      char* dstk = dqbase + 2 * H;        // (byte offsets: K part at + H elements, V part at + 2 H elements)
-      char* dstv = dqbase + 4 * H;
+      char* dstk = dqbase + 2 * (size_t)lay.pl;        // (byte offsets: K part at + pl elements, V part at + 2 pl elements)
+      char* dstv = dqbase + 4 * (size_t)lay.pl;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {    // tiles (2 hf, 2 hf + 1): d = 32 hf + 8 g + 0..7 of this lane's row
         const f32x4 ka = dk[2 * hf], kb2 = dk[2 * hf + 1], va = dv[2 * hf], vb2 = dv[2 * hf + 1];
@@ -1132,6 +1146,7 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
   if (!a || !a->qkv || (!a->ctx && !a->ctx_split3) || !a->lse || a->S <= 0 || a->B <= 0 || a->H != a->heads * 64)
     return VAULT_EINVAL;
   if (a->S > 320) return VAULT_EINVAL;
+  if (a->qkv_hm != 0 && (a->qkv_hm < a->B * a->S || a->ctx_split3 != nullptr)) return VAULT_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const AttnDrop dr{a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale};
   dim3 grid(a->heads, a->B), block(256);
@@ -1139,7 +1154,7 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
 #define FWD_V(NK, NW, WP, DR)                                                                                          \
     hipLaunchKernelGGL((attn_fwd_kernel<NK, NW, WP, DR>), grid, dim3(NW * 64), attn_lds_bytes<NK>(), st,                \
                        reinterpret_cast<const h16*>(a->qkv), a->keymask, reinterpret_cast<h16*>(a->ctx), a->lse, a->S, \
-                       a->H, a->heads, scale, dr, reinterpret_cast<h16*>(a->ctx_split3))
+                       a->H, a->heads, scale, dr, reinterpret_cast<h16*>(a->ctx_split3), a->qkv_hm)
   // (dropout is a template switch: a per-element run-time test splits the loop body into basic blocks that the
   //  instruction scheduler cannot move MFMAs and LDS reads across)
   const bool drop = a->drop_thresh != 0u;
@@ -1158,7 +1173,7 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
     }
     hipLaunchKernelGGL(kern, grid, dim3(ATTN_L9_FWD_W * 64), attn_lds_bytes<9>(), st, reinterpret_cast<const h16*>(a->qkv),
                        a->keymask, reinterpret_cast<h16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
-                       reinterpret_cast<h16*>(a->ctx_split3));
+                       reinterpret_cast<h16*>(a->ctx_split3), a->qkv_hm);
   } else {   // long sequences of padded, larger images: K/V image 80 KiB -> one block per CU
     auto kern = attn_fwd_kernel<10, ATTN_LONG_WAVES_FWD, 1>;
     static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];
@@ -1170,7 +1185,7 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
     }
     hipLaunchKernelGGL(kern, grid, dim3(ATTN_LONG_WAVES_FWD * 64), attn_lds_bytes<10>(), st, reinterpret_cast<const h16*>(a->qkv),
                        a->keymask, reinterpret_cast<h16*>(a->ctx), a->lse, a->S, a->H, a->heads, scale, dr,
-                       reinterpret_cast<h16*>(a->ctx_split3));
+                       reinterpret_cast<h16*>(a->ctx_split3), a->qkv_hm);
   }
 #undef FWD_V
   return (int)hipGetLastError();
@@ -1181,6 +1196,8 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
       a->H != a->heads * 64)
     return VAULT_EINVAL;
   if (a->S > 320) return VAULT_EINVAL;
+  // head-major qkv / dqkv: the single-pass kernels (S <= 192), not the split3 (precise) output
+  if (a->qkv_hm != 0 && (a->qkv_hm < a->B * a->S || a->S > 192)) return VAULT_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const AttnDrop dr{a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale};
   dim3 grid(a->heads, a->B), block(256);
@@ -1218,7 +1235,7 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
       hipLaunchKernelGGL(kern, dim3(items < 256 ? items : 256), dim3(768), attn_one_lds_bytes<6>(), st,                       \
                          reinterpret_cast<const h16*>(a->qkv), a->keymask, reinterpret_cast<const h16*>(a->ctx),            \
                          reinterpret_cast<const h16*>(a->dctx), a->lse, reinterpret_cast<h16*>(a->dqkv), a->S, a->H,        \
-                         a->heads, items, scale, dr);                                                                         \
+                         a->heads, items, scale, dr, a->qkv_hm);                                                              \
     }
   static const bool one_pass_s = [] { const char* e = getenv("VAULT_ATTN_BWD_S"); return !(e && e[0] == '0'); }();   // development A/B switch
   if (a->S <= 64 && one_pass_s) {
@@ -1229,16 +1246,18 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
     if (drop) hipLaunchKernelGGL((attn_bwd_one_kernel<2, 4, true, 3>), dim3(grid), dim3(256), attn_one_lds_bytes<2>(), st,
                                  reinterpret_cast<const h16*>(a->qkv), a->keymask, reinterpret_cast<const h16*>(a->ctx),
                                  reinterpret_cast<const h16*>(a->dctx), a->lse, reinterpret_cast<h16*>(a->dqkv), a->S, a->H,
-                                 a->heads, items, scale, dr);
+                                 a->heads, items, scale, dr, a->qkv_hm);
     else hipLaunchKernelGGL((attn_bwd_one_kernel<2, 4, false, 3>), dim3(grid), dim3(256), attn_one_lds_bytes<2>(), st,
                             reinterpret_cast<const h16*>(a->qkv), a->keymask, reinterpret_cast<const h16*>(a->ctx),
                             reinterpret_cast<const h16*>(a->dctx), a->lse, reinterpret_cast<h16*>(a->dqkv), a->S, a->H,
-                            a->heads, items, scale, dr);
+                            a->heads, items, scale, dr, a->qkv_hm);
   } else if (a->S <= 64) {
+    if (a->qkv_hm) return VAULT_EINVAL;      // (head-major qkv: the single-pass kernels only)
     if (drop) OLD_V(2, true); else OLD_V(2, false);
   } else if (a->S <= 192) {
     const int items = a->B * a->heads;
     static const bool one_pass = [] { const char* e = getenv("VAULT_ATTN_BWD"); return !(e && e[0] == '0'); }();   // development A/B switch: 0 = the two-pass resident kernel
+    if (!one_pass && a->qkv_hm) return VAULT_EINVAL;
     if (one_pass) {
       if (drop) ONE_V(true) else ONE_V(false)
     } else {

@@ -23,6 +23,7 @@ static GemmParams params_of(const vault_gemm_args* a) {
   p.persist = a->persist;
   p.batch = a->batch; p.batch_a = a->batch_a; p.batch_b = a->batch_b; p.batch_o = a->batch_o;
   p.aux_u8 = a->aux_u8;
+  p.out_hm = a->out_hm; p.a_hm = a->a_hm;
   return p;
 }
 
@@ -62,6 +63,9 @@ extern "C" int vault_wgrad_grouped(const vault_wgrad_grouped_args* a, void* stre
     t.first = g.first; t.count = g.count;
     if (g.first < 0 || g.count < 1 || g.first + g.count > t.tiles * g.batch) return VAULT_EINVAL;
     t.batch_a = g.batch_dy; t.batch_b = g.batch_x; t.batch_o = g.batch_dw;
+    t.a_hm = g.dy_hm;
+    if (g.dy_hm < 0 || (g.dy_hm > 0 && g.dy_hm < a->tokens)) return VAULT_EINVAL;
+    if (g.dy_hm > 0) t.lda = 64;
   }
   return vault_gemm256_grouped_launch(p, reinterpret_cast<hipStream_t>(stream));
 }

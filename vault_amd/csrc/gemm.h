@@ -48,6 +48,11 @@ struct GemmParams {
   int batch;
   long long batch_a, batch_b, batch_o;
   int aux_u8;       // 8-wave kernel only: gelu' (out2 of EPI_BF16_GELU, aux of EPI_BF16_DGELU) is the 8-bit tile-native form
+  // Head-major 16-bit tensors (the attention kernels' qkv / dqkv, vault_attn_args.qkv_hm): [N / 64][R][64] instead of [R][N].
+  //   out_hm = R: the EPI_BF16 output of the 8-wave kernel is written in that layout (QKV forward);
+  //   a_hm = R:   the A operand of the ring kernel's (0, *) modes is read from it ([K / 64][R][64]: a K tile = one plane,
+  //               rows contiguous - the QKV data gradient's dqkv); 0 = row-major.
+  int out_hm, a_hm;
   // Grouped weight gradients (ring kernel, (1,1) operand modes, EPI_F32_ATOMIC): ONE launch over up to three segments of
   // DIFFERENT weight-gradient kinds that share the contraction (the tokens) and therefore the cost per 256 x 256 tile: the
   // work list is their concatenation, so a launch can be sized to exactly one round of the 256 CUs (e.g. the 216 FFN-out
@@ -61,6 +66,7 @@ struct GemmParams {
     int lda, ldb, ldo;
     int first, count;                 // items [first, first + count) of the kind's (problem-major, tile-minor) numbering
     long long batch_a, batch_b, batch_o;   // element strides between the kind's problems (layers)
+    int a_hm;                         // > 0: dY is head-major [M / 64][a_hm rows][64] (the QKV kind's dqkv)
   } seg[3];
 };
 

@@ -392,6 +392,12 @@ int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) 
   if (cfg == 8 && (p.M % 256 || p.N % 128 || p.K % 64 || p.splits > 1 || p.batch > 1 || a_mode != 0 ||
                    !((b_mode == 0 && epi == EPI_F32_RES && p.res != nullptr) || (b_mode == 1 && epi == EPI_BF16))))
     return -VAULT_EINVAL;
+  // head-major tensors (GemmParams::out_hm / a_hm): written by the 8-wave kernel's plain 16-bit epilogue, read as the ring
+  // kernel's row-major-side A operand; anything else refuses
+  if (p.out_hm && !((cfg == 5 || cfg == 6) && epi == EPI_BF16 && p.out_hm >= p.M && p.N % 64 == 0 && p.split3 == 0 &&
+                    (long long)(p.N / 64) * p.out_hm * 128 < (1ll << 32)))
+    return -VAULT_EINVAL;
+  if (p.a_hm && !((cfg == 3 || cfg == 4 || cfg == 8) && a_mode == 0 && p.a_hm >= p.M)) return -VAULT_EINVAL;
   if (cfg < 0 || cfg > 8) return -VAULT_EINVAL;
   if (cfg == 7 && (a_mode != 0 || epi == EPI_F32_ATOMIC || p.splits > 1 || p.batch > 1)) return -VAULT_EINVAL;
   return cfg;

@@ -113,13 +113,14 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   const char* b_base;
   uint32_t a_off[4], b_off[4];
   uint32_t a_half, b_half, a_step, b_step;   // bytes
-  if constexpr (A_MODE == 0) { a_half = 64u * p.lda * 2u; a_step = 128u; }
+  // (A_MODE 0 with a head-major A, p.a_hm rows per plane [K / 64][a_hm][64]: a K tile is one plane, lda = 64 - the launcher)
+  if constexpr (A_MODE == 0) { a_half = 64u * p.lda * 2u; a_step = p.a_hm ? (uint32_t)p.a_hm * 128u : 128u; }
   else { a_half = 128u; a_step = 64u * p.lda * 2u; }
   if constexpr (B_MODE == 0) { b_half = (uint32_t)(NTQ * 16) * p.ldb * 2u; b_step = 128u; }
   else { b_half = (uint32_t)(NTQ * 16) * 2u; b_step = 64u * p.ldb * 2u; }
   // per-lane staging offsets of the four 1-KiB pieces per half-tile (they depend on the leading dimensions: recomputed
   // per work item in grouped launches, from an opaque copy of the lane id so that nothing extra stays live)
-  auto lane_offsets = [&](int lda_, int ldb_) {
+  auto lane_offsets = [&](int lda_, int ldb_, int a_hm_ = 0) {
     const int ln_ = lane_id_volatile();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -130,7 +131,9 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
       const int hk = (krow & 3) | (((krow >> 3) & 1) << 2);
       const int cb = (pos16 >> 1) ^ hk;
       if constexpr (A_MODE == 0) a_off[i] = (uint32_t)(((r >> 6) * 128 + (r & 63)) * lda_ + c * 8) * 2u;
-      else a_off[i] = (uint32_t)(krow * lda_ + (cb >> 2) * 128 + (cb & 3) * 16 + (pos16 & 1) * 8) * 2u;
+      else if (a_hm_ == 0) a_off[i] = (uint32_t)(krow * lda_ + (cb >> 2) * 128 + (cb & 3) * 16 + (pos16 & 1) * 8) * 2u;
+      // head-major dY [M / 64][a_hm][64]: column (cb >> 2) * 128 + 64 h + (cb & 3) * 16 + .. lies in plane 2 (cb >> 2) + h
+      else a_off[i] = ((uint32_t)krow * 64u + (uint32_t)(cb >> 2) * 2u * (uint32_t)a_hm_ * 64u + (uint32_t)((cb & 3) * 16 + (pos16 & 1) * 8)) * 2u;
       if constexpr (B_MODE == 0) {
         // half-tile image: 2 wave-columns x NTQ*16 rows of 128 B; piece jb = wave*PB + i covers rows 8jb..8jb+7
         const int jb = wave * PB + (i < PB ? i : PB - 1), rb = 8 * jb + r8;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
 #define SEGF(F) ((si == 0) ? p.seg[0].F : ((si == 1) ? p.seg[1].F : p.seg[2].F))
         const int idx = SEGF(first) + r, tiles_k = SEGF(tiles), tn_k = SEGF(tiles_n);
         const int bz = idx / tiles_k, tl = idx - bz * tiles_k;
-        const int lda_ = SEGF(lda), ldb_ = SEGF(ldb);
+        const int lda_ = SEGF(lda), ldb_ = SEGF(ldb), ahm_ = SEGF(a_hm);
         const h16* pA = SEGF(A) + (size_t)bz * SEGF(batch_a);
         const h16* pB = SEGF(B) + (size_t)bz * SEGF(batch_b);
         out_cur = SEGF(out) + (size_t)bz * SEGF(batch_o);
@@ -167,9 +170,11 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
         m0 = tile_m << 8; n0 = tile_n << 8;
         const int kt0 = z * per;
         nk = min(nk_total, kt0 + per) - kt0;
-        a_step = 64u * (uint32_t)lda_ * 2u; b_step = 64u * (uint32_t)ldb_ * 2u;
-        lane_offsets(lda_, ldb_);
-        a_base = reinterpret_cast<const char*>(pA + (size_t)kt0 * 64 * lda_ + m0);
+        a_step = 64u * (uint32_t)lda_ * 2u; b_step = 64u * (uint32_t)ldb_ * 2u;       // (head-major dY: lda_ = 64)
+        a_half = ahm_ ? (uint32_t)ahm_ * 128u : 128u;
+        lane_offsets(lda_, ldb_, ahm_);
+        a_base = ahm_ ? reinterpret_cast<const char*>(pA + ((size_t)(m0 >> 6) * ahm_ + (size_t)kt0 * 64) * 64)
+                      : reinterpret_cast<const char*>(pA + (size_t)kt0 * 64 * lda_ + m0);
         b_base = reinterpret_cast<const char*>(pB + (size_t)kt0 * 64 * ldb_ + n0);
         return;
       }
@@ -195,7 +200,8 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     m0 = tile_m << 8; n0 = tile_n * BNT;
     const int kt0 = z * per;
     nk = min(nk_total, kt0 + per) - kt0;
-    if constexpr (A_MODE == 0) a_base = reinterpret_cast<const char*>(pA + (size_t)m0 * p.lda + (size_t)kt0 * 64);
+    if constexpr (A_MODE == 0) a_base = p.a_hm ? reinterpret_cast<const char*>(pA + ((size_t)kt0 * p.a_hm + m0) * 64)
+                                               : reinterpret_cast<const char*>(pA + (size_t)m0 * p.lda + (size_t)kt0 * 64);
     else a_base = reinterpret_cast<const char*>(pA + (size_t)kt0 * 64 * p.lda + m0);
     if constexpr (B_MODE == 0) b_base = reinterpret_cast<const char*>(pB + (size_t)n0 * p.ldb + (size_t)kt0 * 64);
     else b_base = reinterpret_cast<const char*>(pB + (size_t)kt0 * 64 * p.ldb + n0);
@@ -558,6 +564,11 @@ int launch256(const GemmParams& p, hipStream_t st) {
     attr_done[dev] = true;
   }
   GemmParams q = p;
+  if (p.a_hm) {     // head-major A: a_mode 0 only, planes of >= M rows, no batching
+    if (A_MODE != 0 || p.a_hm < p.M || p.batch > 1) return VAULT_EINVAL;
+    q.lda = 64;
+  }
+  if (p.out_hm) return VAULT_EINVAL;      // (head-major output: the 8-wave kernel's EPI_BF16 only)
   q.gn = (p.gn > 0) ? std::min(p.gn, p.N / BNT) : p.N / BNT;   // default: plain m-major raster (see gemm.hip)
   const int nk_total = p.K >> 6;
   const int per = (nk_total + p.splits - 1) / p.splits;
@@ -615,7 +626,8 @@ int vault_gemm256_grouped_launch(const GemmParams& p, hipStream_t st) {
     const GemmParams::Seg& g = p.seg[k];
     if (!g.A || !g.B || !g.out || g.tiles_n < 1 || g.tiles < g.tiles_n || g.tiles % g.tiles_n || g.count < 1 || g.first < 0 ||
         (g.lda & 7) || (g.ldb & 7) || (g.ldo & 3) || (g.batch_a & 7) || (g.batch_b & 7) || (g.batch_o & 3) ||
-        g.lda < (g.tiles / g.tiles_n) * 256 || g.ldb < g.tiles_n * 256 || g.ldo < g.tiles_n * 256)
+        (g.a_hm == 0 && g.lda < (g.tiles / g.tiles_n) * 256) || (g.a_hm != 0 && g.lda != 64) || g.ldb < g.tiles_n * 256 ||
+        g.ldo < g.tiles_n * 256)
       return VAULT_EINVAL;
     total += g.count;
   }

@@ -338,6 +338,18 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
       const uint32_t off0 = (uint32_t)(((size_t)(mw + el15) * p.ldo + nc) * 2);
 #endif
       const uint32_t step = (uint32_t)p.ldo * 32u;
+      // store offsets: the output rows, or - head-major output (p.out_hm = rows per plane: the QKV forward writing what the
+      // attention kernels read, [N / 64][out_hm][64]) - column c in plane c >> 6 at position c & 63: the units of a lane are
+      // 16 (8) bytes inside ONE plane row, so only the three constants change
+      uint32_t so0 = off0, sstep = step, sc1 = c1;
+      if (EPI == EPI_BF16 && p.out_hm) {
+        const int nc1 = nc + (int)(c1 >> 1);
+        const uint32_t cp0 = (uint32_t)(nc >> 6) * (uint32_t)p.out_hm * 128u + (uint32_t)(nc & 63) * 2u;
+        const uint32_t cp1 = (uint32_t)(nc1 >> 6) * (uint32_t)p.out_hm * 128u + (uint32_t)(nc1 & 63) * 2u;
+        so0 = (uint32_t)(mw + el15) * 128u + cp0;
+        sstep = 2048u;
+        sc1 = cp1 - cp0;
+      }
       // WL: rows (l15 & 7) [+ 8 for the second instruction], byte half (l15 >> 3) of the 128-byte segment
       const uint32_t offw = (uint32_t)(((size_t)(mw + (el15 & 7)) * p.ldo + nc) * 2) + (uint32_t)(el15 >> 3) * 64u;
       const char* outp = reinterpret_cast<const char*>(p.out);
@@ -509,7 +521,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
 #else
           if (FULL || m < p.m_valid) {
 #endif
-            const uint32_t o = off0 + (uint32_t)mt * step + (j ? c1 : 0u);
+            const uint32_t o = so0 + (uint32_t)mt * sstep + (j ? sc1 : 0u);
             if (nv == 8) {
               if constexpr (EPI == EPI_BF16_GELU)
                 asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(o), "v"(w2), "s"(o2_) : "memory");

@@ -383,6 +383,29 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const h16* __restrict__ in
   }
 }
 
+// column sums of a head-major tensor [planes][hm_rows][64]: block (plane, row block): 1024 threads = 64 rows x 16 lanes of 8 bytes
+__global__ __launch_bounds__(1024) void colsum_hm_kernel(const h16* __restrict__ in, int rows, int hm_rows, int rows_per_block,
+                                                         float* __restrict__ out, long long batch_in, long long batch_out) {
+  __shared__ float red[64][65];
+  const h16* base = in + (size_t)blockIdx.z * batch_in + (size_t)blockIdx.x * hm_rows * 64;
+  const int t = threadIdx.x, r_in = t >> 4, c4 = (t & 15) * 4;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int r = r0 + r_in; r < r1; r += 64) {
+    const uint2 w = *reinterpret_cast<const uint2*>(base + (size_t)r * 64 + c4);
+    const float2 x = unpack_h16x2(w.x), y = unpack_h16x2(w.y);
+    a0 += x.x; a1 += x.y; a2 += y.x; a3 += y.y;
+  }
+  red[r_in][c4] = a0; red[r_in][c4 + 1] = a1; red[r_in][c4 + 2] = a2; red[r_in][c4 + 3] = a3;
+  __syncthreads();
+  if (t < 64) {
+    float s_ = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 64; ++r) s_ += red[r][t];
+    atomicAdd(out + (size_t)blockIdx.z * batch_out + blockIdx.x * 64 + t, s_);
+  }
+}
+
 }  // namespace
 
 extern "C" int vault_layernorm_fwd(const vault_ln_fwd_args* a, void* stream) {
@@ -471,6 +494,19 @@ extern "C" int vault_layernorm_bwd(const vault_ln_bwd_args* a, void* stream) {
   }
 #undef LN_BWD
 #undef LN_BWD_W
+  return (int)hipGetLastError();
+}
+
+extern "C" int vault_colsum_hm(const void* in_bf16, int rows, int hm_rows, int planes, float* out, int batch, long long batch_in,
+                               long long batch_out, void* stream) {
+  if (!in_bf16 || !out || rows <= 0 || hm_rows < rows || planes <= 0 || batch <= 0 || batch > 65535 || (batch_in & 3))
+    return VAULT_EINVAL;
+  const int row_blocks = std::max(4, 256 / (planes * batch));
+  int rpb = (rows + row_blocks - 1) / row_blocks;
+  rpb = ((rpb + 63) / 64) * 64;
+  dim3 grid(planes, (rows + rpb - 1) / rpb, batch);
+  hipLaunchKernelGGL(colsum_hm_kernel, grid, dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const h16*>(in_bf16), rows, hm_rows, rpb, out, batch_in, batch_out);
   return (int)hipGetLastError();
 }
 

@@ -323,6 +323,8 @@ class VaultEngine:
             self.WGRAD_BATCH_RING = False
         if os.environ.get("VAULT_WGRAD_GROUPED") in ("0", "1"):   # development override (same-box A/B)
             self.WGRAD_GROUPED = os.environ["VAULT_WGRAD_GROUPED"] == "1"
+        if os.environ.get("VAULT_HEAD_MAJOR") in ("0", "1"):      # development override (same-box A/B)
+            self.HEAD_MAJOR = os.environ["VAULT_HEAD_MAJOR"] == "1"
         if os.environ.get("VAULT_WGRAD_BATCH_MAX_ROWS"):
             self.WGRAD_BATCH_MAX_ROWS = int(os.environ["VAULT_WGRAD_BATCH_MAX_ROWS"])
         if os.environ.get("VAULT_GELU8") in ("0", "1"):   # development override (same-box A/B)
@@ -561,6 +563,7 @@ class VaultEngine:
             ops.pycall(lambda: self._prof_end("wgrad", fl, st))
 
     WGRAD_GROUPED = True           # the four weight-gradient kinds of a group of layers packed into full rounds of 256 tiles
+    HEAD_MAJOR = True              # qkv / dqkv of large batches in the head-major layout [3][heads][rows][64] (see _plan_head_major)
     WGRAD_SIDE_ITEMS = int(os.environ.get("VAULT_WGRAD_SIDE_ITEMS", "224"))   # items per grouped launch on the second stream (B = 64, same box: 256: 13.50 / 13.59 ms, 224: 13.32 / 13.46, 192: 13.23 / 13.47, 160: 13.63 / 13.53)
 
     def _wgrad_group_size(self, n_layers, after_layer):
@@ -583,6 +586,8 @@ class VaultEngine:
         Falls back to one batched launch per kind when a shape is not a multiple of 256 (the tiny test models)."""
         P = self.params
         G = hi - i0
+        hms = [k[5] if len(k) > 5 else 0 for k in kinds]        # rows per plane of a head-major dY (the QKV kind's dqkv), 0 = row-major
+        kinds = [k[:5] for k in kinds]
         ok = self.WGRAD_GROUPED and self.WGRAD_BATCH_RING and all(no % 256 == 0 and ki % 256 == 0 for *_, no, ki in kinds)
         strides = []
         for dY_all, X_all, wsel, Nout, Kin in kinds:
@@ -591,6 +596,8 @@ class VaultEngine:
             ok = ok and all(offs[k + 1] - offs[k] == so for k in range(G - 1))
             strides.append(so)
         if not ok:
+            if any(hms):
+                raise RuntimeError("head-major dqkv needs the grouped ring weight-gradient launches (_plan_head_major)")
             for dY_all, X_all, wsel, Nout, Kin in kinds:
                 self._wgrad_batched(dY_all, X_all, [getattr(l_, wsel) for l_ in layers[i0:hi]], i0, Mtok_pad, Nout, Kin, m_valid)
             return
@@ -628,13 +635,13 @@ class VaultEngine:
                 dY_all, X_all, wsel, Nout, Kin = kinds[k]
                 gw = P.gr(getattr(layers[i0], wsel), n_elems=Nout * Kin, shape=(Nout, Kin))
                 args.append(dict(dy=dY_all[i0], x=X_all[i0], dw=gw, n_out=Nout, n_in=Kin, batch=G, first=first, count=c,
-                                 batch_dy=dY_all.stride(0), batch_x=X_all.stride(0), batch_dw=strides[k]))
+                                 batch_dy=dY_all.stride(0), batch_x=X_all.stride(0), batch_dw=strides[k], dy_hm=hms[k]))
             ops.pycall(lambda: self._prof_begin("wgrad", st))
             ops.wgrad_grouped(args, Mtok_pad, splits=splits, accumulate=acc)
             fl = 2.0 * m_valid * 65536.0 * count
             ops.pycall(lambda fl=fl: self._prof_end("wgrad", fl, st))
 
-    def _qkv_bias_grads_batched(self, dqkv_all, layers, i0, hi, ld, rows, N):
+    def _qkv_bias_grads_batched(self, dqkv_all, layers, i0, hi, ld, rows, N, hm=0):
         """QKV bias gradients of layers i0 .. hi - 1 (column sums over the token rows of the first N columns of their dqkv) in
         ONE launch, issued with the group's batched weight gradients: at small batches a single layer's pass is a 4 us read
         behind a 10 us launch + reduction tail, and next to the weight gradients it is off the backward chain."""
@@ -644,6 +651,9 @@ class VaultEngine:
         if any(offs[k + 1] - offs[k] != stride_o for k in range(len(offs) - 1)):
             raise RuntimeError("batched bias gradients need identically laid out layers")
         gqb = P.gr(layers[i0].qb, n_elems=ld, shape=(ld,))
+        if hm:       # head-major dqkv: plane p = columns 64 p .. 64 p + 63
+            ops.colsum_hm(dqkv_all[i0], rows, hm, N // 64, gqb, hi - i0, dqkv_all.stride(0), stride_o)
+            return
         ops.colsum_batched(dqkv_all[i0], ld, rows, N, gqb, hi - i0, dqkv_all.stride(0), stride_o)
 
     def _plan_gelu8(self, ws, n2, act, u, ln, Mp, M):
@@ -666,6 +676,38 @@ class VaultEngine:
                 cfg = c1
         ws["gelu8_cfg"] = cfg
         return cfg
+
+    def _plan_head_major(self, ws, key, a16, wname, rows_pad, rows, S, pr, train):
+        """Rows per plane (= rows_pad) when this stack's qkv / dqkv live HEAD-MAJOR in this workspace, else 0.  Head-major
+        ([3][heads][rows_pad][64] in the same buffers) makes a (batch, head) item's rows contiguous: the attention kernels'
+        loads and the backward's dq / dk / dv stores stream instead of touching 128-byte segments at a 4.6 KB stride
+        (tools/attn_bench.py, B = 256: backward 201-206 -> 188 us, LM shape 31 -> 28).  Needs every producer / consumer on a
+        kernel that serves the layout - QKV forward on the 8-wave kernel (out_hm), QKV data gradient on the ring kernel (a_hm),
+        weight gradients through the grouped ring launches (dy_hm), the single-pass attention backward (S <= 192) - which the
+        library is asked about once per workspace (vault_gemm_plan); small batches, the precise and fp8-forward modes and the
+        stage-level calls keep the row-major layout."""
+        mode = (bool(self.fp8_forward), ops.GEMM_SCHED, bool(pr), bool(train), self.HEAD_MAJOR, self.WGRAD_GROUPED)
+        if ws.get(key + "_mode") == mode:
+            return ws[key]
+        ws[key + "_mode"] = mode
+        P, H, FF = self.params, ws["H"], ws["FF"]
+        hm = 0
+        if (self.HEAD_MAJOR and not pr and not self.fp8_forward and S <= 192 and rows_pad % 256 == 0 and H % 256 == 0 and FF % 256 == 0
+                and rows_pad <= self.WGRAD_BATCH_MAX_ROWS and os.environ.get("VAULT_ATTN_BWD", "1") != "0" and os.environ.get("VAULT_ATTN_BWD_S", "1") != "0"):
+            w = P.wb(wname, n_elems=3 * H * H, shape=(3 * H, H))
+            # (plan only: the pointers are not dereferenced, but must not be null)
+            c1 = ops.gemm(a16, w, a16, rows_pad, 3 * H, H, H, H, 3 * H, 0, 0, ops.EPI_BF16, m_valid=rows,
+                          bias=P.w(wname.replace("weight", "bias"), n_elems=3 * H, shape=(3 * H,)), out_hm=rows_pad, plan_only=True)
+            ok = c1 in (5, 6)
+            if ok and train:
+                c2 = ops.gemm(a16, w, a16, rows_pad, H, 3 * H, 3 * H, H, H, 0, 1, ops.EPI_BF16, m_valid=rows, a_hm=rows_pad,
+                              plan_only=True)
+                ok = c2 in (3, 4, 8) and self.LM_WGRAD_BATCHED and self.WGRAD_GROUPED and self.WGRAD_BATCH_RING \
+                    and P.gr(wname) is not None
+            if ok:
+                hm = rows_pad
+        ws[key] = hm
+        return hm
 
     def _use_stage(self, rows_pad: int, pr: bool) -> bool:
         e = os.environ.get("VAULT_STAGE_ABI")
@@ -1018,6 +1060,7 @@ class VaultEngine:
                 act = buf(f"lm_act{sfx}{p3}", (Mlp, W3 * FF), bf)
                 h2 = buf(f"lm_h2{sfx}", (Mlp, H))
                 if lm_stage:
+                    ws["lm_qkv_hm"], ws["lm_qkv_hm_mode"] = 0, None
                     da, dh = self._drop(pda, 16 * i + 2, lm_train), self._drop(pdh, 16 * i + 3, lm_train)
                     a = self._stage_layer_args(
                         ws, ln, "lm", i, Ml, Mlp, T, amf, y[i], y[i + 1],
@@ -1027,10 +1070,12 @@ class VaultEngine:
                         drops=(da, dh), x_in_bf16=yb[i], x_out_bf16=yb[i + 1])
                     ops.layer_call("vault_lm_layer_fwd", a, seeded=bool(da.thresh or dh.thresh))
                     continue
+                lhm = self._plan_head_major(ws, "lm_qkv_hm", yb[i], ln.qw, Mlp, Ml, T, pr, keep)
                 self._linear(yb[i], ln.qw, qkv, Mlp, 3 * H, H, ops.EPI_BF16, Ml,
-                             bias=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)), precise=pr, prequant=q8l[0] is not None)
+                             bias=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)), precise=pr, prequant=q8l[0] is not None,
+                             **(dict(out_hm=lhm) if lhm else {}))
                 ops.attention_fwd(qkv, amf, None if pr else ctx, lse, B, T, H, heads,
-                                  drop=self._drop(pda, 16 * i + 2, lm_train), ctx_split3=ctx if pr else None)
+                                  drop=self._drop(pda, 16 * i + 2, lm_train), ctx_split3=ctx if pr else None, qkv_hm=lhm)
                 if pt:
                     self._keep_hi(ctx, buf(f"lm_ctx{sfx}", (Mlp, H), bf), H)
                 self._linear(ctx, ln.ow, h1, Mlp, H, H, ops.EPI_F32_RES, Ml, bias=P.w(ln.ob), res=y[i],
@@ -1144,6 +1189,7 @@ class VaultEngine:
             act = buf(f"act{sfx}{p3}", (Mp, W3 * FF), bf)
             if self._use_stage(Mp, pr):
                 ws["vilt_stage"] = True
+                ws["qkv_hm"], ws["qkv_hm_mode"] = 0, None
                 a = self._stage_layer_args(
                     ws, ln, "vilt", i, M, Mp, S, km, x[i], x[i + 1],
                     dict(n1=n1, qkv=qkv, ctx=ctx, lse=lse, xm=xm, n2=n2, act=act, u=u, m1=buf(f"m1{sfx}", (Mp,)),
@@ -1155,9 +1201,10 @@ class VaultEngine:
             ops.layernorm_fwd(x[i], P.w(ln.ln1w), P.w(ln.ln1b), v.layer_norm_eps, M, H,
                               y_bf16=(buf(f"n1{sfx}", (Mp, H), bf) if pt else None) if pr else n1, y_split3=n1 if pr else None, mean=buf(f"m1{sfx}", (Mp,)), rstd=buf(f"r1{sfx}", (Mp,)),
                               y_q=q8[0], y_scale=q8[1])
+            vhm = self._plan_head_major(ws, "qkv_hm", n1, ln.qw, Mp, M, S, pr, train)
             self._linear(n1, ln.qw, qkv, Mp, 3 * H, H, ops.EPI_BF16, M, bias=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)),
-                         precise=pr, prequant=q8[0] is not None)
-            ops.attention_fwd(qkv, km, None if pr else ctx, lse, B, S, H, heads, ctx_split3=ctx if pr else None)
+                         precise=pr, prequant=q8[0] is not None, **(dict(out_hm=vhm) if vhm else {}))
+            ops.attention_fwd(qkv, km, None if pr else ctx, lse, B, S, H, heads, ctx_split3=ctx if pr else None, qkv_hm=vhm)
             if pt:
                 self._keep_hi(ctx, buf(f"ctx{sfx}", (Mp, H), bf), H)
             self._linear(ctx, ln.ow, xm, Mp, H, H, ops.EPI_F32_RES, M, bias=P.w(ln.ob), res=x[i], precise=pr)
@@ -1577,8 +1624,9 @@ class VaultEngine:
             self._dgrad(dyB, ln.ow, dctx, Mp, H, H, ops.EPI_BF16, M, **(dict(colsum=gqb[2 * H:]) if short else {}))
             if not vbatch:
                 self._wgrad(dyB, g("ctx"), ln.ow, None, Mp, H, H, M)
-            ops.attention_bwd(g("qkv"), km, g("ctx"), g("lse"), dctx, dqkv, B, S, H, heads)
-            self._dgrad(dqkv, ln.qw, dN, Mp, H, 3 * H, ops.EPI_BF16, M)
+            vhm = ws.get("qkv_hm", 0)
+            ops.attention_bwd(g("qkv"), km, g("ctx"), g("lse"), dctx, dqkv, B, S, H, heads, qkv_hm=vhm)
+            self._dgrad(dqkv, ln.qw, dN, Mp, H, 3 * H, ops.EPI_BF16, M, **(dict(a_hm=vhm) if vhm else {}))
             if not vbatch:
                 self._wgrad(dqkv, g("n1"), ln.qw, ln.qb, Mp, 3 * H, H, M)
             # (vbatch: the query third - or, without the shortcut, all of it - with the group's batched launches below)
@@ -1596,10 +1644,10 @@ class VaultEngine:
                 note(f"vilt{i}")
             elif i % vgroup == 0:
                 hi = min(nv, i + vgroup)
-                def launch(i=i, hi=hi, short=short):
-                    self._qkv_bias_grads_batched(dqkv_all, self.vl, i, hi, 3 * H, M, H if short else 3 * H)
+                def launch(i=i, hi=hi, short=short, vhm=vhm):
+                    self._qkv_bias_grads_batched(dqkv_all, self.vl, i, hi, 3 * H, M, H if short else 3 * H, hm=vhm)
                     self._wgrad_group(((dxbA_all, ws["act_all"], "fw", H, FF), (dU_all, ws["n2_all"], "iw", FF, H),
-                                       (dxbB_all, ws["ctx_all"], "ow", H, H), (dqkv_all, ws["n1_all"], "qw", 3 * H, H)),
+                                       (dxbB_all, ws["ctx_all"], "ow", H, H), (dqkv_all, ws["n1_all"], "qw", 3 * H, H, vhm)),
                                       self.vl, i, hi, Mp, M)
                 self._wgrads_aside(launch, after_layer)
                 for j in reversed(range(i, hi)):
@@ -1738,9 +1786,10 @@ class VaultEngine:
             self._dgrad(dh1b, ln.ow, ldctx, Mlp, H, H, ops.EPI_BF16, Ml)
             if not batched:
                 self._wgrad(dh1b, g("ctx"), ln.ow, None, Mlp, H, H, Ml)
+            lhm = ws.get("lm_qkv_hm", 0)
             ops.attention_bwd(g("qkv"), amf, g("ctx"), g("lse"), ldctx, ldqkv, B, T, H, heads,
-                              drop=self._drop(pda, 16 * i + 2, True))
-            self._dgrad(ldqkv, ln.qw, ldN, Mlp, H, 3 * H, ops.EPI_BF16, Ml)
+                              drop=self._drop(pda, 16 * i + 2, True), qkv_hm=lhm)
+            self._dgrad(ldqkv, ln.qw, ldN, Mlp, H, 3 * H, ops.EPI_BF16, Ml, **(dict(a_hm=lhm) if lhm else {}))
             if not batched:
                 self._wgrad(ldqkv, yb[i], ln.qw, ln.qb, Mlp, 3 * H, H, Ml)
             # (batched: the QKV bias gradient with the group's launches below)
@@ -1754,10 +1803,10 @@ class VaultEngine:
                     embed_backward(dyb, dyf)
                     embed_done = True
                     note("lm_embed")
-                def launch(i=i, hi=hi):
-                    self._qkv_bias_grads_batched(ldqkv_all, self.ll, i, hi, 3 * H, Ml, 3 * H)
+                def launch(i=i, hi=hi, lhm=lhm):
+                    self._qkv_bias_grads_batched(ldqkv_all, self.ll, i, hi, 3 * H, Ml, 3 * H, hm=lhm)
                     self._wgrad_group(((dhb_all, ws["lm_act_all"], "fw", H, FF), (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
-                                       (dh1b_all, ws["lm_ctx_all"], "ow", H, H), (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H)),
+                                       (dh1b_all, ws["lm_ctx_all"], "ow", H, H), (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H, lhm)),
                                       self.ll, i, hi, Mlp, Ml)
                 self._wgrads_aside(launch, after_layer)
                 for j in reversed(range(i, hi)):

@@ -27,7 +27,7 @@ class GemmArgs(C.Structure):
         ("drop_thresh", C.c_uint32), ("drop_seed", C.c_uint32), ("drop_stream", C.c_uint32),
         ("drop_scale", C.c_float), ("gn", C.c_int), ("persist", C.c_int),
         ("batch", C.c_int), ("batch_a", C.c_longlong), ("batch_b", C.c_longlong), ("batch_o", C.c_longlong),
-        ("aux_u8", C.c_int),
+        ("aux_u8", C.c_int), ("out_hm", C.c_int), ("a_hm", C.c_int),
     ]
 
 

@@ -41,7 +41,7 @@ class AttnArgs(C.Structure):
                 ("dctx", C.c_void_p), ("dqkv", C.c_void_p),
                 ("B", C.c_int), ("S", C.c_int), ("H", C.c_int), ("heads", C.c_int),
                 ("drop_thresh", C.c_uint32), ("drop_seed", C.c_uint32), ("drop_stream", C.c_uint32),
-                ("drop_scale", C.c_float), ("ctx_split3", C.c_void_p)]
+                ("drop_scale", C.c_float), ("ctx_split3", C.c_void_p), ("qkv_hm", C.c_int)]
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -178,9 +178,10 @@ GEMM_SCHED = int(__import__("os").environ.get("VAULT_GEMM_SCHED", "0"))   # env:
 
 def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_valid=0, splits=1, accumulate=0,
          bias=None, res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, drop: Drop = NO_DROP,
-         colsum=None, split3=False, batch=0, batch_a=0, batch_b=0, batch_o=0, aux_u8=False, plan_only=False):
+         colsum=None, split3=False, batch=0, batch_a=0, batch_b=0, batch_o=0, aux_u8=False, plan_only=False, out_hm=0, a_hm=0):
     a = L.GemmArgs()
     a.aux_u8 = 1 if aux_u8 else 0
+    a.out_hm, a.a_hm = int(out_hm), int(a_hm)     # head-major output / A operand (vault_gemm_args.out_hm / a_hm)
     a.A, a.B, a.out, a.out2 = _h(A), _h(B), _h(out), _h(out2)
     a.bias, a.res, a.aux, a.addtab = _p(bias), _p(res), _h(aux), _p(addtab)
     a.colsum = _p(colsum)
@@ -201,7 +202,7 @@ class WgradSeg(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p),
                 ("n_out", C.c_int), ("n_in", C.c_int), ("ld_dy", C.c_int), ("ld_x", C.c_int), ("ld_dw", C.c_int),
                 ("batch", C.c_int), ("first", C.c_int), ("count", C.c_int),
-                ("batch_dy", C.c_longlong), ("batch_x", C.c_longlong), ("batch_dw", C.c_longlong)]
+                ("batch_dy", C.c_longlong), ("batch_x", C.c_longlong), ("batch_dw", C.c_longlong), ("dy_hm", C.c_int)]
 
 
 class WgradGroupedArgs(C.Structure):
@@ -222,6 +223,7 @@ def wgrad_grouped(segs, tokens, splits=1, accumulate=1):
         t.n_out, t.n_in, t.ld_dy, t.ld_x, t.ld_dw = g["n_out"], g["n_in"], g["n_out"], g["n_in"], g["n_in"]
         t.batch, t.first, t.count = g["batch"], g["first"], g["count"]
         t.batch_dy, t.batch_x, t.batch_dw = g["batch_dy"], g["batch_x"], g["batch_dw"]
+        t.dy_hm = int(g.get("dy_hm", 0))
     _invoke("vault_wgrad_grouped", C.byref(a), _stream(), struct=a)
 
 
@@ -281,12 +283,18 @@ def colsum_batched(x_bf16, ld, rows, N, out, batch, batch_in, batch_out):
             C.c_int(batch), C.c_longlong(batch_in), C.c_longlong(batch_out), _stream())
 
 
+def colsum_hm(x_bf16, rows, hm_rows, planes, out, batch=1, batch_in=0, batch_out=0):
+    _invoke("vault_colsum_hm", C.c_void_p(_h(x_bf16)), C.c_int(rows), C.c_int(hm_rows), C.c_int(planes), C.c_void_p(_p(out)),
+            C.c_int(batch), C.c_longlong(batch_in), C.c_longlong(batch_out), _stream())
+
+
 def colsum(x_bf16, ld, rows, N, out):
     _invoke("vault_colsum", C.c_void_p(_p(x_bf16)), C.c_int(ld), C.c_int(rows), C.c_int(N), C.c_void_p(_p(out)), _stream())
 
 
-def _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, dctx=None, dqkv=None, drop: Drop = NO_DROP, ctx_split3=None):
+def _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, dctx=None, dqkv=None, drop: Drop = NO_DROP, ctx_split3=None, qkv_hm=0):
     a = AttnArgs()
+    a.qkv_hm = int(qkv_hm)      # > 0: qkv / dqkv in the head-major layout [3][heads][qkv_hm rows][64] (vault_attn_args.qkv_hm)
     a.ctx_split3 = _h(ctx_split3)
     a.qkv, a.keymask, a.ctx, a.lse, a.dctx, a.dqkv = _h(qkv), _p(keymask), _h(ctx), _p(lse), _h(dctx), _h(dqkv)
     a.B, a.S, a.H, a.heads = B, S, H, heads
@@ -294,13 +302,13 @@ def _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, dctx=None, dqkv=None, dro
     return a
 
 
-def attention_fwd(qkv, keymask, ctx, lse, B, S, H, heads, drop: Drop = NO_DROP, ctx_split3=None):
-    a = _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, drop=drop, ctx_split3=ctx_split3)
+def attention_fwd(qkv, keymask, ctx, lse, B, S, H, heads, drop: Drop = NO_DROP, ctx_split3=None, qkv_hm=0):
+    a = _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, drop=drop, ctx_split3=ctx_split3, qkv_hm=qkv_hm)
     _invoke("vault_attention_fwd", C.byref(a), _stream(), struct=a, drop=drop)
 
 
-def attention_bwd(qkv, keymask, ctx, lse, dctx, dqkv, B, S, H, heads, drop: Drop = NO_DROP):
-    a = _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, dctx, dqkv, drop)
+def attention_bwd(qkv, keymask, ctx, lse, dctx, dqkv, B, S, H, heads, drop: Drop = NO_DROP, qkv_hm=0):
+    a = _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, dctx, dqkv, drop, qkv_hm=qkv_hm)
     _invoke("vault_attention_bwd", C.byref(a), _stream(), struct=a, drop=drop)
 
 
