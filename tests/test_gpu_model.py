@@ -834,6 +834,7 @@ def test_full_size_batch_48_forward_backward_vs_oracle():
     assert "act_all" in eng.last and "lm_act_all" in eng.last          # the deferred, batched weight gradients ran
     assert eng.last.get("gelu8_cfg") in (5, 6)                         # ... with the 8-bit tile-native gelu' in the ViLT FFN
     assert eng.GRAD_STREAM_BF16                                        # ... and the bf16 residual-gradient stream
+    assert eng.last.get("qkv_hm") == eng.last["Mp"]                    # ... and head-major qkv / dqkv in the ViLT stack
     torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
     P = O.to_torch_state(state, requires_grad=True)
     loss, ref = O.vault_loss(P, spec, O.torch_batch(bn))
@@ -902,6 +903,7 @@ def test_full_size_batch_256_equals_its_sub_batches():
     big.zero_grad(); big.backward()
     torch.cuda.synchronize()
     assert big.last.get("gelu8_cfg") in (5, 6) and "act_all" in big.last
+    assert big.last.get("qkv_hm") == big.last["Mp"]                    # head-major qkv / dqkv in the ViLT stack (47,360 rows)
     loss_big = float(out["loss"]); tr_big = out["logits"].clone()
     g_big = big.params.g[: big.params.n_train].clone()
     names = list(big.params.trainable)
@@ -930,6 +932,39 @@ def test_full_size_batch_256_equals_its_sub_batches():
         gs = small.params.gr(n)
         cos = float((gb * gs).sum() / (gb.norm() * gs.norm() + 1e-30))
         assert cos > 0.9995, (n, cos)
+
+
+def test_head_major_layout_changes_addresses_not_results():
+    """qkv / dqkv head-major ([3][heads][rows][64]: engine._plan_head_major) against the row-major layout on one model and batch:
+    full width, 2 + 2 layers, B = 208 (38,480 fused / 8,320 text rows: both stacks on the per-kernel path), with LM dropout on -
+    logits, loss and every activation-side quantity bit-identical (the same arithmetic on other addresses), parameter gradients
+    equal up to the summation order of float atomics and of the bias column sums."""
+    spec = VaultSpec(vilt=ViltSpec(num_hidden_layers=2), lm=LMSpec.bertweet_base(), n_classes=3)
+    spec.lm.num_hidden_layers = 2
+    state = build_state(spec, 3)
+    bn = synthetic_batch(spec, 208, seed=708, n_classes=3)
+    db = _dev(bn)
+    res = []
+    for hm in (True, False):
+        eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.1)
+        eng.HEAD_MAJOR, eng.HEAD_MAJOR_MIN_ROWS = hm, 0
+        eng.drop_seed = 77
+        out = eng.forward(db, train=True, labels=db["labels"], need_hidden=False)
+        eng.zero_grad()
+        eng.backward()
+        torch.cuda.synchronize()
+        assert (eng.last["qkv_hm"], eng.last["lm_qkv_hm"]) == ((eng.last["Mp"], eng.last["Mlp"]) if hm else (0, 0))
+        res.append((out["logits"].clone(), float(out["loss"]), eng.params.g[:eng.params.n_train].clone(), eng.last["ctx1"].clone(),
+                    eng.last["lm_ctx1"].clone()))
+        del eng
+    a, b = res
+    assert torch.equal(a[0], b[0])                         # logits
+    assert abs(a[1] - b[1]) < 1e-6                         # loss (a float-atomic sum over the samples: order only)
+    assert torch.equal(a[3], b[3])                         # ViLT layer 1 attention output
+    assert torch.equal(a[4], b[4])                         # LM layer 1 attention output (dropout on the probabilities)
+    rel = float((a[2] - b[2]).norm() / b[2].norm())
+    print(f"head-major vs row-major qkv: gradient rel diff {rel:.2e}")
+    assert rel < 1e-5
 
 
 def test_experiment_script_call_sequence(tmp_path):

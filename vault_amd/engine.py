@@ -564,6 +564,7 @@ class VaultEngine:
 
     WGRAD_GROUPED = True           # the four weight-gradient kinds of a group of layers packed into full rounds of 256 tiles
     HEAD_MAJOR = True              # qkv / dqkv of large batches in the head-major layout [3][heads][rows][64] (see _plan_head_major)
+    HEAD_MAJOR_MIN_ROWS = int(os.environ.get("VAULT_HEAD_MAJOR_MIN_ROWS", "16384"))   # ... from this many (padded) token rows of a stack
     WGRAD_SIDE_ITEMS = int(os.environ.get("VAULT_WGRAD_SIDE_ITEMS", "224"))   # items per grouped launch on the second stream (B = 64, same box: 256: 13.50 / 13.59 ms, 224: 13.32 / 13.46, 192: 13.23 / 13.47, 160: 13.63 / 13.53)
 
     def _wgrad_group_size(self, n_layers, after_layer):
@@ -693,7 +694,7 @@ class VaultEngine:
         P, H, FF = self.params, ws["H"], ws["FF"]
         hm = 0
         if (self.HEAD_MAJOR and not pr and not self.fp8_forward and S <= 192 and rows_pad % 256 == 0 and H % 256 == 0 and FF % 256 == 0
-                and rows_pad <= self.WGRAD_BATCH_MAX_ROWS and os.environ.get("VAULT_ATTN_BWD", "1") != "0" and os.environ.get("VAULT_ATTN_BWD_S", "1") != "0"):
+                and self.HEAD_MAJOR_MIN_ROWS <= rows_pad <= self.WGRAD_BATCH_MAX_ROWS and os.environ.get("VAULT_ATTN_BWD", "1") != "0" and os.environ.get("VAULT_ATTN_BWD_S", "1") != "0"):
             w = P.wb(wname, n_elems=3 * H * H, shape=(3 * H, H))
             # (plan only: the pointers are not dereferenced, but must not be null)
             c1 = ops.gemm(a16, w, a16, rows_pad, 3 * H, H, H, H, 3 * H, 0, 0, ops.EPI_BF16, m_valid=rows,
