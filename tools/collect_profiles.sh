@@ -18,5 +18,10 @@ rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity --no-h2d --no-other-configs > $O/pmc_mfma.log 2>&1
 python tools/pmc_mfma.py $O/pmc_mfma > $O/pmc_mfma_util.txt
 rm -rf $O/pmc_mfma
+# the fp16 operand build: kernel table of the same steps (same box)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats16 -o run -- python3 bench.py --half fp16 --steps 8 --warmup 3 --no-cpu-baseline --no-parity --no-h2d --no-other-configs > $O/bench_fp16_under_rocprof.log 2>&1
+grep '^{"metric' $O/bench_fp16_under_rocprof.log | tail -1 > $O/bench_fp16_under_rocprof.json
+python tools/prof_summary.py $O/stats16 > $O/kernel_stats_fp16.txt
+rm -rf $O/stats16
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 ls -la $O

@@ -7,6 +7,7 @@ cp $F/kernel_by_shape.txt $P/${R}_bench_b256_kernel_by_shape.txt; cp $F/bench_un
 cp $F/pmc_FETCH_SIZE.txt $P/${R}_pmc_FETCH_SIZE_bench_b256.txt; cp $F/pmc_WRITE_SIZE.txt $P/${R}_pmc_WRITE_SIZE_bench_b256.txt
 cp $F/pmc_gemm_wgrad.json $P/${R}_pmc_gemm_wgrad.json; cp $F/pmc_gemm_ffn1.json $P/${R}_pmc_gemm_ffn1.json
 cp $F/pmc_mfma_util.txt $P/${R}_pmc_mfma_util_bench_b256.txt
+[ -f $F/kernel_stats_fp16.txt ] && cp $F/kernel_stats_fp16.txt $P/${R}_bench_b256_fp16_kernel_stats.txt && cp $F/bench_fp16_under_rocprof.json $P/${R}_bench_b256_fp16_under_rocprof.json
 cp $E/bench_b64.json $P/${R}_bench_b64.json; cp $E/b64_kernel_stats.txt $P/${R}_bench_b64_kernel_stats.txt; cp $E/bench_b8.json $P/${R}_bench_b8.json
 cp $E/bench_cfg4.json $P/${R}_bench_cfg4_frozen_bert_b128.json; cp $E/cfg4_kernel_stats.txt $P/${R}_bench_cfg4_kernel_stats.txt
 cp $E/bench_fp8.json $P/${R}_bench_b256_fp8_forward.json; cp $E/bench_bf16_same_box.json $P/${R}_bench_b256_bf16_same_box_as_fp8.json
