@@ -123,11 +123,32 @@ __device__ __forceinline__ f32x2 norm_cdf_f2(f32x2 x) {
   const f32x2 d = 0.5f - 0.5f * r;   // 0.5 erf(|x|/sqrt2) >= 0
   return f32x2{0.5f + __builtin_copysignf(d[0], x[0]), 0.5f + __builtin_copysignf(d[1], x[1])};
 }
-// y = gelu(x), dy = gelu'(x) = Phi(x) + x phi(x)
+// y = gelu(x), dy = gelu'(x) = Phi(x) + x phi(x).  gelu' needs e = exp(-x^2 / 2) anyway, and with u = |x| / sqrt 2 that is
+// exp(-u^2): the erf of Abramowitz-Stegun 7.1.26, 1 - (a1 t + .. + a5 t^5) exp(-u^2) with t = 1 / (1 + p u) (|err| <= 1.5e-7),
+// comes out of the same exponential - 26 instead of 31 issue slots per pair against the exponential-free form above plus
+// its own exp (the GELU epilogue of the FFN-in forward is VALU-bound: ~9 of a tile's 32 us).
+#ifndef VAULT_GELU_SHARED_EXP
+#define VAULT_GELU_SHARED_EXP 1
+#endif
 __device__ __forceinline__ void gelu_fwd_f2(f32x2 x, f32x2& y, f32x2& dy) {
+#if VAULT_GELU_SHARED_EXP
+  const f32x2 a = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+  const f32x2 den = a * (0.3275911f * 0.70710678118654752f) + 1.0f;
+  const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  f32x2 pl = t * 1.061405429f + (-1.453152027f);
+  pl = pl * t + 1.421413741f;
+  pl = pl * t + (-0.284496736f);
+  pl = pl * t + 0.254829592f;
+  pl = pl * t;
+  const f32x2 q = (x * x) * (-0.5f * 1.4426950408889634f);
+  const f32x2 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+  const f32x2 d = 0.5f - 0.5f * (pl * e);          // 0.5 erf(|x| / sqrt 2) >= 0
+  const f32x2 cdf = {0.5f + __builtin_copysignf(d[0], x[0]), 0.5f + __builtin_copysignf(d[1], x[1])};
+#else
   const f32x2 cdf = norm_cdf_f2(x);
   const f32x2 q = (x * x) * (-0.5f * 1.4426950408889634f);
   const f32x2 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+#endif
   y = x * cdf;
   dy = cdf + x * (e * 0.3989422804014327f);
 }
