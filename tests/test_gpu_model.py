@@ -826,6 +826,7 @@ def test_full_size_batch_48_forward_backward_vs_oracle():
     bn = synthetic_batch(spec, B, seed=77, n_classes=3)
     state = build_state(spec, 0)
     eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    eng.HEAD_MAJOR_MIN_ROWS = 0                                        # (the bench shape's head-major qkv / dqkv at this row count too)
     db = _dev(bn)
     out = eng.forward(db, train=True, labels=db["labels"], need_hidden=False)
     eng.zero_grad()
