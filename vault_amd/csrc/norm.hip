@@ -383,25 +383,36 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const h16* __restrict__ in
   }
 }
 
-// column sums of a head-major tensor [planes][hm_rows][64]: block (plane, row block): 1024 threads = 64 rows x 16 lanes of 8 bytes
+// column sums of a head-major tensor [planes][hm_rows][64]: block (plane, row block): 1024 threads = 128 rows x 8 lanes of 16
+// bytes, two rows in flight per thread
 __global__ __launch_bounds__(1024) void colsum_hm_kernel(const h16* __restrict__ in, int rows, int hm_rows, int rows_per_block,
                                                          float* __restrict__ out, long long batch_in, long long batch_out) {
-  __shared__ float red[64][65];
+  __shared__ float red[128][65];
   const h16* base = in + (size_t)blockIdx.z * batch_in + (size_t)blockIdx.x * hm_rows * 64;
-  const int t = threadIdx.x, r_in = t >> 4, c4 = (t & 15) * 4;
+  const int t = threadIdx.x, r_in = t >> 3, c8 = (t & 7) * 8;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  for (int r = r0 + r_in; r < r1; r += 64) {
-    const uint2 w = *reinterpret_cast<const uint2*>(base + (size_t)r * 64 + c4);
-    const float2 x = unpack_h16x2(w.x), y = unpack_h16x2(w.y);
-    a0 += x.x; a1 += x.y; a2 += y.x; a3 += y.y;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto add = [&](const u32x4& w) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float2 x = unpack_h16x2(w[k]);
+      a[2 * k] += x.x; a[2 * k + 1] += x.y;
+    }
+  };
+  int r = r0 + r_in;
+  for (; r + 128 < r1; r += 256) {
+    const u32x4 w0 = *reinterpret_cast<const u32x4*>(base + (size_t)r * 64 + c8);
+    const u32x4 w1 = *reinterpret_cast<const u32x4*>(base + (size_t)(r + 128) * 64 + c8);
+    add(w0); add(w1);
   }
-  red[r_in][c4] = a0; red[r_in][c4 + 1] = a1; red[r_in][c4 + 2] = a2; red[r_in][c4 + 3] = a3;
+  if (r < r1) add(*reinterpret_cast<const u32x4*>(base + (size_t)r * 64 + c8));
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[r_in][c8 + k] = a[k];
   __syncthreads();
   if (t < 64) {
     float s_ = 0.f;
 #pragma unroll 8
-    for (int r = 0; r < 64; ++r) s_ += red[r][t];
+    for (int q = 0; q < 128; ++q) s_ += red[q][t];
     atomicAdd(out + (size_t)blockIdx.z * batch_out + blockIdx.x * 64 + t, s_);
   }
 }
@@ -503,7 +514,7 @@ extern "C" int vault_colsum_hm(const void* in_bf16, int rows, int hm_rows, int p
     return VAULT_EINVAL;
   const int row_blocks = std::max(4, 256 / (planes * batch));
   int rpb = (rows + row_blocks - 1) / row_blocks;
-  rpb = ((rpb + 63) / 64) * 64;
+  rpb = ((rpb + 127) / 128) * 128;
   dim3 grid(planes, (rows + rpb - 1) / rpb, batch);
   hipLaunchKernelGGL(colsum_hm_kernel, grid, dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<const h16*>(in_bf16), rows, hm_rows, rpb, out, batch_in, batch_out);
