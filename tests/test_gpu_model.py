@@ -945,27 +945,36 @@ def test_head_major_layout_changes_addresses_not_results():
     state = build_state(spec, 3)
     bn = synthetic_batch(spec, 208, seed=708, n_classes=3)
     db = _dev(bn)
+    from vault_amd import ops
     res = []
-    for hm in (True, False):
-        eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.1)
-        eng.HEAD_MAJOR, eng.HEAD_MAJOR_MIN_ROWS = hm, 0
-        eng.drop_seed = 77
-        out = eng.forward(db, train=True, labels=db["labels"], need_hidden=False)
-        eng.zero_grad()
-        eng.backward()
-        torch.cuda.synchronize()
+    # third run: the data-parallel step's way through the same kernels - dynamic tile scheduling in the GEMMs (persist bit 0)
+    # and a stage listener, i.e. weight-gradient groups of LM_WGRAD_GROUP layers instead of the whole stack
+    for hm, dp_like in ((True, False), (False, False), (True, True)):
+        sched = ops.GEMM_SCHED
+        try:
+            ops.GEMM_SCHED = 3 if dp_like else 0
+            eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.1)
+            eng.HEAD_MAJOR, eng.HEAD_MAJOR_MIN_ROWS, eng.LM_WGRAD_GROUP = hm, 0, 1
+            eng.drop_seed = 77
+            out = eng.forward(db, train=True, labels=db["labels"], need_hidden=False)
+            eng.zero_grad()
+            eng.backward(after_layer=(lambda tag: None) if dp_like else None)
+            torch.cuda.synchronize()
+        finally:
+            ops.GEMM_SCHED = sched
         assert (eng.last["qkv_hm"], eng.last["lm_qkv_hm"]) == ((eng.last["Mp"], eng.last["Mlp"]) if hm else (0, 0))
         res.append((out["logits"].clone(), float(out["loss"]), eng.params.g[:eng.params.n_train].clone(), eng.last["ctx1"].clone(),
                     eng.last["lm_ctx1"].clone()))
         del eng
-    a, b = res
-    assert torch.equal(a[0], b[0])                         # logits
-    assert abs(a[1] - b[1]) < 1e-6                         # loss (a float-atomic sum over the samples: order only)
-    assert torch.equal(a[3], b[3])                         # ViLT layer 1 attention output
-    assert torch.equal(a[4], b[4])                         # LM layer 1 attention output (dropout on the probabilities)
-    rel = float((a[2] - b[2]).norm() / b[2].norm())
-    print(f"head-major vs row-major qkv: gradient rel diff {rel:.2e}")
-    assert rel < 1e-5
+    a, b, c = res
+    for x in (b, c):
+        assert torch.equal(a[0], x[0])                         # logits
+        assert abs(a[1] - x[1]) < 1e-6                         # loss (a float-atomic sum over the samples: order only)
+        assert torch.equal(a[3], x[3])                         # ViLT layer 1 attention output
+        assert torch.equal(a[4], x[4])                         # LM layer 1 attention output (dropout on the probabilities)
+        rel = float((a[2] - x[2]).norm() / x[2].norm())
+        print(f"head-major vs {'row-major' if x is b else 'head-major under dynamic scheduling and per-layer groups'}: gradient rel diff {rel:.2e}")
+        assert rel < 1e-5
 
 
 def test_experiment_script_call_sequence(tmp_path):
