@@ -35,6 +35,7 @@
 // Replaces (with gemm256.hip / gemm.hip): every nn.Linear forward of HF:models/vilt/modeling_vilt.py:303-414 and
 // HF:models/roberta/modeling_roberta.py:222-398, and - on the transposed bf16 weight shadow - their data gradients.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "gemm.h"
@@ -640,7 +641,16 @@ int launch8w(const GemmParams& p, hipStream_t st) {
     q.bias = reinterpret_cast<const float*>(z);
   }
   const int tiles_n = p.N / (64 * NTW);
-  q.gn = (p.gn > 0) ? std::min(p.gn, tiles_n) : tiles_n;
+  // Raster: column groups of gn n-tiles, all row panels of a group before the next group (gemm_raster).  Default: a group is
+  // about ONE round of the chip - gn = ceil(256 / row panels), at least 2: the CUs of an XCD then keep the same gn weight panels
+  // in their L2 while the row panels stream through (an m-major walk cycles all N / 256 weight panels - 4.7 MB at N = 3072,
+  // more than an XCD's L2 - through every round).  tools/raster_bench.py, same box, us: M = 47,360 FFN-in forward 280 -> 265,
+  // gelu'-product dgrad 247 -> 233, QKV 171 -> 165; M = 23,808: 156 -> 139, 158 -> 144, 84-90 -> 77; M = 12,032 (192-wide
+  // tiles): 73-82 -> 64-65, 76-80 -> 65-66, QKV unchanged.  The ring kernel (deeper pipeline, N = 768: 4 n-tiles) gains nothing.
+  static const bool grouped_raster = [] { const char* e = getenv("VAULT_GEMM8W_RASTER"); return !(e && e[0] == '0'); }();
+  const int tiles_m = p.M >> 8;
+  const int gn_auto = grouped_raster ? std::max(2, (256 + tiles_m - 1) / std::max(tiles_m, 1)) : tiles_n;
+  q.gn = std::min((p.gn > 0) ? p.gn : gn_auto, tiles_n);
   const int nwork = (p.M >> 8) * tiles_n;
   dim3 grid(std::min(nwork, 256), 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(512), LDS, st, q);
