@@ -1,6 +1,7 @@
 """GEMMs of the step under raster group widths gn (n-tiles per column group; 0 = the launcher's default) - development.
    python tools/raster_bench.py [M]"""
 import ctypes as C
+import os
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -59,4 +60,8 @@ CASES = {
 t(CASES["8w FFN-in fwd (12 n-tiles)"](0), n=200)   # clocks
 for name, mk in CASES.items():
     gns = (0, 1, 2, 3, 4, 6, 0, 2, 3, 6) if name.startswith("8w") else (0, 1, 2, 3, 0, 1, 2)
+    if os.environ.get("RASTER_BENCH_GNS"):
+        gns = tuple(int(x) for x in os.environ["RASTER_BENCH_GNS"].split(","))
+        if not name.startswith("8w"):
+            continue
     print(f"M {M} {name:28s}: " + "  ".join(f"gn{g} {t(mk(g)):6.1f}" for g in gns))

@@ -86,13 +86,20 @@ __device__ __forceinline__ float w8_row16_sum(float t) {
   }
 #define W8_C(N) case N: asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); break;
 
-template <int EPI, int NTW>
+// A3 (round 4): THREE slots for the A image, two for B (3 x 32 + 2 x 32 / 24 KiB = 160 / 144 KiB).  The activation panel is the
+// operand that misses the L2 (the weight panels of a column group stay there: launch8w's raster), and with one K tile of
+// look-ahead an HBM round trip does not fit under a K tile's 64 MFMAs per wave: A tile t + 3 is requested while tile t is
+// multiplied (B tile t + 2, as before), the B pieces first, so that the mid wait leaves the 4 A pieces of tile t + 2 in flight.
+template <int EPI, int NTW, bool A3 = false>
 __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
   H16_SATURATE();
   constexpr bool F32OUT = (EPI == EPI_F32_RES);
   constexpr int BN = 64 * NTW;                       // block tile width
   constexpr int B_BYTES = BN * 128;
   constexpr int STAGE = W8_A_BYTES + B_BYTES;
+  // LDS layout: [A0 B0][A1 B1], or (A3) [A0][A1][A2][B0][B1]
+  auto a_base = [](int sa) -> int { return A3 ? sa * W8_A_BYTES : sa * STAGE; };
+  auto b_base = [](int sb) -> int { return A3 ? 3 * W8_A_BYTES + sb * B_BYTES : sb * STAGE + W8_A_BYTES; };
   constexpr int NPC = 4 + NTW;                       // staging pieces per wave and K tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -119,14 +126,19 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
     int tm, tn;
     gemm_raster(gemm_xcd_contiguous(nwork, w), tiles_m, tiles_n, p.gn, tm, tn);
     m0 = tm << 8; n0 = tn * BN;
+#if W8_ABLATE == 3 || W8_ABLATE == 4   // development: every tile loads the first row / column panel (operands stay in L2)
+    ab = reinterpret_cast<const char*>(p.A);
+    bb = reinterpret_cast<const char*>(p.B);
+#else
     ab = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
     bb = reinterpret_cast<const char*>(p.B + (size_t)n0 * p.ldb);
+#endif
   };
-  auto pieceA = [&](const char* tile, int stage, int i) {   // tile = panel base + 128 kt ; piece i of this wave's 4
+  auto pieceA = [&](const char* tile, int sa_, int i) {   // tile = panel base + 128 kt ; piece i of this wave's 4 ; A slot
     const int j = wave * 4 + i;
-    w8_glds16(tile + (size_t)j * a_piece, a_voff, lds0 + stage * STAGE + j * 1024);
+    w8_glds16(tile + (size_t)j * a_piece, a_voff, lds0 + a_base(sa_) + j * 1024);
   };
-  auto pieceB = [&](const char* tile, int stage, int i) {   // piece i of this wave's NTW
+  auto pieceB = [&](const char* tile, int sb_, int i) {   // piece i of this wave's NTW ; B slot
     const int j = wave * NTW + i;
     int rows;
     uint32_t vo = b_voff;
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
       if (nt < 2) { rows = wcol * 48 + (jj & 1) * 16 + nt * 4; }
       else { rows = wcol * 48 + 32 + (jj & 1) * 8; vo = b_voff2; }
     }
-    w8_glds16(tile + (size_t)rows * b_row, vo, lds0 + stage * STAGE + W8_A_BYTES + j * 1024);
+    w8_glds16(tile + (size_t)rows * b_row, vo, lds0 + b_base(sb_) + j * 1024);
   };
 
   const char *a_cur, *b_cur, *a_nxt, *b_nxt;
@@ -158,24 +170,30 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
       for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
     }
   }
-  // K tiles 0 and 1 of the first item (K >= 128: the launcher)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) pieceA(a_cur, 0, i);
+  // K tiles 0 and 1 of the first item (K >= 128: the launcher) - and (A3; K >= 256) the A part of tile 2
 #pragma unroll
   for (int i = 0; i < NTW; ++i) pieceB(b_cur, 0, i);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) pieceA(a_cur + 128, 1, i);
+  for (int i = 0; i < 4; ++i) pieceA(a_cur, 0, i);
 #pragma unroll
   for (int i = 0; i < NTW; ++i) pieceB(b_cur + 128, 1, i);
-  W8_WAITBAR(NPC);   // tile 0 landed in every wave's share
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pieceA(a_cur + 128, 1, i);
+  if constexpr (A3) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pieceA(a_cur + 256, 2, i);
+    W8_WAITBAR(NPC + 4);
+  } else {
+    W8_WAITBAR(NPC);   // tile 0 landed in every wave's share
+  }
 
   // ---- fragment read offsets (bytes inside a stage)
   const int g = lane >> 4, l15 = lane & 15;
   const int fx = ((l15 >> 1) & 3) << 1;
   const uint32_t a_rd0 = (uint32_t)((wr * 128 + l15) * 128 + ((g ^ fx) << 4));
   const uint32_t a_rd1 = (uint32_t)((wr * 128 + l15) * 128 + (((4 + g) ^ fx) << 4));
-  const uint32_t b_rd0 = (uint32_t)(W8_A_BYTES + (wc * 16 * NTW + l15) * 128 + ((g ^ fx) << 4));
-  const uint32_t b_rd1 = (uint32_t)(W8_A_BYTES + (wc * 16 * NTW + l15) * 128 + (((4 + g) ^ fx) << 4));
+  const uint32_t b_rd0 = (uint32_t)((wc * 16 * NTW + l15) * 128 + ((g ^ fx) << 4));          // (inside the B image)
+  const uint32_t b_rd1 = (uint32_t)((wc * 16 * NTW + l15) * 128 + (((4 + g) ^ fx) << 4));
 
   f32x4 acc[8][NTW];
   h16x8 FA0[8], FA1[8], FB0[NTW], FB1[NTW];
@@ -192,7 +210,8 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
 #define W8_ROW0(MT, FA, FB) W8_MMA0(MT, 0, FA, FB); W8_MMA0(MT, 1, FA, FB); W8_MMA0(MT, 2, FA, FB); W8_MMA0(MT, 3, FA, FB)
 
   f32x4 bq[4];     // bias of the lane's columns (loaded in an item's last K tile, used by its epilogue)
-  int stage = 0;
+  int stage = 0;   // B slot (and A slot of the two-stage form)
+  int sa = 0;      // A slot
   int extra = 0;   // VMEM operations of the previous epilogue certain to have been issued behind the staged tile
   int kt = 0;      // K tile of the current item
   // One K tile.  FIRST: first K tile of an item (its mid wait must let the previous epilogue's stores pass);
@@ -200,12 +219,13 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
   // they would be live across it).
   auto ktile = [&](auto first_tag, auto last_tag) {
     constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
-    const char* st = smem + stage * STAGE;
-    const char* sn = smem + (stage ^ 1) * STAGE;
-    const int kn = kt + 2;
-    const size_t koff = (size_t)((kn < nk) ? kn : kn - nk) * 128;
-    const char* ta = ((kn < nk) ? a_cur : a_nxt) + koff;
-    const char* tb = ((kn < nk) ? b_cur : b_nxt) + koff;
+    const int san = A3 ? (sa == 2 ? 0 : sa + 1) : (sa ^ 1);
+    const char* stA = smem + a_base(sa);
+    const char* snA = smem + a_base(san);
+    const char* snB = smem + b_base(stage ^ 1);
+    const int kn = kt + 2, kna = kt + (A3 ? 3 : 2);
+    const char* ta = ((kna < nk) ? a_cur : a_nxt) + (size_t)((kna < nk) ? kna : kna - nk) * 128;
+    const char* tb = ((kn < nk) ? b_cur : b_nxt) + (size_t)((kn < nk) ? kn : kn - nk) * 128;
     // ---- k-step 0 (fragments FA0, FB0, FB1 of this tile are in registers), A fragments of k-step 1 read meanwhile
     if constexpr (LAST) {
       // the bias of this item's columns: requested here, retired by the mid wait below (nothing of the epilogue
@@ -228,39 +248,60 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
       if constexpr (FIRST) { W8_ROW0(mt, FA0, FB0); } else { W8_ROW(mt, FA0, FB0); }
-      FA1[mt] = *LDS_PTR(const h16x8, st + a_rd1 + mt * 2048);
+      FA1[mt] = *LDS_PTR(const h16x8, stA + a_rd1 + mt * 2048);
     }
     // ---- mid: tile t + 1 landed (this wave's share: its pieces are the only staging loads in flight), every fragment
     //      of tile t is in registers; barrier: stage (t + 1) & 1 is readable, stage t & 1 is free
-    if constexpr (FIRST) {
+    if constexpr (FIRST && A3) {
+      // behind tile t + 1's B pieces sit the 4 A pieces of tile t + 2 and the previous epilogue's `extra` operations
+      if (extra >= 59) W8_WAITBAR(63);
+      else if (extra >= 48) W8_WAITBAR(52);
+      else if (extra >= 32) W8_WAITBAR(36);
+      else if (extra >= 16) W8_WAITBAR(20);
+      else W8_WAITBAR(4);
+    } else if constexpr (FIRST) {
       // behind tile t + 1's pieces sit the previous epilogue's `extra` operations (VMEM retires in order)
       if (extra >= 63) W8_WAITBAR(63);
       else if (extra >= 48) W8_WAITBAR(48);
       else if (extra >= 32) W8_WAITBAR(32);
       else if (extra >= 16) W8_WAITBAR(16);
       else W8_WAITBAR(0);
+    } else if constexpr (A3) {
+      if constexpr (LAST) { W8_WAITBAR(8); } else { W8_WAITBAR(4); }   // (LAST: + the 4 bias loads requested above)
     } else {
       W8_WAITBAR(0);
     }
     // ---- k-step 1, with tile t + 2's staging pieces (into the stage just freed) and the first fragments of
     //      tile t + 1 (FA0, FB0: their registers are free) spread between the MFMAs
-#define W8_NEXT_A(MT) if constexpr (!LAST) FA0[MT] = *LDS_PTR(const h16x8, sn + a_rd0 + (MT) * 2048)
-#define W8_NEXT_B(NT) if constexpr (!LAST && (NT) < NTW) FB0[NT] = *LDS_PTR(const h16x8, sn + b_rd0 + (NT) * 2048)
-    W8_ROW(0, FA1, FB1); pieceA(ta, stage, 0); W8_NEXT_B(0); W8_NEXT_B(1);
-    W8_ROW(1, FA1, FB1); pieceA(ta, stage, 1); W8_NEXT_B(2); W8_NEXT_B(3);
-    W8_ROW(2, FA1, FB1); pieceA(ta, stage, 2); W8_NEXT_A(0); W8_NEXT_A(1);
-    W8_ROW(3, FA1, FB1); pieceA(ta, stage, 3); W8_NEXT_A(2); W8_NEXT_A(3);
-    W8_ROW(4, FA1, FB1); pieceB(tb, stage, 0); W8_NEXT_A(4); W8_NEXT_A(5);
-    W8_ROW(5, FA1, FB1); pieceB(tb, stage, 1); W8_NEXT_A(6); W8_NEXT_A(7);
-    W8_ROW(6, FA1, FB1); pieceB(tb, stage, 2);
-    W8_ROW(7, FA1, FB1); if constexpr (NTW == 4) pieceB(tb, stage, 3);
+#define W8_NEXT_A(MT) if constexpr (!LAST) FA0[MT] = *LDS_PTR(const h16x8, snA + a_rd0 + (MT) * 2048)
+#define W8_NEXT_B(NT) if constexpr (!LAST && (NT) < NTW) FB0[NT] = *LDS_PTR(const h16x8, snB + b_rd0 + (NT) * 2048)
+    if constexpr (A3) {   // B pieces (tile t + 2) first, then the A pieces (tile t + 3): the next mid wait passes over those
+      W8_ROW(0, FA1, FB1); pieceB(tb, stage, 0); W8_NEXT_B(0); W8_NEXT_B(1);
+      W8_ROW(1, FA1, FB1); pieceB(tb, stage, 1); W8_NEXT_B(2); W8_NEXT_B(3);
+      W8_ROW(2, FA1, FB1); pieceB(tb, stage, 2); W8_NEXT_A(0); W8_NEXT_A(1);
+      W8_ROW(3, FA1, FB1); if constexpr (NTW == 4) pieceB(tb, stage, 3); W8_NEXT_A(2); W8_NEXT_A(3);
+      W8_ROW(4, FA1, FB1); pieceA(ta, sa, 0); W8_NEXT_A(4); W8_NEXT_A(5);
+      W8_ROW(5, FA1, FB1); pieceA(ta, sa, 1); W8_NEXT_A(6); W8_NEXT_A(7);
+      W8_ROW(6, FA1, FB1); pieceA(ta, sa, 2);
+      W8_ROW(7, FA1, FB1); pieceA(ta, sa, 3);
+    } else {
+      W8_ROW(0, FA1, FB1); pieceA(ta, sa, 0); W8_NEXT_B(0); W8_NEXT_B(1);
+      W8_ROW(1, FA1, FB1); pieceA(ta, sa, 1); W8_NEXT_B(2); W8_NEXT_B(3);
+      W8_ROW(2, FA1, FB1); pieceA(ta, sa, 2); W8_NEXT_A(0); W8_NEXT_A(1);
+      W8_ROW(3, FA1, FB1); pieceA(ta, sa, 3); W8_NEXT_A(2); W8_NEXT_A(3);
+      W8_ROW(4, FA1, FB1); pieceB(tb, stage, 0); W8_NEXT_A(4); W8_NEXT_A(5);
+      W8_ROW(5, FA1, FB1); pieceB(tb, stage, 1); W8_NEXT_A(6); W8_NEXT_A(7);
+      W8_ROW(6, FA1, FB1); pieceB(tb, stage, 2);
+      W8_ROW(7, FA1, FB1); if constexpr (NTW == 4) pieceB(tb, stage, 3);
+    }
 #undef W8_NEXT_A
 #undef W8_NEXT_B
     if constexpr (!LAST) {   // (FB1 is free once the last MFMA of the k-step has been issued)
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) FB1[nt] = *LDS_PTR(const h16x8, sn + b_rd1 + nt * 2048);
+      for (int nt = 0; nt < NTW; ++nt) FB1[nt] = *LDS_PTR(const h16x8, snB + b_rd1 + nt * 2048);
     }
     stage ^= 1;
+    sa = san;
     ++kt;
   };
 
@@ -269,20 +310,25 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
     if (w + G < nwork) bases_of(w + G, a_nxt, b_nxt, m0n, n0n);
     else { a_nxt = a_cur; b_nxt = b_cur; m0n = m0; n0n = n0; }   // past the end: valid tiles into stages nobody reads
     {   // first fragments of the item's first K tile (landed: the wait that ended the previous item / the prologue)
-      const char* st = smem + stage * STAGE;
+      const char* stA = smem + a_base(sa);
+      const char* stB = smem + b_base(stage);
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
-        FB0[nt] = *LDS_PTR(const h16x8, st + b_rd0 + nt * 2048);
-        FB1[nt] = *LDS_PTR(const h16x8, st + b_rd1 + nt * 2048);
+        FB0[nt] = *LDS_PTR(const h16x8, stB + b_rd0 + nt * 2048);
+        FB1[nt] = *LDS_PTR(const h16x8, stB + b_rd1 + nt * 2048);
       }
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt) FA0[mt] = *LDS_PTR(const h16x8, st + a_rd0 + mt * 2048);
+      for (int mt = 0; mt < 8; ++mt) FA0[mt] = *LDS_PTR(const h16x8, stA + a_rd0 + mt * 2048);
     }
     kt = 0;
     ktile(std::true_type{}, std::false_type{});
 #pragma clang loop unroll(disable)
     while (kt < nk - 1) ktile(std::false_type{}, std::false_type{});
     ktile(std::false_type{}, std::true_type{});   // (K >= 192: the launcher; two-tile items take the path below)
+    if constexpr (A3) {
+      // the bias loads (requested at the start of the last tile) have landed; behind them: that tile's staging pieces
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NTW + 4) : "memory");
+    }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> accumulator reads (invisible inside asm)
 
     // =============================== epilogue: registers -> global ===============================
@@ -333,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
       for (int e = 0; e < (HAS_CSUM ? 16 : 1); ++e) csum[e] = 0.f;
       // addresses: uniform 64-bit base (SGPR pair) + ONE 32-bit byte offset per lane, stepped by 16 rows per mt
       // (the launcher keeps M x ldo x 4 B below 4 GiB)
-#if W8_ABLATE == 2   // development: every tile writes the same 256 rows (the stores stay in L2)
+#if W8_ABLATE == 2 || W8_ABLATE == 4   // development: every tile writes the same 256 rows (the stores stay in L2)
       const uint32_t off0 = (uint32_t)(((size_t)(wr * 128 + el15) * p.ldo + nc) * 2);
 #else
       const uint32_t off0 = (uint32_t)(((size_t)(mw + el15) * p.ldo + nc) * 2);
@@ -622,10 +668,15 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
 #undef W8_MMA
 }
 
-template <int EPI, int NTW>
+template <int EPI, int NTW, bool A3 = false>
 int launch8w(const GemmParams& p, hipStream_t st) {
-  constexpr int LDS = 2 * (W8_A_BYTES + 64 * NTW * 128);
-  auto kern = gemm8w_kernel<EPI, NTW>;
+  if constexpr (!A3) {
+    // three A slots (kernel header) where the contraction has at least four K tiles
+    static const bool a3 = [] { const char* e = getenv("VAULT_GEMM8W_A3"); return !(e && e[0] == '0'); }();
+    if (a3 && p.K >= 256) return launch8w<EPI, NTW, true>(p, st);
+  }
+  constexpr int LDS = (A3 ? 3 : 2) * W8_A_BYTES + 2 * 64 * NTW * 128;
+  auto kern = gemm8w_kernel<EPI, NTW, A3>;
   static bool attr_done[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VAULT_EINVAL;
