@@ -62,6 +62,6 @@ for name, mk in CASES.items():
     gns = (0, 1, 2, 3, 4, 6, 0, 2, 3, 6) if name.startswith("8w") else (0, 1, 2, 3, 0, 1, 2)
     if os.environ.get("RASTER_BENCH_GNS"):
         gns = tuple(int(x) for x in os.environ["RASTER_BENCH_GNS"].split(","))
-        if not name.startswith("8w"):
+        if not name.startswith(os.environ.get("RASTER_BENCH_KIND", "8w")):
             continue
     print(f"M {M} {name:28s}: " + "  ".join(f"gn{g} {t(mk(g)):6.1f}" for g in gns))

@@ -33,6 +33,10 @@
 #include "gemm.h"
 #include "gemm_epi.h"
 
+#ifndef R256_ABLATE
+#define R256_ABLATE 0
+#endif
+
 namespace {
 
 // Dynamic tile scheduler state (a `__device__` global: one copy per device; the launcher grants dynamic hand-out to
@@ -200,11 +204,16 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     m0 = tile_m << 8; n0 = tile_n * BNT;
     const int kt0 = z * per;
     nk = min(nk_total, kt0 + per) - kt0;
-    if constexpr (A_MODE == 0) a_base = p.a_hm ? reinterpret_cast<const char*>(pA + ((size_t)kt0 * p.a_hm + m0) * 64)
-                                               : reinterpret_cast<const char*>(pA + (size_t)m0 * p.lda + (size_t)kt0 * 64);
-    else a_base = reinterpret_cast<const char*>(pA + (size_t)kt0 * 64 * p.lda + m0);
-    if constexpr (B_MODE == 0) b_base = reinterpret_cast<const char*>(pB + (size_t)n0 * p.ldb + (size_t)kt0 * 64);
-    else b_base = reinterpret_cast<const char*>(pB + (size_t)kt0 * 64 * p.ldb + n0);
+#if R256_ABLATE & 1   // development: every tile loads the first row / column panel (operands stay in L2)
+    const int lm0 = 0, ln0 = 0;
+#else
+    const int lm0 = m0, ln0 = n0;
+#endif
+    if constexpr (A_MODE == 0) a_base = p.a_hm ? reinterpret_cast<const char*>(pA + ((size_t)kt0 * p.a_hm + lm0) * 64)
+                                               : reinterpret_cast<const char*>(pA + (size_t)lm0 * p.lda + (size_t)kt0 * 64);
+    else a_base = reinterpret_cast<const char*>(pA + (size_t)kt0 * 64 * p.lda + lm0);
+    if constexpr (B_MODE == 0) b_base = reinterpret_cast<const char*>(pB + (size_t)ln0 * p.ldb + (size_t)kt0 * 64);
+    else b_base = reinterpret_cast<const char*>(pB + (size_t)kt0 * 64 * p.ldb + ln0);
   };
   int w = blockIdx.x;
   setup(w);
@@ -446,7 +455,11 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     WAITBAR(0);   // every wave has read its last fragments: the ring may be refilled
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> accumulator reads (hazard is invisible inside asm)
 
+#if R256_ABLATE & 2   // development: every tile's epilogue reads / writes the first tile's rows and columns (they stay in L2)
+    const int em0 = 0, en0 = 0;
+#else
     const int em0 = m0, en0 = n0;
+#endif
     float* const eout = out_cur;
     const int eldo = ldo_cur, emvalid = mvalid_cur;
     // ---- next work item: own XCD's ticket, else steal; broadcast through LDS
