@@ -606,7 +606,7 @@ def main():
                                 f"of all four Linear kinds (FFN-out, FFN-in, attention-out, QKV) of a stack's layers packed into "
                                 f"rounds of 256 ({M} ViLT tokens / {B * 40} LM tokens per layer), and the patch projection",
                        "r04_pmc_gemm_wgrad.json")
-        r_ffn1 = roof("ffn1", "gemm8w_kernel<7,4> / <1,4> (GELU epilogue with the 8-bit tile-native / bf16 gelu', 256-wide tiles, register-direct): FFN-in forward, ViLT "
+        r_ffn1 = roof("ffn1", "gemm8w_kernel<7,4,true> / <1,4,true> (GELU epilogue with the 8-bit tile-native / bf16 gelu', 256-wide tiles, register-direct): FFN-in forward, ViLT "
                               f"[{M}x{v.intermediate_size}x{v.hidden_size}] + LM [{B * 40}x{v.intermediate_size}x{v.hidden_size}]",
                       "r04_pmc_gemm_ffn1.json")
         out = {
