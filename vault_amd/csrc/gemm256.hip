@@ -164,8 +164,13 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
         const int idx = SEGF(first) + r, tiles_k = SEGF(tiles), tn_k = SEGF(tiles_n);
         const int bz = idx / tiles_k, tl = idx - bz * tiles_k;
         const int lda_ = SEGF(lda), ldb_ = SEGF(ldb), ahm_ = SEGF(a_hm);
+#if R256_ABLATE & 1   // development: every item contracts the first layer's first panels (operands stay in L2)
+        const h16* pA = SEGF(A);
+        const h16* pB = SEGF(B);
+#else
         const h16* pA = SEGF(A) + (size_t)bz * SEGF(batch_a);
         const h16* pB = SEGF(B) + (size_t)bz * SEGF(batch_b);
+#endif
         out_cur = SEGF(out) + (size_t)bz * SEGF(batch_o);
         ldo_cur = SEGF(ldo);
         mvalid_cur = (tiles_k / tn_k) << 8;            // every row of the kind's dW exists
@@ -177,9 +182,14 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
         a_step = 64u * (uint32_t)lda_ * 2u; b_step = 64u * (uint32_t)ldb_ * 2u;       // (head-major dY: lda_ = 64)
         a_half = ahm_ ? (uint32_t)ahm_ * 128u : 128u;
         lane_offsets(lda_, ldb_, ahm_);
-        a_base = ahm_ ? reinterpret_cast<const char*>(pA + ((size_t)(m0 >> 6) * ahm_ + (size_t)kt0 * 64) * 64)
-                      : reinterpret_cast<const char*>(pA + (size_t)kt0 * 64 * lda_ + m0);
-        b_base = reinterpret_cast<const char*>(pB + (size_t)kt0 * 64 * ldb_ + n0);
+#if R256_ABLATE & 1
+        const int lm0 = 0, ln0 = 0;
+#else
+        const int lm0 = m0, ln0 = n0;
+#endif
+        a_base = ahm_ ? reinterpret_cast<const char*>(pA + ((size_t)(lm0 >> 6) * ahm_ + (size_t)kt0 * 64) * 64)
+                      : reinterpret_cast<const char*>(pA + (size_t)kt0 * 64 * lda_ + lm0);
+        b_base = reinterpret_cast<const char*>(pB + (size_t)kt0 * 64 * ldb_ + ln0);
         return;
       }
     }
