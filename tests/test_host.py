@@ -413,6 +413,38 @@ def _dp_worker(rank, world, port, q):
             r6.on_stage(tag)
         r6.finish()
         ok[f"sparse table {wire}: no ids"] = float(g6.abs().max()) == 0.0
+    # VAULT_DP_CHECK_SPARSE (debug): the row-sparse result against a dense all-reduce of the table - passes on a consistent step,
+    # raises when a rank holds a gradient row outside the union of the step's token ids (it would stay un-reduced)
+    os.environ["VAULT_DP_CHECK_SPARSE"] = "2"
+    try:
+        for wire in ("fp32", "bf16"):
+            ids = torch.tensor([[3, 7, 7, 1], [19, 3, 0, 1]][rank], dtype=torch.int64)
+            g8 = torch.zeros(n)
+            tab8 = g8[:V * H].view(V, H)
+            tab8[ids] = torch.arange(H, dtype=torch.float32) + 10.0 * (rank + 1)
+            r8 = BucketReducer(g8, lo5, "lm_embed", bucket_elems=2500, dist=dist, wire=wire, sparse=sp, kernels=HostKernels)
+            r8.begin_step(ids)
+            for tag in ["head", "vilt_embed", "lm0", "lm_embed"]:
+                r8.on_stage(tag)
+            r8.finish()
+            ok[f"sparse check {wire}: consistent step passes"] = r8.sparse_checks == 1
+            g8.zero_()
+            tab8[ids] = 1.0
+            if rank == 1:
+                tab8[11] = 5.0                       # a row no rank's ids name
+            r8.begin_step(ids)
+            try:
+                for tag in ["head", "vilt_embed", "lm0", "lm_embed"]:
+                    r8.on_stage(tag)
+                ok[f"sparse check {wire}: stray row raises"] = False
+            except RuntimeError as e:
+                ok[f"sparse check {wire}: stray row raises"] = "differs from the dense" in str(e)
+            try:
+                r8.finish()
+            except RuntimeError:
+                pass
+    finally:
+        del os.environ["VAULT_DP_CHECK_SPARSE"]
     # ranks that disagree on the token count of the first step: every rank raises instead of hanging in the all-gather
     g7 = torch.zeros(n)
     r7 = BucketReducer(g7, lo5, "lm_embed", bucket_elems=2500, dist=dist, sparse=sp, kernels=HostKernels)

@@ -20,6 +20,7 @@ trainer.py:369); read ``TrainStep.loss`` when needed.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -143,6 +144,11 @@ class BucketReducer:
         self._key_capacity = None   # per-rank key count agreed on in the first step (begin_step)
         self._keys_given = None
         self.union_waits = 0        # steps in which the host had to WAIT for the union (diagnostics: expected 0)
+        # VAULT_DP_CHECK_SPARSE=N (debug): in the first N steps the row-sparse result is compared with a dense f32 all-reduce of
+        # the whole table (a host sync per step): a gradient row that some rank holds outside the union of the step's token
+        # ids - a second source of gradient on the table - would otherwise stay un-reduced without an error
+        self._check_sparse_left = int(os.environ.get("VAULT_DP_CHECK_SPARSE", "0") or 0)
+        self.sparse_checks = 0
 
     # ---- plumbing -------------------------------------------------------------------------------------------
     def _buf(self, name: str, n: int, dtype) -> torch.Tensor:
@@ -296,10 +302,25 @@ class BucketReducer:
             return
         table = self.g[sp.lo:sp.hi]
         uniq = self._scratch["uniq"]
+        dense = None
+        if self._check_sparse_left > 0:
+            dense = table.clone()
+            self.dist.all_reduce(dense, op=self.dist.ReduceOp.SUM, group=self.group)
         compact = self._buf("rows", min(sp.rows, self._n_keys) * sp.H, torch.float32)[:U * sp.H]
         self.k.rows_gather(table, uniq, U, sp.H, compact)
         self._sum_over_ranks(compact)
         self.k.rows_scatter(compact, uniq, U, sp.H, table)
+        if dense is not None:
+            self._check_sparse_left -= 1
+            self.sparse_checks += 1
+            both = torch.stack([(table - dense).abs().max(), dense.abs().max()])
+            self.dist.all_reduce(both, op=self.dist.ReduceOp.MAX, group=self.group)   # (every rank takes the same decision)
+            err, ref = float(both[0]), float(both[1])
+            tol = (1e-2 if self.wire == "bf16" else 1e-5) * ref + 1e-30
+            if not err <= tol:
+                raise RuntimeError(f"row-sparse embedding exchange differs from the dense all-reduce of the table: max |diff| "
+                                   f"{err:.3e} against max |gradient| {ref:.3e} (VAULT_DP_CHECK_SPARSE) - some rank holds "
+                                   "gradient rows outside the union of this step's token ids")
 
     # ---- bucket logic ---------------------------------------------------------------------------------------
     def on_stage(self, tag: str):
@@ -394,7 +415,6 @@ class TrainStep:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
             self.world = dist.get_world_size(process_group)
-        import os
         # VAULT_FORCE_DP=1 exercises the bucketed all-reduce path even with a single rank (debug/testing)
         if self.world > 1:
             # every rank draws its own dropout masks: the keep/drop hash takes (seed, stream, LOCAL element index), so
