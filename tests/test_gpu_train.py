@@ -1,4 +1,6 @@
 """GPU tests of the optimizer kernel and of the fine-tune step (ref: vault/tmsc_utils/trainer.py:353-369)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -277,7 +279,8 @@ def _dp_worker(rank, world, port, out_path, kind, nsteps, use_tape, wire, sparse
         torch.cuda.synchronize()
         torch.save({"p": eng.params.p.cpu(), "losses": losses, "wire_bytes": wire_bytes, "n_train": eng.params.n_train,
                     "launched": len(step.reducer.launched) if step.reducer.launched else None,
-                    "bucket_elems": step.reducer.bucket_elems, "union_waits": step.reducer.union_waits},
+                    "bucket_elems": step.reducer.bucket_elems, "union_waits": step.reducer.union_waits,
+                    "sparse_checks": step.reducer.sparse_checks},
                    f"{out_path}.{rank}")
     finally:
         dist.destroy_process_group()
@@ -579,8 +582,14 @@ def test_data_parallel_full_width_default_buckets(tmp_path, wire, half):
     nsteps, world = 2, 2
     out = str(tmp_path / "dpfw")
     port = 29700 + (1 if wire == "bf16" else 0) + (2 if half == "fp16" else 0)
-    mp.spawn(_dp_worker, args=(world, port, out, "full-width", nsteps, True, wire, True, None, half), nprocs=world, join=True)
+    # (the first step also runs the debug comparison of the row-sparse exchange with a dense all-reduce of the table)
+    os.environ["VAULT_DP_CHECK_SPARSE"] = "1"
+    try:
+        mp.spawn(_dp_worker, args=(world, port, out, "full-width", nsteps, True, wire, True, None, half), nprocs=world, join=True)
+    finally:
+        del os.environ["VAULT_DP_CHECK_SPARSE"]
     rs = [torch.load(out + f".{r}") for r in range(world)]
+    assert rs[0]["sparse_checks"] == 1 and rs[1]["sparse_checks"] == 1
     assert torch.equal(rs[0]["p"], rs[1]["p"])                                   # replicas stay bit-identical
     assert rs[0]["bucket_elems"] == 64 * 1024 * 1024 // 4                        # the default bucket size was in force
     dense_fp32 = 2 * 4 * rs[0]["n_train"] * (world - 1) // world
