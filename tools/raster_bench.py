@@ -54,6 +54,8 @@ CASES = {
     "8w attention-out dgrad": lambda gn: (lambda i: run(X[i & 1], Wo, oh[i & 1], H, H, EPI_BF16, gn, -1)),
     "ring attention-out fwd (4)": lambda gn: (lambda i: run(X[i & 1], Wo, o32[i & 1], H, H, EPI_RES, gn, -1, bias=bh, res=res[i & 1])),
     "ring FFN-out fwd (4)": lambda gn: (lambda i: run(XF[i & 1], W2, o32[i & 1], H, FF, EPI_RES, gn, -1, bias=bh, res=res[i & 1])),
+    "res8w attention-out fwd (cfg 6)": lambda gn: (lambda i: run(X[i & 1], Wo, o32[i & 1], H, H, EPI_RES, gn, 6, bias=bh, res=res[i & 1])),
+    "res8w FFN-out fwd (cfg 6)": lambda gn: (lambda i: run(XF[i & 1], W2, o32[i & 1], H, FF, EPI_RES, gn, 6, bias=bh, res=res[i & 1])),
     "ring FFN-in dgrad (4)": lambda gn: (lambda i: run(XF[i & 1], W1, oh[i & 1], H, FF, EPI_BF16, gn, -1, b_mode=1, ldb=H)),
     "ring QKV dgrad (4)": lambda gn: (lambda i: run(XQ[i & 1], Wq, oh[i & 1], H, 3 * H, EPI_BF16, gn, -1, b_mode=1, ldb=H)),
 }
