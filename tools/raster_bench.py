@@ -12,7 +12,7 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 47360
 H, FF = 768, 3072
 rb = lambda *s: torch.randn(*s, device="cuda").bfloat16()   # noqa: E731
 X = [rb(M, H) for _ in range(2)]; XF = [rb(M, FF) for _ in range(2)]; XQ = [rb(M, 3 * H) for _ in range(2)]
-W1 = rb(FF, H) * 0.05; Wq = rb(3 * H, H) * 0.05; W2t = rb(FF, H) * 0.05; Wo = rb(H, H) * 0.05; W2 = rb(H, FF) * 0.05
+W1 = rb(FF, H) * 0.05; Wq = rb(3 * H, H) * 0.05; W2t = rb(FF, H) * 0.05; Wo = rb(H, H) * 0.05; W2 = rb(H, FF) * 0.05; WqT = rb(H, 3 * H) * 0.05
 of = [torch.empty(M, FF, dtype=torch.bfloat16, device="cuda") for _ in range(2)]
 oh = [torch.empty(M, H, dtype=torch.bfloat16, device="cuda") for _ in range(2)]
 o32 = [torch.empty(M, H, device="cuda") for _ in range(2)]; res = [torch.randn(M, H, device="cuda") for _ in range(2)]
@@ -56,6 +56,9 @@ CASES = {
     "ring FFN-out fwd (4)": lambda gn: (lambda i: run(XF[i & 1], W2, o32[i & 1], H, FF, EPI_RES, gn, -1, bias=bh, res=res[i & 1])),
     "res8w attention-out fwd (cfg 6)": lambda gn: (lambda i: run(X[i & 1], Wo, o32[i & 1], H, H, EPI_RES, gn, 6, bias=bh, res=res[i & 1])),
     "res8w FFN-out fwd (cfg 6)": lambda gn: (lambda i: run(XF[i & 1], W2, o32[i & 1], H, FF, EPI_RES, gn, 6, bias=bh, res=res[i & 1])),
+    "r8wT FFN-in dgrad on W^T (cfg 6)": lambda gn: (lambda i: run(XF[i & 1], W2, oh[i & 1], H, FF, EPI_BF16, gn, 6)),
+    "r8wT FFN-in dgrad on W^T (cfg 5)": lambda gn: (lambda i: run(XF[i & 1], W2, oh[i & 1], H, FF, EPI_BF16, gn, 5)),
+    "r8wT QKV dgrad on W^T (cfg 6)": lambda gn: (lambda i: run(XQ[i & 1], WqT, oh[i & 1], H, 3 * H, EPI_BF16, gn, 6)),
     "ring FFN-in dgrad (4)": lambda gn: (lambda i: run(XF[i & 1], W1, oh[i & 1], H, FF, EPI_BF16, gn, -1, b_mode=1, ldb=H)),
     "ring QKV dgrad (4)": lambda gn: (lambda i: run(XQ[i & 1], Wq, oh[i & 1], H, 3 * H, EPI_BF16, gn, -1, b_mode=1, ldb=H)),
 }
