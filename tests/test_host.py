@@ -472,6 +472,61 @@ def test_bucket_reducer_gloo_world2():
     assert res[0][3] == res[1][3]
 
 
+def _dp_worker8(rank, world, port, q):
+    """BucketReducer at the rank count of the scaling run (8): ragged range sizes, both wires, row-sparse table with
+    rank-dependent token ids, two steps on one reducer - every rank ends with the dense all-reduce's result."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vault_amd.train import SparseTable
+    try:
+        n, H, V = 30_000, 48, 100
+        lo = {"head": 29_000, "vilt1": 21_000, "vilt0": 13_000, "vilt_embed": 9_000, "lm1": 7_000, "lm0": V * H, "lm_embed": 0}
+        sp = SparseTable(0, V, H)
+        ok = {}
+        for wire in ("fp32", "bf16"):
+            g = torch.zeros(n)
+            red = BucketReducer(g, lo, "lm_embed", bucket_elems=6_000, dist=dist, wire=wire, sparse=sp, kernels=HostKernels)
+            for step in range(2):
+                gen = torch.Generator().manual_seed(1000 * step + rank)
+                g.copy_(torch.randn(n, generator=gen))
+                ids = torch.randint(0, V, (12,), generator=gen)
+                tab = g[:V * H].view(V, H)
+                keep = torch.zeros(V, dtype=torch.bool); keep[ids] = True
+                tab[~keep] = 0.0                                  # only the rows this rank's ids name carry gradient
+                dense = g.clone()
+                dist.all_reduce(dense)
+                red.begin_step(ids)
+                for tag in ("head", "vilt1", "vilt0", "vilt_embed", "lm1", "lm0", "lm_embed"):
+                    red.on_stage(tag)
+                red.finish()
+                if wire == "fp32":
+                    ok[f"{wire} step {step}"] = float((g - dense).abs().max()) <= 1e-5 * float(dense.abs().max())
+                else:
+                    ok[f"{wire} step {step}"] = float((g - dense).abs().max()) <= 2.0 ** -6 * float(dense.abs().max())
+                same = [torch.zeros_like(g) for _ in range(world)]
+                dist.all_gather(same, g)
+                ok[f"{wire} step {step}: replicas identical"] = all(torch.equal(same[0], t) for t in same)
+        q.put((rank, all(ok.values()), [k for k, v in ok.items() if not v]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_reducer_gloo_world8():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_dp_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), [bad for _, _, bad in res]
+
+
 def test_embedding_surgery_api_and_vault_alias_package():
     """ref model.py:130-149 / 499-509 on the CPU-resident module: resize_token_embeddings keeps the old rows, the
     get -> rewrite -> set sequence of ``integrate_entities_into_model`` (ref: vault/entity_linking.py:133-148) lands in
