@@ -10,6 +10,7 @@ RCCL all-reduce of gradients).
   python bench.py --gpus N ...          (no torchrun environment: starts the N ranks itself, fails when the node has < N GPUs)
   python bench.py --config {2,3,4,5}    (BASELINE.json configs: per-GPU batch 64 | 64 x N ranks | frozen bert-base-uncased,
                                          batch 128 | MXFP8 forward, batch 256)
+  python bench.py --gpus N --scaling strong   (global batch 256 = 256 / N per GPU; default weak: 256 per GPU)
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").  `roofline` is the dominant kernel of the
 step by GPU time (rocprofv3 --stats, profiles/): the weight-gradient instantiation of the bf16 MFMA ring
@@ -38,6 +39,8 @@ from vault_amd.spec import LMSpec, VaultSpec, ViltSpec, build_state, synthetic_b
 from vault_amd.train import TrainStep  # noqa: E402
 
 FLOP_PER_SAMPLE_TRAIN = 120.67e9      # BASELINE.md §2 (fwd 40.22 GF x 3)
+FLOP_VILT_BLOCK_FWD = 32.687493120e9  # 12 ViLT layers (GEMMs + attention, S = 185 unpadded), forward, per sample
+FLOP_LM_BLOCK_FWD = 6.853754880e9     # 12 LM layers (S = 40), forward, per sample
 PEAK_BF16 = 2.5e15                    # MI355X dense bf16 MFMA, MI355X_MICROARCH.md
 
 
@@ -177,6 +180,9 @@ CONFIGS = {   # BASELINE.json `configs` (1 is the CPU plumbing case: a test, not
     3: dict(batch=64, what="config 3: bf16 fine-tune, global batch 64 x ranks (512 at DP = 8)"),
     4: dict(batch=128, lm="bert-base-uncased", freeze_lm=True, what="config 4: frozen bert-base-uncased LM, batch 128"),
     5: dict(batch=256, fp8_forward=True, what="config 5: MXFP8 forward GEMMs, bf16 backward, batch 256"),
+    # not a BASELINE config: the single-GPU anchor of the strong-scaling reading of the metric (global batch 256
+    # = 256 / N per GPU; N = 8 -> 32) - what one rank of `--scaling strong --gpus 8` computes, without the exchange
+    "b32": dict(batch=32, what="per-GPU batch 32 on one GPU: the per-rank shape of --scaling strong at 8 GPUs (global batch 256)"),
 }
 
 
@@ -225,7 +231,7 @@ def quick_config(cfg: int, dev, world: int, steps: int = 10, warmup: int = 3):
     spec = VaultSpec(vilt=ViltSpec(), lm=lm, n_classes=3)
     B = c["batch"]
     eng = VaultEngine(spec, dev, seed=0, freeze_lm=c.get("freeze_lm", False), classifier_dropout=0.1,
-                      fp8_forward=c.get("fp8_forward", False))
+                      fp8_forward=c.get("fp8_forward", False), half="bf16")
     stepper = TrainStep(eng, learning_rate=2e-5, warmup_ratio=0.1, total_steps=steps + warmup, assume_full_pixel_mask=True)
     rank = int(os.environ.get("RANK", "0"))
     bn = synthetic_batch(spec, B, seed=1234 + rank, n_classes=3)
@@ -270,7 +276,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 256: the metric's)")
-    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default, the headline): per-GPU batch fixed at --batch, global = batch x ranks; strong: GLOBAL batch "
+                         "fixed at --batch (256), per-GPU batch = batch / ranks (BASELINE.md §4's second reading of 'bs256')")
+    ap.add_argument("--config", type=int, default=None, choices=sorted(k for k in CONFIGS if isinstance(k, int)),
                     help="a BASELINE.json configuration as the timed workload (sets batch / LM / freeze / fp8 as it states)")
     ap.add_argument("--wire", default=None, choices=["fp32", "bf16"],
                     help="data-parallel gradient wire format (default fp32 all-reduce; bf16 = reduce-scatter + all-gather "
@@ -329,6 +338,10 @@ def main():
                        wire=args.wire)
 
     B = args.batch
+    if args.scaling == "strong":
+        if args.batch % world:
+            raise SystemExit(f"--scaling strong: the global batch {args.batch} does not divide over {world} ranks")
+        B = args.batch // world
     parity = None
     if rank == 0 and not args.no_parity:
         gname, par = measure_parity(eng, spec, args, dev)
@@ -355,7 +368,9 @@ def main():
 
     # live timing of the dominant kernels: event pairs on the launch stream around their launches, in every 4th
     # timed step (an event pair costs ~1-2 us of stream time: sampling keeps `value` undisturbed)
-    evs = {"wgrad": [], "ffn1": []}
+    # ... and of the two encoder stacks as blocks (the north star's own target metric): one pair around each stack's forward
+    # layer loop, one around its backward layer loop including the stack's weight-gradient launches
+    evs = {"wgrad": [], "ffn1": [], "vilt_fwd": [], "vilt_bwd": [], "lm_fwd": [], "lm_bwd": []}
     eng.profile_events = None
 
     def sync_all():
@@ -565,11 +580,12 @@ def main():
         eng._ws.clear()
         torch.cuda.empty_cache()
         others = {}
-        for cfg in ((2, 4, 5) if world == 1 else (3,)):
+        for cfg in ((2, 4, 5, "b32") if world == 1 else (3,)):
+            okey = f"config{cfg}" if isinstance(cfg, int) else f"batch_{cfg[1:]}"
             try:
-                others[f"config{cfg}"] = quick_config(cfg, dev, world)
+                others[okey] = quick_config(cfg, dev, world)
             except Exception as e:  # pragma: no cover
-                others[f"config{cfg}"] = {"error": repr(e)}
+                others[okey] = {"error": repr(e)}
 
     if rank == 0:
         sps = B * world * args.steps / dt
@@ -601,6 +617,29 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_src, "launches_timed": len(ms),
                     "avg_launch_ms": round(float(np.mean(ms)), 4)}
 
+        def block(fwd_site, bwd_site, flop_fwd, what):
+            """A stack's layers as one block: algorithmic FLOPs (forward x 3 when its backward runs) over the event-timed
+            duration of its forward + backward layer loops (backward: data gradients, attention / LayerNorm backward AND the
+            stack's weight-gradient launches), against the dense bf16 peak."""
+            tf = [a.elapsed_time(b) for a, b, _ in evs[fwd_site]]
+            tb = [a.elapsed_time(b) for a, b, _ in evs[bwd_site]]
+            if not tf:
+                return None
+            trained = bool(tb)
+            if trained and eng._wgrad_side:       # (small batches: weight gradients on a second stream - the pair would miss them)
+                return {"what": what, "frac": None, "why": "deferred weight gradients run on a second stream at this batch"}
+            ms_f, ms_b = float(np.mean(tf)), (float(np.mean(tb)) if trained else 0.0)
+            fl = B * flop_fwd * (3.0 if trained else 1.0)
+            return {"what": what, "ms_forward": round(ms_f, 3), "ms_backward": round(ms_b, 3) if trained else None,
+                    "gflop_per_sample": round(fl / B / 1e9, 2), "achieved_tflops": round(fl / ((ms_f + ms_b) * 1e-3) / 1e12, 1),
+                    "frac": round(fl / ((ms_f + ms_b) * 1e-3) / PEAK_BF16, 4), "steps_timed": len(tf)}
+
+        blk_vilt = block("vilt_fwd", "vilt_bwd", FLOP_VILT_BLOCK_FWD,
+                         f"12 ViLT layers (HF modeling_vilt.py:303-451), {M} token rows: LayerNorms, QKV / attention-out / FFN GEMMs, "
+                         "attention, their data gradients, attention / LayerNorm backward and the stack's weight-gradient launches")
+        blk_lm = block("lm_fwd", "lm_bwd", FLOP_LM_BLOCK_FWD,
+                       f"12 LM layers (HF modeling_roberta.py:222-398), {B * 40} token rows, "
+                       + ("forward only (frozen LM)" if args.freeze_lm else "forward + backward + weight gradients"))
         r_wgrad = roof("wgrad", "gemm256_kernel<1,1,5,4> (A[K][M]^T B[K][N], EPI_F32_ATOMIC): the weight-gradient GEMMs, "
                                 f"dW[N x K] += dY[tokens][N]^T X[tokens][K] - grouped launches (vault_wgrad_grouped): the 256 x 256 tiles "
                                 f"of all four Linear kinds (FFN-out, FFN-in, attention-out, QKV) of a stack's layers packed into "
@@ -614,7 +653,7 @@ def main():
             "value": round(sps, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_per_step_median": round(ms_median, 3),
             "ms_per_step_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)],
-            "higher_is_better": True, "scaling": "weak",
+            "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "mxfp8 forward GEMMs / bf16 backward" if args.fp8_forward else args.half,
             "data": "synthetic",
             "config": {"workload": f"ViLT-B32 + {args.lm} fine-tune step (fwd+bwd+AdamW), per-GPU batch {B}, "
@@ -626,6 +665,9 @@ def main():
             "ms_per_step_by_rank": ms_by_rank,
             "roofline": r_wgrad, "roofline_ffn1": r_ffn1,
             "step_mfma_frac": round(sps / world * flop_per_sample / PEAK_BF16, 4),
+            "vilt_block_frac": None if blk_vilt is None else blk_vilt["frac"],
+            "lm_block_frac": None if blk_lm is None else blk_lm["frac"],
+            "blocks": {"vilt": blk_vilt, "lm": blk_lm},
             "final_loss": round(loss, 5),
         }
         if exchange is not None:

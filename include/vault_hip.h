@@ -295,6 +295,11 @@ int vault_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, long 
                      float beta2, float eps, float weight_decay, float bias_corr_factor, float grad_scale,
                      int zero_grad, void* stream);
 int vault_cast_bf16(const float* x, void* y_bf16, long long n, void* stream);
+/* Debug census of a 16-bit tensor in the library's operand format (ABI 9; nothing in the reference, which runs fp32:
+ * ref vault/tmsc_utils/trainer.py:353-367 has no autocast): out4[0] += elements at the largest finite magnitude (what a
+ * saturating conversion leaves), out4[1] += infinities / NaNs, out4[2] += subnormals, out4[3] += zeros.  out4: four
+ * unsigned 64-bit counters the caller zeroed.  Behind VaultEngine's VAULT_H16_CENSUS=1 switch (tests/test_gpu_fp16.py). */
+int vault_h16_census(const void* x_h16, long long n, unsigned long long* out4, void* stream);
 /* ---- data-parallel gradient exchange (ABI 6) -------------------------------------------------------------------
  * The reference is single-device (ref: vault/tmsc_utils/trainer.py:353-369: backward -> optimizer.step on one GPU); these
  * serve the build's own data-parallel step, between the RCCL collectives that vault_amd/train.py issues.

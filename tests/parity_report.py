@@ -27,7 +27,7 @@ for name in which:
     loss = torch.nn.functional.cross_entropy(out["logits"], batch["labels"])
     loss.backward()
     print(name, "oracle time %.1fs" % (time.time() - t0))
-    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half="bf16")
     db = {k: torch.from_numpy(v).cuda() for k, v in bn.items()}
     res = eng.forward(db, train=True, labels=db["labels"], need_hidden=True)
     eng.zero_grad()

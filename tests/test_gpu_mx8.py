@@ -149,7 +149,7 @@ def _tiny_engine(fp8, kind="roberta", seed=0):
     if spec.lm is not None:
         spec.lm.hidden_dropout_prob = 0.0
         spec.lm.attention_probs_dropout_prob = 0.0
-    return spec, VaultEngine(spec, "cuda:0", seed=seed, classifier_dropout=0.0, fp8_forward=fp8)
+    return spec, VaultEngine(spec, "cuda:0", seed=seed, classifier_dropout=0.0, fp8_forward=fp8, half="bf16")
 
 
 def test_engine_fp8_forward_tracks_the_bf16_path_and_backward_stays_bf16():
@@ -190,7 +190,7 @@ def test_engine_fp8_forward_full_size_against_reference_golden():
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "full_bertweet_b2.npz"))
     spec = VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3)
     bn = synthetic_batch(spec, int(g["meta_batch"]), seed=int(g["meta_data_seed"]), n_classes=3)
-    eng = VaultEngine(spec, "cuda:0", seed=0, classifier_dropout=0.0, fp8_forward=True, with_grads=False)
+    eng = VaultEngine(spec, "cuda:0", seed=0, classifier_dropout=0.0, fp8_forward=True, with_grads=False, half="bf16")
     db = {k: torch.from_numpy(v).cuda() for k, v in bn.items()}
     out = eng.forward(db, train=False, need_hidden=True)
     torch.cuda.synchronize()
@@ -236,7 +236,9 @@ def test_model_class_switch():
     from vault_amd.spec import VaultSpec, synthetic_batch
     spec = VaultSpec.tiny(3, "roberta")
     bn = synthetic_batch(spec, 3, seed=11, n_classes=3)
-    model = VaultForTMSC(spec.vilt, n_classes=3, vilt_dropout_prob=0.0, bert_config=spec.lm).to("cuda").eval()
+    model = VaultForTMSC(spec.vilt, n_classes=3, vilt_dropout_prob=0.0, bert_config=spec.lm)
+    model.half_format = "bf16"            # (the MXFP8 forward quantises bf16 operands; the default format is fp16)
+    model = model.to("cuda").eval()
     kw = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
     with torch.no_grad():
         a = model(**kw).clone()

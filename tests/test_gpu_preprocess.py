@@ -57,7 +57,7 @@ def test_preprocessed_batch_feeds_the_model():
     bn = synthetic_batch(spec, 2, seed=1)
     batch = {"input_ids": torch.from_numpy(bn["input_ids"]).cuda(), "attention_mask": torch.from_numpy(bn["attention_mask"]).cuda(),
              "pixel_values": px["pixel_values"], "pixel_mask": px["pixel_mask"]}
-    eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0))
+    eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0), half="bf16")
     out = eng.forward(batch, train=False)
     assert out["logits"].shape == (2, 3) and torch.isfinite(out["logits"]).all()
     # the loader-facing form also returns the valid sizes it padded from: with that host-side hint the engine builds the patch
@@ -137,7 +137,7 @@ def test_patch_unfold_straight_from_the_resize_kernel():
     state = build_state(spec, 0)
     outs, params = [], []
     for form in ("pixel_values", "pixel_patches"):
-        eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+        eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half="bf16")
         img = {"pixel_values": pv} if form == "pixel_values" else {"pixel_patches": po}
         batch = dict(input_ids=ids, attention_mask=am, **img)
         outs.append(eng.forward(batch, train=False)["logits"].clone())

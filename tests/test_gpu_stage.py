@@ -176,7 +176,7 @@ def test_embedding_and_head_stages_one_c_call_each_match_the_engine():
     bn = synthetic_batch(spec, B, seed=5, n_classes=3)
     bn["token_type_ids"] = (np.arange(bn["input_ids"].shape[1])[None, :] >= 20).astype(np.int64).repeat(B, 0)
     state = build_state(spec, 9)
-    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half="bf16")
     db = {k: torch.from_numpy(val).cuda() for k, val in bn.items() if k != "labels"}
     labels = torch.from_numpy(bn["labels"]).cuda()
     out = eng.forward(db, train=True, labels=labels)

@@ -42,7 +42,7 @@ def test_two_step_trajectory_vs_oracle():
     spec.lm.hidden_dropout_prob = 0.0; spec.lm.attention_probs_dropout_prob = 0.0
     bn = synthetic_batch(spec, 4, seed=21, n_classes=3)
     state = build_state(spec, 0)
-    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half="bf16")
     step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10)
     db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
     labels = torch.from_numpy(bn["labels"]).cuda()
@@ -87,7 +87,7 @@ def test_bce_single_logit_fine_tune_step_vs_oracle():
     bn = synthetic_batch(spec, 6, seed=33, n_classes=2)
     bn["labels"] = bn["labels"].astype(np.float32)            # 0. / 1. targets
     state = build_state(spec, 2)
-    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half="bf16")
     db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
     labels = torch.from_numpy(bn["labels"]).cuda()
     # forward + backward: loss, logits and head / pooler gradients
@@ -108,7 +108,7 @@ def test_bce_single_logit_fine_tune_step_vs_oracle():
             {k: torch.from_numpy(v).cuda() for k, v in synthetic_batch(VaultSpec.tiny(3, "bert"), 6, seed=33).items()
              if k != "labels"}, train=True, labels=labels)
     # three optimisation steps (step 2 and 3 replay the tape)
-    eng2 = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    eng2 = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half="bf16")
     step = TrainStep(eng2, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10)
     losses = [float(step(db, labels)) for _ in range(3)]
     P = O.to_torch_state(state, requires_grad=True)
@@ -138,7 +138,7 @@ def test_bce_single_logit_against_reference_golden():
     spec = VaultSpec.tiny(1, "bert")
     spec.lm.hidden_dropout_prob = 0.0; spec.lm.attention_probs_dropout_prob = 0.0
     bn = synthetic_batch(spec, int(g["meta_batch"]), seed=int(g["meta_data_seed"]), n_classes=2)
-    eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0), classifier_dropout=0.0)
+    eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0), classifier_dropout=0.0, half="bf16")
     db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
     out = eng.forward(db, train=True, labels=torch.from_numpy(bn["labels"].astype(np.float32)).cuda())
     eng.zero_grad(); eng.backward()
@@ -155,7 +155,7 @@ def test_bce_single_logit_against_reference_golden():
 def test_train_mode_dropout_is_active_and_reproducible():
     spec = VaultSpec.tiny(3, "roberta")
     bn = synthetic_batch(spec, 4, seed=22, n_classes=3)
-    eng = VaultEngine(spec, "cuda:0", classifier_dropout=0.1)
+    eng = VaultEngine(spec, "cuda:0", classifier_dropout=0.1, half="bf16")
     db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
     labels = torch.from_numpy(bn["labels"]).cuda()
     ev = eng.forward(db, train=False, need_hidden=False)["logits"].clone()
@@ -177,7 +177,7 @@ def test_tape_replay_matches_eager_steps():
     batches = [synthetic_batch(spec, 4, seed=40 + i, n_classes=3) for i in range(4)]
     res = {}
     for use_tape in (False, True):
-        eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.1)
+        eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.1, half="bf16")
         step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10, use_tape=use_tape)
         losses = []
         for bn in batches:
@@ -220,7 +220,7 @@ def test_train_step_on_padded_image_batches_mixed_with_square_ones():
             batches.append(synthetic_ragged_batch(spec, gspec[0], gspec[1], seed=70 + i, n_classes=3))
     res = {}
     for use_tape in (False, True):
-        eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+        eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half="bf16")
         step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10, use_tape=use_tape)
         losses = []
         for bn in batches:
@@ -230,7 +230,7 @@ def test_train_step_on_padded_image_batches_mixed_with_square_ones():
     la, lb = res[False], res[True]
     assert max(abs(a - b) for a, b in zip(la, lb)) < 5e-4, (la, lb)
     # repeat one padded batch: the loss must fall
-    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half="bf16")
     step = TrainStep(eng, learning_rate=2e-4, warmup_ratio=0.0, total_steps=100, constant_lr=True)
     bn = batches[0]
     db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
@@ -312,7 +312,7 @@ def test_data_parallel_two_ranks_equal_one_rank_on_the_global_batch(tmp_path, us
     spec = VaultSpec.tiny(3, "roberta")
     spec.lm.hidden_dropout_prob = 0.0
     spec.lm.attention_probs_dropout_prob = 0.0
-    eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0), classifier_dropout=0.0)
+    eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0), classifier_dropout=0.0, half="bf16")
     step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10, use_tape=False)
     ref_losses = []
     for i in range(nsteps):
@@ -379,7 +379,7 @@ def test_evaluate_pass_matches_oracle_predictions():
     from vault_amd.train import evaluate, evaluation_metrics
     spec = VaultSpec.tiny(3, "roberta")
     state = build_state(spec, 0)
-    eng = VaultEngine(spec, "cuda:0", state=state, with_grads=False)
+    eng = VaultEngine(spec, "cuda:0", state=state, with_grads=False, half="bf16")
     batches, ref_pred, ref_true, ref_loss, n = [], [], [], 0.0, 0
     P = O.to_torch_state(state)
     for i, B in enumerate((5, 3, 4)):
@@ -405,7 +405,7 @@ def test_frozen_lm_train_step_trajectory_vs_oracle():
     spec.lm.hidden_dropout_prob = 0.0; spec.lm.attention_probs_dropout_prob = 0.0
     bn = synthetic_batch(spec, 4, seed=31, n_classes=3)
     state = build_state(spec, 0)
-    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, freeze_lm=True)
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, freeze_lm=True, half="bf16")
     step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10)
     db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
     labels = torch.from_numpy(bn["labels"]).cuda()
@@ -453,7 +453,7 @@ def test_train_step_over_rccl_single_rank(wire):
     labels = torch.from_numpy(bn["labels"]).cuda()
 
     def run(dp):
-        eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0), classifier_dropout=0.0)
+        eng = VaultEngine(spec, "cuda:0", state=build_state(spec, 0), classifier_dropout=0.0, half="bf16")
         st = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10, bucket_mb=0.05, wire=wire)
         assert (st.reducer is not None) == dp
         if dp:   # RCCL's all_gather_into_tensor (token ids) + all_reduce / all_to_all_single + all_gather_into_tensor
@@ -482,19 +482,47 @@ def test_train_step_over_rccl_single_rank(wire):
         assert float(d.mean()) < 4e-6 and float((d > 2e-5).float().mean()) < 0.03
 
 
-def test_full_size_loss_trajectory_20_steps_vs_fp32_oracle():
-    """What a fine-tune user sees: 20 optimisation steps of the full-size model (12 + 12 layers, B = 4, lr 2e-5 with the
-    reference's 10 % linear warm-up, HF-AdamW without bias correction) in the bf16 fast mode against the same 20 steps
-    of the fp32 CPU oracle (the measured deviations are printed; bound: 8e-3 per step - the deviation is rounding noise of the
-    bf16 operand format, |dloss| 1.7e-3 on one forward, amplified along the trajectory: 5.0e-3 at most with the round-3 erf
-    polynomial in the GELU epilogue, 6.2e-3 with round 4's; the fp16 operand build stays below 1e-3: test_gpu_fp16.py)."""
+_TRAJ = {}
+
+
+def _fp32_oracle_trajectory(spec, state, batches, nsteps):
+    """20 fine-tune steps of the fp32 CPU oracle (computed once per session: both operand formats compare with it)."""
     import os
+    if "ref" not in _TRAJ:
+        torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+        P = O.to_torch_state(state, requires_grad=True)
+        m = {k: torch.zeros_like(v) for k, v in P.items()}; v2 = {k: torch.zeros_like(v) for k, v in P.items()}
+        ref = []
+        for t in range(1, nsteps + 1):
+            for p in P.values():
+                p.grad = None
+            loss, _ = O.vault_loss(P, spec, O.torch_batch(batches[(t - 1) % 4]))
+            loss.backward()
+            ref.append(float(loss.detach()))
+            lr = O.linear_schedule_lr(2e-5, t - 1, int(0.1 * nsteps), nsteps)
+            with torch.no_grad():
+                for k, p in P.items():
+                    if p.grad is not None:
+                        O.hf_adamw_step(p, p.grad, m[k], v2[k], lr, t)
+        _TRAJ["ref"] = ref
+    return _TRAJ["ref"]
+
+
+@pytest.mark.parametrize("half", ["fp16", "bf16"])
+def test_full_size_loss_trajectory_20_steps_vs_fp32_oracle(half):
+    """What a fine-tune user sees: 20 optimisation steps of the full-size model (12 + 12 layers, B = 4, lr 2e-5 with the
+    reference's 10 % linear warm-up, HF-AdamW without bias correction) against the same 20 steps of the fp32 CPU oracle (the
+    measured deviations are printed).  fp16 operands (the API default): every loss of the trajectory inside the north star's
+    1e-3.  bf16 operands: 8e-3 per step - rounding noise of the operand format, |dloss| 1.7e-3 on one forward, amplified along
+    the trajectory; over three data seeds and both GELU epilogue forms the maximum lies at 4.6e-3 .. 6.5e-3
+    (profiles/r05_bf16_trajectory_seeds.txt, tools/traj_seeds.py: the round-4 change of the erf form re-drew this noise, it did
+    not raise it)."""
     from vault_amd.spec import LMSpec, ViltSpec
     spec = VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3)
     spec.lm.hidden_dropout_prob = 0.0; spec.lm.attention_probs_dropout_prob = 0.0
     nsteps, B = 20, 4
     state = build_state(spec, 0)
-    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half=half)
     step = TrainStep(eng, learning_rate=2e-5, warmup_ratio=0.1, total_steps=nsteps)
     batches = [synthetic_batch(spec, B, seed=300 + i, n_classes=3) for i in range(4)]
     losses = []
@@ -502,24 +530,12 @@ def test_full_size_loss_trajectory_20_steps_vs_fp32_oracle():
         bn = batches[i % 4]
         db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
         losses.append(float(step(db, torch.from_numpy(bn["labels"]).cuda())))
-    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
-    P = O.to_torch_state(state, requires_grad=True)
-    m = {k: torch.zeros_like(v) for k, v in P.items()}; v2 = {k: torch.zeros_like(v) for k, v in P.items()}
-    ref = []
-    for t in range(1, nsteps + 1):
-        for p in P.values():
-            p.grad = None
-        loss, _ = O.vault_loss(P, spec, O.torch_batch(batches[(t - 1) % 4]))
-        loss.backward()
-        ref.append(float(loss.detach()))
-        lr = O.linear_schedule_lr(2e-5, t - 1, int(0.1 * nsteps), nsteps)
-        with torch.no_grad():
-            for k, p in P.items():
-                if p.grad is not None:
-                    O.hf_adamw_step(p, p.grad, m[k], v2[k], lr, t)
+    del step, eng
+    torch.cuda.empty_cache()
+    ref = _fp32_oracle_trajectory(spec, state, batches, nsteps)
     diffs = [abs(a - b) for a, b in zip(losses, ref)]
-    print(f"20-step trajectory: max |dloss| {max(diffs):.2e}, final |dloss| {diffs[-1]:.2e}, loss {ref[0]:.4f} -> {ref[-1]:.4f}")
-    assert max(diffs) < 8e-3, (max(diffs), losses, ref)
+    print(f"{half}: 20-step trajectory: max |dloss| {max(diffs):.2e}, final |dloss| {diffs[-1]:.2e}, loss {ref[0]:.4f} -> {ref[-1]:.4f}")
+    assert max(diffs) < (1e-3 if half == "fp16" else 8e-3), (max(diffs), losses, ref)
     assert ref[-1] < ref[0] and losses[-1] < losses[0]                 # both trajectories descend
     # the drop over the run agrees within 15 %
     assert abs((losses[0] - losses[-1]) - (ref[0] - ref[-1])) < 0.15 * abs(ref[0] - ref[-1]) + 2e-3
@@ -543,7 +559,7 @@ def test_8bit_gelu_prime_follows_the_kernel_choice():
         old = ops.GEMM_SCHED
         ops.GEMM_SCHED = sched
         try:
-            eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+            eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half="bf16")
             eng.GELU8 = g8
             out = eng.forward(db, train=True, labels=labels, need_hidden=False)
             eng.zero_grad(); eng.backward()
@@ -628,13 +644,13 @@ def test_train_step_after_an_api_backward_starts_from_zero_gradients():
     db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
     labels = torch.from_numpy(bn["labels"]).cuda()
     state = build_state(spec, 0)
-    a = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    a = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half="bf16")
     a.forward(dict(db), train=True, labels=labels)
     a.backward()                                    # leaves gradients in the flat buffer
     assert a._g_dirty
     sa = TrainStep(a, learning_rate=1e-4, warmup_ratio=0.0, total_steps=10, constant_lr=True)
     la = float(sa(db, labels))
-    b = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0)
+    b = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half="bf16")
     sb = TrainStep(b, learning_rate=1e-4, warmup_ratio=0.0, total_steps=10, constant_lr=True)
     lb = float(sb(db, labels))
     torch.cuda.synchronize()

@@ -64,7 +64,7 @@ def test_library_exports_every_declared_symbol(fmt):
     for n in names:
         assert hasattr(lib, n), n
     lib.vault_abi_version.restype = ctypes.c_int
-    assert lib.vault_abi_version() == 8
+    assert lib.vault_abi_version() == 9
     lib.vault_operand_format.restype = ctypes.c_int
     assert lib.vault_operand_format() == ("bf16", "fp16").index(fmt)
 
@@ -383,13 +383,20 @@ def _dp_worker(rank, world, port, q):
         r5.finish()
         ok[f"sparse table {wire}: short batch"] = (bool(torch.equal(g5, dense)) if wire == "fp32" else
                                                    float((g5 - dense).abs().max()) <= 2.0 ** -7 * float(dense.abs().max()))
-        # more ids than agreed on, or a switch to inputs_embeds: the rank that sees it raises (before any collective)
-        for bad_keys in (torch.cat([ids, ids]), None):
+        # more ids than agreed on, or a switch to inputs_embeds, on ONE rank: EVERY rank raises when the table is exchanged (the
+        # header words travel in the step's key all-gather) - no rank is left waiting in a collective - and steps on afterwards
+        for what, bad_keys in (("too many ids", torch.cat([ids, ids])), ("switch to inputs_embeds", None)):
+            r5.begin_step(bad_keys if rank == 1 else ids)
             try:
-                r5.begin_step(bad_keys)
-                ok[f"sparse table {wire}: raises {bad_keys is None}"] = False
+                for tag in ["head", "vilt_embed", "lm0", "lm_embed"]:
+                    r5.on_stage(tag)
+                ok[f"sparse table {wire}: {what} raises on every rank"] = False
+            except RuntimeError as e:
+                ok[f"sparse table {wire}: {what} raises on every rank"] = "rank(s)" in str(e) and ("[(1, 8)]" in str(e) or "[1]" in str(e))
+            try:
+                r5.finish()
             except RuntimeError:
-                ok[f"sparse table {wire}: raises {bad_keys is None}"] = True
+                pass
         # a token id outside the table: its row would be left out of the union - raised when the table is exchanged, and
         # the reducer is usable again afterwards (finish() resets before it raises)
         r5.begin_step(torch.tensor([3, V + 5, 1, 0], dtype=torch.int64))
@@ -441,6 +448,28 @@ def _dp_worker(rank, world, port, q):
                 ok[f"sparse check {wire}: stray row raises"] = "differs from the dense" in str(e)
             try:
                 r8.finish()
+            except RuntimeError:
+                pass
+            # the steps WITHOUT any touched row (inputs_embeds on every rank; an empty union) are checked too - a second source of
+            # gradient on the table would go un-reduced altogether there - and count down like the others
+            g9 = torch.zeros(n)
+            r9 = BucketReducer(g9, lo5, "lm_embed", bucket_elems=2500, dist=dist, wire=wire, sparse=sp, kernels=HostKernels)
+            r9.begin_step(None)
+            for tag in ["head", "vilt_embed", "lm0", "lm_embed"]:
+                r9.on_stage(tag)
+            r9.finish()
+            ok[f"sparse check {wire}: no-ids step is checked"] = r9.sparse_checks == 1 and r9._check_sparse_left == 1
+            if rank == 1:
+                g9[:V * H].view(V, H)[4] = 2.0
+            r9.begin_step(None)
+            try:
+                for tag in ["head", "vilt_embed", "lm0", "lm_embed"]:
+                    r9.on_stage(tag)
+                ok[f"sparse check {wire}: stray row in a no-ids step raises"] = False
+            except RuntimeError as e:
+                ok[f"sparse check {wire}: stray row in a no-ids step raises"] = "differs from the dense" in str(e)
+            try:
+                r9.finish()
             except RuntimeError:
                 pass
     finally:
@@ -596,3 +625,20 @@ def test_sysfs_device_count_honours_visibility_variables(monkeypatch):
     assert bench.count_gpus_sysfs() == min(have, 1)
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0,1,2")
     assert bench.count_gpus_sysfs() == min(have, 1)
+
+
+def test_operand_format_is_a_context_variable_per_thread():
+    """the current operand format (which of the two libraries a launch goes to) must not leak into other host
+    threads - a prefetch / preprocessing thread that launches while an fp16 engine is inside its context stays on its own
+    default."""
+    import threading
+    from vault_amd import ops
+    seen = []
+    with ops.operand_format("fp16"):
+        t = threading.Thread(target=lambda: seen.append(ops.current_format()))
+        t.start(); t.join()
+        assert ops.current_format() == "fp16"
+        with ops.operand_format("bf16"):
+            assert ops.current_format() == "bf16"
+        assert ops.current_format() == "fp16"
+    assert seen == ["bf16"] and ops.current_format() == "bf16"

@@ -6,7 +6,7 @@ from vault_amd.spec import LMSpec, VaultSpec, ViltSpec, synthetic_batch
 from vault_amd.train import TrainStep
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 spec = VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3)
-eng = VaultEngine(spec, "cuda:0", seed=0, classifier_dropout=0.1)
+eng = VaultEngine(spec, "cuda:0", seed=0, classifier_dropout=0.1, half="bf16")
 step = TrainStep(eng, total_steps=1000, assume_full_pixel_mask=True)
 bn = synthetic_batch(spec, B, seed=1)
 db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}; lab = torch.from_numpy(bn["labels"]).cuda()

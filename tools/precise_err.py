@@ -6,7 +6,7 @@ g = np.load("tests/golden/full_bertweet_b2.npz")
 spec = VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3)
 spec.lm.hidden_dropout_prob = 0; spec.lm.attention_probs_dropout_prob = 0
 bn = synthetic_batch(spec, 2, seed=13, n_classes=3)
-eng = VaultEngine(spec, "cuda:0", seed=0, classifier_dropout=0.0, with_grads=False)
+eng = VaultEngine(spec, "cuda:0", seed=0, classifier_dropout=0.0, with_grads=False, half="bf16")
 db = {k: torch.from_numpy(v).cuda() for k, v in bn.items()}
 for pr in (False, True):
     out = eng.forward(db, train=False, labels=db["labels"], need_hidden=True, precise=pr)

@@ -8,7 +8,7 @@ from vault_amd.spec import LMSpec, VaultSpec, ViltSpec, synthetic_ragged_batch
 from vault_amd.train import TrainStep
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 spec = VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3)
-eng = VaultEngine(spec, "cuda:0", seed=0, classifier_dropout=0.1)
+eng = VaultEngine(spec, "cuda:0", seed=0, classifier_dropout=0.1, half="bf16")
 step = TrainStep(eng, learning_rate=2e-5, total_steps=100)
 rng = np.random.default_rng(0)
 hw = [(384, int(rng.integers(12, 21)) * 32) if rng.random() < 0.7 else (int(rng.integers(8, 13)) * 32, 384) for _ in range(B)]

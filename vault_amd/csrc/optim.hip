@@ -46,6 +46,33 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   }
 }
 
+// Debug census of a 16-bit tensor in the library's operand format (VAULT_H16_CENSUS): what its narrow exponent did to it.
+// out[0] += elements at the largest finite magnitude (what a saturating conversion leaves: H16_SATURATE), out[1] += infinities
+// and NaNs, out[2] += subnormals (gradual underflow: significant bits already lost), out[3] += zeros.
+__global__ __launch_bounds__(256) void h16_census_kernel(const uint16_t* __restrict__ x, long long n,
+                                                         unsigned long long* __restrict__ out) {
+#ifdef VAULT_F16
+  constexpr uint16_t EXP = 0x7C00, MAN = 0x03FF, MAXF = 0x7BFF;
+#else
+  constexpr uint16_t EXP = 0x7F80, MAN = 0x007F, MAXF = 0x7F7F;
+#endif
+  unsigned c[4] = {0u, 0u, 0u, 0u};
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256ll) {
+    const uint16_t a = x[i] & 0x7FFF;
+    c[0] += a == MAXF;
+    c[1] += (a & EXP) == EXP;
+    c[2] += (a & EXP) == 0 && (a & MAN) != 0;
+    c[3] += a == 0;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    unsigned v = c[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out + k, (unsigned long long)v);
+  }
+}
+
 // out[r][3K]: layout 0 (activation/A operand) = [hi | lo | hi], layout 1 (weight/B operand) = [hi | hi | lo]
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, h16* __restrict__ out, long long rows,
                                                      int K, int layout) {
@@ -87,6 +114,14 @@ extern "C" int vault_adamw_step(float* p, float* g, float* m, float* v, void* p_
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v,
                      reinterpret_cast<h16*>(p_bf16), n4, lr * bias_corr_factor, lr * weight_decay, beta1, beta2, eps,
                      grad_scale, zero_grad);
+  return (int)hipGetLastError();
+}
+
+extern "C" int vault_h16_census(const void* x_h16, long long n, unsigned long long* out4, void* stream) {
+  if (!x_h16 || !out4 || n <= 0) return VAULT_EINVAL;
+  const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(h16_census_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const uint16_t*>(x_h16), n, out4);
   return (int)hipGetLastError();
 }
 

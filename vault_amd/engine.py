@@ -260,6 +260,7 @@ class _LayerNames:
 class VaultEngine:
     """Forward / backward of VaultModel / VaultForTMSC over one batch resident in HBM."""
 
+    DEFAULT_HALF = "fp16"          # operand format of an engine constructed without `half` (see __init__)
     WGRAD_TARGET_WGS = 768
     # Weight gradients of the encoder layers are deferred and contracted `LM_WGRAD_GROUP` layers per launch (vault_gemm
     # batch, ABI 3): one layer alone fills the GPU only with split-K partial sums through float atomics (and, for the
@@ -284,17 +285,20 @@ class VaultEngine:
 
     def __init__(self, spec: VaultSpec, device="cuda:0", state=None, seed: int = 0, freeze_lm: bool = False,
                  with_grads: bool = True, classifier_dropout: float = 0.1, fp8_forward: bool = False,
-                 half: str = "bf16", grad_scale_pow2: Optional[float] = None):
+                 half: Optional[str] = None, grad_scale_pow2: Optional[float] = None):
         self.spec, self.device = spec, torch.device(device)
-        # 16-bit operand format of every GEMM / attention operand, saved activation and data gradient: "bf16" (default,
-        # BASELINE's format) or "fp16" - the same kernels compiled for IEEE half operands (libvault_hip_f16.so), same
-        # matrix rate, 11 instead of 8 significant bits: logits / loss of the full-size stack inside 1e-3 of the fp32
-        # reference (ref: vault/models/vault/model.py:557-570 runs fp32) at the bf16 mode's speed.  fp16's narrow
+        # 16-bit operand format of every GEMM / attention operand, saved activation and data gradient: "fp16" (DEFAULT_HALF: the
+        # format that meets the reference's tolerance) - IEEE half operands (libvault_hip_f16.so), 11 significant bits: logits /
+        # loss of the full-size stack inside 1e-3 of the fp32 reference (ref: vault/models/vault/model.py:557-570 runs fp32) -
+        # or "bf16" (BASELINE's format, what bench.py times as `value`): the same kernels compiled for bf16 operands
+        # (libvault_hip.so), same matrix rate, 8 significant bits (4e-3 on the logits).  fp16's narrow
         # exponent range is handled the classic way: the backward runs on gradients multiplied by the static power of
         # two `grad_scale` (exact in every format; default 2^12: |dlogits| <= 1 becomes 4096, elements down to 1.5e-8
         # stay normal numbers), the flat gradient buffer holds SCALED gradients while a backward runs, the fused
         # optimizer divides the scale out (TrainStep), the autograd bridge un-scales after each backward (backward());
         # conversions saturate at +-65504 (csrc/common.h H16_SATURATE) instead of producing infinities.
+        if half is None:      # (the fp8-forward mode quantises bf16 operands)
+            half = "bf16" if fp8_forward else self.DEFAULT_HALF
         if half not in ops.HALF_DTYPE:
             raise ValueError("half must be 'bf16' or 'fp16'")
         self.half, self.hdt = half, ops.HALF_DTYPE[half]
@@ -355,6 +359,11 @@ class VaultEngine:
         # the FFN-in forward GEMM gemm256_kernel<0,0,EPI_BF16_GELU,4> (ViLT and LM layers).
         self.profile_events: Optional[Dict[str, list]] = None
         self._e0: Dict[str, torch.cuda.Event] = {}
+        # VAULT_H16_CENSUS=1 (debug; synchronises): after every eager forward / backward, what the 16-bit operand format did to
+        # each 16-bit tensor of the workspace - {"forward" | "backward": {tensor name: {"saturated", "nonfinite", "subnormal",
+        # "zero", "n"}}} (vault_h16_census: elements at the largest finite magnitude = what a saturating conversion leaves)
+        self.census_on = os.environ.get("VAULT_H16_CENSUS") == "1"
+        self.census: Dict[str, Dict[str, dict]] = {}
 
     def _prof_begin(self, site: str, stream=None):
         if self.profile_events is not None and site in self.profile_events:
@@ -367,6 +376,26 @@ class VaultEngine:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(stream)
             self.profile_events[site].append((self._e0[site], e1, flops))
+
+    def _run_census(self, ws: dict, phase: str):
+        if not self.census_on or ops.taping():
+            return
+        import re
+        skip_u = ws.get("gelu8_active") is not None       # (the ViLT `u` buffers then hold the 8-bit tile-native gelu' image)
+        names = [k for k, t in ws.items() if isinstance(k, str) and isinstance(t, torch.Tensor) and t.dtype == self.hdt
+                 and not k.endswith("_all") and not (skip_u and re.fullmatch(r"u\d*", k))]
+        seen, todo = set(), []
+        for k in sorted(names):
+            key = (ws[k].data_ptr(), ws[k].numel())
+            if key not in seen and ws[k].is_contiguous():
+                seen.add(key)
+                todo.append(k)
+        cnt = torch.zeros((max(1, len(todo)), 4), dtype=torch.int64, device=self.device)
+        for j, k in enumerate(todo):
+            ops.h16_census(ws[k], cnt[j])
+        host = cnt.cpu().tolist()
+        self.census[phase] = {k: dict(saturated=host[j][0], nonfinite=host[j][1], subnormal=host[j][2], zero=host[j][3],
+                                      n=ws[k].numel()) for j, k in enumerate(todo)}
 
     # ---- deferred weight gradients on a second stream -------------------------------------------
     def _wgrads_aside(self, launch, after_layer):
@@ -1049,6 +1078,7 @@ class VaultEngine:
                               y_q=q8l[0], y_scale=q8l[1])
             lm_stage = self._use_stage(Mlp, pr)
             ws["lm_stage"] = lm_stage
+            ops.pycall(lambda: self._prof_begin("lm_fwd"))
             for i, ln in enumerate(self.ll):
                 sfx = f"{i}" if keep else ""
                 qkv = buf(f"lm_qkv{sfx}", (Mlp, 3 * H), bf)
@@ -1104,6 +1134,7 @@ class VaultEngine:
                                   y_bf16=(ybs[i + 1] if pt else None) if pr else yb[i + 1], y_split3=yb[i + 1] if pr else None,
                                   mean=buf(f"lm_m2{sfx}", (Mlp,)), rstd=buf(f"lm_r2{sfx}", (Mlp,)),
                                   y_q=q8l[0], y_scale=q8l[1])
+            ops.pycall(lambda: self._prof_end("lm_fwd"))
             text_src = y[nl]
             use_pos = spec.use_vilt_position_embeddings
             tables = [(P.w("embeddings.text_embeddings.token_type_embeddings.weight"), tt if tt is not None else 0)]
@@ -1180,6 +1211,7 @@ class VaultEngine:
             # the ViLT layers' weight gradients are deferred and batched like the LM's
             for base, width in (("n1", H), ("ctx", H), ("n2", H), ("act", FF)):
                 self._stack(ws, base, nv, (Mp, width), bf)
+        ops.pycall(lambda: self._prof_begin("vilt_fwd"))
         for i, ln in enumerate(self.vl):
             sfx = f"{i}" if train else ""
             p3 = "_3" if pr else ""
@@ -1227,6 +1259,7 @@ class VaultEngine:
             ops.pycall(lambda: self._prof_end("ffn1", fl_v))
             self._linear(act, ln.fw, x[i + 1], Mp, H, FF, ops.EPI_F32_RES, M, bias=P.w(ln.fb), res=xm, precise=pr)
 
+        ops.pycall(lambda: self._prof_end("vilt_fwd"))
         # ------------------------------ tail ------------------------------
         out: Dict[str, torch.Tensor] = {}
         xl = x[nv]
@@ -1268,6 +1301,7 @@ class VaultEngine:
             out["pooler_output"] = pooled[:B]
         ws["x"] = x
         self.last = ws
+        self._run_census(ws, "forward")
         return out
 
     # ---- MLP task head (HF ViltForQuestionAnswering / ViltForImagesAndTextClassification .classifier) ------------
@@ -1561,6 +1595,7 @@ class VaultEngine:
         # Residual-gradient stream of the pre-LN ViLT stack in bf16 only (GRAD_STREAM_BF16): a layer's incoming gradient is ONE
         # bf16 tensor - stream and FFN-out dY at once -, the LayerNorm backward adds it as `dres_bf16` and writes only the bf16
         # result (10 instead of 16 B per element); the bottom layer also writes f32 for the embedding backward.
+        ops.pycall(lambda: self._prof_begin("vilt_bwd"))
         for i in reversed(range(nv)):
             ln = self.vl[i]
             g = lambda k: ws[f"{k}{i}"]  # noqa: E731
@@ -1654,6 +1689,7 @@ class VaultEngine:
                 for j in reversed(range(i, hi)):
                     note(f"vilt{j}")
 
+        ops.pycall(lambda: self._prof_end("vilt_bwd"))
         # ------------------------------ ViLT embeddings ------------------------------
         dx0 = dx[cur]
         Kp, Mpp = ws["Kp"], ws["Mpp"]
@@ -1697,6 +1733,7 @@ class VaultEngine:
         note("vilt_embed")
         if spec.lm is None or self.freeze_lm:
             self._join_wgrads()
+            self._run_census(ws, "backward")
             return
 
         # ------------------------------ language model ------------------------------
@@ -1733,6 +1770,7 @@ class VaultEngine:
                                     (P.gr("bert.embeddings.position_embeddings.weight"), ws["lm_pos"]),
                                     (P.gr("bert.embeddings.token_type_embeddings.weight"), ws["lm_tt"])], Ml, H,
                             rowmask=amf)   # padded positions are masked keys everywhere: their gradient is exactly 0
+        ops.pycall(lambda: self._prof_begin("lm_bwd"))
         for i in reversed(range(nl)):
             ln = self.ll[i]
             g = lambda k: ws[f"lm_{k}{i}"]  # noqa: E731
@@ -1812,8 +1850,10 @@ class VaultEngine:
                 self._wgrads_aside(launch, after_layer)
                 for j in reversed(range(i, hi)):
                     note(f"lm{j}")
+        ops.pycall(lambda: self._prof_end("lm_bwd"))
         if not embed_done:
             embed_backward(dyb, dyf)
         self._join_wgrads()
         if not embed_done:
             note("lm_embed")
+        self._run_census(ws, "backward")

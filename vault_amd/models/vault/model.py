@@ -137,6 +137,9 @@ class _VaultFunction(torch.autograd.Function):
             batch["inputs_embeds"] = inputs_embeds.detach().to(eng.device, torch.float32)
         if image_embeds is not None:
             batch["image_embeds"] = image_embeds.detach().to(eng.device, torch.float32)
+        if model.fp8_forward and eng.half != "bf16":
+            raise ValueError("fp8_forward quantises bf16 operands: set model.half_format = 'bf16' (or VAULT_HALF=bf16) before "
+                             "moving the model to the GPU")
         eng.fp8_forward = bool(model.fp8_forward)
         extra = batch.pop("__pass__", None)     # (ws_tag, image_token_type_idx, advance_seed) of multi-image heads
         kw = {} if extra is None else dict(ws_tag=extra[0], image_token_type_idx=extra[1], advance_seed=extra[2])
@@ -231,11 +234,11 @@ class VaultMixin(nn.Module):
     #: forward Linear layers fed by a LayerNorm (QKV, FFN-in) on MXFP8 operands, backward in bf16 (BASELINE config
     #: "fp8 MFMA forward, bf16 backward"): faster, outside the 1e-3 parity bar
     fp8_forward = False
-    #: 16-bit operand format of the HIP engine, read when the model is moved to a GPU: "bf16" (default) or "fp16" - IEEE
-    #: half operands at the same matrix rate, logits / loss inside 1e-3 of the fp32 reference in training and inference
-    #: (bf16: 4e-3), gradients carried under a static power-of-two scale that is divided out before ``p.grad`` is
-    #: published (engine.VaultEngine).  Environment override: VAULT_HALF.
-    half_format = "bf16"
+    #: 16-bit operand format of the HIP engine, read when the model is moved to a GPU: "fp16" (default) - IEEE half operands,
+    #: logits / loss inside 1e-3 of the fp32 reference in training and inference, gradients carried under a static
+    #: power-of-two scale that is divided out before ``p.grad`` is published (engine.VaultEngine) - or "bf16" (the same kernels
+    #: and matrix rate on bf16 operands: 4e-3 on the logits; required by ``fp8_forward``).  Environment override: VAULT_HALF.
+    half_format = "fp16"
 
     def __init__(self, vilt_config, bert_config=None, freeze_lm: bool = False, vilt_dropout_prob: float = 0.0,
                  use_vilt_position_embeddings: bool = False, add_pooling_layer: bool = True, *, _n_classes: int = 0,
@@ -296,7 +299,7 @@ class VaultMixin(nn.Module):
         import os
         self._engine = VaultEngine(self.spec, device, state=state, freeze_lm=self.freeze_lm,
                                    classifier_dropout=self.vilt_dropout_prob if (self._n_classes and self._head_dropout) else 0.0,
-                                   half=os.environ.get("VAULT_HALF") or self.half_format)
+                                   half=os.environ.get("VAULT_HALF") or ("bf16" if self.fp8_forward else self.half_format))
         P = self._engine.params
         for n, p in self._params_by_name.items():
             p.data = P.w(n)

@@ -4,6 +4,7 @@ No arithmetic happens here; every function enqueues HIP kernels on torch's curre
 """
 from __future__ import annotations
 
+import contextvars
 import ctypes as C
 from typing import Optional
 
@@ -52,8 +53,10 @@ def _p(t: Optional[torch.Tensor]):
 # Every wrapper below launches through the library of the CURRENT format ("bf16": libvault_hip.so, "fp16":
 # libvault_hip_f16.so - the same kernels compiled for the other operand type, csrc/common.h).  An engine makes its own
 # format current around its entry points (``with ops.operand_format(fmt):``); a recorded tape holds the function
-# pointers of the library it was recorded on.  One host thread per device (include/vault_hip.h): a plain module global.
-_FMT = "bf16"
+# pointers of the library it was recorded on.  The current format is a context variable: another host thread (a prefetch /
+# preprocessing thread, a second engine) starts from the default and is never re-routed by an engine that is inside its
+# own ``with`` on this thread.
+_FMT: contextvars.ContextVar = contextvars.ContextVar("vault_operand_format", default="bf16")
 HALF_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16}
 
 
@@ -66,18 +69,16 @@ class operand_format:
         self.fmt = fmt
 
     def __enter__(self):
-        global _FMT
-        self.prev, _FMT = _FMT, self.fmt
+        self._token = _FMT.set(self.fmt)
         return self
 
     def __exit__(self, *exc):
-        global _FMT
-        _FMT = self.prev
+        _FMT.reset(self._token)
         return False
 
 
 def current_format() -> str:
-    return _FMT
+    return _FMT.get()
 
 
 def _h(t: Optional[torch.Tensor]):
@@ -85,8 +86,9 @@ def _h(t: Optional[torch.Tensor]):
     kernels, or the reverse, would be read as garbage without any error from the device)."""
     if t is None:
         return None
-    if t.dtype != HALF_DTYPE[_FMT] and t.dtype in (torch.bfloat16, torch.float16):
-        raise TypeError(f"{t.dtype} operand in a launch on the {_FMT} library")
+    fmt = _FMT.get()
+    if t.dtype != HALF_DTYPE[fmt] and t.dtype in (torch.bfloat16, torch.float16):
+        raise TypeError(f"{t.dtype} operand in a launch on the {fmt} library")
     return t.data_ptr()
 
 
@@ -126,6 +128,10 @@ def stop_tape() -> Optional[Tape]:
     return t
 
 
+def taping() -> bool:
+    return _TAPE is not None
+
+
 def pycall(fn):
     """Run a host-side action now and, when recording, put it on the tape (must return None / 0).  Kernel launches made
     INSIDE the action are live every time it runs (they are not recorded a second time): the data-parallel gradient
@@ -142,7 +148,7 @@ def pycall(fn):
 
 
 def _invoke(name: str, *args, struct=None, drop=None):
-    fn = getattr(L.load(_FMT), name)
+    fn = getattr(L.load(_FMT.get()), name)
     if _TAPE is not None:
         _TAPE.calls.append((fn, args))
         if struct is not None and drop is not None and drop.thresh:
@@ -193,7 +199,7 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_va
     a.batch, a.batch_a, a.batch_b, a.batch_o = batch, batch_a, batch_b, batch_o   # batched weight gradients (ABI 3)
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
     if plan_only:      # the kernel configuration these arguments would run on (vault_gemm_plan): >= 0, or -EINVAL
-        return int(L.load(_FMT).vault_gemm_plan(C.byref(a)))
+        return int(L.load(_FMT.get()).vault_gemm_plan(C.byref(a)))
     _invoke("vault_gemm", C.byref(a), _stream(), struct=a, drop=drop)
 
 
@@ -468,6 +474,12 @@ def cast_bf16(x, y_bf16, n):
     _invoke("vault_cast_bf16", C.c_void_p(_p(x)), C.c_void_p(_h(y_bf16)), C.c_longlong(n), _stream())
 
 
+def h16_census(x_h16, out4_u64):
+    """Debug (VaultEngine VAULT_H16_CENSUS=1): out4 += [largest-finite-magnitude, non-finite, subnormal, zero] element counts
+    of a 16-bit tensor in the current operand format (vault_h16_census)."""
+    _invoke("vault_h16_census", C.c_void_p(_h(x_h16)), C.c_longlong(x_h16.numel()), C.c_void_p(_p(out4_u64)), _stream())
+
+
 # ---- data-parallel gradient exchange (csrc/exchange.hip) ----
 def rows_union(keys_i64, n_keys, V, flags_i32, uniq_i64, count_i32):
     _invoke("vault_rows_union", C.c_void_p(_p(keys_i64)), C.c_longlong(n_keys), C.c_int(V), C.c_void_p(_p(flags_i32)),
@@ -575,7 +587,7 @@ def stage_args(struct_type, /, **kw):
 
 
 def workspace_bytes(H, FF, heads, lm_layers, vilt_layers, IMG, ps, Cn, n_classes, B, T, train) -> int:
-    fn = L.load(_FMT).vault_workspace_bytes
+    fn = L.load(_FMT.get()).vault_workspace_bytes
     fn.restype = C.c_longlong
     d = ModelDims(H, FF, heads, lm_layers, vilt_layers, IMG, ps, Cn, n_classes)
     return int(fn(C.byref(d), C.c_int(B), C.c_int(T), C.c_int(1 if train else 0)))
@@ -601,7 +613,7 @@ def layer_bwd_args(fwd: LayerArgs, **kw) -> LayerBwdArgs:
 def layer_call(name: str, args, seeded: bool = False):
     """vault_{vilt,lm}_layer_{fwd,bwd}: one layer per C call.  ``seeded``: the struct carries a dropout seed the tape
     re-keys between replays (for the backward form: its forward struct)."""
-    fn = getattr(L.load(_FMT), name)
+    fn = getattr(L.load(_FMT.get()), name)
     call = (C.byref(args), _stream())
     if _TAPE is not None:
         _TAPE.calls.append((fn, call))

@@ -232,9 +232,12 @@ class BucketReducer:
         union's size only when the table's gradient is final (``_exchange_table``).
 
         The all-gather needs the SAME key count on every rank and every rank to agree on ids-or-none: the first step
-        exchanges (count, has-keys) between the ranks and raises on a mismatch (one host synchronisation, once); the count
-        of that step is the capacity afterwards - a later, smaller batch is padded with -1 (ignored by the union), a larger
-        one or a switch between ids and ``inputs_embeds`` raises on the rank that sees it."""
+        exchanges (count, has-keys) between the ranks and raises on a mismatch (one host synchronisation, once).  The count
+        of that step - the first step's B x T - is the CAPACITY afterwards: a later, smaller batch is padded with -1 (ignored
+        by the union).  Every later step carries a two-word header (token count, ids given) per rank in the same all-gather:
+        a rank with more ids than the capacity, or one that switched between ids and ``inputs_embeds``, makes EVERY rank raise
+        when the table is exchanged (``_check_headers``) - a decision taken on one rank only would leave the others waiting
+        in their next collective until it times out."""
         self.wire_bytes = 0
         self._union_ready, self._n_keys = None, 0
         if self.sparse is None:
@@ -249,67 +252,92 @@ class BucketReducer:
                 raise RuntimeError(f"row-sparse embedding exchange: the ranks disagree on (token count, ids given): {rows} - "
                                    "every rank must step the same per-rank batch shape (or pass sparse_embedding=False)")
             self._key_capacity, self._keys_given = n_local, keys is not None
-        if (keys is not None) != self._keys_given:
-            raise RuntimeError("row-sparse embedding exchange: this rank switched between token ids and inputs_embeds "
-                               "(the other ranks cannot know: construct the TrainStep with sparse_embedding=False)")
-        if keys is None:
-            return
-        if n_local > self._key_capacity:
-            raise RuntimeError(f"row-sparse embedding exchange: {n_local} token ids exceed the {self._key_capacity} per rank "
-                               "agreed on in the first step")
-        keys = keys.reshape(-1)
         n = self._key_capacity
-        if n_local < n:                                        # a short (last) batch: pad with -1, ignored by the union
-            padded = self._buf("keys_local", n, torch.int64)
-            padded[:n_local].copy_(keys)
-            padded[n_local:].fill_(-1)
-            keys = padded
         W, V = self.world, self.sparse.rows
-        allk = self._buf("keys", n * W, torch.int64)
-        flags = self._buf("flags", V, torch.int32)
-        uniq = self._buf("uniq", min(V, n * W), torch.int64)
-        cnt = self._buf("count", 2, torch.int32)               # [distinct rows, keys outside the table]
-        host = self._scratch.get("count_host")
-        if host is None:
-            host = torch.zeros(2, dtype=torch.int32)
+        # this rank's slice of the all-gather: [token count, ids given, keys (capacity n; short batches padded with -1, a
+        # batch beyond the capacity truncated - its header makes every rank raise)]
+        mine = self._buf("keys_local", n + 2, torch.int64)
+        mine[0], mine[1] = n_local, (0 if keys is None else 1)
+        if n:
+            m = min(n_local, n)
+            if m:
+                mine[2:2 + m].copy_(keys.reshape(-1)[:m])
+            if m < n:
+                mine[2 + m:].fill_(-1)
+        allk = self._buf("keys", (n + 2) * W, torch.int64)
+        hdrs = self._buf("headers", 2 * W, torch.int64)
+        host_h = self._scratch.get("headers_host")
+        if host_h is None:
+            host_h = torch.zeros(2 * W, dtype=torch.int64)
             if self.comm_stream is not None:
-                host = host.pin_memory()
-            self._scratch["count_host"] = host
+                host_h = host_h.pin_memory()
+            self._scratch["headers_host"] = host_h
+        if n:
+            flags = self._buf("flags", V, torch.int32)
+            uniq = self._buf("uniq", min(V, n * W), torch.int64)
+            cnt = self._buf("count", 2, torch.int32)               # [distinct rows, keys outside the table]
+            host = self._scratch.get("count_host")
+            if host is None:
+                host = torch.zeros(2, dtype=torch.int32)
+                if self.comm_stream is not None:
+                    host = host.pin_memory()
+                self._scratch["count_host"] = host
 
         def go():
-            self._all_gather(allk, keys)
-            self.k.rows_union(allk, n * W, V, flags, uniq, cnt)
-            host.copy_(cnt, non_blocking=True)
+            self._all_gather(allk, mine)
+            slots = allk.view(W, n + 2)[:, :2]
+            hdrs.view(W, 2).copy_(slots)
+            host_h.copy_(hdrs, non_blocking=True)
+            if n:
+                slots.fill_(-1)                                   # (the header words are no keys: padding for the union)
+                self.k.rows_union(allk, (n + 2) * W, V, flags, uniq, cnt)
+                host.copy_(cnt, non_blocking=True)
 
         self._union_ready = self._on_comm_stream(go)
-        self._n_keys = n * W
-        self.wire_bytes += 8 * n * (W - 1)
+        self._n_keys = n * W if (keys is not None and self._keys_given) else 0
+        self.wire_bytes += 8 * (n + 2) * (W - 1)
 
-    def _exchange_table(self):
-        sp = self.sparse
-        if self._n_keys == 0:
-            return                                            # no row touched on any rank: the gradient is zero everywhere
+    def _check_headers(self):
+        """Every rank reads the same (token count, ids given) words of all ranks and takes the same decision."""
         if self._union_ready is not None and not self._union_ready.query():
             # (enqueued at the start of the step: normally long done - the host only blocks, and counts it, when the
             #  first collective of the step was slow)
             self.union_waits += 1
             self._union_ready.synchronize()
-        U, bad = int(self._scratch["count_host"][0]), int(self._scratch["count_host"][1])
-        if bad:
-            raise RuntimeError(f"row-sparse embedding exchange: {bad} token ids lie outside the table's {sp.rows} rows - their "
-                               "gradient rows would be left un-reduced (replicas would diverge)")
-        if U == 0:
-            return
+        h = self._scratch["headers_host"].view(self.world, 2).tolist()
+        over = [(r, int(c)) for r, (c, _) in enumerate(h) if c > self._key_capacity]
+        if over:
+            raise RuntimeError(f"row-sparse embedding exchange: rank(s) {over} stepped more token ids than the "
+                               f"{self._key_capacity} per rank agreed on in the first step (the capacity is the first step's "
+                               "B x T: start with the largest batch, or pass sparse_embedding=False)")
+        switched = [r for r, (_, g_) in enumerate(h) if bool(g_) != self._keys_given]
+        if switched:
+            raise RuntimeError(f"row-sparse embedding exchange: rank(s) {switched} switched between token ids and inputs_embeds "
+                               "(construct the TrainStep with sparse_embedding=False)")
+
+    def _exchange_table(self):
+        sp = self.sparse
+        self._check_headers()
+        U = 0
+        if self._n_keys:
+            U, bad = int(self._scratch["count_host"][0]), int(self._scratch["count_host"][1])
+            if bad:
+                raise RuntimeError(f"row-sparse embedding exchange: {bad} token ids lie outside the table's {sp.rows} rows - their "
+                                   "gradient rows would be left un-reduced (replicas would diverge)")
         table = self.g[sp.lo:sp.hi]
-        uniq = self._scratch["uniq"]
         dense = None
         if self._check_sparse_left > 0:
+            # (debug; VAULT_DP_CHECK_SPARSE must be set identically on every rank - the comparison is a collective.  It runs in
+            #  the steps without any touched row too - inputs_embeds steps, an empty union: exactly the steps in which a second
+            #  source of gradient on the table would go un-reduced altogether)
             dense = table.clone()
             self.dist.all_reduce(dense, op=self.dist.ReduceOp.SUM, group=self.group)
-        compact = self._buf("rows", min(sp.rows, self._n_keys) * sp.H, torch.float32)[:U * sp.H]
-        self.k.rows_gather(table, uniq, U, sp.H, compact)
-        self._sum_over_ranks(compact)
-        self.k.rows_scatter(compact, uniq, U, sp.H, table)
+        if U > 0:
+            uniq = self._scratch["uniq"]
+            compact = self._buf("rows", min(sp.rows, self._n_keys) * sp.H, torch.float32)[:U * sp.H]
+            self.k.rows_gather(table, uniq, U, sp.H, compact)
+            self._sum_over_ranks(compact)
+            self.k.rows_scatter(compact, uniq, U, sp.H, table)
         if dense is not None:
             self._check_sparse_left -= 1
             self.sparse_checks += 1
@@ -471,6 +499,10 @@ class TrainStep:
             key = ws["key"] + (ws["tt"] is None, torch.cuda.current_stream().cuda_stream, ops.GEMM_SCHED,
                                bool(eng.fp8_forward), labels.dtype.is_floating_point, bool(ws.get("patches_in")), self.precise_forward,
                                eng.half, eng.grad_scale)
+            # from here to the enqueued AdamW (which clears it) the flat gradient buffer holds this step's partial gradients: an
+            # exception in between (the reducer's checks raise and stay usable) must not leave them for the next step, which
+            # STORES its un-split weight-gradient tiles but atomically ADDS bias / LayerNorm / embedding / split-K gradients
+            eng._g_dirty = True
             if self.reducer:
                 # the token ids of every rank name the rows of the word-embedding table this step touches: their
                 # all-gather + union start now on the communication stream (inputs_embeds: no row is touched)
@@ -502,6 +534,7 @@ class TrainStep:
                     self.optimizer_step()
             else:
                 self.optimizer_step()
+            eng._g_dirty = False       # (the optimizer pass over [0, n_train) is enqueued: it zeroes what it reads)
         self.loss = self._loss_buf
         return self.loss
 
