@@ -5,13 +5,17 @@ sys.path.insert(0, ".")
 from vault_amd import ops
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 246_000_000
+fmt = sys.argv[2] if len(sys.argv) > 2 else "bf16"          # operand format of the 16-bit shadow (which library runs)
+zero = (sys.argv[3] != "0") if len(sys.argv) > 3 else True   # zero the gradients in the pass
 n -= n % 4
 p = torch.randn(n, device="cuda"); g = torch.randn(n, device="cuda") * 1e-3
-m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda"); pb = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
+m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda"); pb = torch.zeros(n, device="cuda", dtype=ops.HALF_DTYPE[fmt])
 
 
 def fn():
-    ops.adamw_step(p, g, m, v, pb, n, 2e-5, 0.9, 0.999, 1e-8, 0.01, zero_grad=True)
+    with ops.operand_format(fmt):
+        ops.adamw_step(p, g, m, v, pb, n, 2e-5, 0.9, 0.999, 1e-8, 0.01, grad_scale=1.0 if fmt == "bf16" else 1.0 / 4096.0,
+                       zero_grad=zero)
 
 
 for _ in range(3):
@@ -24,4 +28,4 @@ for _ in range(10):
 e.record()
 torch.cuda.synchronize()
 t = s.elapsed_time(e) / 10
-print(f"n={n}: {t * 1e3:.1f} us, {34 * n / t / 1e9:.2f} TB/s of 34 B per parameter")
+print(f"{fmt} zero_grad={zero} n={n}: {t * 1e3:.1f} us, {34 * n / t / 1e9:.2f} TB/s of 34 B per parameter")
