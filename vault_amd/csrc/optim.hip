@@ -2,7 +2,9 @@
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= step_size * m / (sqrt(v) + eps) ; p -= lr*wd*p
 //   step_size = lr (correct_bias=False, the reference default: ref vault/tmsc_utils/trainer.py:69,244-254)
 //               or lr*sqrt(1-b2^t)/(1-b1^t), computed on the host.
-// One pass: 16 B/param read (p,g,m,v), 12 B written (p,m,v) + 2 B bf16 shadow (+4 B when zeroing g).
+// One pass: 16 B/param read (p,g,m,v), 12 B written (p,m,v) + 2 B bf16 shadow (+4 B when zeroing g; `zero_mask`, one byte
+// per 64 elements, lets the caller skip the zeroing of ranges the next backward STORES into - the un-split weight-gradient
+// tiles of the fused train step - instead of accumulating onto).
 #include "common.h"
 #include "../../include/vault_hip.h"
 
@@ -11,7 +13,7 @@ namespace {
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, h16* __restrict__ pb, long long n4,
                                                     float step_size, float lr_wd, float b1, float b2, float eps,
-                                                    float gscale, int zero_grad) {
+                                                    float gscale, int zero_grad, const uint8_t* __restrict__ zmask) {
   H16_SATURATE();
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256ll) {
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
@@ -29,7 +31,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     reinterpret_cast<f32x4*>(p)[i] = pv;
     reinterpret_cast<f32x4*>(m)[i] = mv;
     reinterpret_cast<f32x4*>(v)[i] = vv;
-    if (zero_grad) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (zero_grad && (zmask == nullptr || zmask[i >> 4])) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (pb) {
       uint2 w = {pack_h16x2(pv[0], pv[1]), pack_h16x2(pv[2], pv[3])};
       reinterpret_cast<uint2*>(pb)[i] = w;
@@ -107,13 +109,13 @@ extern "C" int vault_split3_bf16(const float* x, void* out_bf16, long long rows,
 
 extern "C" int vault_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, long long n, float lr,
                                 float beta1, float beta2, float eps, float weight_decay, float bias_corr_factor,
-                                float grad_scale, int zero_grad, void* stream) {
-  if (!p || !g || !m || !v || n <= 0 || (n & 3)) return VAULT_EINVAL;
+                                float grad_scale, int zero_grad, const unsigned char* zero_mask, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || (n & 3) || (zero_mask && (n & 63))) return VAULT_EINVAL;
   const long long n4 = n / 4;
   const int blocks = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v,
                      reinterpret_cast<h16*>(p_bf16), n4, lr * bias_corr_factor, lr * weight_decay, beta1, beta2, eps,
-                     grad_scale, zero_grad);
+                     grad_scale, zero_grad, zero_mask);
   return (int)hipGetLastError();
 }
 

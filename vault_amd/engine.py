@@ -353,6 +353,8 @@ class VaultEngine:
         self._wgrad_side = False
         self._grads_zero = False
         self._g_dirty = False      # the flat gradient buffer may hold gradients of an API-level backward (not yet consumed / zeroed)
+        self._g_stale_key = None   # tape key of the fused step whose stored weight-gradient ranges the optimizer left un-zeroed
+        self._stored_ranges: List[Tuple[int, int]] = []
         # optional live kernel timing (bench.py): {site: [(start, end, flops), ...]} of torch.cuda.Event pairs recorded
         # on the launch stream around every launch of a kernel instantiation.  Sites: "wgrad" = the ring kernel's
         # weight-gradient form gemm256_kernel<1,1,EPI_F32_ATOMIC,4> (every _wgrad launch that takes it), "ffn1" =
@@ -587,6 +589,8 @@ class VaultEngine:
         ops.gemm(dY_all[i0], X_all[i0], gw, Nout, Kin, Mtok_pad, Nout, Kin, Kin, 1, 1, ops.EPI_F32_ATOMIC, cfg=cfg,
                  splits=splits, accumulate=acc, batch=G, batch_a=dY_all.stride(0), batch_b=X_all.stride(0),
                  batch_o=stride_o)
+        if acc == 0:
+            self._stored_ranges += [(o, Nout * Kin) for o in offs]
         if cfg == 3:
             fl = 2.0 * m_valid * Nout * Kin * G
             ops.pycall(lambda: self._prof_end("wgrad", fl, st))
@@ -651,6 +655,7 @@ class VaultEngine:
         if cur:
             launches.append(cur)
         st = torch.cuda.current_stream()
+        covered: Dict[tuple, int] = {}      # (kind, layer) -> tiles written by store launches
         for segs in launches:
             count = sum(c for _, _, c in segs)
             if count == CU:
@@ -663,6 +668,10 @@ class VaultEngine:
             args = []
             for k, first, c in segs:
                 dY_all, X_all, wsel, Nout, Kin = kinds[k]
+                if acc == 0:
+                    tpl = (Nout // 256) * (Kin // 256)
+                    for it in range(first, first + c):       # items are (layer-major, tile-minor)
+                        covered[(k, it // tpl)] = covered.get((k, it // tpl), 0) + 1
                 gw = P.gr(getattr(layers[i0], wsel), n_elems=Nout * Kin, shape=(Nout, Kin))
                 args.append(dict(dy=dY_all[i0], x=X_all[i0], dw=gw, n_out=Nout, n_in=Kin, batch=G, first=first, count=c,
                                  batch_dy=dY_all.stride(0), batch_x=X_all.stride(0), batch_dw=strides[k], dy_hm=hms[k]))
@@ -670,6 +679,10 @@ class VaultEngine:
             ops.wgrad_grouped(args, Mtok_pad, splits=splits, accumulate=acc)
             fl = 2.0 * m_valid * 65536.0 * count
             ops.pycall(lambda fl=fl: self._prof_end("wgrad", fl, st))
+        for (k, lay), n in covered.items():
+            _, _, wsel, Nout, Kin = kinds[k]
+            if n == (Nout // 256) * (Kin // 256):
+                self._stored_ranges.append((P.offsets[getattr(layers[i0 + lay], wsel)][0], Nout * Kin))
 
     def _qkv_bias_grads_batched(self, dqkv_all, layers, i0, hi, ld, rows, N, hm=0):
         """QKV bias gradients of layers i0 .. hi - 1 (column sums over the token rows of the first N columns of their dqkv) in
@@ -1396,7 +1409,7 @@ class VaultEngine:
 
     @_in_format
     def mlm_head_backward(self, dlogits: torch.Tensor) -> torch.Tensor:
-        self._g_dirty = True
+        self._api_backward_begins()
         with torch.cuda.device(self.device), self._grads_scaled():
             spec, P = self.spec, self.params
             v = spec.vilt
@@ -1445,7 +1458,7 @@ class VaultEngine:
 
     @_in_format
     def mlp_head_backward(self, dlogits: torch.Tensor) -> torch.Tensor:
-        self._g_dirty = True
+        self._api_backward_begins()
         with torch.cuda.device(self.device), self._grads_scaled():
             B = dlogits.shape[0]
             dx = self._mlp_backward(self._ws[("mlp_head", B)], dlogits.contiguous().float(), B, scale=self.grad_scale)
@@ -1459,6 +1472,7 @@ class VaultEngine:
         if self.params.g is not None:
             self.params.g.zero_()
         self._g_dirty = False
+        self._g_stale_key = None
 
     def backward(self, grad_scale: Optional[float] = None, dlogits: Optional[torch.Tensor] = None,
                  dpooled: Optional[torch.Tensor] = None, dhidden: Optional[torch.Tensor] = None,
@@ -1470,7 +1484,7 @@ class VaultEngine:
         ``after_layer(tag)`` is called after each stage so a DP driver can start all-reducing the
         gradient range that just became final.
         """
-        self._g_dirty = True     # (the fused train step stores un-split weight-gradient tiles: it wants zeros, TrainStep checks)
+        self._api_backward_begins()
         with torch.cuda.device(self.device), self._grads_scaled():
             self._backward(grad_scale, dlogits, dpooled, dhidden, after_layer, ws)
             if self.grad_scale != 1.0:      # gradients handed back to the caller's autograd graph
@@ -1480,6 +1494,14 @@ class VaultEngine:
                     if t is not None:
                         with ops.operand_format(self.half):
                             ops.scale(t, 1.0 / self.grad_scale, t.numel())
+
+    def _api_backward_begins(self):
+        """A backward outside the fused train step ACCUMULATES into the flat gradient buffer: ranges a fused step left un-zeroed
+        (its next step would have stored over them) are cleared first; the buffer then holds gradients the fused step must not
+        build on (it stores its un-split weight-gradient tiles: TrainStep zeroes when it finds the flag)."""
+        if self._g_stale_key is not None:
+            self.zero_grad()
+        self._g_dirty = True
 
     def _grads_scaled(self):
         """Context for a backward outside the fused train step when the operand format carries a gradient scale (fp16): the
@@ -1515,6 +1537,9 @@ class VaultEngine:
         # grads_zero: the caller vouches that the flat gradient buffer is all zero (TrainStep: the fused optimizer cleared
         # it) - un-split weight-gradient launches may then store instead of accumulate
         self._grads_zero = bool(grads_zero) and os.environ.get("VAULT_WGRAD_STORE", "1") != "0"
+        # (element offset, length) of every weight-gradient matrix this backward writes with STORES only (whole matrix covered by
+        # un-split launches): the fused optimizer need not zero them for the next step of the same shape (TrainStep)
+        self._stored_ranges = []
         ws = self.last if ws is None else ws
         if ws is None or not ws.get("train"):
             raise RuntimeError("backward() needs a preceding forward(train=True)")

@@ -463,11 +463,12 @@ def gelu_bwd(x, dy, dx, n):
 
 
 def adamw_step(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay, bias_corr_factor=1.0, grad_scale=1.0,
-               zero_grad=True):
+               zero_grad=True, zero_mask=None):
+    """``zero_mask``: uint8, one byte per 64 elements of the range (0 = the next backward stores there: not zeroed)."""
     _invoke("vault_adamw_step", C.c_void_p(_p(p)), C.c_void_p(_p(g)), C.c_void_p(_p(m)), C.c_void_p(_p(v)),
             C.c_void_p(_h(p_bf16)), C.c_longlong(n), C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps),
             C.c_float(weight_decay), C.c_float(bias_corr_factor), C.c_float(grad_scale),
-            C.c_int(1 if zero_grad else 0), _stream())
+            C.c_int(1 if zero_grad else 0), C.c_void_p(_p(zero_mask)), _stream())
 
 
 def cast_bf16(x, y_bf16, n):

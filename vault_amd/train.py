@@ -433,6 +433,7 @@ class TrainStep:
         self._tape = None
         self._tape_key = None
         self._tape_ws = None
+        self._zero_mask = None      # see _build_zero_mask
         # True: the caller vouches that every pixel_mask is all ones on the square pre-training canvas (no device
         # sync per step); False: the mask is checked each step and padded batches take the general image path
         self.assume_full_pixel_mask = assume_full_pixel_mask
@@ -503,6 +504,10 @@ class TrainStep:
             # exception in between (the reducer's checks raise and stay usable) must not leave them for the next step, which
             # STORES its un-split weight-gradient tiles but atomically ADDS bias / LayerNorm / embedding / split-K gradients
             eng._g_dirty = True
+            if eng._g_stale_key is not None and eng._g_stale_key != key:
+                # the previous fused step (another shape / mode: another tape) left the ranges ITS successor would have stored
+                # un-zeroed; this step may accumulate there
+                eng.zero_grad()
             if self.reducer:
                 # the token ids of every rank name the rows of the word-embedding table this step touches: their
                 # all-gather + union start now on the communication stream (inputs_embeds: no row is touched)
@@ -521,6 +526,7 @@ class TrainStep:
                     if self.use_tape:
                         ops.stop_tape()
                 self._tape, self._tape_key, self._tape_ws, self._loss_buf = tape, key, ws, out["loss"]
+                self._zero_mask = self._build_zero_mask(eng._stored_ranges)
             if self.reducer:
                 # optimizer on the already reduced upper part of the flat buffer while the last bucket (LM / ViLT
                 # embeddings: the lowest addresses) is still being all-reduced, then on the rest
@@ -534,9 +540,27 @@ class TrainStep:
                     self.optimizer_step()
             else:
                 self.optimizer_step()
-            eng._g_dirty = False       # (the optimizer pass over [0, n_train) is enqueued: it zeroes what it reads)
+            eng._g_dirty = False       # (the optimizer pass over [0, n_train) is enqueued: it zeroes what it reads ...)
+            eng._g_stale_key = key if self._zero_mask is not None else None     # (... but for the ranges the next step stores)
         self.loss = self._loss_buf
         return self.loss
+
+    def _build_zero_mask(self, stored):
+        """One byte per 64 gradient elements: 0 over the weight-gradient matrices the recorded backward writes with stores only
+        (engine._stored_ranges: every tensor is 64-element aligned) - the optimizer skips their zeroing (4 of its 34 B/param);
+        None when nothing is stored (small batches: split-K launches accumulate) or with VAULT_ADAMW_ZERO_MASK=0."""
+        if not stored or os.environ.get("VAULT_ADAMW_ZERO_MASK", "1") == "0":
+            return None
+        key = tuple(sorted(stored))
+        if getattr(self, "_zero_mask_key", None) == key:
+            return self._zero_mask
+        n64 = self.engine.params.n_train // 64
+        m = np.ones(n64, np.uint8)
+        for o, n in key:
+            assert o % 64 == 0 and n % 64 == 0
+            m[o // 64:(o + n) // 64] = 0
+        self._zero_mask_key = key
+        return torch.from_numpy(m).to(self.engine.device)
 
     def optimizer_step(self, lo: int = 0, hi: Optional[int] = None, advance: bool = True):
         """Fused HF-AdamW over elements [lo, hi) of the flat parameter buffer (default: all trainable ones);
@@ -552,9 +576,13 @@ class TrainStep:
             if hi > lo:
                 # (the gradients carry the operand format's power-of-two scale - fp16: engine.grad_scale - and the sum
                 #  over the ranks: both are divided out here)
+                zm = self._zero_mask
+                if zm is not None and (lo % 64 or (hi - lo) % 64):
+                    zm = None          # (never for the engine's 64-aligned stage boundaries)
                 ops.adamw_step(P.p[lo:hi], P.g[lo:hi], P.m[lo:hi], P.v[lo:hi], P.pb[lo:hi], hi - lo, self.current_lr(),
                                self.b1, self.b2, self.eps, self.wd, bias_corr_factor=bc,
-                               grad_scale=1.0 / (self.world * eng.grad_scale), zero_grad=True)
+                               grad_scale=1.0 / (self.world * eng.grad_scale), zero_grad=True,
+                               zero_mask=None if zm is None else zm[lo // 64:hi // 64])
         if advance:
             with torch.cuda.device(eng.device):
                 P.refresh_transposed()   # W^T shadow of the data-gradient GEMMs, from the bf16 shadow just written
