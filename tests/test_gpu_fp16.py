@@ -206,7 +206,11 @@ def test_tiny_trainstep_trajectory_fp16_vs_fp32_oracle():
             e2 += float((mk - 0.1 * gk.double()).norm()) ** 2
             r2 += float((0.1 * gk.double()).norm()) ** 2
         assert (e2 / r2) ** 0.5 < 1e-3, (e2 / r2) ** 0.5
-        assert float(eng.params.g.abs().max()) == 0.0                 # (and the fused optimizer cleared the gradients)
+        # (and the fused optimizer cleared the gradients - but for the weight-gradient matrices the next step stores into)
+        gz = eng.params.g[:eng.params.n_train].clone()
+        if step._zero_mask is not None:
+            gz.view(-1, 64)[step._zero_mask == 0] = 0.0
+        assert float(gz.abs().max()) == 0.0
         losses += [float(step(db, labels)) for _ in range(2)]
         print(f"fp16 TrainStep (tape={use_tape}): {losses} vs fp32 oracle {ref}; first moment after step 1: rel {(e2 / r2) ** 0.5:.2e}")
         assert max(abs(a - b) for a, b in zip(losses, ref)) < 3e-4, (losses, ref)

@@ -513,10 +513,14 @@ def test_full_size_loss_trajectory_20_steps_vs_fp32_oracle(half):
     """What a fine-tune user sees: 20 optimisation steps of the full-size model (12 + 12 layers, B = 4, lr 2e-5 with the
     reference's 10 % linear warm-up, HF-AdamW without bias correction) against the same 20 steps of the fp32 CPU oracle (the
     measured deviations are printed).  fp16 operands (the API default): every loss of the trajectory inside the north star's
-    1e-3.  bf16 operands: 8e-3 per step - rounding noise of the operand format, |dloss| 1.7e-3 on one forward, amplified along
-    the trajectory; over three data seeds and both GELU epilogue forms the maximum lies at 4.6e-3 .. 6.5e-3
-    (profiles/r05_bf16_trajectory_seeds.txt, tools/traj_seeds.py: the round-4 change of the erf form re-drew this noise, it did
-    not raise it)."""
+    1e-3.  bf16 operands: the FIRST step carries the format's own error (|dloss| 1.7e-3 on one forward: bound 3e-3); along the
+    trajectory AdamW's sign-like early steps (no bias correction: m / sqrt(v) = +-3.2 at step 1 whatever the gradient's size)
+    amplify rounding noise chaotically - over 11 data seeds the per-trajectory MAXIMUM lies anywhere between 1.7e-3 and 2.3e-2
+    with either form of the GELU epilogue (round-3 polynomial: 2.1e-3 .. 1.4e-2; round 4's shared exponential: 1.7e-3 ..
+    2.3e-2; higher in 6 of the 11 seeds, lower in 5), the per-trajectory MEAN between 0.4e-3 and 2.7e-3
+    (profiles/r05_bf16_trajectory_seeds.txt, tools/traj_seeds.py).  So the bf16 assertions are on the first step, on the
+    mean (4e-3) and on the envelope (3e-2) - a single seed's maximum against a tight bound (6e-3, then 8e-3 in round 4) only
+    tested which way the noise fell."""
     from vault_amd.spec import LMSpec, ViltSpec
     spec = VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3)
     spec.lm.hidden_dropout_prob = 0.0; spec.lm.attention_probs_dropout_prob = 0.0
@@ -535,7 +539,10 @@ def test_full_size_loss_trajectory_20_steps_vs_fp32_oracle(half):
     ref = _fp32_oracle_trajectory(spec, state, batches, nsteps)
     diffs = [abs(a - b) for a, b in zip(losses, ref)]
     print(f"{half}: 20-step trajectory: max |dloss| {max(diffs):.2e}, final |dloss| {diffs[-1]:.2e}, loss {ref[0]:.4f} -> {ref[-1]:.4f}")
-    assert max(diffs) < (1e-3 if half == "fp16" else 8e-3), (max(diffs), losses, ref)
+    if half == "fp16":
+        assert max(diffs) < 1e-3, (max(diffs), losses, ref)
+    else:
+        assert diffs[0] < 3e-3 and sum(diffs) / len(diffs) < 4e-3 and max(diffs) < 3e-2, (diffs, losses, ref)
     assert ref[-1] < ref[0] and losses[-1] < losses[0]                 # both trajectories descend
     # the drop over the run agrees within 15 %
     assert abs((losses[0] - losses[-1]) - (ref[0] - ref[-1])) < 0.15 * abs(ref[0] - ref[-1]) + 2e-3

@@ -13,7 +13,6 @@ python bench.py --config 5 --no-cpu-baseline --no-other-configs > $O/bench_fp8.j
 python bench.py --no-cpu-baseline --no-other-configs > $O/bench_bf16_same_box.json 2> $O/bench_bf16.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fp8 -o run -- python3 bench.py --config 5 --steps 8 --warmup 3 --no-cpu-baseline --no-parity --no-h2d --no-other-configs > $O/fp8_rocprof.log 2>&1
 python tools/prof_summary.py $O/fp8 > $O/fp8_kernel_stats.txt; rm -rf $O/fp8
-VAULT_GEMM_SCHED=3 python bench.py --no-cpu-baseline --no-other-configs > $O/bench_dp_mode_one_gpu.json 2> $O/bench_dp.err
 python tools/ragged_bench.py > $O/ragged.txt 2>&1
 python bench.py --batch 8 --no-cpu-baseline --no-other-configs > $O/bench_b8.json 2> $O/bench_b8.err
 python tools/preprocess_bench.py 256 > $O/preprocess.txt 2>&1

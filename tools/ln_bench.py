@@ -35,7 +35,7 @@ for rows in [int(a) for a in sys.argv[1:]] or [2560, 10240, 11840, 47360]:
           f"   + bf16 copy and its column sums {t_3:7.1f} us, without the three sums {t_3n:7.1f} us")
 
 # the 16-bit gradient stream case of the pre-LN ViLT stack (dy, residual-gradient stream in and out all 16-bit): the general
-# kernel (VAULT_LN_STREAM=0 in the environment) against the straight-line kernel with row prefetch; correctness: both agree
+# kernel (a build without the stream dispatch in norm.hip) against the straight-line kernel with row prefetch; correctness: both agree
 for rows in [int(a) for a in sys.argv[1:]] or [11840, 47360]:
     x = torch.randn(rows, H, device="cuda"); dr = torch.randn(rows, H, device="cuda").bfloat16()
     dy = torch.randn(rows, H, device="cuda").bfloat16(); dxb = torch.empty(rows, H, device="cuda", dtype=torch.bfloat16)
@@ -52,5 +52,5 @@ for rows in [int(a) for a in sys.argv[1:]] or [11840, 47360]:
     eg = float((dg - (dy.float() * xh).sum(0)).abs().max() / (dy.float() * xh).sum(0).abs().max())
     eb = float((dbi - want.sum(0)).abs().max() / want.sum(0).abs().max())
     import os
-    print(f"16-bit stream, rows {rows:6d} (VAULT_LN_STREAM={os.environ.get('VAULT_LN_STREAM', '1')}): {t:7.1f} us ({byts / t / 1e6:5.2f} TB/s); "
+    print(f"16-bit stream, rows {rows:6d} : {t:7.1f} us ({byts / t / 1e6:5.2f} TB/s); "
           f"max rel err dx {err:.1e} dgamma {eg:.1e} dbias {eb:.1e}")

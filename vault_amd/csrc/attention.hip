@@ -470,267 +470,9 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const h16* __re
   }
 }
 
-// Backward, resident form (64 < S <= 192): Q, K, V and dO of a (batch, head) are ALL held in LDS (4 x 24 KiB), so every
-// operand is read from HBM exactly once (the two-phase kernel above reads Q, K, V twice and dO three times: 662 MB
-// per launch measured against 364 MB algorithmic at B = 256), and nothing is re-staged between the dQ and the
-// dK / dV passes (no barrier between them).  One workgroup of NWV waves per CU (a wave owns 2 NKT / NWV 16-row tiles
-// in both passes and works on them together, sharing every fragment read) walks the (batch, head) items
-// persistently; the operands of the NEXT item are fetched into registers (two 16-byte chunks per thread and matrix
-// at 12 waves) before the current item's passes and written to LDS after them, so the loads of item i + 1 are in
-// flight under the arithmetic of item i.  delta = rowsum(dO * O) comes from the same registers.  The item barriers
-// wait for LDS only (`s_waitcnt lgkmcnt(0)`; `__syncthreads()` would also wait for the stores just issued).
-// Measured at B = 256, S = 185 (tools/attn_bench.py, same box): 233 us against 296 us for the two-phase kernel;
-// four waves x three tiles (512 registers per lane, a third of the LDS reads) 287 us: the loop is bound by the LDS
-// round trips in front of the transposed-fragment MFMAs, which the compiler neither hoists (register cap 168 at
-// three waves per SIMD) nor overlaps within one wave.
-template <int NKT, int NWV, bool DROP = true>
-__global__ __launch_bounds__(NWV * 64, 1) void attn_bwd_res_kernel(const h16* __restrict__ qkv, const float* __restrict__ keymask,
-                                                         const h16* __restrict__ ctx, const h16* __restrict__ dctx,
-                                                         const float* __restrict__ lse, h16* __restrict__ dqkv, int S,
-                                                         int H, int heads, int items, float scale, AttnDrop dr) {
-  H16_SATURATE();
-  constexpr int SK = NKT * 32;
-  constexpr int NT = NWV * 64;
-  constexpr int NC = (SK * 8) / NT;   // 16-byte chunks per thread and matrix
-  constexpr int TPW = (2 * NKT) / NWV;   // 16-row tiles per wave, processed together
-  static_assert((2 * NKT) % NWV == 0, "tiles must divide evenly over the waves");
-  static_assert((SK * 8) % NT == 0 && NT % 8 == 0 && SK <= NT, "chunk / row bookkeeping");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Qs = smem;
-  char* Ks = smem + SK * 128;
-  char* Vs = smem + 2 * SK * 128;
-  char* Ds = smem + 3 * SK * 128;   // dO
-  float* mb = reinterpret_cast<float*>(smem + 4 * SK * 128);
-  float* lse_s = mb + SK;          // -lse * log2e ; -inf for q >= S
-  float* dl_s = lse_s + SK;        // delta[q]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, l15 = lane & 15;
-  const int ld = 3 * H;
-  const float sl2 = scale * LOG2E;
-
-  u32x4 rq[NC], rk[NC], rv[NC], rd[NC], ro[NC];
-  float rl = 0.f, rm = 0.f;
-  auto fetch = [&](int item) {
-#if ATTN_ABLATE == 2
-    item = item % heads;
-#endif
-    const int b = item / heads, h = item - b * heads;
-    const size_t row0 = (size_t)b * S;
-    const h16* qb = qkv + row0 * ld + h * 64;
-    const h16* ob = ctx + row0 * H + h * 64;
-    const h16* db = dctx + row0 * H + h * 64;
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-      const int c = tid + i * NT, row = c >> 3, pos = c & 7;
-      rq[i] = rk[i] = rv[i] = rd[i] = ro[i] = u32x4{0u, 0u, 0u, 0u};
-      if (row < S) {
-        const h16* r = qb + (size_t)row * ld + pos * 8;
-        rq[i] = *reinterpret_cast<const u32x4*>(r);
-        rk[i] = *reinterpret_cast<const u32x4*>(r + H);
-        rv[i] = *reinterpret_cast<const u32x4*>(r + 2 * H);
-        rd[i] = *reinterpret_cast<const u32x4*>(db + (size_t)row * H + pos * 8);
-        ro[i] = *reinterpret_cast<const u32x4*>(ob + (size_t)row * H + pos * 8);
-      }
-    }
-    if (tid < SK) {
-      rl = (tid < S) ? lse[(size_t)item * S + tid] : INFINITY;
-      rm = (tid < S && keymask != nullptr) ? keymask[(size_t)b * S + tid] : 1.f;
-    }
-  };
-
-  int item = blockIdx.x;
-  if (item < items) fetch(item);
-  for (; item < items; item += gridDim.x) {
-    // ---- registers -> LDS images, delta, key bias, -lse ----
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-      const int c = tid + i * NT, row = c >> 3, pos = c & 7;
-      const int off = row * 128 + ((pos ^ (swz_row(row) << 1)) << 4);
-      *reinterpret_cast<u32x4*>(Qs + off) = rq[i];
-      *reinterpret_cast<u32x4*>(Ks + off) = rk[i];
-      *reinterpret_cast<u32x4*>(Vs + off) = rv[i];
-      *reinterpret_cast<u32x4*>(Ds + off) = rd[i];
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const float2 a = unpack_h16x2(ro[i][w]), d = unpack_h16x2(rd[i][w]);
-        s += a.x * d.x + a.y * d.y;
-      }
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      if (pos == 0) dl_s[row] = s;   // rows >= S hold zeros: delta = 0
-    }
-    if (tid < SK) {
-      mb[tid] = (tid < S && rm != 0.f) ? 0.f : -INFINITY;
-      lse_s[tid] = -rl * LOG2E;      // -inf for rows >= S
-    }
-#if ATTN_ABLATE == 2
-    const int b = 0, h = item % heads;
-#else
-    const int b = item / heads, h = item - b * heads;
-#endif
-    const uint32_t bh = (uint32_t)item;
-    h16* dqbase = dqkv + (size_t)b * S * ld + h * 64;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (no vmcnt wait: the previous item's stores stay in flight)
-    if (item + (int)gridDim.x < items) fetch(item + gridDim.x);
-
-    // ---------------- dQ: wave = TPW query tiles at once (they share every K / V fragment read) ----------------
-    {
-      h16x8 qf[TPW][2], df[TPW][2];
-      float nl[TPW], dl[TPW];
-      f32x4 o[TPW][4];
-#pragma unroll
-      for (int j = 0; j < TPW; ++j) {
-        const int qt = wave * TPW + j;
-        qf[j][0] = frag_rows(Qs, qt, 0, g, l15); qf[j][1] = frag_rows(Qs, qt, 1, g, l15);
-        df[j][0] = frag_rows(Ds, qt, 0, g, l15); df[j][1] = frag_rows(Ds, qt, 1, g, l15);
-        nl[j] = lse_s[qt * 16 + l15]; dl[j] = dl_s[qt * 16 + l15];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll 1
-      for (int T = 0; T < (ATTN_ABLATE == 1 ? 0 : NKT); ++T) {
-        f32x4 ds2[TPW][2];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const int kt = 2 * T + hh;
-          const h16x8 k0 = frag_rows(Ks, kt, 0, g, l15), k1 = frag_rows(Ks, kt, 1, g, l15);
-          const h16x8 v0 = frag_rows(Vs, kt, 0, g, l15), v1 = frag_rows(Vs, kt, 1, g, l15);
-          const f32x4 m4 = *reinterpret_cast<const f32x4*>(mb + kt * 16 + 4 * g);
-#pragma unroll
-          for (int j = 0; j < TPW; ++j) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            a = mfma16(k0, qf[j][0], a);
-            a = mfma16(k1, qf[j][1], a);
-            dp = mfma16(v0, df[j][0], dp);
-            dp = mfma16(v1, df[j][1], dp);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float pv = __builtin_amdgcn_exp2f((a[r] + m4[r]) * sl2 + nl[j]);
-              float dpv = dp[r];
-              if (DROP && dr.thresh != 0u) {
-                const uint32_t q_l = (uint32_t)((wave * TPW + j) * 16 + l15);
-                const uint32_t idx = (bh * (uint32_t)S + q_l) * (uint32_t)S + (uint32_t)(kt * 16 + 4 * g + r);
-                dpv = dropout_keep(dr.seed, dr.stream, idx, dr.thresh) ? dpv * dr.scale : 0.f;
-              }
-              ds2[j][hh][r] = pv * (dpv - dl[j]) * scale;
-            }
-          }
-        }
-        h16x8 dsf[TPW];
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) dsf[j] = pack_frag(ds2[j][0], ds2[j][1]);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const h16x8 kt_ = frag_tr(Ks, T, dt, g, l15);
-#pragma unroll
-          for (int j = 0; j < TPW; ++j) o[j][dt] = mfma16(kt_, dsf[j], o[j][dt]);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < TPW; ++j) {
-        const int q_l = (wave * TPW + j) * 16 + l15;
-        if (q_l < S) {
-          h16* dst = dqbase + (size_t)q_l * ld + 4 * g;
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            const uint2 w = {pack_h16x2(o[j][dt][0], o[j][dt][1]), pack_h16x2(o[j][dt][2], o[j][dt][3])};
-            *reinterpret_cast<uint2*>(dst + dt * 16) = w;
-          }
-        }
-      }
-    }
-    // ---------------- dK, dV: wave = TPW key tiles at once (they share every Q / dO fragment read) ----------------
-    {
-      h16x8 kf[TPW][2], vf[TPW][2];
-      float mk[TPW];
-      f32x4 dk[TPW][4], dv[TPW][4];
-#pragma unroll
-      for (int j = 0; j < TPW; ++j) {
-        const int kt = wave * TPW + j;
-        kf[j][0] = frag_rows(Ks, kt, 0, g, l15); kf[j][1] = frag_rows(Ks, kt, 1, g, l15);
-        vf[j][0] = frag_rows(Vs, kt, 0, g, l15); vf[j][1] = frag_rows(Vs, kt, 1, g, l15);
-        mk[j] = mb[kt * 16 + l15];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          dk[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-          dv[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-#pragma unroll 1
-      for (int T = 0; T < (ATTN_ABLATE == 1 ? 0 : NKT); ++T) {
-        f32x4 p2[TPW][2], ds2[TPW][2];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const int qt = 2 * T + hh;
-          const h16x8 q0 = frag_rows(Qs, qt, 0, g, l15), q1 = frag_rows(Qs, qt, 1, g, l15);
-          const h16x8 d0 = frag_rows(Ds, qt, 0, g, l15), d1 = frag_rows(Ds, qt, 1, g, l15);
-          const f32x4 nl4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * g);
-          const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dl_s + qt * 16 + 4 * g);
-#pragma unroll
-          for (int j = 0; j < TPW; ++j) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            a = mfma16(q0, kf[j][0], a);
-            a = mfma16(q1, kf[j][1], a);
-            dp = mfma16(d0, vf[j][0], dp);
-            dp = mfma16(d1, vf[j][1], dp);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float pv = __builtin_amdgcn_exp2f((a[r] + mk[j]) * sl2 + nl4[r]);
-              float dpv = dp[r];
-              if (DROP && dr.thresh != 0u) {
-                const uint32_t k_l = (uint32_t)((wave * TPW + j) * 16 + l15);
-                const uint32_t idx = (bh * (uint32_t)S + (uint32_t)(qt * 16 + 4 * g + r)) * (uint32_t)S + k_l;
-                const bool keep = dropout_keep(dr.seed, dr.stream, idx, dr.thresh);
-                dpv = keep ? dpv * dr.scale : 0.f;
-                ds2[j][hh][r] = pv * (dpv - dl4[r]) * scale;
-                pv = keep ? pv * dr.scale : 0.f;
-              } else {
-                ds2[j][hh][r] = pv * (dpv - dl4[r]) * scale;
-              }
-              p2[j][hh][r] = pv;
-            }
-          }
-        }
-        h16x8 pf[TPW], dsf[TPW];
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-          pf[j] = pack_frag(p2[j][0], p2[j][1]);
-          dsf[j] = pack_frag(ds2[j][0], ds2[j][1]);
-        }
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const h16x8 dt_ = frag_tr(Ds, T, dt, g, l15), qt_ = frag_tr(Qs, T, dt, g, l15);
-#pragma unroll
-          for (int j = 0; j < TPW; ++j) {
-            dv[j][dt] = mfma16(dt_, pf[j], dv[j][dt]);
-            dk[j][dt] = mfma16(qt_, dsf[j], dk[j][dt]);
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < TPW; ++j) {
-        const int k_l = (wave * TPW + j) * 16 + l15;
-        if (k_l < S) {
-          h16* dstk = dqbase + H + (size_t)k_l * ld + 4 * g;
-          h16* dstv = dqbase + 2 * H + (size_t)k_l * ld + 4 * g;
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            const uint2 wk = {pack_h16x2(dk[j][dt][0], dk[j][dt][1]), pack_h16x2(dk[j][dt][2], dk[j][dt][3])};
-            const uint2 wv = {pack_h16x2(dv[j][dt][0], dv[j][dt][1]), pack_h16x2(dv[j][dt][2], dv[j][dt][3])};
-            *reinterpret_cast<uint2*>(dstk + dt * 16) = wk;
-            *reinterpret_cast<uint2*>(dstv + dt * 16) = wv;
-          }
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the images before the next item overwrites them
-  }
-}
-
-// Backward, single-pass resident form (round 3; 64 < S <= 192).  The two-pass kernel above recomputes the scores, the
-// probabilities and dP twice (once per orientation) and is bound by its own instruction stream: with the HBM traffic of a
+// Backward, single-pass resident form (round 3; S <= 192).  The two-pass resident kernel it replaced (deleted in round 5; a
+// (batch, head) item's Q, K, V, dO all in LDS, one pass per orientation) recomputed the scores, the
+// probabilities and dP twice and was bound by its own instruction stream: with the HBM traffic of a
 // launch served from L2 it still takes 180 us at B = 256, with the arithmetic removed 143 us (tools/attn_bench.py on the
 // ATTN_ABLATE builds) - the exp / dS arithmetic of BOTH passes saturates the vector issue of a SIMD (3 waves x ~100 VALU
 // per 32 keys against 28 MFMAs).  Here every score is computed ONCE:
@@ -1135,9 +877,6 @@ template <int NKT>
 constexpr int attn_one_lds_bytes() { return NKT * 32 * 128 * 3 + NKT * 32 * ds_ld<NKT * 32>() + NKT * 32 * 4 * 3; }
 
 template <int NKT>
-constexpr int attn_res_lds_bytes() { return NKT * 32 * 128 * 4 + NKT * 32 * 4 * 3; }
-
-template <int NKT>
 constexpr int attn_lds_bytes() { return NKT * 32 * 128 * 2 + NKT * 32 * 4 * 3; }
 
 }  // namespace
@@ -1203,25 +942,6 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
   dim3 grid(a->heads, a->B), block(256);
   const float scale = 0.125f;
   const bool drop = a->drop_thresh != 0u;
-#define OLD_V(NK, DR)                                                                                                         \
-    hipLaunchKernelGGL((attn_bwd_kernel<NK, 4, 3, DR>), grid, dim3(256), attn_lds_bytes<NK>(), st, reinterpret_cast<const h16*>(a->qkv), \
-                       a->keymask, reinterpret_cast<const h16*>(a->ctx), reinterpret_cast<const h16*>(a->dctx), a->lse,     \
-                       reinterpret_cast<h16*>(a->dqkv), a->S, a->H, a->heads, scale, dr)
-#define RES_V(DR)                                                                                                             \
-    {                                                                                                                         \
-      auto kern = attn_bwd_res_kernel<6, 12, DR>;   /* 98.3 KiB of LDS: one 12-wave workgroup per CU, persistent */           \
-      static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];                                                                                          \
-      if (!attr_done) {                                                                                                       \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                           attn_res_lds_bytes<6>());                                                          \
-        if (e != hipSuccess) return (int)e;                                                                                   \
-        attr_done = true;                                                                                                     \
-      }                                                                                                                       \
-      hipLaunchKernelGGL(kern, dim3(items < 256 ? items : 256), dim3(768), attn_res_lds_bytes<6>(), st,                       \
-                         reinterpret_cast<const h16*>(a->qkv), a->keymask, reinterpret_cast<const h16*>(a->ctx),            \
-                         reinterpret_cast<const h16*>(a->dctx), a->lse, reinterpret_cast<h16*>(a->dqkv), a->S, a->H,        \
-                         a->heads, items, scale, dr);                                                                         \
-    }
 #define ONE_V(DR)                                                                                                             \
     {                                                                                                                         \
       auto kern = attn_bwd_one_kernel<6, 12, DR>;   /* 152 KiB of LDS: one 12-wave workgroup per CU, persistent */            \
@@ -1237,8 +957,7 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
                          reinterpret_cast<const h16*>(a->dctx), a->lse, reinterpret_cast<h16*>(a->dqkv), a->S, a->H,        \
                          a->heads, items, scale, dr, a->qkv_hm);                                                              \
     }
-  static const bool one_pass_s = [] { const char* e = getenv("VAULT_ATTN_BWD_S"); return !(e && e[0] == '0'); }();   // development A/B switch
-  if (a->S <= 64 && one_pass_s) {
+  if (a->S <= 64) {
     // text-only sequences (the LM stack): the single-pass kernel with four waves per workgroup (one 16-key tile each) and
     // three workgroups per CU (35 KiB of LDS, <= 168 registers), persistent over the (batch, head) items
     const int items = a->B * a->heads;
@@ -1251,18 +970,9 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
                             reinterpret_cast<const h16*>(a->qkv), a->keymask, reinterpret_cast<const h16*>(a->ctx),
                             reinterpret_cast<const h16*>(a->dctx), a->lse, reinterpret_cast<h16*>(a->dqkv), a->S, a->H,
                             a->heads, items, scale, dr, a->qkv_hm);
-  } else if (a->S <= 64) {
-    if (a->qkv_hm) return VAULT_EINVAL;      // (head-major qkv: the single-pass kernels only)
-    if (drop) OLD_V(2, true); else OLD_V(2, false);
   } else if (a->S <= 192) {
     const int items = a->B * a->heads;
-    static const bool one_pass = [] { const char* e = getenv("VAULT_ATTN_BWD"); return !(e && e[0] == '0'); }();   // development A/B switch: 0 = the two-pass resident kernel
-    if (!one_pass && a->qkv_hm) return VAULT_EINVAL;
-    if (one_pass) {
-      if (drop) ONE_V(true) else ONE_V(false)
-    } else {
-      if (drop) RES_V(true) else RES_V(false)
-    }
+    if (drop) ONE_V(true) else ONE_V(false)
   } else if (a->S <= 288) {
     auto kern = attn_bwd_kernel<9, ATTN_L9_BWD_W, ATTN_L9_BWD_WPE>;
     static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];
@@ -1288,8 +998,6 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
                        a->keymask, reinterpret_cast<const h16*>(a->ctx), reinterpret_cast<const h16*>(a->dctx), a->lse,
                        reinterpret_cast<h16*>(a->dqkv), a->S, a->H, a->heads, scale, dr);
   }
-#undef OLD_V
-#undef RES_V
 #undef ONE_V
   return (int)hipGetLastError();
 }

@@ -278,14 +278,12 @@ template <int A_MODE, int B_MODE, int EPI>
 int launch_modes(const GemmParams& p, int cfg, hipStream_t st) {
   switch (cfg) {
     case 0: {
-      // four-stage form for forward / data-gradient launches (development A/B switch: VAULT_GEMM_DEEP=0 keeps two stages)
-      static const bool deep = [] { const char* e = getenv("VAULT_GEMM_DEEP"); return !(e && e[0] == '0'); }();
-      // ... where one block per CU covers the launch and the K loop is long: M = 2560 (tools/gemm_bench.py, same box) FFN-in
+      // four-stage form for forward / data-gradient launches where one block per CU covers the launch and the K loop is long: M = 2560 (tools/gemm_bench.py, same box) FFN-in
       // dgrad 50.0 -> 34.1 us, QKV dgrad 38.6 -> 26.3, FFN-out forward 36.6 -> 34.7; with more tiles than CUs two
       // double-buffered blocks per CU are faster (QKV forward 20.3 against 23.3 us), and a single block's K loop stays bound
       // by its CU's L2 -> LDS rate (32 KiB per 2.1 MFLOP step)
       if constexpr (A_MODE == 0 && EPI != EPI_F32_ATOMIC) {
-        if (deep && p.splits <= 1 && (long)(p.M / 128) * (p.N / 128) <= 256 && p.K >= 1536)
+        if (p.splits <= 1 && (long)(p.M / 128) * (p.N / 128) <= 256 && p.K >= 1536)
           return launch_cfg<128, 128, 2, 2, A_MODE, B_MODE, EPI, 4>(p, st);
       }
       return launch_cfg<128, 128, 2, 2, A_MODE, B_MODE, EPI>(p, st);
@@ -344,9 +342,8 @@ int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) 
   // block's K loop runs alone on its CU - 128x128 tiles spread the same work over 4x the blocks (tools/gemm_bench.py,
   // M = 2560: attention-out 13.4 against 21.0 us, FFN-out 36.3 against 53.3, FFN-in 23.4 against 26.6, gelu'-product
   // dgrad 20.5 against 31; M = 5120: FFN-in 41.2 against 45.8, FFN-out 40.5 against 56.3; from M = 10240 the big tiles win)
-  static const bool use_small = [] { const char* e = getenv("VAULT_GEMM_SMALL"); return !(e && e[0] == '0'); }();   // development A/B switch
   bool small = false;
-  if (auto_cfg && use_small && p.batch <= 1 && epi != EPI_F32_ATOMIC && a_mode == 0 && p.M % 256 == 0 && p.N % 128 == 0) {
+  if (auto_cfg && p.batch <= 1 && epi != EPI_F32_ATOMIC && a_mode == 0 && p.M % 256 == 0 && p.N % 128 == 0) {
     const long c192 = (long)(p.M / 256) * ((p.N + 191) / 192), c256 = (long)(p.M / 256) * ((p.N + 255) / 256);
     small = c192 < 128 || (p.N >= 3072 && c256 <= 256);
     if (small) cfg = 0;
@@ -355,10 +352,12 @@ int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) 
     // (tools/small_tile_bench.py, M = 2560, N = 768: FFN-in dgrad 34.1 -> 23.9 us, QKV dgrad 27.5 -> 18.9, FFN-out forward
     // 34.1 -> 24.3, attention-out forward 12.8 -> 9.6, its dgrad 11.5 -> 8.4; the same ratios down to M = 512; from 257 blocks
     // on the second round costs more: M = 3072 32.5 -> 41.0)
-    static const bool use64 = [] { const char* e = getenv("VAULT_GEMM_64"); return !(e && e[0] == '0'); }();   // development A/B switch
-    if (small && use64 && p.splits <= 1 && (long)(p.M / 64) * (p.N / 128) <= 256) cfg = 7;
+    if (small && p.splits <= 1 && (long)(p.M / 64) * (p.N / 128) <= 256) cfg = 7;
   }
-  static const bool use8w = [] { const char* e = getenv("VAULT_GEMM8W"); return !(e && e[0] == '0'); }();   // development A/B switch
+  // VAULT_GEMM8W=0 (read once per process) keeps the 8-wave kernel out of the automatic choice: the one kernel-choice switch
+  // kept, because the engine's 8-bit gelu' plan must FOLLOW the choice (tests/test_gpu_train.py::
+  // test_8bit_gelu_prime_follows_the_kernel_choice)
+  static const bool use8w = [] { const char* e = getenv("VAULT_GEMM8W"); return !(e && e[0] == '0'); }();
   // (also in data-parallel steps - persist bit 0 -: its static tile walk under an RCCL kernel that holds 8-64 CUs costs what the
   //  ring kernel's dynamic scheduler costs there, 235-250 against 207-240 us for the QKV shape, and nothing when the GPU is
   //  not shared, 165 against 196-239 us: tools/contention_test.py)
@@ -375,8 +374,7 @@ int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) 
   // still cover in one: N = 768 at 32..42 row tiles (the LM stack at per-GPU batch 256: 160 -> 240 tiles on 256 CUs;
   // tools/tile128_bench.py, M = 10240: attention-out 27.9 -> 23.9 us, FFN-out 62.6 -> 51.6, FFN-in dgrad 59.9 -> 48.1, QKV
   // dgrad 45.5 -> 37.7; one row tile more and the second round costs 45 %)
-  static const bool use128 = [] { const char* e = getenv("VAULT_GEMM_128"); return !(e && e[0] == '0'); }();   // development A/B switch
-  if (auto_cfg && use128 && cfg == 4 && a_mode == 0 && p.splits == 1 && p.batch <= 1 && p.N % 128 == 0 &&
+  if (auto_cfg && cfg == 4 && a_mode == 0 && p.splits == 1 && p.batch <= 1 && p.N % 128 == 0 &&
       ((b_mode == 0 && epi == EPI_F32_RES && p.res != nullptr) || (b_mode == 1 && epi == EPI_BF16 && p.colsum == nullptr))) {
     const long c192 = (long)(p.M / 256) * (p.N / 192), c128 = (long)(p.M / 256) * (p.N / 128);
     if (c192 < 256 && c128 <= 256) cfg = 8;

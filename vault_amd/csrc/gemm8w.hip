@@ -672,8 +672,7 @@ template <int EPI, int NTW, bool A3 = false>
 int launch8w(const GemmParams& p, hipStream_t st) {
   if constexpr (!A3) {
     // three A slots (kernel header) where the contraction has at least four K tiles
-    static const bool a3 = [] { const char* e = getenv("VAULT_GEMM8W_A3"); return !(e && e[0] == '0'); }();
-    if (a3 && p.K >= 256) return launch8w<EPI, NTW, true>(p, st);
+    if (p.K >= 256) return launch8w<EPI, NTW, true>(p, st);
   }
   constexpr int LDS = (A3 ? 3 : 2) * W8_A_BYTES + 2 * 64 * NTW * 128;
   auto kern = gemm8w_kernel<EPI, NTW, A3>;
@@ -698,9 +697,8 @@ int launch8w(const GemmParams& p, hipStream_t st) {
   // more than an XCD's L2 - through every round).  tools/raster_bench.py, same box, us: M = 47,360 FFN-in forward 280 -> 265,
   // gelu'-product dgrad 247 -> 233, QKV 171 -> 165; M = 23,808: 156 -> 139, 158 -> 144, 84-90 -> 77; M = 12,032 (192-wide
   // tiles): 73-82 -> 64-65, 76-80 -> 65-66, QKV unchanged.  The ring kernel (deeper pipeline, N = 768: 4 n-tiles) gains nothing.
-  static const bool grouped_raster = [] { const char* e = getenv("VAULT_GEMM8W_RASTER"); return !(e && e[0] == '0'); }();
   const int tiles_m = p.M >> 8;
-  const int gn_auto = grouped_raster ? std::max(2, (256 + tiles_m - 1) / std::max(tiles_m, 1)) : tiles_n;
+  const int gn_auto = std::max(2, (256 + tiles_m - 1) / std::max(tiles_m, 1));
   q.gn = std::min((p.gn > 0) ? p.gn : gn_auto, tiles_n);
   const int nwork = (p.M >> 8) * tiles_n;
   dim3 grid(std::min(nwork, 256), 1, 1);

@@ -445,16 +445,15 @@ extern "C" int vault_layernorm_bwd(const vault_ln_bwd_args* a, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const RowMap dym{a->dy_rpg, a->dy_gstride, a->dy_goff}, xm{a->x_rpg, a->x_gstride, a->x_goff},
       dxm{a->dx_rpg, a->dx_gstride, a->dx_goff};
-  static const int waves = [] { const char* e = getenv("VAULT_LN_WAVES"); return (e && atoi(e) == 4) ? 4 : 16; }();   // development A/B switch: 4 or 16 (anything else: 16)
-  const int maxb = 4096 / waves;      // 16 resident waves per CU either way
+  constexpr int waves = 16;
+  const int maxb = 4096 / waves;      // 16 resident waves per CU
   int rpb = (a->rows + maxb - 1) / maxb;
   rpb = ((rpb + waves - 1) / waves) * waves;
   dim3 grid((a->rows + rpb - 1) / rpb), block(waves * 64);
   int lds_bytes = 0;
   // the 16-bit gradient stream of the pre-LN stack (engine.GRAD_STREAM_BF16): straight-line kernel with row prefetch
-  static const bool stream_ok = [] { const char* e = getenv("VAULT_LN_STREAM"); return !(e && atoi(e) == 0); }();   // development A/B switch
   const bool ident = a->dy_rpg == 0 && a->x_rpg == 0 && a->dx_rpg == 0;
-  if (stream_ok && waves == 16 && a->H == 768 && ident && a->dy_bf16 && !a->dy_f32 && !a->dres && a->dres_bf16 && !a->dx_f32 &&
+  if (a->H == 768 && ident && a->dy_bf16 && !a->dy_f32 && !a->dres && a->dres_bf16 && !a->dx_f32 &&
       a->dx_bf16 && a->drop_thresh == 0 && a->dgamma && a->dbeta) {
     constexpr int LDS = 8 * 3 * 768 * 4;
     static bool done[64] = {};
@@ -473,8 +472,7 @@ extern "C" int vault_layernorm_bwd(const vault_ln_bwd_args* a, void* stream) {
                        reinterpret_cast<h16*>(a->dx_bf16), a->dgamma, a->dbeta, a->dbias, rpb8);
     return (int)hipGetLastError();
   }
-#define LN_BWD(V)                                                                                              \
-  if (waves == 16) LN_BWD_W(V, 16) else LN_BWD_W(V, 4)
+#define LN_BWD(V) LN_BWD_W(V, 16)
 #define LN_BWD_W(V, W)                                                                                              \
   {                                                                                                                 \
   {                                                                                                                 \

@@ -179,7 +179,7 @@ NO_DROP = Drop()
 # stream (train.TrainStep sets it for world size > 1): tiles are handed out dynamically / one block per tile, so a CU
 # held by the collective costs its share of throughput instead of a second pass over a static tile list
 # (tools/contention_probe.py: 196-230 us instead of 271-281 us with 8-64 CUs held, 189 us alone)
-GEMM_SCHED = int(__import__("os").environ.get("VAULT_GEMM_SCHED", "0"))   # env: exercise the mode on one GPU
+GEMM_SCHED = 0       # (tests set it directly to exercise the mode on one GPU)
 
 
 def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_valid=0, splits=1, accumulate=0,

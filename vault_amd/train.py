@@ -459,9 +459,9 @@ class TrainStep:
             b = GradBuckets(engine, bucket_mb)
             # wire format of the dense ranges ("fp32": sum all-reduce; "bf16": reduce-scatter + all-gather with bf16 on the
             # wire and f32 accumulation) and the row-sparse exchange of the word-embedding table: BucketReducer
-            self.wire = wire or os.environ.get("VAULT_DP_WIRE", "fp32")
+            self.wire = wire or "fp32"
             if sparse_embedding is None:
-                sparse_embedding = os.environ.get("VAULT_DP_SPARSE_EMBEDDING", "1") != "0"
+                sparse_embedding = True
             self._sparse_name = None
             sparse = None
             if sparse_embedding:
