@@ -703,7 +703,7 @@ def test_optimizer_leaves_stored_weight_gradient_ranges_unzeroed_and_nobody_buil
     print(f"{half}: zero mask skips {share:.1%} of the gradient buffer; losses {la} / {lb}")
     # (two runs differ in the order of their float atomics; AdamW's sign-like early steps amplify that along the trajectory -
     #  see test_tape_replay_matches_eager_steps - bf16 operands faster than fp16: measured 2.5e-4 / 1.3e-5 at the fifth step)
-    assert la[0] == lb[0] and max(abs(a - b) for a, b in zip(la, lb)) < (1e-3 if half == "bf16" else 1e-4)
+    assert abs(la[0] - lb[0]) < 1e-6 and max(abs(a - b) for a, b in zip(la, lb)) < (1e-3 if half == "bf16" else 1e-4)
     d = (ea.params.p - eb.params.p).abs()
     assert float(d.mean()) < 2e-6 and float((d > 2e-5).float().mean()) < 0.03
     # an API-level backward after the fused steps accumulates onto a CLEARED buffer: equal to the same backward on the mask-off engine
