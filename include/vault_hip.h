@@ -189,9 +189,20 @@ typedef struct vault_attn_args {
                        so the attention kernels' loads and - above all - the backward's dq / dk / dv stores stream instead of
                        touching 128-byte segments at a 6 H byte stride.  Written by vault_gemm with out_hm, read by
                        vault_gemm a_hm / vault_wgrad_seg.dy_hm / vault_colsum_hm.  S <= 192 in backward, no ctx_split3. */
+  float* bias_partials; /* ABI 9, bwd, optional: the QKV bias gradient (column sums of dq | dk | dv over the tokens: autograd of the
+                       q / k / v nn.Linear biases, HF modeling_vilt.py:303-320 / modeling_roberta.py:222-224) without a pass over
+                       dqkv - every workgroup of the launch writes the sums over ITS (batch, head) items to row blockIdx of this
+                       [vault_attention_bwd_partials(args)][bias_thirds * H] f32 matrix (plain stores, every row written whole);
+                       vault_colsum_partials adds the rows up.  S <= 192. */
+  int bias_thirds;   /* 1 = the query third only (H sums; the key third is analytically zero and, without attention dropout, the
+                       value third is the column sum of dctx: the caller's shortcut), 3 = q | k | v (S <= 64 only) */
 } vault_attn_args;
 int vault_attention_fwd(const vault_attn_args* args, void* stream);
 int vault_attention_bwd(const vault_attn_args* args, void* stream);
+int vault_attention_bwd_partials(const vault_attn_args* args);   /* rows of bias_partials that launch writes; 0 = unsupported shape */
+/* out[b][c] += sum over p < nparts of part[b][p][c], c < n  (b < batch; element strides batch_in / batch_out) */
+int vault_colsum_partials(const float* part, int nparts, int n, float* out, int batch, long long batch_in,
+                          long long batch_out, void* stream);
 
 
 /* ---- embeddings -----------------------------------------------------------------------------

@@ -340,3 +340,47 @@ def test_colsum_head_major():
     got = out.view(batch, stride_o)
     assert (got[:, :planes * 64] - 0.5 - ref).abs().max().item() <= 2e-5 * rows ** 0.5 * ref.abs().max().item() + 1e-3
     assert float((got[:, planes * 64:] - 0.5).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,S,heads,drop_p,thirds,hm", [(50, 185, 12, 0.0, 1, True), (300, 185, 12, 0.0, 1, True), (3, 185, 12, 0.0, 1, False),
+                                                         (9, 40, 12, 0.1, 3, False), (300, 40, 12, 0.1, 3, True), (5, 129, 5, 0.0, 1, False),
+                                                         (2, 17, 1, 0.0, 3, False)])
+def test_attention_backward_leaves_the_qkv_bias_gradient_as_partial_sums(B, S, heads, drop_p, thirds, hm):
+    """``vault_attn_args.bias_partials``: every workgroup of the backward launch writes the column sums of dq (| dk | dv) over
+    its (batch, head) items; ``vault_colsum_partials`` adds the rows - equal to the column sums of the dqkv the same launch
+    stores (f32 sums of values the kernel rounds to 16 bits when storing: tolerance of that rounding), dqkv itself bit-identical
+    to a launch without the partials, in both layouts, with more items than workgroups, with dropout."""
+    H = heads * 64
+    M = B * S
+    R = ((M + 255) // 256) * 256
+    qkv = (_rand(M, 3 * H, seed=40) * 1.5).bfloat16()
+    keymask = torch.ones(B, S, device="cuda")
+    keymask[B - 1, S - min(9, S - 2):] = 0
+    drop = ops.Drop(drop_p, seed=3, stream=2) if drop_p else ops.NO_DROP
+    q_in = _to_head_major(qkv, R) if hm else qkv
+    kw = dict(qkv_hm=R) if hm else {}
+    ctx = torch.zeros(M, H, dtype=torch.bfloat16, device="cuda"); lse = torch.zeros(B, heads, S, device="cuda")
+    ops.attention_fwd(q_in, keymask, ctx, lse, B, S, H, heads, drop=drop, **kw)
+    dctx = _rand(M, H, seed=41).bfloat16()
+    shape = (3 * heads, R, 64) if hm else (M, 3 * H)
+    d0 = torch.zeros(shape, dtype=torch.bfloat16, device="cuda"); d1 = torch.zeros(shape, dtype=torch.bfloat16, device="cuda")
+    ops.attention_bwd(q_in, keymask, ctx, lse, dctx, d0, B, S, H, heads, drop=drop, **kw)
+    n = ops.attention_bwd_partials(B, S, H, heads, thirds)
+    assert n == min(B * heads, 768 if S <= 64 else 256)
+    part = torch.full((n, thirds * H), 3.0, device="cuda")             # (every row is written whole: no zeroing needed)
+    ops.attention_bwd(q_in, keymask, ctx, lse, dctx, d1, B, S, H, heads, drop=drop, bias_partials=part, bias_thirds=thirds, **kw)
+    out = torch.full((thirds * H + 64,), 0.25, device="cuda")
+    ops.colsum_partials(part, n, thirds * H, out)
+    torch.cuda.synchronize()
+    assert torch.equal(d0, d1)
+    dq = (_from_head_major(d1, M) if hm else d1).float()
+    ref = dq[:, :thirds * H].sum(0)
+    got = out[:thirds * H] - 0.25
+    tol = 2.0 ** -8 * float(dq.abs().max()) * M ** 0.5 + 1e-4           # un-rounded sums against sums of bf16-rounded values
+    assert float((got - ref).abs().max()) <= tol, (float((got - ref).abs().max()), tol)
+    assert float((got - ref).norm() / ref.norm()) < 5e-3
+    assert float((out[thirds * H:] - 0.25).abs().max()) == 0.0
+    if S > 64:       # all three thirds exist in the S <= 64 kernel only (LDS), none beyond the single-pass kernels
+        assert ops.attention_bwd_partials(B, S, H, heads, 3) == 0 and ops.attention_bwd_partials(B, 200, H, heads, 1) == 0
+        with pytest.raises(RuntimeError):
+            ops.attention_bwd(q_in, keymask, ctx, lse, dctx, d1, B, S, H, heads, bias_partials=part, bias_thirds=3, **kw)

@@ -187,7 +187,7 @@ class BackwardMixin:
             if n == (Nout // 256) * (Kin // 256):
                 self._stored_ranges.append((P.offsets[getattr(layers[i0 + lay], wsel)][0], Nout * Kin))
 
-    def _qkv_bias_grads_batched(self, dqkv_all, layers, i0, hi, ld, rows, N, hm=0):
+    def _qkv_bias_grads_batched(self, dqkv_all, layers, i0, hi, ld, rows, N, hm=0, parts=None):
         """QKV bias gradients of layers i0 .. hi - 1 (column sums over the token rows of the first N columns of their dqkv) in
         ONE launch, issued with the group's batched weight gradients: at small batches a single layer's pass is a 4 us read
         behind a 10 us launch + reduction tail, and next to the weight gradients it is off the backward chain."""
@@ -197,6 +197,10 @@ class BackwardMixin:
         if any(offs[k + 1] - offs[k] != stride_o for k in range(len(offs) - 1)):
             raise RuntimeError("batched bias gradients need identically laid out layers")
         gqb = P.gr(layers[i0].qb, n_elems=ld, shape=(ld,))
+        if parts is not None:      # the attention backward left its workgroups' partial column sums: add the rows up
+            part_all, nparts = parts
+            ops.colsum_partials(part_all[i0], nparts, N, gqb, hi - i0, part_all.stride(0), stride_o)
+            return
         if hm:       # head-major dqkv: plane p = columns 64 p .. 64 p + 63
             ops.colsum_hm(dqkv_all[i0], rows, hm, N // 64, gqb, hi - i0, dqkv_all.stride(0), stride_o)
             return
@@ -346,6 +350,13 @@ class BackwardMixin:
         dN = buf("dN", (Mp, H), bf); dctx = buf("dctx", (Mp, H), bf)
         if not vbatch:
             dU = buf("dU", (Mp, FF), bf); dqkv = buf("dqkv", (Mp, 3 * H), bf)
+        # QKV bias gradient from inside the attention backward (vault_attn_args.bias_partials) where the deferred launches would
+        # otherwise re-read dqkv for it: the query third (the shortcut below covers key / value: no attention dropout here)
+        vparts, vthirds = None, 1
+        if vbatch and self.QKV_BIAS_SHORTCUT and not ws.get("vilt_stage"):
+            npart = ops.attention_bwd_partials(B, S, H, heads, vthirds)
+            if npart:
+                vparts = (self._stack(ws, "v_qbpart", nv, (npart, vthirds * H), torch.float32), npart)
         km = ws["keymask"]
         cur = 0
         # Residual-gradient stream of the pre-LN ViLT stack in bf16 only (GRAD_STREAM_BF16): a layer's incoming gradient is ONE
@@ -409,7 +420,8 @@ class BackwardMixin:
             if not vbatch:
                 self._wgrad(dyB, g("ctx"), ln.ow, None, Mp, H, H, M)
             vhm = ws.get("qkv_hm", 0)
-            ops.attention_bwd(g("qkv"), km, g("ctx"), g("lse"), dctx, dqkv, B, S, H, heads, qkv_hm=vhm)
+            ops.attention_bwd(g("qkv"), km, g("ctx"), g("lse"), dctx, dqkv, B, S, H, heads, qkv_hm=vhm,
+                              **(dict(bias_partials=vparts[0][i], bias_thirds=vthirds) if vparts else {}))
             self._dgrad(dqkv, ln.qw, dN, Mp, H, 3 * H, ops.EPI_BF16, M, **(dict(a_hm=vhm) if vhm else {}))
             if not vbatch:
                 self._wgrad(dqkv, g("n1"), ln.qw, ln.qb, Mp, 3 * H, H, M)
@@ -422,7 +434,7 @@ class BackwardMixin:
             elif i % vgroup == 0:
                 hi = min(nv, i + vgroup)
                 def launch(i=i, hi=hi, short=short, vhm=vhm):
-                    self._qkv_bias_grads_batched(dqkv_all, self.vl, i, hi, 3 * H, M, H if short else 3 * H, hm=vhm)
+                    self._qkv_bias_grads_batched(dqkv_all, self.vl, i, hi, 3 * H, M, H if short else 3 * H, hm=vhm, parts=vparts)
                     self._wgrad_group(((dxbA_all, ws["act_all"], "fw", H, FF), (dU_all, ws["n2_all"], "iw", FF, H),
                                        (dxbB_all, ws["ctx_all"], "ow", H, H), (dqkv_all, ws["n1_all"], "qw", 3 * H, H, vhm)),
                                       self.vl, i, hi, Mp, M)
@@ -494,6 +506,14 @@ class BackwardMixin:
             dhb = buf("lm_dhb", (Mlp, H), bf); dh1b = buf("lm_dh1b", (Mlp, H), bf)
             ldU = buf("lm_dU", (Mlp, FF), bf); ldqkv = buf("lm_dqkv", (Mlp, 3 * H), bf)
         ldN = buf("lm_dN", (Mlp, H), bf); ldctx = buf("lm_dctx", (Mlp, H), bf)
+        # (the LM has attention dropout: it needs all three thirds of the QKV bias gradient - in-kernel partial sums of three
+        #  tiles per wave cost the S <= 64 kernel 11 us per launch against the 10 us per layer of the batched pass over dqkv:
+        #  LM_BIAS_PARTIALS stays off; the form is exercised by tests/test_gpu_ops.py)
+        lparts = None
+        if self.LM_BIAS_PARTIALS and batched and not ws.get("lm_stage"):
+            npart = ops.attention_bwd_partials(B, T, H, heads, 3)
+            if npart:
+                lparts = (self._stack(ws, "lm_qbpart", nl, (npart, 3 * H), torch.float32), npart)
         dyb = None          # bf16 part of d y2 (from the next layer's QKV dgrad)
         dyf = dvs           # f32 part of d y2
         embed_done = False
@@ -568,7 +588,8 @@ class BackwardMixin:
                 self._wgrad(dh1b, g("ctx"), ln.ow, None, Mlp, H, H, Ml)
             lhm = ws.get("lm_qkv_hm", 0)
             ops.attention_bwd(g("qkv"), amf, g("ctx"), g("lse"), ldctx, ldqkv, B, T, H, heads,
-                              drop=self._drop(pda, 16 * i + 2, True), qkv_hm=lhm)
+                              drop=self._drop(pda, 16 * i + 2, True), qkv_hm=lhm,
+                              **(dict(bias_partials=lparts[0][i], bias_thirds=3) if lparts else {}))
             self._dgrad(ldqkv, ln.qw, ldN, Mlp, H, 3 * H, ops.EPI_BF16, Ml, **(dict(a_hm=lhm) if lhm else {}))
             if not batched:
                 self._wgrad(ldqkv, yb[i], ln.qw, ln.qb, Mlp, 3 * H, H, Ml)
@@ -584,7 +605,7 @@ class BackwardMixin:
                     embed_done = True
                     note("lm_embed")
                 def launch(i=i, hi=hi, lhm=lhm):
-                    self._qkv_bias_grads_batched(ldqkv_all, self.ll, i, hi, 3 * H, Ml, 3 * H, hm=lhm)
+                    self._qkv_bias_grads_batched(ldqkv_all, self.ll, i, hi, 3 * H, Ml, 3 * H, hm=lhm, parts=lparts)
                     self._wgrad_group(((dhb_all, ws["lm_act_all"], "fw", H, FF), (ldU_all, ws["lm_y1b_all"], "iw", FF, H),
                                        (dh1b_all, ws["lm_ctx_all"], "ow", H, H), (ldqkv_all, ws["lm_yb_all"], "qw", 3 * H, H, lhm)),
                                       self.ll, i, hi, Mlp, Ml)

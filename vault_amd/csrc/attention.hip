@@ -520,6 +520,42 @@ __device__ __forceinline__ void attn_gload16(u32x4& dst, const char* sbase, uint
 __device__ __forceinline__ void attn_gload4(float& dst, const char* sbase, uint32_t voff) {
   asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
+// Column sums of a 16-row x 64-column accumulator tile (t[dt][r] of lane (g, l15): row l15, column 32 (dt >> 1) + 8 g +
+// 4 (dt & 1) + r - the d order of frag_tr8) over the wave's 16 rows, added to 64 floats in LDS: the rows of a lane group are
+// the 16 lanes of a DPP row (no LDS traffic for the reduction), lane e of a group then owns value e, and ONE LDS float add
+// per wave writes 64 distinct addresses.  The QKV bias gradient (column sums of dq / dk / dv over the tokens) without a pass
+// over dqkv: vault_attn_args.bias_partials.
+__device__ __forceinline__ void attn_tile_colsum(const f32x4 (&t)[4], float mul, float* dst64, int g, int l15) {
+  // transpose-reduce over the 16 lanes of a DPP row: at the step of lane bit b a lane keeps the values whose index has its own
+  // bit b and adds the partner's share of them (partner = the lane that differs in bit b and agrees in the bits already done:
+  // quad_perm for bits 0 / 1, a rotation by 4 / 8 for bits 2 / 3) - 15 DPP adds + 30 selects instead of 16 four-step trees;
+  // lane e ends with the total of value e = 4 dt + r
+#define ATTN_DPP(X, CTRL) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, X), CTRL, 0xF, 0xF, true))
+  float a[8], b[4], c[2];
+  const bool b0 = l15 & 1, b1 = l15 & 2, b2 = l15 & 4, b3 = l15 & 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float lo = t[j >> 1][2 * (j & 1)], hi = t[j >> 1][2 * (j & 1) + 1];
+    const float keep = b0 ? hi : lo, snd = b0 ? lo : hi;
+    a[j] = keep + ATTN_DPP(snd, 0xB1);      // quad_perm [1,0,3,2]
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float keep = b1 ? a[2 * j + 1] : a[2 * j], snd = b1 ? a[2 * j] : a[2 * j + 1];
+    b[j] = keep + ATTN_DPP(snd, 0x4E);      // quad_perm [2,3,0,1]
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float keep = b2 ? b[2 * j + 1] : b[2 * j], snd = b2 ? b[2 * j] : b[2 * j + 1];
+    c[j] = keep + ATTN_DPP(snd, 0x124);     // row_ror:4
+  }
+  const float keep = b3 ? c[1] : c[0], snd = b3 ? c[0] : c[1];
+  const float sel = keep + ATTN_DPP(snd, 0x128);   // row_ror:8
+#undef ATTN_DPP
+  const int d = 32 * (l15 >> 3) + 8 * g + 4 * ((l15 >> 2) & 1) + (l15 & 3);
+  __builtin_amdgcn_ds_faddf(LDS_PTR(float, dst64 + d), sel * mul, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
+}
+
 // a pointer that is uniform by construction, pinned to scalar registers (asm "s" operands)
 __device__ __forceinline__ const char* attn_uniform(const void* p) {
   const uint64_t u = (uint64_t)p;
@@ -531,7 +567,8 @@ template <int NKT, int NWV, bool DROP = true, int WPE = 1>
 __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* __restrict__ qkv, const float* __restrict__ keymask,
                                                          const h16* __restrict__ ctx, const h16* __restrict__ dctx,
                                                          const float* __restrict__ lse, h16* __restrict__ dqkv, int S,
-                                                         int H, int heads, int items, float scale, AttnDrop dr, int hm_rows) {
+                                                         int H, int heads, int items, float scale, AttnDrop dr, int hm_rows,
+                                                         float* __restrict__ cs_out, int cs_thirds) {
   H16_SATURATE();
   constexpr int SK = NKT * 32;
   constexpr int DS_LD = ds_ld<SK>();
@@ -547,6 +584,9 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
   float* mb = reinterpret_cast<float*>(smem + 3 * SK * 128 + SK * DS_LD);
   float* lse_s = mb + SK;          // -lse * log2e ; -inf for q >= S
   float* dl_s = lse_s + SK;        // delta[q]
+  // this block's share of the QKV bias gradient (cs_out != null): cs_thirds x H column sums of dq (| dk | dv) over the rows of
+  // its items, written to row blockIdx.x of cs_out at exit (a small kernel adds the blocks' rows: vault_colsum_partials)
+  float* cs_lds = dl_s + SK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
   const QkvLayout lay(H, heads, hm_rows);
@@ -667,6 +707,8 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
 
   int item = blockIdx.x;
   if (item >= items) return;
+  if (cs_out != nullptr)
+    for (int i = tid; i < cs_thirds * H; i += NT) cs_lds[i] = 0.f;
 #pragma unroll
   for (int i = 0; i < NC; ++i) *reinterpret_cast<u32x4*>(Ks + (tid + i * NT) * 16) = u32x4{0u, 0u, 0u, 0u};
   fetch_q_do(item);
@@ -750,6 +792,10 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
     // this item (DMA issued an item ago), the Q / dO / O registers of the next item (requested an item ago) and old stores -
     // is needed right behind the barrier; phase 1 issued no memory operation
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (cs_out != nullptr && cs_thirds == 3) {      // key / value bias gradient: column sums of this wave's dk (scaled) / dv tile
+      attn_tile_colsum(dk, scale, cs_lds + H + h * 64, g, l15);
+      attn_tile_colsum(dv, 1.0f, cs_lds + 2 * H + h * 64, g, l15);
+    }
     if (more) write_q_do();                                           // images of the next item: phase 2 reads only K and dS^T
 #if ATTN_LOADS_FIRST
     if (more) fetch_kv_frags(item + G);
@@ -814,6 +860,8 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
         for (int dt = 0; dt < 4; ++dt)
           o[dt] = mfma16(frag_tr8(Ks, T, dt >> 1, dt & 1, g, l15), dsB, o[dt]);
       }
+      // query bias gradient: column sums of this wave's dq tile (rows q >= S are zero: their probabilities are)
+      if (cs_out != nullptr) attn_tile_colsum(o, scale, cs_lds + h * 64, g, l15);
 #if ATTN_WL
       {
         u32x4 wq[2], qa_, qb_;
@@ -870,6 +918,11 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
 #endif
       dma_k(item + G);
     }
+  }
+  if (cs_out != nullptr) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    float* dst = cs_out + (size_t)blockIdx.x * (size_t)(cs_thirds * H);
+    for (int i = tid; i < cs_thirds * H; i += NT) dst[i] = cs_lds[i];
   }
 }
 
@@ -930,6 +983,15 @@ extern "C" int vault_attention_fwd(const vault_attn_args* a, void* stream) {
   return (int)hipGetLastError();
 }
 
+// rows of `bias_partials` a backward launch with these arguments writes (= its grid), 0 when the shape has no such form
+extern "C" int vault_attention_bwd_partials(const vault_attn_args* a) {
+  if (!a || a->S <= 0 || a->B <= 0 || a->heads <= 0 || a->H != a->heads * 64 || a->S > 192) return 0;
+  if (a->bias_thirds != 1 && a->bias_thirds != 3) return 0;
+  const int items = a->B * a->heads;
+  if (a->S <= 64) return a->bias_thirds * a->H * 4 <= 16384 ? (items < 768 ? items : 768) : 0;
+  return (a->bias_thirds == 1 && a->H <= 1024) ? (items < 256 ? items : 256) : 0;
+}
+
 extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
   if (!a || !a->qkv || !a->ctx || !a->lse || !a->dctx || !a->dqkv || a->S <= 0 || a->B <= 0 ||
       a->H != a->heads * 64)
@@ -937,6 +999,9 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
   if (a->S > 320) return VAULT_EINVAL;
   // head-major qkv / dqkv: the single-pass kernels (S <= 192), not the split3 (precise) output
   if (a->qkv_hm != 0 && (a->qkv_hm < a->B * a->S || a->S > 192)) return VAULT_EINVAL;
+  // bias partials: the single-pass kernels; the query third alone, or (S <= 64: LDS) all three
+  if (a->bias_partials != nullptr && vault_attention_bwd_partials(a) == 0) return VAULT_EINVAL;
+  const int cs_bytes = a->bias_partials ? a->bias_thirds * a->H * 4 : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const AttnDrop dr{a->drop_thresh, a->drop_seed, a->drop_stream, a->drop_scale};
   dim3 grid(a->heads, a->B), block(256);
@@ -944,32 +1009,32 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
   const bool drop = a->drop_thresh != 0u;
 #define ONE_V(DR)                                                                                                             \
     {                                                                                                                         \
-      auto kern = attn_bwd_one_kernel<6, 12, DR>;   /* 152 KiB of LDS: one 12-wave workgroup per CU, persistent */            \
+      auto kern = attn_bwd_one_kernel<6, 12, DR>;   /* 152 KiB of LDS (+ 4 KiB of bias partials): one 12-wave workgroup per CU, persistent */ \
       static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];                                                                                          \
       if (!attr_done) {                                                                                                       \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                           attn_one_lds_bytes<6>());                                                          \
+                                           attn_one_lds_bytes<6>() + 4096);                                                   \
         if (e != hipSuccess) return (int)e;                                                                                   \
         attr_done = true;                                                                                                     \
       }                                                                                                                       \
-      hipLaunchKernelGGL(kern, dim3(items < 256 ? items : 256), dim3(768), attn_one_lds_bytes<6>(), st,                       \
+      hipLaunchKernelGGL(kern, dim3(items < 256 ? items : 256), dim3(768), attn_one_lds_bytes<6>() + cs_bytes, st,            \
                          reinterpret_cast<const h16*>(a->qkv), a->keymask, reinterpret_cast<const h16*>(a->ctx),            \
                          reinterpret_cast<const h16*>(a->dctx), a->lse, reinterpret_cast<h16*>(a->dqkv), a->S, a->H,        \
-                         a->heads, items, scale, dr, a->qkv_hm);                                                              \
+                         a->heads, items, scale, dr, a->qkv_hm, a->bias_partials, a->bias_thirds);                            \
     }
   if (a->S <= 64) {
     // text-only sequences (the LM stack): the single-pass kernel with four waves per workgroup (one 16-key tile each) and
     // three workgroups per CU (35 KiB of LDS, <= 168 registers), persistent over the (batch, head) items
     const int items = a->B * a->heads;
     const int grid = items < 768 ? items : 768;
-    if (drop) hipLaunchKernelGGL((attn_bwd_one_kernel<2, 4, true, 3>), dim3(grid), dim3(256), attn_one_lds_bytes<2>(), st,
+    if (drop) hipLaunchKernelGGL((attn_bwd_one_kernel<2, 4, true, 3>), dim3(grid), dim3(256), attn_one_lds_bytes<2>() + cs_bytes, st,
                                  reinterpret_cast<const h16*>(a->qkv), a->keymask, reinterpret_cast<const h16*>(a->ctx),
                                  reinterpret_cast<const h16*>(a->dctx), a->lse, reinterpret_cast<h16*>(a->dqkv), a->S, a->H,
-                                 a->heads, items, scale, dr, a->qkv_hm);
-    else hipLaunchKernelGGL((attn_bwd_one_kernel<2, 4, false, 3>), dim3(grid), dim3(256), attn_one_lds_bytes<2>(), st,
+                                 a->heads, items, scale, dr, a->qkv_hm, a->bias_partials, a->bias_thirds);
+    else hipLaunchKernelGGL((attn_bwd_one_kernel<2, 4, false, 3>), dim3(grid), dim3(256), attn_one_lds_bytes<2>() + cs_bytes, st,
                             reinterpret_cast<const h16*>(a->qkv), a->keymask, reinterpret_cast<const h16*>(a->ctx),
                             reinterpret_cast<const h16*>(a->dctx), a->lse, reinterpret_cast<h16*>(a->dqkv), a->S, a->H,
-                            a->heads, items, scale, dr, a->qkv_hm);
+                            a->heads, items, scale, dr, a->qkv_hm, a->bias_partials, a->bias_thirds);
   } else if (a->S <= 192) {
     const int items = a->B * a->heads;
     if (drop) ONE_V(true) else ONE_V(false)

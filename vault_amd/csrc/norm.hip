@@ -506,6 +506,33 @@ extern "C" int vault_layernorm_bwd(const vault_ln_bwd_args* a, void* stream) {
   return (int)hipGetLastError();
 }
 
+// out[b][c] += sum over rows of part[b][rows][n]: grid (n / 256, batch, row slices); a thread sums its slice of one column with
+// four loads in flight, one float atomic per slice
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, int nparts, int n,
+                                                              float* __restrict__ out, long long batch_in, long long batch_out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  const int per = (nparts + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int r0 = blockIdx.z * per, r1 = min(nparts, r0 + per);
+  const float* p = part + (size_t)blockIdx.y * batch_in + c;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
+    a0 += p[(size_t)r * n]; a1 += p[(size_t)(r + 1) * n]; a2 += p[(size_t)(r + 2) * n]; a3 += p[(size_t)(r + 3) * n];
+  }
+  for (; r < r1; ++r) a0 += p[(size_t)r * n];
+  if (r1 > r0) atomicAdd(out + (size_t)blockIdx.y * batch_out + c, (a0 + a1) + (a2 + a3));
+}
+
+extern "C" int vault_colsum_partials(const float* part, int nparts, int n, float* out, int batch, long long batch_in,
+                                     long long batch_out, void* stream) {
+  if (!part || !out || nparts <= 0 || n <= 0 || batch <= 0 || batch > 65535) return VAULT_EINVAL;
+  const int slices = nparts >= 64 ? 16 : 1;
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((n + 255) / 256, batch, slices), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), part, nparts, n, out, batch_in, batch_out);
+  return (int)hipGetLastError();
+}
+
 extern "C" int vault_colsum_hm(const void* in_bf16, int rows, int hm_rows, int planes, float* out, int batch, long long batch_in,
                                long long batch_out, void* stream) {
   if (!in_bf16 || !out || rows <= 0 || hm_rows < rows || planes <= 0 || batch <= 0 || batch > 65535 || (batch_in & 3))

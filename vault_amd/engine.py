@@ -48,6 +48,7 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
     # rows; larger batches keep the per-kernel calls below (same kernels, same order) so that bench.py can bracket single
     # GEMM call sites with events.
     STAGE_MAX_ROWS = 8192
+    LM_BIAS_PARTIALS = False       # LM QKV bias gradient from the attention backward's in-kernel partial sums (see backward.py)
     QKV_BIAS_SHORTCUT = True       # ViLT QKV bias gradient: value part from the dctx GEMM's epilogue, key part zero (see _backward)
     GELU8 = True                   # ViLT FFN: gelu' kept for backward as the 8-wave kernel's 8-bit tile-native image (vault_gemm aux_u8)
     GRAD_STREAM_BF16 = True        # (fixed) ViLT residual-gradient stream as ONE 16-bit tensor per layer (what autocast training carries): see _backward

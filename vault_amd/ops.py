@@ -42,7 +42,8 @@ class AttnArgs(C.Structure):
                 ("dctx", C.c_void_p), ("dqkv", C.c_void_p),
                 ("B", C.c_int), ("S", C.c_int), ("H", C.c_int), ("heads", C.c_int),
                 ("drop_thresh", C.c_uint32), ("drop_seed", C.c_uint32), ("drop_stream", C.c_uint32),
-                ("drop_scale", C.c_float), ("ctx_split3", C.c_void_p), ("qkv_hm", C.c_int)]
+                ("drop_scale", C.c_float), ("ctx_split3", C.c_void_p), ("qkv_hm", C.c_int),
+                ("bias_partials", C.c_void_p), ("bias_thirds", C.c_int)]
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -313,9 +314,25 @@ def attention_fwd(qkv, keymask, ctx, lse, B, S, H, heads, drop: Drop = NO_DROP, 
     _invoke("vault_attention_fwd", C.byref(a), _stream(), struct=a, drop=drop)
 
 
-def attention_bwd(qkv, keymask, ctx, lse, dctx, dqkv, B, S, H, heads, drop: Drop = NO_DROP, qkv_hm=0):
+def attention_bwd(qkv, keymask, ctx, lse, dctx, dqkv, B, S, H, heads, drop: Drop = NO_DROP, qkv_hm=0, bias_partials=None,
+                  bias_thirds=1):
+    """``bias_partials``: f32 [attention_bwd_partials(...), bias_thirds * H] - the launch's workgroups leave the column sums of
+    dq (| dk | dv) over their items there (the QKV bias gradient without a pass over dqkv; colsum_partials adds the rows)."""
     a = _attn_args(qkv, keymask, ctx, lse, B, S, H, heads, dctx, dqkv, drop, qkv_hm=qkv_hm)
+    a.bias_partials, a.bias_thirds = _p(bias_partials), (int(bias_thirds) if bias_partials is not None else 0)
     _invoke("vault_attention_bwd", C.byref(a), _stream(), struct=a, drop=drop)
+
+
+def attention_bwd_partials(B, S, H, heads, thirds) -> int:
+    """Rows of ``bias_partials`` a backward launch of this shape writes; 0 = the shape has no such form."""
+    a = AttnArgs()
+    a.B, a.S, a.H, a.heads, a.bias_thirds = B, S, H, heads, thirds
+    return int(L.load(_FMT.get()).vault_attention_bwd_partials(C.byref(a)))
+
+
+def colsum_partials(part_f32, nparts, n, out, batch=1, batch_in=0, batch_out=0):
+    _invoke("vault_colsum_partials", C.c_void_p(_p(part_f32)), C.c_int(nparts), C.c_int(n), C.c_void_p(_p(out)), C.c_int(batch),
+            C.c_longlong(batch_in), C.c_longlong(batch_out), _stream())
 
 
 class GatherArgs(C.Structure):
