@@ -13,7 +13,7 @@ cp $E/bench_cfg4.json $P/${R}_bench_cfg4_frozen_bert_b128.json; cp $E/cfg4_kerne
 cp $E/bench_fp8.json $P/${R}_bench_b256_fp8_forward.json; cp $E/bench_bf16_same_box.json $P/${R}_bench_b256_bf16_same_box_as_fp8.json
 cp $E/fp8_kernel_stats.txt $P/${R}_bench_b256_fp8_forward_kernel_stats.txt
 cp $E/ragged.txt $P/${R}_ragged_384x640.txt; cp $E/preprocess.txt $P/${R}_preprocess_b256.txt
-for f in bench_b256_default bench_b256_under_rocprof bench_b64 bench_b8 bench_cfg4_frozen_bert_b128 bench_b256_fp8_forward bench_b256_bf16_same_box_as_fp8 bench_b256_dp_mode_one_gpu; do
+for f in bench_b256_default bench_b256_under_rocprof bench_b64 bench_b8 bench_cfg4_frozen_bert_b128 bench_b256_fp8_forward bench_b256_bf16_same_box_as_fp8; do
 python - <<PY
 import json
 d=json.loads(open('$P/${R}_$f.json').read().strip().splitlines()[-1]); r=d.get('roofline') or {}; q=d.get('roofline_ffn1') or {}

@@ -37,6 +37,19 @@
 #define R256_ABLATE 0
 #endif
 
+// Diagnostic build only (-DR256_STAMP=1, tools/clock_stamp.py; no stamp executes in the shipped kernel): every block leaves the
+// shader-clock and the 100 MHz real-time ticks it ran for - the clock the chip HOLDS under this kernel is their quotient
+// (MI355X_MICROARCH.md "DVFS give-back" item 6).  The values go to a buffer nothing else reads.
+#ifndef R256_STAMP
+#define R256_STAMP 0
+#endif
+#if R256_STAMP
+__device__ unsigned long long g_r256_stamp[256 * 2];
+extern "C" int vault_debug_r256_stamps(unsigned long long* out512) {
+  return (int)hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_r256_stamp), sizeof(g_r256_stamp));
+}
+#endif
+
 namespace {
 
 // Dynamic tile scheduler state (a `__device__` global: one copy per device; the launcher grants dynamic hand-out to
@@ -76,6 +89,9 @@ __device__ __forceinline__ s16x4 tr16_asm(uint32_t lds_addr) {
 template <int A_MODE, int B_MODE, int EPI, int NTQ>
 __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   H16_SATURATE();
+#if R256_STAMP
+  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int BNT = NTQ * 64;                     // block tile width
   constexpr int PB = (B_MODE == 0) ? NTQ : 4;       // global_load_lds pieces per wave per B half-tile
   constexpr int W32 = 3 * 4 + 2 * PB;               // pieces of the five youngest half-tiles: 3 A + 2 B
@@ -546,6 +562,12 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     behind_stores = (em0 + 256 <= emvalid);
     w = wnext;
   }
+#if R256_STAMP
+  if (threadIdx.x == 0) {
+    g_r256_stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c0;
+    g_r256_stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+  }
+#endif
 #undef HALF_A
 #undef HALF_A_LAST
 #undef NOLOAD_UH

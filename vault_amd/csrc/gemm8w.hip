@@ -47,6 +47,17 @@
 #define W8_STORE_MOD ""   // development: cache policy of the bf16 output stores (" nt", " sc1", ...)
 #endif
 
+// Diagnostic build only (-DW8_STAMP=1, tools/clock_stamp.py): see gemm256.hip R256_STAMP.
+#ifndef W8_STAMP
+#define W8_STAMP 0
+#endif
+#if W8_STAMP
+__device__ unsigned long long g_w8_stamp[256 * 2];
+extern "C" int vault_debug_w8_stamps(unsigned long long* out512) {
+  return (int)hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_w8_stamp), sizeof(g_w8_stamp));
+}
+#endif
+
 namespace {
 
 constexpr int W8_A_BYTES = 32768;   // 256 rows x 64 k x 2 B
@@ -93,6 +104,9 @@ __device__ __forceinline__ float w8_row16_sum(float t) {
 template <int EPI, int NTW, bool A3 = false>
 __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
   H16_SATURATE();
+#if W8_STAMP
+  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr bool F32OUT = (EPI == EPI_F32_RES);
   constexpr int BN = 64 * NTW;                       // block tile width
   constexpr int B_BYTES = BN * 128;
@@ -664,6 +678,12 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
     a_cur = a_nxt; b_cur = b_nxt; m0 = m0n; n0 = n0n;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the cursor's last (unused) tiles must not land after exit
+#if W8_STAMP
+  if (threadIdx.x == 0) {
+    g_w8_stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c0;
+    g_w8_stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+  }
+#endif
 #undef W8_ROW
 #undef W8_MMA
 }
