@@ -389,10 +389,11 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     MMA1(KS, MT, 0, MB, NB, RA, RB) INS_A;                                                 \
     MMA1(KS, MT, 1, MB, NB, RA, RB) MMA1(KS, MT, 2, MB, NB, RA, RB) INS_B;                 \
     MMA1(KS, MT, 3, MB, NB, RA, RB)
-#define PHASE(WAITN, WAITF, LOADUH, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB) \
-  {                                                                            \
-    __builtin_amdgcn_s_setprio(1);                                             \
-    asm volatile("s_nop 1");                                                   \
+#ifndef R256_ORDER
+#define R256_ORDER 0   // development: placement of a phase's four staging pieces against its eight fragment reads
+#endif
+#if R256_ORDER == 0
+#define PHASE_BODY(LOADUH, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB) \
     GA(0, 0, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 0), LOADUH(RN, LBUF, LH, 0, 0)) \
     GA(0, 1, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 1), LOADUH(RN, LBUF, LH, 1, 0)) \
     GA(0, 2, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 2), LOADUH(RN, LBUF, LH, 2, 0)) \
@@ -400,7 +401,33 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     GA(1, 0, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 0, 1), LOADUH(RN, LBUF, LH, 1, 1)) \
     GA(1, 1, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 2, 1), LOADUH(RN, LBUF, LH, 3, 1)) \
     GA(1, 2, MB, NB, RA, RB, , )                                               \
-    GA(1, 3, MB, NB, RA, RB, , )                                               \
+    GA(1, 3, MB, NB, RA, RB, , )
+#elif R256_ORDER == 1   // the reads first, the pieces in gaps of their own
+#define PHASE_BODY(LOADUH, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB) \
+    GA(0, 0, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 0, 0), LOADUH(RN, LBUF, LH, 1, 0)) \
+    GA(0, 1, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 2, 0), LOADUH(RN, LBUF, LH, 3, 0)) \
+    GA(0, 2, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 0, 1), LOADUH(RN, LBUF, LH, 1, 1)) \
+    GA(0, 3, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 2, 1), LOADUH(RN, LBUF, LH, 3, 1)) \
+    GA(1, 0, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 0), )                         \
+    GA(1, 1, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 1), )                         \
+    GA(1, 2, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 2), )                         \
+    GA(1, 3, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 3), )
+#else                   // the pieces first, in gaps of their own, then the reads
+#define PHASE_BODY(LOADUH, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB) \
+    GA(0, 0, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 0), )                         \
+    GA(0, 1, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 1), )                         \
+    GA(0, 2, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 2), )                         \
+    GA(0, 3, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 3), )                         \
+    GA(1, 0, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 0, 0), LOADUH(RN, LBUF, LH, 1, 0)) \
+    GA(1, 1, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 2, 0), LOADUH(RN, LBUF, LH, 3, 0)) \
+    GA(1, 2, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 0, 1), LOADUH(RN, LBUF, LH, 1, 1)) \
+    GA(1, 3, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 2, 1), LOADUH(RN, LBUF, LH, 3, 1))
+#endif
+#define PHASE(WAITN, WAITF, LOADUH, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB) \
+  {                                                                            \
+    __builtin_amdgcn_s_setprio(1);                                             \
+    asm volatile("s_nop 1");                                                   \
+    PHASE_BODY(LOADUH, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB)      \
     __builtin_amdgcn_s_setprio(0);                                             \
     if constexpr ((WAITF) != (WAITN)) { WAITBAR2(first, WAITF, WAITN); } else { WAITBAR(WAITN); } \
   }
@@ -573,6 +600,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
 #undef NOLOAD_UH
 #undef HALF_B
 #undef PHASE
+#undef PHASE_BODY
 #undef LOADA
 #undef LOADB
 #undef LOADA_U
