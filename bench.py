@@ -590,6 +590,17 @@ def main():
     if rank == 0 and world == 1 and not args.no_parity and not args.fp8_forward and args.half == "bf16":
         try:
             fp16_line = measure_fp16(spec, args, dev, bn, B, steps=args.steps, warmup=args.warmup)
+            # the bf16 steps once more, right behind the fp16 loop (same clock / thermal state of the box: the headline loop ran
+            # minutes earlier, and a box's clock under load drifts by 1-2 % over a bench run)
+            for _ in range(args.warmup):
+                stepper(batch, labels)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                stepper(batch, labels)
+            torch.cuda.synchronize(dev)
+            fp16_line["bf16_right_after_samples_per_s"] = round(B * args.steps / (time.perf_counter() - t0), 2)
+            fp16_line["ratio_to_bf16_right_after"] = round(fp16_line["train_samples_per_s"] / fp16_line["bf16_right_after_samples_per_s"], 4)
         except Exception as e:  # pragma: no cover
             fp16_line = {"error": repr(e)}
 

@@ -594,6 +594,39 @@ def test_bench_refuses_two_ranks_on_the_one_gpu_box():
     assert have >= 1
 
 
+def test_bench_line_carries_the_contract_fields_and_the_block_fractions():
+    """`python bench.py` as the driver runs it (a short loop at per-GPU batch 32 here): ONE JSON line on stdout with the
+    contract's fields, the `roofline` / `cpu_baseline`-shaped objects, and round 5's driver-visible north-star numbers -
+    `vilt_block_frac` / `lm_block_frac` with the four block times behind them - consistent with each other; `--scaling strong`
+    on one rank is the same workload labelled "strong"."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--batch", "256", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+           "--no-other-configs", "--no-h2d", "--no-parity", "--scaling", "strong"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "step_mfma_frac", "vilt_block_frac", "lm_block_frac", "blocks"):
+        assert k in d, k
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["dtype"] == "bf16" and d["config"]["global_batch"] == 256
+    assert d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert abs(d["value"] - 256 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]
+    bv, bl = d["blocks"]["vilt"], d["blocks"]["lm"]
+    assert 0.2 < d["vilt_block_frac"] < 0.6 and 0.1 < d["lm_block_frac"] < 0.6
+    assert abs(d["vilt_block_frac"] - 256 * 98.06e9 / ((bv["ms_forward"] + bv["ms_backward"]) * 1e-3) / 2.5e15) < 2e-3
+    assert abs(d["lm_block_frac"] - 256 * 20.56e9 / ((bl["ms_forward"] + bl["ms_backward"]) * 1e-3) / 2.5e15) < 2e-3
+    # the two stacks' blocks are most of the step, never more than it
+    blocks_ms = bv["ms_forward"] + bv["ms_backward"] + bl["ms_forward"] + bl["ms_backward"]
+    assert 0.85 * d["ms_per_step"] < blocks_ms < d["ms_per_step"]
+
+
 @pytest.mark.parametrize("wire,half", [("fp32", "bf16"), ("bf16", "bf16"), ("fp32", "fp16")])
 def test_data_parallel_full_width_default_buckets(tmp_path, wire, half):
     """The data-parallel step at FULL WIDTH with the DEFAULT bucket size: hidden 768, FFN 3072, the 64,001 x 768 word-embedding
