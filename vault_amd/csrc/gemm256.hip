@@ -389,8 +389,13 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     MMA1(KS, MT, 0, MB, NB, RA, RB) INS_A;                                                 \
     MMA1(KS, MT, 1, MB, NB, RA, RB) MMA1(KS, MT, 2, MB, NB, RA, RB) INS_B;                 \
     MMA1(KS, MT, 3, MB, NB, RA, RB)
+// Placement of a phase's four staging pieces against its eight fragment reads.  1 (default since round 5): the reads in the first
+// four MFMA groups, the pieces in gaps of their own behind them - in the step 38.02 -> 37.91 ms (three interleaved same-box pairs,
+// tools/r05_call15.sh; weight gradients 0.5763 -> 0.5729 ms per launch); 0: a piece and a read per group (rounds 1-4); 2: pieces first
+// (slower).  tools/pf_bench.py: within 1 % on the isolated kernels either way - the kernel is bound by the aggregate of its address
+// path, not by where in a phase its instructions sit.
 #ifndef R256_ORDER
-#define R256_ORDER 0   // development: placement of a phase's four staging pieces against its eight fragment reads
+#define R256_ORDER 1
 #endif
 #if R256_ORDER == 0
 #define PHASE_BODY(LOADUH, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB) \
