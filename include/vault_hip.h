@@ -118,9 +118,15 @@ int vault_wgrad_grouped(const vault_wgrad_grouped_args* args, void* stream);
  * vault_gemm_mxfp8: out = epilogue(A . B^T) with A = [M][K], B = [N][K] in that format (args->A / args->B point to
  * the element bytes, lda = ldb = K, a_mode = b_mode = 0, splits <= 1), fp32 accumulation in
  * v_mfma_scale_f32_16x16x128_f8f6f4, epilogues EPI_BF16, EPI_BF16_GELU, EPI_F32_RES as vault_gemm.
- * M % 256 == 0, N % 256 == 0, K % 128 == 0.  Same Linear layers as vault_gemm (forward only). */
+ * M % 256 == 0, N % 256 == 0, K % 128 == 0.  Same Linear layers as vault_gemm (forward only).
+ * Kernels (args->cfg; ABI 10): 0 = the simple double-buffered kernel (csrc/gemm_mx8.hip); 5 / 6 = the 8-wave kernel of
+ * vault_gemm on MXFP8 operands, 256- / 192-wide tiles (csrc/gemm8w.hip, MX: K >= 384, no dropout in the residual epilogue;
+ * N % 192 == 0 suffices for 6) - the only ones that take aux_u8 (epi 1: the gelu' image the epi-2 vault_gemm of the same cfg
+ * reads back) and out_hm; -1 = 5 / 6 where they take the call, else 0.  The three give bit-identical accumulators (one scaled
+ * MFMA per 128 k, same order).  vault_gemm_mxfp8_plan: the kernel a call would run on (0, 5, 6), or -EINVAL. */
 int vault_quant_mxfp8(const void* src_bf16, long long rows, int K, int ld_src, void* dst_q, void* dst_scale, void* stream);
 int vault_gemm_mxfp8(const vault_gemm_args* args, const void* a_scale, const void* b_scale, void* stream);
+int vault_gemm_mxfp8_plan(const vault_gemm_args* args);
 
 
 /* ---- LayerNorm ----------------------------------------------------------------------------

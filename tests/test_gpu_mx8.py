@@ -125,6 +125,59 @@ def test_gemm_gelu_and_bf16_epilogues():
     assert (out2.float().cpu() - xs.grad).abs().max().item() <= 1e-2
 
 
+@pytest.mark.parametrize("M,N,K,epi,cfg", [
+    (8192, 2304, 768, EPI_BF16, 5),     # 288 items on 256 CUs: the load cursor crosses into a second item
+    (2048, 2304, 768, EPI_BF16, 6),     # 192-wide tiles
+    (1024, 3072, 768, EPI_GELU, 5),
+    (1024, 3072, 768, EPI_GELU, 6),
+    (16640, 768, 3072, EPI_RES, 5),     # 24 K tiles, 195 items
+    (1024, 768, 768, EPI_RES, 6),
+    (512, 768, 384, EPI_BF16, 5),       # the shortest contraction the form takes: first, one middle, last K tile
+])
+def test_8wave_form_equals_the_simple_kernel_bit_for_bit(M, N, K, epi, cfg):
+    """The 8-wave kernel's MXFP8 form (gemm8w.hip, MX) issues the same scaled MFMAs in the same K order as the simple kernel of
+    gemm_mx8.hip, so the accumulators agree to the bit; rows past m_valid are not stored."""
+    g = torch.Generator().manual_seed(M + N + K + cfg)
+    x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    q_a, s_a = _quant_gpu(x)
+    q_w, s_w = _quant_gpu(w)
+    bias = torch.randn(N, generator=g).cuda()
+    m_valid = M - 37
+    kw = dict(bias=bias, m_valid=m_valid)
+    if epi == EPI_RES:
+        kw["res"] = torch.randn(M, N, generator=g).cuda()
+    outs = []
+    for c in (0, cfg):
+        o2 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda") if epi == EPI_GELU else None
+        o = _run_gemm(q_a, s_a, q_w, s_w, M, N, K, epi, cfg=c, **kw, **({"out2": o2} if o2 is not None else {}))
+        outs.append((o, o2))
+    (o0, u0), (o1, u1) = outs
+    assert torch.equal(o0[:m_valid], o1[:m_valid])
+    assert o1[m_valid:].abs().max().item() == 0.0
+    if u0 is not None:
+        assert torch.equal(u0[:m_valid], u1[:m_valid])
+
+
+def test_8wave_form_exact_on_integer_data():
+    """The operand map, the scale bytes (two per register, selected by op_sel_hi) and the permuted weight rows of the 8-wave
+    form: integer data with power-of-two block scales that differ from row to row and block to block."""
+    M, N, K = 1024, 768, 512
+    g = torch.Generator().manual_seed(6)
+    ia = torch.randint(-3, 4, (M, K), generator=g).float()
+    iw = torch.randint(-3, 4, (N, K), generator=g).float()
+    q_a = ia.to(torch.float8_e4m3fn).view(torch.uint8).cuda()
+    q_w = iw.to(torch.float8_e4m3fn).view(torch.uint8).cuda()
+    s_a = torch.randint(124, 131, (M, K // 32), generator=g).to(torch.uint8).cuda()
+    s_w = torch.randint(125, 130, (N, K // 32), generator=g).to(torch.uint8).cuda()
+    ref = _dequant(q_a, s_a).double() @ _dequant(q_w, s_w).double().t()
+    for cfg in (5, 6):
+        out = _run_gemm(q_a, s_a, q_w, s_w, M, N, K, EPI_RES, res=torch.zeros(M, N, device="cuda"), cfg=cfg)
+        assert torch.equal(out.cpu().double(), ref), cfg
+        out = _run_gemm(q_a, s_a, q_w, s_w, M, N, K, EPI_BF16, cfg=cfg)      # (|values| < 2^8 * 2^k: exact in bf16? no - compare rounded)
+        assert torch.equal(out.cpu(), ref.float().bfloat16()), cfg
+
+
 def test_rejects_what_the_kernel_cannot_do():
     from vault_amd import lib as L, ops
     q = torch.zeros(256, 128, dtype=torch.uint8, device="cuda")
@@ -136,6 +189,10 @@ def test_rejects_what_the_kernel_cannot_do():
         ops.gemm_mxfp8(q, s, q, s, out, 256, 256, 128, 256, 5)             # split-K atomics: backward stays bf16
     with pytest.raises(RuntimeError):
         ops.quant_mxfp8(out, 256, 100, 256, q, s)                          # K % 32
+    with pytest.raises(RuntimeError):
+        ops.gemm_mxfp8(q, s, q, s, out, 256, 256, 128, 256, EPI_BF16, cfg=5)   # 8-wave form: K >= 384
+    with pytest.raises(RuntimeError):
+        ops.gemm_mxfp8(q, s, q, s, out, 256, 256, 128, 256, EPI_BF16, cfg=0, out_hm=256)   # head-major: 8-wave form only
 
 
 # ---- the fp8-forward configuration of the engine ---------------------------------------------------------------

@@ -3,7 +3,7 @@
 #include "gemm.h"
 #include "../../include/vault_hip.h"
 
-int vault_gemm_mx8_launch(const GemmParams& p, const void* a_scale, const void* b_scale, int epi, hipStream_t st);
+int vault_gemm_mx8_launch(const GemmParams& p, const void* a_scale, const void* b_scale, int epi, int cfg, hipStream_t st);
 
 static GemmParams params_of(const vault_gemm_args* a) {
   GemmParams p{};
@@ -42,7 +42,15 @@ extern "C" int vault_gemm_plan(const vault_gemm_args* a) {
 
 extern "C" int vault_gemm_mxfp8(const vault_gemm_args* a, const void* a_scale, const void* b_scale, void* stream) {
   if (a == nullptr || a->a_mode != 0 || a->b_mode != 0 || a->splits > 1) return VAULT_EINVAL;
-  return vault_gemm_mx8_launch(params_of(a), a_scale, b_scale, a->epi, reinterpret_cast<hipStream_t>(stream));
+  return vault_gemm_mx8_launch(params_of(a), a_scale, b_scale, a->epi, a->cfg, reinterpret_cast<hipStream_t>(stream));
+}
+
+int vault_gemm_mx8_resolve(const GemmParams& p, const void* a_scale, const void* b_scale, int epi, int cfg, GemmParams& q);
+
+extern "C" int vault_gemm_mxfp8_plan(const vault_gemm_args* a) {
+  if (a == nullptr || a->a_mode != 0 || a->b_mode != 0 || a->splits > 1) return -VAULT_EINVAL;
+  GemmParams q;
+  return vault_gemm_mx8_resolve(params_of(a), a->A, a->B, a->epi, a->cfg, q);   // (any non-null pointers stand in for the scales)
 }
 
 extern "C" int vault_wgrad_grouped(const vault_wgrad_grouped_args* a, void* stream) {
@@ -70,7 +78,7 @@ extern "C" int vault_wgrad_grouped(const vault_wgrad_grouped_args* a, void* stre
   return vault_gemm256_grouped_launch(p, reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" int vault_abi_version(void) { return 9; }
+extern "C" int vault_abi_version(void) { return 10; }
 #ifdef VAULT_F16
 extern "C" int vault_operand_format(void) { return 1; }
 #else

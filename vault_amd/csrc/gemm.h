@@ -53,6 +53,11 @@ struct GemmParams {
   //   a_hm = R:   the A operand of the ring kernel's (0, *) modes is read from it ([K / 64][R][64]: a K tile = one plane,
   //               rows contiguous - the QKV data gradient's dqkv); 0 = row-major.
   int out_hm, a_hm;
+  // MXFP8 operands (gemm_mx8.hip, the 8-wave kernel's MX form): E8M0 block scales [rows][lds_*] of A and B (one byte per 32
+  // consecutive k), null for the 16-bit kernels
+  const uint8_t* a_scale;
+  const uint8_t* b_scale;
+  int lds_a, lds_b;
   // Grouped weight gradients (ring kernel, (1,1) operand modes, EPI_F32_ATOMIC): ONE launch over up to three segments of
   // DIFFERENT weight-gradient kinds that share the contraction (the tokens) and therefore the cost per 256 x 256 tile: the
   // work list is their concatenation, so a launch can be sized to exactly one round of the 256 CUs (e.g. the 216 FFN-out

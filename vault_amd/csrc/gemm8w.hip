@@ -73,7 +73,15 @@ __device__ __forceinline__ void w8_glds16(const char* sbase, uint32_t voff, uint
                :: "v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
 }
 
+// the 4-byte form (MXFP8: one dword = the four E8M0 block scales of a row's 128-deep K tile; lane l lands at + 4 l)
+__device__ __forceinline__ void w8_glds4(const char* sbase, uint32_t voff, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+               :: "v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
+}
+
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef int w8_i32x8 __attribute__((ext_vector_type(8)));
+typedef int w8_i32x4 __attribute__((ext_vector_type(4)));
 
 // sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), result in every lane of the row
 __device__ __forceinline__ float w8_row16_sum(float t) {
@@ -101,8 +109,23 @@ __device__ __forceinline__ float w8_row16_sum(float t) {
 // operand that misses the L2 (the weight panels of a column group stay there: launch8w's raster), and with one K tile of
 // look-ahead an HBM round trip does not fit under a K tile's 64 MFMAs per wave: A tile t + 3 is requested while tile t is
 // multiplied (B tile t + 2, as before), the B pieces first, so that the mid wait leaves the 4 A pieces of tile t + 2 in flight.
-template <int EPI, int NTW, bool A3 = false>
+//
+// MX (round 5): the same kernel on MXFP8 operands (e4m3 bytes + one E8M0 scale per 32 consecutive k, gemm_mx8.hip's formats):
+// a tile row is still 128 BYTES, so a K tile is 128 deep, and v_mfma_scale_f32_16x16x128_f8f6f4 takes as its eight operand
+// registers exactly the two fragments of the 16-bit form's k-steps (16-byte chunks g and 4 + g of the row image, gemm_mx8.hip
+// header) - same LDS images, same staging, same swizzle, same accumulator layout and therefore the same epilogues, half the
+// K tiles.  One MFMA set per K tile (8 x NTW instructions of twice the cycles); the two halves of the pipeline are the ROW
+// halves of the tile instead of its k-steps:
+//   rows 0-3   4 x NTW MFMAs on XA[0..3] / XB (in registers since the previous K tile), the fragments XA[4..7] read meanwhile
+//   mid        as above
+//   rows 4-7   4 x NTW MFMAs on XA[4..7] / XB with tile t + 2's staging pieces and tile t + 1's XA[0..3] between them; XB
+//              of tile t + 1 behind the last MFMA
+// The block scales ride along: per K tile and wave ONE 4-byte LDS-DMA piece (a dword per row: waves 0-3 the 256 activation
+// rows, waves 4-7 the weight rows in the order of the permuted LDS image), read back as single bytes (byte g of the lane's
+// rows).  Two stages (the third A slot has no room beside the scales: 2 x 66 KiB).
+template <int EPI, int NTW, bool A3 = false, bool MX = false>
 __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
+  static_assert(!(MX && A3), "the MXFP8 form is two-stage");
   H16_SATURATE();
 #if W8_STAMP
   const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
@@ -110,29 +133,32 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
   constexpr bool F32OUT = (EPI == EPI_F32_RES);
   constexpr int BN = 64 * NTW;                       // block tile width
   constexpr int B_BYTES = BN * 128;
-  constexpr int STAGE = W8_A_BYTES + B_BYTES;
-  // LDS layout: [A0 B0][A1 B1], or (A3) [A0][A1][A2][B0][B1]
+  constexpr int SC_BYTES = MX ? 2048 : 0;             // 512 dwords: 256 activation rows, up to 256 weight rows
+  constexpr int ESZ = MX ? 1 : 2;                      // bytes per operand element
+  constexpr int STAGE = W8_A_BYTES + B_BYTES + SC_BYTES;
+  // LDS layout: [A0 B0][A1 B1], or (A3) [A0][A1][A2][B0][B1], or (MX) [A0 B0 S0][A1 B1 S1]
   auto a_base = [](int sa) -> int { return A3 ? sa * W8_A_BYTES : sa * STAGE; };
   auto b_base = [](int sb) -> int { return A3 ? 3 * W8_A_BYTES + sb * B_BYTES : sb * STAGE + W8_A_BYTES; };
-  constexpr int NPC = 4 + NTW;                       // staging pieces per wave and K tile
+  auto s_base = [](int sb) -> int { return sb * STAGE + W8_A_BYTES + B_BYTES; };
+  constexpr int NPC = 4 + NTW + (MX ? 1 : 0);        // staging pieces per wave and K tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int tiles_m = p.M >> 8, tiles_n = p.N / BN, nwork = tiles_m * tiles_n;
-  const int nk = p.K >> 6;
+  const int nk = p.K >> (MX ? 7 : 6);
   const int G = (int)gridDim.x;
 
   // ---- staging sources: scalar base (per work item and K tile) + scalar piece offset + a per-lane offset
   const int r8 = lane >> 3;
   const int csw = (lane & 7) ^ (((r8 >> 1) & 3) << 1);     // source chunk of LDS position lane & 7 (XOR swizzle by row)
-  const uint32_t a_voff = (uint32_t)(r8 * p.lda + csw * 8) * 2u;
+  const uint32_t a_voff = (uint32_t)(r8 * p.lda * ESZ + csw * 16);
   // B: LDS row 8 j + r8 of piece j  <-  weight row (header); the piece part is scalar, the row-in-piece part per lane
-  const uint32_t b_voff = (uint32_t)((F32OUT ? r8 : (8 * (r8 >> 2) + (r8 & 3))) * p.ldb + csw * 8) * 2u;
-  const uint32_t b_voff2 = (uint32_t)((4 * (r8 >> 2) + (r8 & 3)) * p.ldb + csw * 8) * 2u;   // NTW == 3: the 4-column tail tile
-  const size_t a_piece = (size_t)8 * p.lda * 2;            // bytes between consecutive A pieces (8 rows)
-  const size_t b_row = (size_t)p.ldb * 2;
+  const uint32_t b_voff = (uint32_t)((F32OUT ? r8 : (8 * (r8 >> 2) + (r8 & 3))) * p.ldb * ESZ + csw * 16);
+  const uint32_t b_voff2 = (uint32_t)((4 * (r8 >> 2) + (r8 & 3)) * p.ldb * ESZ + csw * 16);   // NTW == 3: the 4-column tail tile
+  const size_t a_piece = (size_t)8 * p.lda * ESZ;          // bytes between consecutive A pieces (8 rows)
+  const size_t b_row = (size_t)p.ldb * ESZ;
   const uint32_t lds0 = (uint32_t)(size_t)LDS_PTR(char, smem);   // LDS byte address of the dynamic segment
 
   // per work item: base of its A row panel / B column panel (the divisions of the raster run once per item)
@@ -144,9 +170,40 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
     ab = reinterpret_cast<const char*>(p.A);
     bb = reinterpret_cast<const char*>(p.B);
 #else
-    ab = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
-    bb = reinterpret_cast<const char*>(p.B + (size_t)n0 * p.ldb);
+    ab = reinterpret_cast<const char*>(p.A) + (size_t)m0 * p.lda * ESZ;
+    bb = reinterpret_cast<const char*>(p.B) + (size_t)n0 * p.ldb * ESZ;
 #endif
+  };
+  // MX: this wave's scale piece - dword (wave < 4 ? 64 wave : 256 + 64 (wave - 4)) + lane of the stage's scale block; waves 0-3
+  // take the activation rows in order, waves 4-7 the weight row that pieceB stages into LDS row R = 64 (wave - 4) + lane
+  uint32_t s_voff = 0;
+  if constexpr (MX) {
+    if (wave < 4) {
+      s_voff = (uint32_t)((wave * 64 + lane) * p.lds_a);
+    } else {
+      int R = (wave - 4) * 64 + lane;
+      if (R >= BN) R -= 64;                         // (192-wide tiles: wave 7 re-loads rows 128..191 into the spare dwords)
+      const int j = R >> 3, q8 = R & 7;
+      int wrow;
+      if constexpr (F32OUT) {
+        wrow = R;
+      } else if constexpr (NTW == 4) {
+        wrow = (j >> 3) * 64 + ((j >> 2) & 1) * 32 + (j & 1) * 16 + ((j >> 1) & 1) * 4 + 8 * (q8 >> 2) + (q8 & 3);
+      } else {
+        const int wcol = j / 6, jj = j - wcol * 6, nt = jj >> 1;
+        wrow = (nt < 2) ? wcol * 48 + (jj & 1) * 16 + nt * 4 + 8 * (q8 >> 2) + (q8 & 3)
+                        : wcol * 48 + 32 + (jj & 1) * 8 + 4 * (q8 >> 2) + (q8 & 3);
+      }
+      s_voff = (uint32_t)(wrow * p.lds_b);
+    }
+  }
+  const uint32_t s_lds = (uint32_t)((wave < 4 ? wave * 64 : 256 + (wave - 4) * 64) * 4);
+  auto scales_of = [&](int m0_, int n0_) -> const char* {   // scale panel of a work item, this wave's side
+    return wave < 4 ? reinterpret_cast<const char*>(p.a_scale) + (size_t)m0_ * p.lds_a
+                    : reinterpret_cast<const char*>(p.b_scale) + (size_t)n0_ * p.lds_b;
+  };
+  auto pieceS = [&](const char* tile, int st_) {   // tile = scale panel + 4 kt
+    w8_glds4(tile, s_voff, lds0 + s_base(st_) + s_lds);
   };
   auto pieceA = [&](const char* tile, int sa_, int i) {   // tile = panel base + 128 kt ; piece i of this wave's 4 ; A slot
     const int j = wave * 4 + i;
@@ -169,8 +226,10 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
   };
 
   const char *a_cur, *b_cur, *a_nxt, *b_nxt;
+  const char *s_cur = nullptr, *s_nxt = nullptr;
   int m0, n0, m0n, n0n;
   bases_of((int)blockIdx.x, a_cur, b_cur, m0, n0);
+  if constexpr (MX) s_cur = scales_of(m0, n0);
   // Start stagger (persist bits 4..7 = sixteenths of one tile's duration, spread linearly over the blocks): a tile's
   // 128 KiB of output leaves each CU in one burst, and with all 256 CUs in step a round's 32 MiB take HBM ~7 us to
   // absorb - the waves then wait for those stores in front of the second K tile's staging loads (VMEM operations
@@ -189,10 +248,12 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
   for (int i = 0; i < NTW; ++i) pieceB(b_cur, 0, i);
 #pragma unroll
   for (int i = 0; i < 4; ++i) pieceA(a_cur, 0, i);
+  if constexpr (MX) pieceS(s_cur, 0);
 #pragma unroll
   for (int i = 0; i < NTW; ++i) pieceB(b_cur + 128, 1, i);
 #pragma unroll
   for (int i = 0; i < 4; ++i) pieceA(a_cur + 128, 1, i);
+  if constexpr (MX) pieceS(s_cur + 4, 1);
   if constexpr (A3) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) pieceA(a_cur + 256, 2, i);
@@ -319,10 +380,143 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
     ++kt;
   };
 
+  // ---- MXFP8 form: fragments = the two 16-byte chunks side by side (eight registers per MFMA operand), scale bytes
+  w8_i32x8 XA[MX ? 8 : 1], XB[MX ? NTW : 1];
+  int sX[MX ? 4 : 1] = {}, sW[MX ? 2 : 1] = {};   // scale bytes, two per register: byte 0 = tile 2 k, byte 2 = tile 2 k + 1 (op_sel_hi)
+  // byte g of the row's scale dword: activation row wr * 128 + 16 mt + l15, weight LDS row wc * 16 NTW + 16 nt + l15
+  const uint32_t sx_rd = (uint32_t)((wr * 128 + l15) * 4 + g);
+  const uint32_t sw_rd = (uint32_t)((256 + wc * 16 * NTW + l15) * 4 + g);
+  // (scale byte select: op_sel = bit 0, op_sel_hi = bit 1 of the byte index, first entry the A-operand's scale = weights)
+  // The host pass of hipcc parses kernel bodies too and drops - silently: the stub stays an undefined symbol - a kernel whose
+  // asm operands it cannot type for x86 (a 256-bit "v" operand without AVX): the host sees no statement at all.
+#define W8_XASM(CSRC, HI) "v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, " CSRC ", %3, %4 op_sel_hi:" HI
+#if !defined(__HIP_DEVICE_COMPILE__)
+#define W8_XMMA(MT, NT) (void)0
+#define W8_XMMA0(MT, NT) (void)0
+#else
+#define W8_XMMA(MT, NT) \
+  if constexpr ((NT) < NTW) { \
+    if constexpr (((NT) & 1) == 0 && ((MT) & 1) == 0) \
+      asm volatile(W8_XASM("%0", "[0,0,0]") : "+a"(acc[MT][NT]) : "v"(XB[NT]), "v"(XA[MT]), "v"(sW[(NT) >> 1]), "v"(sX[(MT) >> 1])); \
+    else if constexpr (((NT) & 1) == 1 && ((MT) & 1) == 0) \
+      asm volatile(W8_XASM("%0", "[1,0,0]") : "+a"(acc[MT][NT]) : "v"(XB[NT]), "v"(XA[MT]), "v"(sW[(NT) >> 1]), "v"(sX[(MT) >> 1])); \
+    else if constexpr (((NT) & 1) == 0) \
+      asm volatile(W8_XASM("%0", "[0,1,0]") : "+a"(acc[MT][NT]) : "v"(XB[NT]), "v"(XA[MT]), "v"(sW[(NT) >> 1]), "v"(sX[(MT) >> 1])); \
+    else \
+      asm volatile(W8_XASM("%0", "[1,1,0]") : "+a"(acc[MT][NT]) : "v"(XB[NT]), "v"(XA[MT]), "v"(sW[(NT) >> 1]), "v"(sX[(MT) >> 1])); \
+  }
+#define W8_XMMA0(MT, NT) \
+  if constexpr ((NT) < NTW) { \
+    if constexpr (((NT) & 1) == 0 && ((MT) & 1) == 0) \
+      asm volatile(W8_XASM("0", "[0,0,0]") : "=a"(acc[MT][NT]) : "v"(XB[NT]), "v"(XA[MT]), "v"(sW[(NT) >> 1]), "v"(sX[(MT) >> 1])); \
+    else if constexpr (((NT) & 1) == 1 && ((MT) & 1) == 0) \
+      asm volatile(W8_XASM("0", "[1,0,0]") : "=a"(acc[MT][NT]) : "v"(XB[NT]), "v"(XA[MT]), "v"(sW[(NT) >> 1]), "v"(sX[(MT) >> 1])); \
+    else if constexpr (((NT) & 1) == 0) \
+      asm volatile(W8_XASM("0", "[0,1,0]") : "=a"(acc[MT][NT]) : "v"(XB[NT]), "v"(XA[MT]), "v"(sW[(NT) >> 1]), "v"(sX[(MT) >> 1])); \
+    else \
+      asm volatile(W8_XASM("0", "[1,1,0]") : "=a"(acc[MT][NT]) : "v"(XB[NT]), "v"(XA[MT]), "v"(sW[(NT) >> 1]), "v"(sX[(MT) >> 1])); \
+  }
+#endif
+  // four row tiles against ONE weight fragment (nt-major order: a weight fragment is free - and the next tile's can be read -
+  // as soon as its group has been issued; the first group of a tile waits for one weight fragment, not for all of them)
+#define W8_XCOL(NT, M0) \
+  if constexpr (FIRST) { W8_XMMA0((M0), NT); W8_XMMA0((M0) + 1, NT); W8_XMMA0((M0) + 2, NT); W8_XMMA0((M0) + 3, NT); } \
+  else { W8_XMMA((M0), NT); W8_XMMA((M0) + 1, NT); W8_XMMA((M0) + 2, NT); W8_XMMA((M0) + 3, NT); }
+  // even tile: its byte 0, keeping the odd tile's byte 2 ; odd tile: its byte 2, keeping byte 0
+#define W8_XSET(REG, ODD, BYTE) \
+  REG = (ODD) ? (((REG) & 0xffff) | ((BYTE) << 16)) : ((int)((uint32_t)(REG) & 0xffff0000u) | (BYTE))
+#define W8_XREAD_A(MT, SA, SS) \
+  XA[MT].lo = *LDS_PTR(const w8_i32x4, (SA) + a_rd0 + (MT) * 2048); \
+  XA[MT].hi = *LDS_PTR(const w8_i32x4, (SA) + a_rd1 + (MT) * 2048); \
+  W8_XSET(sX[(MT) >> 1], (MT) & 1, (int)*LDS_PTR(const uint8_t, (SS) + sx_rd + (MT) * 64))
+#define W8_XREAD_B(NT, SB, SS) \
+  XB[NT].lo = *LDS_PTR(const w8_i32x4, (SB) + b_rd0 + (NT) * 2048); \
+  XB[NT].hi = *LDS_PTR(const w8_i32x4, (SB) + b_rd1 + (NT) * 2048); \
+  W8_XSET(sW[(NT) >> 1], (NT) & 1, (int)*LDS_PTR(const uint8_t, (SS) + sw_rd + (NT) * 64))
+  auto ktile_mx = [&](auto first_tag, auto last_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
+    const char* stA = smem + a_base(stage);
+    const char* stS = smem + s_base(stage);
+    const char* snA = smem + a_base(stage ^ 1);
+    const char* snB = smem + b_base(stage ^ 1);
+    const char* snS = smem + s_base(stage ^ 1);
+    const int kn = kt + 2;
+    const bool here = kn < nk;
+    const int ko = here ? kn : kn - nk;
+    const char* ta = (here ? a_cur : a_nxt) + (size_t)ko * 128;
+    const char* tb = (here ? b_cur : b_nxt) + (size_t)ko * 128;
+    const char* ts = (here ? s_cur : s_nxt) + (size_t)ko * 4;
+    // ---- rows 0-3 (XA[0..3], XB of this tile are in registers), the fragments of rows 4-7 read meanwhile
+    W8_XCOL(0, 0); W8_XREAD_A(4, stA, stS);
+    W8_XCOL(1, 0); W8_XREAD_A(5, stA, stS);
+    W8_XCOL(2, 0); W8_XREAD_A(6, stA, stS);
+    if constexpr (NTW == 4) { W8_XCOL(3, 0); }
+    W8_XREAD_A(7, stA, stS);
+    // ---- mid: tile t + 1 landed, every fragment of tile t is in registers
+    if constexpr (FIRST) {
+      if (extra >= 63) W8_WAITBAR(63);
+      else if (extra >= 48) W8_WAITBAR(48);
+      else if (extra >= 32) W8_WAITBAR(32);
+      else if (extra >= 16) W8_WAITBAR(16);
+      else W8_WAITBAR(0);
+    } else {
+      W8_WAITBAR(0);
+    }
+    // ---- rows 4-7, with tile t + 2's staging pieces (into the stage just freed) and tile t + 1's fragments between the groups
+    if constexpr (LAST) {   // the bias of this item's columns: requested here (the registers of XA[0..3] are free: no next tile
+                            // is read under a last tile), retired behind the loop by a wait that leaves this tile's pieces in flight
+      if constexpr (F32OUT) {
+        const uint32_t bo = (uint32_t)(n0 + wc * 16 * NTW + 4 * g) * 4u;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(bq[0]) : "v"(bo), "s"(p.bias));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=&v"(bq[1]) : "v"(bo), "s"(p.bias));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:128" : "=&v"(bq[2]) : "v"(bo), "s"(p.bias));
+        if constexpr (NTW == 4) asm volatile("global_load_dwordx4 %0, %1, %2 offset:192" : "=&v"(bq[3]) : "v"(bo), "s"(p.bias));
+      } else {
+        const uint32_t bo = (uint32_t)(n0 + wc * 16 * NTW + 8 * g) * 4u;
+        const uint32_t bo1 = bo + ((NTW == 4) ? 128u : (uint32_t)(128 - 16 * g));
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(bq[0]) : "v"(bo), "s"(p.bias));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=&v"(bq[1]) : "v"(bo), "s"(p.bias));
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(bq[2]) : "v"(bo1), "s"(p.bias));
+        if constexpr (NTW == 4) asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=&v"(bq[3]) : "v"(bo1), "s"(p.bias));
+      }
+    }
+    W8_XCOL(0, 4); pieceA(ta, stage, 0); pieceA(ta, stage, 1);
+    if constexpr (!LAST) { W8_XREAD_B(0, snB, snS); W8_XREAD_A(0, snA, snS); }
+    W8_XCOL(1, 4); pieceA(ta, stage, 2); pieceA(ta, stage, 3);
+    if constexpr (!LAST) { W8_XREAD_B(1, snB, snS); W8_XREAD_A(1, snA, snS); }
+    W8_XCOL(2, 4); pieceB(tb, stage, 0); pieceB(tb, stage, 1);
+    if constexpr (NTW == 3) { pieceB(tb, stage, 2); pieceS(ts, stage); }
+    if constexpr (!LAST) {
+      W8_XREAD_B(2, snB, snS); W8_XREAD_A(2, snA, snS);
+      if constexpr (NTW == 3) { W8_XREAD_A(3, snA, snS); }
+    }
+    if constexpr (NTW == 4) {
+      W8_XCOL(3, 4); pieceB(tb, stage, 2); pieceB(tb, stage, 3); pieceS(ts, stage);
+      if constexpr (!LAST) { W8_XREAD_B(3, snB, snS); W8_XREAD_A(3, snA, snS); }
+    }
+    stage ^= 1;
+    ++kt;
+  };
+
   for (int w = (int)blockIdx.x; w < nwork; w += G) {
     // the load cursor (two K tiles ahead) crosses into the next item inside this item's loop
     if (w + G < nwork) bases_of(w + G, a_nxt, b_nxt, m0n, n0n);
     else { a_nxt = a_cur; b_nxt = b_cur; m0n = m0; n0n = n0; }   // past the end: valid tiles into stages nobody reads
+    if constexpr (MX) {
+      s_nxt = scales_of(m0n, n0n);
+      const char* stA = smem + a_base(stage);
+      const char* stB = smem + b_base(stage);
+      const char* stS = smem + s_base(stage);
+      W8_XREAD_B(0, stB, stS); W8_XREAD_B(1, stB, stS); W8_XREAD_B(2, stB, stS);
+      if constexpr (NTW == 4) { W8_XREAD_B(3, stB, stS); }
+      W8_XREAD_A(0, stA, stS); W8_XREAD_A(1, stA, stS); W8_XREAD_A(2, stA, stS); W8_XREAD_A(3, stA, stS);
+      kt = 0;
+      ktile_mx(std::true_type{}, std::false_type{});
+#pragma clang loop unroll(disable)
+      while (kt < nk - 1) ktile_mx(std::false_type{}, std::false_type{});
+      ktile_mx(std::false_type{}, std::true_type{});   // (K >= 384: the launcher)
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_nop 15\n\ts_nop 15" ::"i"(NPC) : "memory");   // the bias has landed
+    } else {
     {   // first fragments of the item's first K tile (landed: the wait that ended the previous item / the prologue)
       const char* stA = smem + a_base(sa);
       const char* stB = smem + b_base(stage);
@@ -342,6 +536,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
     if constexpr (A3) {
       // the bias loads (requested at the start of the last tile) have landed; behind them: that tile's staging pieces
       asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NTW + 4) : "memory");
+    }
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> accumulator reads (invisible inside asm)
 
@@ -676,6 +871,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
     }
 #undef W8_ACC
     a_cur = a_nxt; b_cur = b_nxt; m0 = m0n; n0 = n0n;
+    s_cur = s_nxt;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the cursor's last (unused) tiles must not land after exit
 #if W8_STAMP
@@ -686,16 +882,23 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
 #endif
 #undef W8_ROW
 #undef W8_MMA
+#undef W8_XCOL
+#undef W8_XSET
+#undef W8_XASM
+#undef W8_XMMA
+#undef W8_XMMA0
+#undef W8_XREAD_A
+#undef W8_XREAD_B
 }
 
-template <int EPI, int NTW, bool A3 = false>
+template <int EPI, int NTW, bool A3 = false, bool MX = false>
 int launch8w(const GemmParams& p, hipStream_t st) {
-  if constexpr (!A3) {
+  if constexpr (!A3 && !MX) {
     // three A slots (kernel header) where the contraction has at least four K tiles
     if (p.K >= 256) return launch8w<EPI, NTW, true>(p, st);
   }
-  constexpr int LDS = (A3 ? 3 : 2) * W8_A_BYTES + 2 * 64 * NTW * 128;
-  auto kern = gemm8w_kernel<EPI, NTW, A3>;
+  constexpr int LDS = (A3 ? 3 : 2) * W8_A_BYTES + 2 * 64 * NTW * 128 + (MX ? 2 * 2048 : 0);
+  auto kern = gemm8w_kernel<EPI, NTW, A3, MX>;
   static bool attr_done[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VAULT_EINVAL;
@@ -727,6 +930,19 @@ int launch8w(const GemmParams& p, hipStream_t st) {
 }
 
 template <int NTW>
+int dispatch8w_mx(const GemmParams& p, int epi, hipStream_t st) {
+  switch (epi) {
+    case EPI_BF16: return launch8w<EPI_BF16, NTW, false, true>(p, st);
+    case EPI_BF16_GELU:
+      if (p.aux_u8) return p.out2 != nullptr ? launch8w<EPI_BF16_GELU_U8, NTW, false, true>(p, st) : VAULT_EINVAL;
+      return p.out2 != nullptr ? launch8w<EPI_BF16_GELU, NTW, false, true>(p, st)
+                               : launch8w<EPI_BF16_GELU_INF, NTW, false, true>(p, st);
+    case EPI_F32_RES: return launch8w<EPI_F32_RES, NTW, false, true>(p, st);
+    default: return VAULT_EINVAL;
+  }
+}
+
+template <int NTW>
 int dispatch8w(const GemmParams& p, int epi, hipStream_t st) {
   switch (epi) {
     case EPI_BF16: return launch8w<EPI_BF16, NTW>(p, st);
@@ -754,6 +970,27 @@ bool vault_gemm8w_supports(const GemmParams& p, int a_mode, int b_mode, int epi,
   if (epi == EPI_BF16_DGELU) return p.aux != nullptr;
   if (epi == EPI_BF16_GELU) return p.colsum == nullptr;
   return epi == EPI_BF16;
+}
+
+// MXFP8 operands (p.A / p.B: e4m3 bytes, lda / ldb in bytes; p.a_scale / p.b_scale: E8M0 [rows][lds_*]): the forward epilogues
+bool vault_gemm8w_mx_supports(const GemmParams& p, int epi, int ntw) {
+  if ((p.M & 255) || (p.N % (64 * ntw)) || (p.K & 127) || p.K < 384 || p.splits > 1 || p.split3 || p.batch > 1) return false;
+  if ((p.lda & 15) || (p.ldb & 15) || p.a_scale == nullptr || p.b_scale == nullptr || p.lds_a < p.K / 32 || p.lds_b < p.K / 32 ||
+      (p.lds_a & 3) || (p.lds_b & 3))
+    return false;
+  if ((long long)p.M * p.ldo * 4 >= (1ll << 32) || (long long)p.M * p.lda >= (1ll << 32) || p.m_valid < 1) return false;
+  if (p.bias == nullptr && p.N > 8192) return false;
+  if (p.aux_u8 && !(epi == EPI_BF16_GELU && p.out2 != nullptr)) return false;
+  if (p.out_hm && !(epi == EPI_BF16 && p.out_hm >= p.M && p.N % 64 == 0 &&
+                    (long long)(p.N / 64) * p.out_hm * 128 < (1ll << 32)))
+    return false;
+  if (epi == EPI_F32_RES) return p.res != nullptr && p.drop_thresh == 0u && p.colsum == nullptr;
+  if (epi == EPI_BF16_GELU) return p.colsum == nullptr;
+  return epi == EPI_BF16 && p.colsum == nullptr;
+}
+
+int vault_gemm8w_mx_launch(const GemmParams& p, int epi, int ntw, hipStream_t st) {
+  return ntw == 3 ? dispatch8w_mx<3>(p, epi, st) : dispatch8w_mx<4>(p, epi, st);
 }
 
 int vault_gemm8w_launch(const GemmParams& p, int epi, int ntw, hipStream_t st) {

@@ -210,9 +210,38 @@ extern "C" int vault_quant_mxfp8(const void* src_bf16, long long rows, int K, in
   return (int)hipGetLastError();
 }
 
-int vault_gemm_mx8_launch(const GemmParams& p, const void* a_scale, const void* b_scale, int epi, hipStream_t st) {
-  if (p.A == nullptr || p.B == nullptr || p.out == nullptr || a_scale == nullptr || b_scale == nullptr) return VAULT_EINVAL;
-  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.lda != p.K || p.ldb != p.K || (p.ldo & 7)) return VAULT_EINVAL;
+bool vault_gemm8w_mx_supports(const GemmParams& p, int epi, int ntw);
+int vault_gemm8w_mx_launch(const GemmParams& p, int epi, int ntw, hipStream_t st);
+
+// p.cfg semantics of the C entry point (vault_gemm_args.cfg): -1 = automatic (the 8-wave kernel's MXFP8 form where it takes
+// the shape, 256-wide tiles unless only the 192-wide ones divide N), 0 = the simple double-buffered kernel of this file,
+// 5 / 6 = the 8-wave form with 256- / 192-wide tiles (EINVAL where it does not take the call)
+// argument checks + kernel choice: 0 (simple kernel), 5 / 6 (8-wave form; q = the parameters it runs on), or -VAULT_EINVAL.
+// The scale pointers only have to be non-null (a plan does not dereference them).
+int vault_gemm_mx8_resolve(const GemmParams& p, const void* a_scale, const void* b_scale, int epi, int cfg, GemmParams& q) {
+  if (p.A == nullptr || p.B == nullptr || p.out == nullptr || a_scale == nullptr || b_scale == nullptr) return -VAULT_EINVAL;
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.lda != p.K || p.ldb != p.K || (p.ldo & 7)) return -VAULT_EINVAL;
+  if (cfg != -1 && cfg != 0 && cfg != 5 && cfg != 6) return -VAULT_EINVAL;
+  q = p;
+  q.a_scale = reinterpret_cast<const uint8_t*>(a_scale); q.b_scale = reinterpret_cast<const uint8_t*>(b_scale);
+  q.lds_a = p.K / 32; q.lds_b = p.K / 32;
+  if (q.m_valid <= 0) q.m_valid = q.M;
+  if (cfg != 0) {
+    const int ntw = (cfg == 6) ? 3 : ((cfg == 5 || p.N % 256 == 0) ? 4 : 3);
+    if (vault_gemm8w_mx_supports(q, epi, ntw)) return ntw == 4 ? 5 : 6;
+    if (cfg > 0) return -VAULT_EINVAL;
+  }
+  if (p.aux_u8 || p.out_hm) return -VAULT_EINVAL;   // (8-wave form only)
+  if (p.M % 256 || p.N % 256 || p.K % BKB) return -VAULT_EINVAL;
+  if (epi != EPI_BF16 && epi != EPI_BF16_GELU && epi != EPI_F32_RES) return -VAULT_EINVAL;
+  return 0;
+}
+
+int vault_gemm_mx8_launch(const GemmParams& p, const void* a_scale, const void* b_scale, int epi, int cfg, hipStream_t st) {
+  GemmParams q;
+  const int k = vault_gemm_mx8_resolve(p, a_scale, b_scale, epi, cfg, q);
+  if (k < 0) return -k;
+  if (k != 0) return vault_gemm8w_mx_launch(q, epi, k == 5 ? 4 : 3, st);
   const uint8_t* as = reinterpret_cast<const uint8_t*>(a_scale);
   const uint8_t* bs = reinterpret_cast<const uint8_t*>(b_scale);
   switch (epi) {

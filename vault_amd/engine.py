@@ -239,8 +239,7 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
             aq, asc = self._fp8_scratch(M, K)
             if not prequant:          # (the LayerNorm in front wrote the MXFP8 image of its bf16 output itself)
                 ops.quant_mxfp8(a_bf16, M, K, K, aq, asc)
-            for k in ("split3", "cfg", "aux_u8"):   # (precise mode / the bf16 8-wave kernel's 8-bit gelu' only)
-                kw.pop(k, None)
+            kw.pop("split3", None)    # (precise mode only)
             ops.gemm_mxfp8(aq, asc, wq, wsc, out, M, N, K, N, epi, m_valid=m_valid, bias=bias, **kw)
         else:
             ops.gemm(a_bf16, P.wb(wname, n_elems=N * K, shape=(N, K)), out, M, N, K, K, K, N if ldo is None else ldo,
@@ -267,16 +266,21 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
         """Kernel configuration (5 / 6) on which BOTH the FFN-in forward and the gelu'-product data gradient of this ViLT
         workspace run with the 8-bit tile-native gelu' (vault_gemm aux_u8: an opaque image only the same kernel and shape reads
         back), or None: asked from the library once per workspace (vault_gemm_plan) - the automatic kernel choice must land on
-        the 8-wave kernel with equal tile width for both (not in data-parallel steps, small batches, fp8-forward)."""
+        the 8-wave kernel with equal tile width for both (not in data-parallel steps or small batches; fp8-forward: the forward
+        half of the pair is the 8-wave kernel's MXFP8 form, vault_gemm_mxfp8_plan)."""
         mode = (bool(self.fp8_forward), ops.GEMM_SCHED, self.GELU8)
         if ws.get("gelu8_mode") == mode:
             return ws["gelu8_cfg"]
         ws["gelu8_mode"] = mode
         P, H, FF = self.params, ws["H"], ws["FF"]
         cfg, wt = None, P.pbT.get(ln.fw)
-        if self.GELU8 and u is not None and wt is not None and not self.fp8_forward and Mp % 256 == 0:
-            c1 = ops.gemm(n2, P.wb(ln.iw, n_elems=FF * H, shape=(FF, H)), act, Mp, FF, H, H, H, FF, 0, 0, ops.EPI_BF16_GELU,
-                          m_valid=M, bias=P.w(ln.ib), out2=u, aux_u8=True, plan_only=True)
+        if self.GELU8 and u is not None and wt is not None and Mp % 256 == 0:
+            if self.fp8_forward:
+                c1 = (ops.gemm_mxfp8(n2, n2, n2, n2, act, Mp, FF, H, FF, ops.EPI_BF16_GELU, m_valid=M, bias=P.w(ln.ib), out2=u,
+                                     aux_u8=True, plan_only=True) if ln.iw in self._w8 else -1)
+            else:
+                c1 = ops.gemm(n2, P.wb(ln.iw, n_elems=FF * H, shape=(FF, H)), act, Mp, FF, H, H, H, FF, 0, 0,
+                              ops.EPI_BF16_GELU, m_valid=M, bias=P.w(ln.ib), out2=u, aux_u8=True, plan_only=True)
             c2 = ops.gemm(n2, wt, act, Mp, FF, H, H, H, FF, 0, 0, ops.EPI_BF16_DGELU, m_valid=M, aux=u,
                           colsum=P.gr(ln.ib), aux_u8=True, plan_only=True)
             if c1 in (5, 6) and c1 == c2:
@@ -291,20 +295,25 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
         (tools/attn_bench.py, B = 256: backward 201-206 -> 188 us, LM shape 31 -> 28).  Needs every producer / consumer on a
         kernel that serves the layout - QKV forward on the 8-wave kernel (out_hm), QKV data gradient on the ring kernel (a_hm),
         weight gradients through the grouped ring launches (dy_hm), the single-pass attention backward (S <= 192) - which the
-        library is asked about once per workspace (vault_gemm_plan); small batches, the precise and fp8-forward modes and the
-        stage-level calls keep the row-major layout."""
+        library is asked about once per workspace (vault_gemm_plan / vault_gemm_mxfp8_plan); small batches, the precise mode and
+        the stage-level calls keep the row-major layout."""
         mode = (bool(self.fp8_forward), ops.GEMM_SCHED, bool(pr), bool(train), self.HEAD_MAJOR)
         if ws.get(key + "_mode") == mode:
             return ws[key]
         ws[key + "_mode"] = mode
         P, H, FF = self.params, ws["H"], ws["FF"]
         hm = 0
-        if (self.HEAD_MAJOR and not pr and not self.fp8_forward and S <= 192 and rows_pad % 256 == 0 and H % 256 == 0 and FF % 256 == 0
+        if (self.HEAD_MAJOR and not pr and S <= 192 and rows_pad % 256 == 0 and H % 256 == 0 and FF % 256 == 0
                 and self.HEAD_MAJOR_MIN_ROWS <= rows_pad <= self.WGRAD_BATCH_MAX_ROWS):
             w = P.wb(wname, n_elems=3 * H * H, shape=(3 * H, H))
             # (plan only: the pointers are not dereferenced, but must not be null)
-            c1 = ops.gemm(a16, w, a16, rows_pad, 3 * H, H, H, H, 3 * H, 0, 0, ops.EPI_BF16, m_valid=rows,
-                          bias=P.w(wname.replace("weight", "bias"), n_elems=3 * H, shape=(3 * H,)), out_hm=rows_pad, plan_only=True)
+            qb = P.w(wname.replace("weight", "bias"), n_elems=3 * H, shape=(3 * H,))
+            if self.fp8_forward:
+                c1 = (ops.gemm_mxfp8(a16, a16, a16, a16, a16, rows_pad, 3 * H, H, 3 * H, ops.EPI_BF16, m_valid=rows, bias=qb,
+                                     out_hm=rows_pad, plan_only=True) if wname in self._w8 else -1)
+            else:
+                c1 = ops.gemm(a16, w, a16, rows_pad, 3 * H, H, H, H, 3 * H, 0, 0, ops.EPI_BF16, m_valid=rows, bias=qb,
+                              out_hm=rows_pad, plan_only=True)
             ok = c1 in (5, 6)
             if ok and train:
                 c2 = ops.gemm(a16, w, a16, rows_pad, H, 3 * H, 3 * H, H, H, 0, 1, ops.EPI_BF16, m_valid=rows, a_hm=rows_pad,

@@ -241,13 +241,19 @@ def quant_mxfp8(src_bf16, rows, K, ld, dst_q, dst_scale):
 
 
 def gemm_mxfp8(Aq, As, Bq, Bs, out, M, N, K, ldo, epi, *, m_valid=0, bias=None, res=None, out2=None,
-               drop: Drop = NO_DROP):
-    """out = epilogue(A . B^T) on MXFP8 operands (forward Linear layers of the fp8-forward configuration)."""
+               drop: Drop = NO_DROP, cfg=-1, aux_u8=False, out_hm=0, plan_only=False):
+    """out = epilogue(A . B^T) on MXFP8 operands (forward Linear layers of the fp8-forward configuration).  ``cfg``: -1 = the
+    8-wave kernel's MXFP8 form where it takes the call (else the simple kernel), 0 = the simple kernel, 5 / 6 = the 8-wave form
+    with 256- / 192-wide tiles; ``aux_u8`` (8-bit gelu' in tile order) and ``out_hm`` (head-major output) as ``gemm``: 8-wave
+    form only."""
     a = L.GemmArgs()
     a.A, a.B, a.out, a.out2 = _p(Aq), _p(Bq), _p(out), _p(out2)
     a.bias, a.res = _p(bias), _p(res)
     a.M, a.N, a.K, a.lda, a.ldb, a.ldo, a.m_valid = M, N, K, K, K, ldo, m_valid
-    a.a_mode, a.b_mode, a.epi, a.cfg, a.splits, a.accumulate = 0, 0, epi, -1, 1, 0
+    a.a_mode, a.b_mode, a.epi, a.cfg, a.splits, a.accumulate = 0, 0, epi, cfg, 1, 0
+    a.aux_u8, a.out_hm = int(bool(aux_u8)), int(out_hm)
+    if plan_only:      # the kernel these arguments would run on (vault_gemm_mxfp8_plan): 0, 5, 6, or -EINVAL
+        return int(L.load(_FMT.get()).vault_gemm_mxfp8_plan(C.byref(a)))
     a.persist = GEMM_SCHED
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
     _invoke("vault_gemm_mxfp8", C.byref(a), C.c_void_p(_p(As)), C.c_void_p(_p(Bs)), _stream(), struct=a, drop=drop)
