@@ -80,6 +80,9 @@ typedef struct vault_gemm_args {
                   of [M][ldo] (R >= M rows per plane): the layout vault_attention_* reads with qkv_hm = R */
   int a_hm;    /* ABI 8, ring kernel (cfg 3 / 4 / 8), a_mode 0: R > 0 = A is head-major [K / 64][R][64] (lda is ignored): the QKV
                   data gradient reading the attention backward's dqkv */
+  void* out_q; void* out_scale;   /* ABI 10, vault_gemm_mxfp8 on kernel 5 with epi 1 only (both or neither): also write the
+                  MXFP8 image of the 16-bit output - e4m3 [M][N] + E8M0 [M][N / 32], byte for byte what vault_quant_mxfp8 makes
+                  of `out` - the A operand of the next vault_gemm_mxfp8 (FFN-in's GELU output feeding FFN-out) */
 } vault_gemm_args;
 int vault_gemm(const vault_gemm_args* args, void* stream);
 /* the kernel / tile configuration vault_gemm would run these arguments on (the resolved `cfg`, 0..8), or -EINVAL */

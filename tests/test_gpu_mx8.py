@@ -178,6 +178,40 @@ def test_8wave_form_exact_on_integer_data():
         assert torch.equal(out.cpu(), ref.float().bfloat16()), cfg
 
 
+@pytest.mark.parametrize("u8", [False, True])
+def test_gelu_epilogue_emits_the_mxfp8_image_of_its_output(u8):
+    """vault_gemm_args.out_q / out_scale (FFN-in feeding FFN-out): byte for byte what vault_quant_mxfp8 makes of the 16-bit
+    output, beside either form of gelu'; the 16-bit output itself is unchanged by the request."""
+    from vault_amd import ops
+    M, N, K = 1280, 3072, 768
+    g = torch.Generator().manual_seed(21 + u8)
+    x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    q_a, s_a = _quant_gpu(x)
+    q_w, s_w = _quant_gpu(w)
+    bias = torch.randn(N, generator=g).cuda()
+    m_valid = M - 5
+    def run(emit):
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        out2 = torch.zeros(M * N, dtype=torch.uint8, device="cuda") if u8 else torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        oq = torch.zeros(M, N, dtype=torch.uint8, device="cuda"); osc = torch.zeros(M, N // 32, dtype=torch.uint8, device="cuda")
+        kw = dict(out_q=oq, out_scale=osc) if emit else {}
+        ops.gemm_mxfp8(q_a, s_a, q_w, s_w, out, M, N, K, N, EPI_GELU, bias=bias, out2=out2, m_valid=m_valid, cfg=5, aux_u8=u8, **kw)
+        torch.cuda.synchronize()
+        return out, out2, oq, osc
+    o0, u0, _, _ = run(False)
+    o1, u1, oq, osc = run(True)
+    assert torch.equal(o0, o1) and torch.equal(u0, u1)
+    q2, s2 = _quant_gpu(o1)
+    assert torch.equal(osc[:m_valid], s2[:m_valid])
+    assert torch.equal(oq[:m_valid], q2[:m_valid])
+    assert oq[m_valid:].abs().max().item() == 0 and osc[m_valid:].abs().max().item() == 0
+    with pytest.raises(RuntimeError):      # 192-wide tiles: a block of 32 columns is not one lane quad
+        ops.gemm_mxfp8(q_a, s_a, q_w, s_w, o1, M, N, K, N, EPI_GELU, bias=bias, out2=u1, cfg=6, aux_u8=u8, out_q=oq, out_scale=osc)
+    with pytest.raises(RuntimeError):      # both pointers or neither
+        ops.gemm_mxfp8(q_a, s_a, q_w, s_w, o1, M, N, K, N, EPI_GELU, bias=bias, out2=u1, cfg=5, aux_u8=u8, out_q=oq)
+
+
 def test_rejects_what_the_kernel_cannot_do():
     from vault_amd import lib as L, ops
     q = torch.zeros(256, 128, dtype=torch.uint8, device="cuda")
@@ -238,7 +272,8 @@ def test_engine_fp8_forward_tracks_the_bf16_path_and_backward_stays_bf16():
     assert 0.8 < float(g8.norm() / g16.norm()) < 1.25
 
 
-def test_engine_fp8_forward_full_size_against_reference_golden():
+@pytest.mark.parametrize("ffn_out", [False, True])
+def test_engine_fp8_forward_full_size_against_reference_golden(ffn_out):
     """ViLT-B32 + bertweet-base shapes, B = 2, eval: against the fp32 reference golden with the tolerance the format
     allows (logits of this random-weight model are O(0.1): absolute bound)."""
     import os
@@ -248,10 +283,11 @@ def test_engine_fp8_forward_full_size_against_reference_golden():
     spec = VaultSpec(vilt=ViltSpec(), lm=LMSpec.bertweet_base(), n_classes=3)
     bn = synthetic_batch(spec, int(g["meta_batch"]), seed=int(g["meta_data_seed"]), n_classes=3)
     eng = VaultEngine(spec, "cuda:0", seed=0, classifier_dropout=0.0, fp8_forward=True, with_grads=False, half="bf16")
+    eng.FFN_OUT_FP8 = ffn_out      # (measured slower in the step and off by default: engine._fp8_refresh_weights)
     db = {k: torch.from_numpy(v).cuda() for k, v in bn.items()}
     out = eng.forward(db, train=False, need_hidden=True)
     torch.cuda.synchronize()
-    assert len(eng._w8) == 2 * 24          # QKV and FFN-in of the 12 + 12 layers
+    assert len(eng._w8) == (3 if ffn_out else 2) * 24          # QKV, FFN-in (and FFN-out) of the 12 + 12 layers
     assert np.abs(out["logits"].cpu().numpy() - g["logits"]).max() < 6e-2
     T = bn["input_ids"].shape[1]
     h = out["last_hidden_state"][:, : T + 1].cpu().numpy()

@@ -678,3 +678,19 @@ def test_every_environment_switch_of_the_product_is_named_by_a_test():
     assert read, "the scan found no switch at all: the patterns are stale"
     missing = sorted(v for v in read if v not in tests)
     assert not missing, missing
+
+
+def test_isa_check_finds_an_unpadded_sgpr_reload_in_front_of_vmem():
+    """vault_amd/isa_check.py (run by the build over every kernel file): a v_readlane_b32 into the SGPR base of a vector-memory
+    instruction needs 5 wait states in between; hipcc does not provide them in front of inline asm."""
+    from vault_amd.isa_check import sgpr_vmem_hazards
+    def kern(name, mid):
+        return (f"{name}:\n\ts_load_dwordx2 s[0:1], s[4:5], 0x0\n\tv_readlane_b32 s66, v114, 28\n\tv_readlane_b32 s67, v114, 29\n"
+                + mid + "\tglobal_load_dwordx4 v[52:55], v40, s[66:67]\n\ts_endpgm\n.Lfunc_end0:\n")
+    bad = kern("_Z3badv", "")
+    padded = kern("_Z6paddedv", "\ts_nop 4\n")
+    far = kern("_Z3farv", "".join(f"\tv_mov_b32_e32 v{i}, 0\n" for i in range(5)))
+    other = kern("_Z5otherv", "").replace("s[66:67]", "s[10:11]")
+    found = sgpr_vmem_hazards(bad + padded + far + other)
+    assert len(found) == 1 and found[0].startswith("_Z3badv") and "0 wait states" in found[0]
+    assert sgpr_vmem_hazards(bad, "padded") == []

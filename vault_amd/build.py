@@ -12,6 +12,8 @@ import os
 import subprocess
 import sys
 
+from .isa_check import sgpr_vmem_hazards
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libvault_hip.so")
@@ -34,6 +36,7 @@ def _digest(path: str, extra=()) -> str:
         p = os.path.join(CSRC, f)
         if os.path.isfile(p) and (f.endswith(".h") or os.path.abspath(p) == os.path.abspath(path)):
             h.update(open(p, "rb").read())
+    h.update(open(os.path.join(HERE, "isa_check.py"), "rb").read())
     h.update(" ".join(FLAGS + list(extra)).encode())
     return h.hexdigest()
 
@@ -46,10 +49,21 @@ def _compile(job) -> str:
     dg = _digest(path, extra)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dg:
         return obj
-    cmd = [HIPCC, *FLAGS, *extra, "-c", path, "-o", obj]
+    # -save-temps=obj: the device ISA text falls out beside the object - checked for the hazard hipcc does not pad inside
+    # inline asm (isa_check.py), then the intermediate files are removed
+    cmd = [HIPCC, *FLAGS, *extra, "-save-temps=obj", "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    stem = src[:-4]
+    isa = os.path.join(objdir, f"{stem}-hip-amdgcn-amd-amdhsa-gfx950.s")
+    found = sgpr_vmem_hazards(open(isa).read())
+    for f in os.listdir(objdir):
+        if f.startswith(stem + "-h") or f.startswith(stem + ".hip-"):
+            os.remove(os.path.join(objdir, f))
+    if found:
+        os.remove(obj)
+        raise RuntimeError(f"{src}: VALU-writes-SGPR -> VMEM hazard in front of an asm statement (isa_check.py):\n" + "\n".join(found))
     open(stamp, "w").write(dg)
     return obj
 

@@ -24,6 +24,7 @@ static GemmParams params_of(const vault_gemm_args* a) {
   p.batch = a->batch; p.batch_a = a->batch_a; p.batch_b = a->batch_b; p.batch_o = a->batch_o;
   p.aux_u8 = a->aux_u8;
   p.out_hm = a->out_hm; p.a_hm = a->a_hm;
+  p.out_q = a->out_q; p.out_scale = a->out_scale;
   return p;
 }
 

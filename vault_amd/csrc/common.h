@@ -153,6 +153,29 @@ __device__ __forceinline__ void gelu_fwd_f2(f32x2 x, f32x2& y, f32x2& dy) {
   dy = cdf + x * (e * 0.3989422804014327f);
 }
 
+// MXFP8 (OCP microscaling) quantisation of 8 consecutive elements of a 32-element block held by 4 lanes: `amax` is the block's
+// max |x| (already reduced over the four).  Shared exponent = floor(log2(amax)) - emax(e4m3 = 8), clamped to E8M0's range
+// (amax == 0 -> the smallest scale); elements round to nearest even and saturate at +-448.  Returns the 8 e4m3 bytes,
+// e8 = the block's E8M0 scale byte.
+__device__ __forceinline__ uint2 mx8_quant8(const float (&x)[8], float amax, int& e8) {
+  e8 = 0;
+  if (amax > 0.f) {
+    const int ex = (int)((__builtin_bit_cast(uint32_t, amax) >> 23) & 0xff);   // (16-bit inputs: never f32-subnormal unless 0)
+    e8 = ex - 8;
+    e8 = e8 < 0 ? 0 : (e8 > 254 ? 254 : e8);
+  }
+  const float inv = __builtin_bit_cast(float, (uint32_t)(254 - e8) << 23);   // 2^(127 - e8); e8 = 0 -> 2^127
+  float y[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) y[e] = fminf(fmaxf(x[e] * inv, -448.f), 448.f);
+  int w0 = 0, w1 = 0;
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], w0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], w0, true);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(y[4], y[5], w1, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(y[6], y[7], w1, true);
+  return uint2{(uint32_t)w0, (uint32_t)w1};
+}
+
 // counter-based keep/drop decision for dropout: a 32-bit mix of (seed, stream, element index).
 // The same function regenerates the mask in backward, so no mask tensor is stored.
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {

@@ -58,6 +58,11 @@ struct GemmParams {
   const uint8_t* a_scale;
   const uint8_t* b_scale;
   int lds_a, lds_b;
+  // MXFP8 image of the 16-bit output (8-wave kernel's MXFP8 form, 256-wide tiles, GELU epilogue): e4m3 bytes [M][N] + one E8M0 scale per 32
+  // consecutive columns [M][N / 32], quantised from the ROUNDED 16-bit values (= what vault_quant_mxfp8 makes of `out`) - the
+  // next forward Linear's A operand without a pass over `out`.  Null = off.
+  void* out_q;
+  void* out_scale;
   // Grouped weight gradients (ring kernel, (1,1) operand modes, EPI_F32_ATOMIC): ONE launch over up to three segments of
   // DIFFERENT weight-gradient kinds that share the contraction (the tokens) and therefore the cost per 256 x 256 tile: the
   // work list is their concatenation, so a launch can be sized to exactly one round of the 256 CUs (e.g. the 216 FFN-out

@@ -308,6 +308,7 @@ int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) 
   if (p.splits < 1) p.splits = 1;
   if (p.A == nullptr || p.B == nullptr || p.out == nullptr) return -VAULT_EINVAL;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -VAULT_EINVAL;
+  if (p.out_q != nullptr || p.out_scale != nullptr) return -VAULT_EINVAL;   // (the MXFP8 output image: vault_gemm_mxfp8 only)
   if ((p.lda & 7) || (p.ldb & 7) || (p.ldo & 7)) return -VAULT_EINVAL;
   if (p.batch > 1) {   // batched weight gradients: double-buffered kernel, atomic epilogue only
     if (epi != EPI_F32_ATOMIC || cfg == 4 || (p.batch_a & 7) || (p.batch_b & 7) || (p.batch_o & 3) ||

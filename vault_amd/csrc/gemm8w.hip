@@ -94,6 +94,12 @@ __device__ __forceinline__ float w8_row16_sum(float t) {
   return t;
 }
 
+// hipcc pads the "VALU writes an SGPR -> VMEM reads it" hazard (5 wait states on gfx9) for its own instructions only: an
+// asm load / store / atomic whose SGPR base hipcc has parked in a VGPR lane (register pressure) gets the v_readlane_b32 that
+// brings it back directly in front of it and then runs on a stale base (seen: garbage bias in the first two of four back-to-back
+// loads; tools/isa_hazard.py finds the pattern in hipcc's -S output).  The first VMEM statement of a group that may follow
+// such a reload starts with this pad; statements behind other asm statements of the same base are far enough.
+#define W8_SGPR_PAD "s_nop 4\n\t"
 #define W8_WAITBAR(N) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(N) : "memory")
 #define W8_LGKBAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // `s_waitcnt vmcnt(N)` with N a compile-time expression of an unrolled loop variable (0 .. 24)
@@ -307,14 +313,14 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
       // waits for it), held in registers across k-step 1 only
       if constexpr (F32OUT) {
         const uint32_t bo = (uint32_t)(n0 + wc * 16 * NTW + 4 * g) * 4u;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(bq[0]) : "v"(bo), "s"(p.bias));
+        asm volatile(W8_SGPR_PAD "global_load_dwordx4 %0, %1, %2" : "=&v"(bq[0]) : "v"(bo), "s"(p.bias));
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=&v"(bq[1]) : "v"(bo), "s"(p.bias));
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:128" : "=&v"(bq[2]) : "v"(bo), "s"(p.bias));
         if constexpr (NTW == 4) asm volatile("global_load_dwordx4 %0, %1, %2 offset:192" : "=&v"(bq[3]) : "v"(bo), "s"(p.bias));
       } else {
         const uint32_t bo = (uint32_t)(n0 + wc * 16 * NTW + 8 * g) * 4u;
         const uint32_t bo1 = bo + ((NTW == 4) ? 128u : (uint32_t)(128 - 16 * g));
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(bq[0]) : "v"(bo), "s"(p.bias));
+        asm volatile(W8_SGPR_PAD "global_load_dwordx4 %0, %1, %2" : "=&v"(bq[0]) : "v"(bo), "s"(p.bias));
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=&v"(bq[1]) : "v"(bo), "s"(p.bias));
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(bq[2]) : "v"(bo1), "s"(p.bias));
         if constexpr (NTW == 4) asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=&v"(bq[3]) : "v"(bo1), "s"(p.bias));
@@ -467,14 +473,14 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
                             // is read under a last tile), retired behind the loop by a wait that leaves this tile's pieces in flight
       if constexpr (F32OUT) {
         const uint32_t bo = (uint32_t)(n0 + wc * 16 * NTW + 4 * g) * 4u;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(bq[0]) : "v"(bo), "s"(p.bias));
+        asm volatile(W8_SGPR_PAD "global_load_dwordx4 %0, %1, %2" : "=&v"(bq[0]) : "v"(bo), "s"(p.bias));
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=&v"(bq[1]) : "v"(bo), "s"(p.bias));
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:128" : "=&v"(bq[2]) : "v"(bo), "s"(p.bias));
         if constexpr (NTW == 4) asm volatile("global_load_dwordx4 %0, %1, %2 offset:192" : "=&v"(bq[3]) : "v"(bo), "s"(p.bias));
       } else {
         const uint32_t bo = (uint32_t)(n0 + wc * 16 * NTW + 8 * g) * 4u;
         const uint32_t bo1 = bo + ((NTW == 4) ? 128u : (uint32_t)(128 - 16 * g));
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(bq[0]) : "v"(bo), "s"(p.bias));
+        asm volatile(W8_SGPR_PAD "global_load_dwordx4 %0, %1, %2" : "=&v"(bq[0]) : "v"(bo), "s"(p.bias));
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=&v"(bq[1]) : "v"(bo), "s"(p.bias));
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(bq[2]) : "v"(bo1), "s"(p.bias));
         if constexpr (NTW == 4) asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=&v"(bq[3]) : "v"(bo1), "s"(p.bias));
@@ -614,6 +620,13 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
       // 8-bit gelu' slots of this wave's tile: uniform base + lane * 16 (+ 1024 mt)
       const char* u8p = (GELU2 ? out2p : auxp) + ((size_t)((m0 >> 8) * tiles_n + n0 / BN) * 8 + wave) * 8192;
       const uint32_t voff8 = (uint32_t)eln * 16u;
+      // MXFP8 image of the output (MX form, 256-wide tiles): the lanes g = 0..3 of a row hold the 32 consecutive columns of
+      // one block (8 each); element offset of unit 0 of row tile 0, and of its scale byte
+      constexpr bool QOUT = MX && NTW == 4 && (GELU2 || EPI == EPI_BF16_GELU_INF);   // (the plain form has no registers for it)
+      const char* oqp = QOUT ? reinterpret_cast<const char*>(p.out_q) : nullptr;
+      const char* osp = reinterpret_cast<const char*>(p.out_scale);
+      const uint32_t offq = (uint32_t)(mw + el15) * (uint32_t)p.N + (uint32_t)nc;
+      const uint32_t offs = (uint32_t)(mw + el15) * (uint32_t)(p.N >> 5) + (uint32_t)((n0 + wc * 16 * NTW) >> 5);
       auto run = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         const char* const o1_ = outp;     // (named here: an asm operand alone does not capture in a generic lambda)
@@ -621,6 +634,8 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
         const char* const ax_ = auxp;
         const char* const u8_ = u8p;
         const uint32_t v8_ = voff8;
+        const char* const oq_ = oqp;
+        const char* const os_ = osp;
         uint32_t q8a = 0u, q8b = 0u;      // 8-bit gelu' of unit 0, held until unit 1 completes the slot
         u32x4 wv0 = {0u, 0u, 0u, 0u};     // WL: unit 0 of the row tile, held until unit 1 is packed
         u32x4 a8q[(HAS_AUX && U8) ? PDM : 1];
@@ -747,6 +762,34 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
           }
           const u32x4 wv = {pack_h16x2(v[0], v[1]), pack_h16x2(v[2], v[3]), pack_h16x2(v[4], v[5]),
                             pack_h16x2(v[6], v[7])};
+          if constexpr (QOUT) {
+            if (oq_ != nullptr) {   // uniform
+              float xq[8];
+              float amax = 0.f;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { xq[e] = (float)(h16)v[e]; amax = fmaxf(amax, fabsf(xq[e])); }
+              // max over the lanes g = 0..3 of the row (lane = 16 g + l15): the row pairs, then the wave halves
+              {
+                const uint32_t ab = __builtin_bit_cast(uint32_t, amax);
+                const auto s16 = __builtin_amdgcn_permlane16_swap(ab, ab, false, false);
+                amax = fmaxf(__builtin_bit_cast(float, (uint32_t)s16[0]), __builtin_bit_cast(float, (uint32_t)s16[1]));
+                const uint32_t ab2 = __builtin_bit_cast(uint32_t, amax);
+                const auto s32 = __builtin_amdgcn_permlane32_swap(ab2, ab2, false, false);
+                amax = fmaxf(__builtin_bit_cast(float, (uint32_t)s32[0]), __builtin_bit_cast(float, (uint32_t)s32[1]));
+              }
+              int e8;
+              const uint2 q2 = mx8_quant8(xq, amax, e8);
+              if (FULL || m < p.m_valid) {
+                const u32x2 qv = {q2.x, q2.y};
+                const uint32_t oq = offq + (uint32_t)mt * (16u * (uint32_t)p.N) + (j ? 32u : 0u);
+                asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(oq), "v"(qv), "s"(oq_) : "memory");
+                if (eg == 0) {
+                  const uint32_t osv = offs + (uint32_t)mt * (16u * (uint32_t)(p.N >> 5)) + (uint32_t)j;
+                  asm volatile("global_store_byte %0, %1, %2\n\ts_nop 1" ::"v"(osv), "v"(e8), "s"(os_) : "memory");
+                }
+              }
+            }
+          }
           if constexpr (WL) {
             if (j == 0) {
               wv0 = wv;
@@ -802,7 +845,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
       };
       if (full) run(std::true_type{}); else run(std::false_type{});
       // stores (+ gelu' loads) of a fully valid wave tile
-      extra = full ? (U8 ? 24 : (16 * SU + (HAS_AUX ? 16 : 0))) : 0;
+      extra = full ? (U8 ? 24 : (16 * SU + (HAS_AUX ? 16 : 0))) + ((QOUT && oqp != nullptr) ? 32 : 0) : 0;
       if (HAS_CSUM && p.colsum != nullptr) {   // uniform: bias gradient = column sums of the stored values
         // fold the 16 lanes (rows) of each column group (DPP: no LDS traffic, no index registers)
 #pragma unroll
@@ -815,7 +858,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
         for (int e = 1; e < 8 + NV1; ++e) sel = (el15 == e) ? csum[e] : sel;
         if (el15 < 8 + NV1) {
           const uint32_t co = (uint32_t)nc * 4u + (el15 < 8 ? (uint32_t)el15 * 4u : 2u * c1 + (uint32_t)(el15 - 8) * 4u);
-          asm volatile("global_atomic_add_f32 %0, %1, %2\n\ts_nop 1" ::"v"(co), "v"(sel), "s"(p.colsum) : "memory");
+          asm volatile(W8_SGPR_PAD "global_atomic_add_f32 %0, %1, %2\n\ts_nop 1" ::"v"(co), "v"(sel), "s"(p.colsum) : "memory");
         }
       }
     } else {
@@ -961,7 +1004,7 @@ int dispatch8w(const GemmParams& p, int epi, hipStream_t st) {
 // the shapes / epilogues this kernel takes (else the caller falls back to the ring / double-buffered kernels);
 // ntw = 4: 256-wide tiles, 3: 192-wide
 bool vault_gemm8w_supports(const GemmParams& p, int a_mode, int b_mode, int epi, int ntw) {
-  if (a_mode != 0 || b_mode != 0) return false;
+  if (a_mode != 0 || b_mode != 0 || p.out_q != nullptr || p.out_scale != nullptr) return false;
   if ((p.M & 255) || (p.N % (64 * ntw)) || (p.K & 63) || p.K < 128 || p.splits > 1 || p.split3 || p.batch > 1) return false;
   if ((long long)p.M * p.ldo * 4 >= (1ll << 32) || p.m_valid < 1) return false;
   if (p.bias == nullptr && p.N > 8192) return false;   // (W8_ZERO_BIAS)   // 32-bit byte offsets in the epilogue
@@ -984,6 +1027,9 @@ bool vault_gemm8w_mx_supports(const GemmParams& p, int epi, int ntw) {
   if (p.out_hm && !(epi == EPI_BF16 && p.out_hm >= p.M && p.N % 64 == 0 &&
                     (long long)(p.N / 64) * p.out_hm * 128 < (1ll << 32)))
     return false;
+  // the MXFP8 image of the output: 256-wide tiles (the four lanes g of a row = one block of 32 columns), GELU epilogues
+  if ((p.out_q == nullptr) != (p.out_scale == nullptr)) return false;
+  if (p.out_q != nullptr && (ntw != 4 || epi != EPI_BF16_GELU || (long long)p.M * p.N >= (1ll << 32))) return false;
   if (epi == EPI_F32_RES) return p.res != nullptr && p.drop_thresh == 0u && p.colsum == nullptr;
   if (epi == EPI_BF16_GELU) return p.colsum == nullptr;
   return epi == EPI_BF16 && p.colsum == nullptr;

@@ -157,13 +157,7 @@ int launch_mx8(const GemmParams& p, const uint8_t* a_scale, const uint8_t* b_sca
   return (int)hipGetLastError();
 }
 
-// ---- quantiser: 4 lanes share a block of 32 (8 elements = 16 bytes of bf16 each)
-__device__ __forceinline__ uint32_t cvt4_e4m3(float a, float b, float c, float d) {
-  int w = 0;
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-  return (uint32_t)w;
-}
+// ---- quantiser: 4 lanes share a block of 32 (8 elements = 16 bytes of bf16 each); the arithmetic is common.h mx8_quant8
 
 __global__ __launch_bounds__(256) void quant_mx8_kernel(const h16* __restrict__ src, int64_t rows, int K, int ld,
                                                         uint8_t* __restrict__ q, uint8_t* __restrict__ scale) {
@@ -178,19 +172,8 @@ __global__ __launch_bounds__(256) void quant_mx8_kernel(const h16* __restrict__ 
     for (int e = 0; e < 8; ++e) { x[e] = (float)v[e]; amax = fmaxf(amax, fabsf(x[e])); }
     amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
     amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-    // OCP MX: shared exponent = floor(log2(amax)) - emax(e4m3 = 8), clamped to E8M0's range; amax == 0 or
-    // subnormal-small -> the smallest scale.  Elements saturate at +-448.
-    int e8 = 0;
-    if (amax > 0.f) {
-      const int ex = (int)((__builtin_bit_cast(uint32_t, amax) >> 23) & 0xff);   // biased exponent of amax (bf16 input: never f32-subnormal unless 0)
-      e8 = ex - 8;
-      e8 = e8 < 0 ? 0 : (e8 > 254 ? 254 : e8);
-    }
-    const float inv = __builtin_bit_cast(float, (uint32_t)(254 - e8) << 23);   // 2^(127 - e8); e8 = 0 -> 2^127
-    float y[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) y[e] = fminf(fmaxf(x[e] * inv, -448.f), 448.f);
-    uint2 w = {cvt4_e4m3(y[0], y[1], y[2], y[3]), cvt4_e4m3(y[4], y[5], y[6], y[7])};
+    int e8;
+    const uint2 w = mx8_quant8(x, amax, e8);
     *reinterpret_cast<uint2*>(q + row * K + c8 * 8) = w;
     if ((c8 & 3) == 0) scale[row * (K / 32) + (c8 >> 2)] = (uint8_t)e8;
   }
@@ -231,7 +214,7 @@ int vault_gemm_mx8_resolve(const GemmParams& p, const void* a_scale, const void*
     if (vault_gemm8w_mx_supports(q, epi, ntw)) return ntw == 4 ? 5 : 6;
     if (cfg > 0) return -VAULT_EINVAL;
   }
-  if (p.aux_u8 || p.out_hm) return -VAULT_EINVAL;   // (8-wave form only)
+  if (p.aux_u8 || p.out_hm || p.out_q != nullptr) return -VAULT_EINVAL;   // (8-wave form only)
   if (p.M % 256 || p.N % 256 || p.K % BKB) return -VAULT_EINVAL;
   if (epi != EPI_BF16 && epi != EPI_BF16_GELU && epi != EPI_F32_RES) return -VAULT_EINVAL;
   return 0;

@@ -201,24 +201,37 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
         return self._ws[key]
 
     def _fp8_refresh_weights(self):
-        """MXFP8 shadow of the encoder Linear weights, re-quantised from the bf16 shadow (a launch per weight: on
-        the tape of a train step, so every step sees the weights the optimizer just wrote)."""
+        """MXFP8 shadow of the encoder Linear weights, re-quantised from the bf16 shadow on the tape of a train step (every step
+        sees the weights the optimizer just wrote): ONE launch per encoder stack over its contiguous range of the flat shadow
+        (parameter offsets and sizes are multiples of 64 elements, so a block of 32 never straddles two tensors; the biases,
+        LayerNorm vectors and the Linears that stay bf16 in between are quantised along and never read: 2 launches of ~45 us
+        instead of 48 of 4.7 us)."""
         P = self.params
-        for ln in self.ll + self.vl:
-            # the two Linears fed by a LayerNorm (K = H): measured at M = 47360 (tools/mx8_bench.py), quantise + MXFP8
-            # GEMM 133 / 246 us against 192 / 336 us in bf16; attention-out is bound by its fp32 epilogue either way and
-            # FFN-out would pay 85 us to quantise its [M, 4H] operand (until the GELU epilogue emits MXFP8 itself)
-            for wname in (ln.qw, ln.iw):
-                o, shp = P.offsets[wname]
-                N = 3 * shp[0] if wname == ln.qw else shp[0]     # fused QKV: three [H, H] blocks stored back to back
-                K = shp[1]
-                if N % 256 or K % 128:
-                    continue
-                if wname not in self._w8:
-                    self._w8[wname] = (torch.empty(N * K, dtype=torch.uint8, device=self.device),
-                                       torch.empty(N * (K // 32), dtype=torch.uint8, device=self.device))
-                wq, wsc = self._w8[wname]
-                ops.quant_mxfp8(P.wb(wname, n_elems=N * K, shape=(N, K)), N, K, K, wq, wsc)
+        if "fp8_flat" not in self._ws:
+            self._ws["fp8_flat"] = (torch.empty(P.n_total, dtype=torch.uint8, device=self.device),
+                                    torch.empty(P.n_total // 32, dtype=torch.uint8, device=self.device))
+        pq, psc = self._ws["fp8_flat"]
+        for stack in (self.ll, self.vl):
+            # The two Linears fed by a LayerNorm (K = H), which writes the MXFP8 image of its output itself.  FFN_OUT_FP8: also
+            # FFN-out, on the image the FFN-in GEMM's GELU epilogue writes (vault_gemm_args.out_q) - measured in the step at
+            # B = 256 and NOT taken (profiles/r05_dev_fp8_8wave_form.txt): the ViLT FFN-out gains 12 us (228 against 240: its f32
+            # residual epilogue and 24 K tiles leave little to halve), the image costs the FFN-in epilogue 20 us, the LM stack's
+            # FFN-out (dropout: simple kernel) loses 22 us.  Attention-out is bound by its f32 residual epilogue either way
+            # (tools/mx8_bench.py: 102 against 101 us) and its operand would need a pass of its own.
+            spans = []
+            for ln in stack:
+                for wname in ((ln.qw, ln.iw, ln.fw) if self.FFN_OUT_FP8 else (ln.qw, ln.iw)):
+                    o, shp = P.offsets[wname]
+                    N = 3 * shp[0] if wname == ln.qw else shp[0]     # fused QKV: three [H, H] blocks stored back to back
+                    K = shp[1]
+                    if N % 256 or K % 128:
+                        continue
+                    spans.append((o, o + N * K))
+                    if wname not in self._w8:
+                        self._w8[wname] = (pq[o:o + N * K], psc[o // 32:(o + N * K) // 32])
+            if spans:
+                lo, hi = min(a for a, _ in spans), max(b for _, b in spans)
+                ops.quant_mxfp8(P.pb[lo:], (hi - lo) // 64, 64, 64, pq[lo:], psc[lo // 32:])
 
     @staticmethod
     def _keep_hi(split3: torch.Tensor, plain: torch.Tensor, K: int):
@@ -227,20 +240,34 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
         ops.pycall(lambda: plain.copy_(split3[:, :K]))
 
     def _linear(self, a_bf16, wname, out, M, N, K, epi, m_valid, bias=None, precise=False, ldo=None, prequant=False,
-                **kw):
+                emit_q=False, **kw):
         """out = epilogue(A . W^T).  ``precise``: A is a [M, 3K] = [hi | lo | hi] split-bf16 operand and the
-        weight its [N, 3K] = [hi | hi | lo] counterpart: the same kernel over a 3x longer contraction."""
+        weight its [N, 3K] = [hi | hi | lo] counterpart: the same kernel over a 3x longer contraction.
+        fp8-forward mode: ``prequant`` - the MXFP8 image of A already lies in the (M, K) scratch (False for a Linear whose
+        producer could not write it: that Linear then runs on bf16 operands unless ``prequant`` is None = quantise here);
+        ``emit_q`` - this GEMM's epilogue also writes the MXFP8 image of its 16-bit output into the (M, N) scratch when the
+        kernel can (asked from the library); returns whether it did."""
         P = self.params
         if precise:
             ops.gemm(a_bf16, P.wb3(wname, N, K), out, M, N, 3 * K, 3 * K, 3 * K, N if ldo is None else ldo, 0, 0, epi,
                      m_valid=m_valid, bias=bias, **kw)
-        elif self.fp8_forward and wname in self._w8 and M % 256 == 0:
+        elif self.fp8_forward and wname in self._w8 and M % 256 == 0 and prequant is not False:
             wq, wsc = self._w8[wname]
             aq, asc = self._fp8_scratch(M, K)
-            if not prequant:          # (the LayerNorm in front wrote the MXFP8 image of its bf16 output itself)
+            if prequant is None:      # (no producer wrote the image)
                 ops.quant_mxfp8(a_bf16, M, K, K, aq, asc)
             kw.pop("split3", None)    # (precise mode only)
+            if emit_q:
+                oq, osc = self._fp8_scratch(M, N)
+                key = ("emit_q", M, N, K, epi, kw.get("cfg", -1), bool(kw.get("aux_u8")))
+                if key not in self._ws:
+                    self._ws[key] = ops.gemm_mxfp8(aq, asc, wq, wsc, out, M, N, K, N, epi, m_valid=m_valid, bias=bias, out_q=oq,
+                                                   out_scale=osc, plan_only=True, **{k: v for k, v in kw.items() if k != "drop"}) == 5
+                emit_q = self._ws[key]
+                if emit_q:
+                    kw.update(out_q=oq, out_scale=osc)
             ops.gemm_mxfp8(aq, asc, wq, wsc, out, M, N, K, N, epi, m_valid=m_valid, bias=bias, **kw)
+            return emit_q
         else:
             ops.gemm(a_bf16, P.wb(wname, n_elems=N * K, shape=(N, K)), out, M, N, K, K, K, N if ldo is None else ldo,
                      0, 0, epi, m_valid=m_valid, bias=bias, **kw)
@@ -257,6 +284,7 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
                  epi, m_valid=m_valid, **kw)
 
 
+    FFN_OUT_FP8 = False            # fp8-forward mode: FFN-out on MXFP8 operands too (see _fp8_refresh_weights: measured, slower)
     HEAD_MAJOR = True              # qkv / dqkv of large batches in the head-major layout [3][heads][rows][64] (see _plan_head_major)
     HEAD_MAJOR_MIN_ROWS = 16384    # ... from this many (padded) token rows of a stack
     WGRAD_SIDE_ITEMS = 224         # items per grouped launch on the second stream (B = 64, same box: 256: 13.50 / 13.59 ms, 224: 13.32 / 13.46, 192: 13.23 / 13.47, 160: 13.63 / 13.53)
@@ -480,8 +508,8 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
                 # (the epilogue addresses gelu' with the row stride of its main output: in the split form a [rows, 3 FF] buffer
                 #  whose first third is written)
                 u_out = buf(f"lm_u{sfx}_3", (Mlp, W3 * FF), bf) if (pt and u is not None) else u
-                self._linear(y1b, ln.iw, act, Mlp, FF, H, ops.EPI_BF16_GELU, Ml, bias=P.w(ln.ib), out2=u_out, precise=pr,
-                             split3=pr, ldo=W3 * FF, prequant=q8l[0] is not None)
+                actq = self._linear(y1b, ln.iw, act, Mlp, FF, H, ops.EPI_BF16_GELU, Ml, bias=P.w(ln.ib), out2=u_out, precise=pr,
+                                    split3=pr, ldo=W3 * FF, prequant=q8l[0] is not None or None, emit_q=self.FFN_OUT_FP8)
                 if pt:
                     self._keep_hi(act, buf(f"lm_act{sfx}", (Mlp, FF), bf), FF)
                     if u is not None:
@@ -489,7 +517,7 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
                 fl_l = 2.0 * Ml * FF * H * W3
                 ops.pycall(lambda: self._prof_end("ffn1", fl_l))
                 self._linear(act, ln.fw, h2, Mlp, H, FF, ops.EPI_F32_RES, Ml, bias=P.w(ln.fb), res=y1,
-                             drop=self._drop(pdh, 16 * i + 4, lm_train), precise=pr)
+                             drop=self._drop(pdh, 16 * i + 4, lm_train), precise=pr, prequant=bool(actq))
                 ops.layernorm_fwd(h2, P.w(ln.ln2w), P.w(ln.ln2b), lm.layer_norm_eps, Ml, H, y_f32=y[i + 1],
                                   y_bf16=(ybs[i + 1] if pt else None) if pr else yb[i + 1], y_split3=yb[i + 1] if pr else None,
                                   mean=buf(f"lm_m2{sfx}", (Mlp,)), rstd=buf(f"lm_r2{sfx}", (Mlp,)),
@@ -609,15 +637,16 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
             ws["gelu8_active"] = g8     # what THIS forward stored in `u` (8-bit tile image or plain 16-bit): backward reads this
             g8kw = dict(cfg=g8, aux_u8=True) if g8 is not None else {}
             u_out = buf(f"u{sfx}_3", (Mp, W3 * FF), bf) if (pt and u is not None) else u      # (row stride of the main output)
-            self._linear(n2, ln.iw, act, Mp, FF, H, ops.EPI_BF16_GELU, M, bias=P.w(ln.ib), out2=u_out, precise=pr,
-                         split3=pr, ldo=W3 * FF, prequant=q8[0] is not None, **g8kw)
+            actq = self._linear(n2, ln.iw, act, Mp, FF, H, ops.EPI_BF16_GELU, M, bias=P.w(ln.ib), out2=u_out, precise=pr,
+                                split3=pr, ldo=W3 * FF, prequant=q8[0] is not None or None, emit_q=self.FFN_OUT_FP8, **g8kw)
             if pt:
                 self._keep_hi(act, buf(f"act{sfx}", (Mp, FF), bf), FF)
                 if u is not None:
                     self._keep_hi(u_out, u, FF)
             fl_v = 2.0 * M * FF * H * W3
             ops.pycall(lambda: self._prof_end("ffn1", fl_v))
-            self._linear(act, ln.fw, x[i + 1], Mp, H, FF, ops.EPI_F32_RES, M, bias=P.w(ln.fb), res=xm, precise=pr)
+            self._linear(act, ln.fw, x[i + 1], Mp, H, FF, ops.EPI_F32_RES, M, bias=P.w(ln.fb), res=xm, precise=pr,
+                         prequant=bool(actq))
 
         ops.pycall(lambda: self._prof_end("vilt_fwd"))
         # ------------------------------ tail ------------------------------

@@ -28,6 +28,7 @@ class GemmArgs(C.Structure):
         ("drop_scale", C.c_float), ("gn", C.c_int), ("persist", C.c_int),
         ("batch", C.c_int), ("batch_a", C.c_longlong), ("batch_b", C.c_longlong), ("batch_o", C.c_longlong),
         ("aux_u8", C.c_int), ("out_hm", C.c_int), ("a_hm", C.c_int),
+        ("out_q", C.c_void_p), ("out_scale", C.c_void_p),
     ]
 
 

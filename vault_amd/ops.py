@@ -241,12 +241,13 @@ def quant_mxfp8(src_bf16, rows, K, ld, dst_q, dst_scale):
 
 
 def gemm_mxfp8(Aq, As, Bq, Bs, out, M, N, K, ldo, epi, *, m_valid=0, bias=None, res=None, out2=None,
-               drop: Drop = NO_DROP, cfg=-1, aux_u8=False, out_hm=0, plan_only=False):
+               drop: Drop = NO_DROP, cfg=-1, aux_u8=False, out_hm=0, out_q=None, out_scale=None, plan_only=False):
     """out = epilogue(A . B^T) on MXFP8 operands (forward Linear layers of the fp8-forward configuration).  ``cfg``: -1 = the
     8-wave kernel's MXFP8 form where it takes the call (else the simple kernel), 0 = the simple kernel, 5 / 6 = the 8-wave form
     with 256- / 192-wide tiles; ``aux_u8`` (8-bit gelu' in tile order) and ``out_hm`` (head-major output) as ``gemm``: 8-wave
-    form only."""
+    form only; ``out_q`` / ``out_scale``: also write the MXFP8 image of the 16-bit output (kernel 5, vault_gemm_args.out_q)."""
     a = L.GemmArgs()
+    a.out_q, a.out_scale = _p(out_q), _p(out_scale)
     a.A, a.B, a.out, a.out2 = _p(Aq), _p(Bq), _p(out), _p(out2)
     a.bias, a.res = _p(bias), _p(res)
     a.M, a.N, a.K, a.lda, a.ldb, a.ldo, a.m_valid = M, N, K, K, K, ldo, m_valid
