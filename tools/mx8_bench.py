@@ -24,7 +24,7 @@ for name, N, K, epi in (("qkv", 3 * H, H, EPI_BF16), ("proj", H, H, EPI_RES), ("
     ops.quant_mxfp8(W, N, K, K, wq, wsc)
     tq = t(lambda: ops.quant_mxfp8(X, M, K, K, xq, xs))
     t8s = t(lambda: ops.gemm_mxfp8(xq, xs, wq, wsc, out, M, N, K, N, epi, bias=bias, res=res, out2=out2, cfg=0))
-    t8 = t(lambda: ops.gemm_mxfp8(xq, xs, wq, wsc, out, M, N, K, N, epi, bias=bias, res=res, out2=out2, cfg=5))
+    t8 = t(lambda: ops.gemm_mxfp8(xq, xs, wq, wsc, out, M, N, K, N, epi, bias=bias, res=res, out2=out2, cfg=-1))
     t16 = t(lambda: _gemm(X, W, out, M, N, K, K, K, N, 0, 0, epi, cfg=-1, bias=bias, res=res, out2=out2))
     fl = 2.0 * M * N * K
     print(f"{name:5s} M={M} N={N} K={K}: quantise A {tq:6.1f} us ({M*K*3/tq/1e6:5.2f} TB/s) | mxfp8 simple {t8s:6.1f} us | mxfp8 8-wave {t8:6.1f} us {fl/t8/1e6:7.1f} TF/s | bf16 GEMM {t16:6.1f} us {fl/t16/1e6:7.1f} TF/s")

@@ -210,7 +210,15 @@ int vault_gemm_mx8_resolve(const GemmParams& p, const void* a_scale, const void*
   q.lds_a = p.K / 32; q.lds_b = p.K / 32;
   if (q.m_valid <= 0) q.m_valid = q.M;
   if (cfg != 0) {
-    const int ntw = (cfg == 6) ? 3 : ((cfg == 5 || p.N % 256 == 0) ? 4 : 3);
+    // automatic tile width: 256 unless only 192 divides N or the 192-wide tiles fill the last round of CUs much better
+    // (N = 768 at 185 row tiles: 740 tiles = 2.9 rounds at 3/4 of the cost against 555 = 2.2 rounds, as vault_gemm chooses);
+    // the output image (out_q) and a requested cfg fix it
+    auto eff = [](long tiles) { return (double)tiles / (double)(((tiles + 255) / 256) * 256); };
+    int ntw = (cfg == 6) ? 3 : ((cfg == 5 || p.N % 256 == 0) ? 4 : 3);
+    if (cfg < 0 && ntw == 4 && p.N % 192 == 0 && p.out_q == nullptr && !p.aux_u8 &&
+        vault_gemm8w_mx_supports(q, epi, 3) &&
+        0.9 * eff((long)(p.M / 256) * (p.N / 192)) > eff((long)(p.M / 256) * (p.N / 256)))
+      ntw = 3;
     if (vault_gemm8w_mx_supports(q, epi, ntw)) return ntw == 4 ? 5 : 6;
     if (cfg > 0) return -VAULT_EINVAL;
   }

@@ -251,7 +251,8 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
         if precise:
             ops.gemm(a_bf16, P.wb3(wname, N, K), out, M, N, 3 * K, 3 * K, 3 * K, N if ldo is None else ldo, 0, 0, epi,
                      m_valid=m_valid, bias=bias, **kw)
-        elif self.fp8_forward and wname in self._w8 and M % 256 == 0 and prequant is not False:
+        elif (self.fp8_forward and wname in self._w8 and M % 256 == 0 and prequant is not False
+              and self._fp8_kernel_ok(M, N, K, epi, out, bias, kw)):
             wq, wsc = self._w8[wname]
             aq, asc = self._fp8_scratch(M, K)
             if prequant is None:      # (no producer wrote the image)
@@ -271,6 +272,19 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
         else:
             ops.gemm(a_bf16, P.wb(wname, n_elems=N * K, shape=(N, K)), out, M, N, K, K, K, N if ldo is None else ldo,
                      0, 0, epi, m_valid=m_valid, bias=bias, **kw)
+
+    def _fp8_kernel_ok(self, M, N, K, epi, out, bias, kw) -> bool:
+        """The Linears fed by a LayerNorm always take the MXFP8 path; one whose operand image comes out of another GEMM's epilogue
+        (FFN-out, FFN_OUT_FP8) only where the 8-wave form takes the call - the simple kernel is slower than the bf16 ring kernel
+        there (LM stack in training: dropout in the residual epilogue)."""
+        if epi != ops.EPI_F32_RES:
+            return True
+        drop = kw.get("drop", NO_DROP)
+        key = ("fp8_ok", M, N, K, epi, bool(drop.thresh))
+        if key not in self._ws:
+            self._ws[key] = ops.gemm_mxfp8(out, out, out, out, out, M, N, K, N, epi, bias=bias, res=kw.get("res"), drop=drop,
+                                           plan_only=True) in (5, 6)
+        return self._ws[key]
 
     def _dgrad(self, dy_bf16, wname, out, M, Kin, Nout, epi, m_valid, **kw):
         # dX[M,Kin] = dY[M,Nout] . W[Nout,Kin]

@@ -253,10 +253,10 @@ def gemm_mxfp8(Aq, As, Bq, Bs, out, M, N, K, ldo, epi, *, m_valid=0, bias=None, 
     a.M, a.N, a.K, a.lda, a.ldb, a.ldo, a.m_valid = M, N, K, K, K, ldo, m_valid
     a.a_mode, a.b_mode, a.epi, a.cfg, a.splits, a.accumulate = 0, 0, epi, cfg, 1, 0
     a.aux_u8, a.out_hm = int(bool(aux_u8)), int(out_hm)
-    if plan_only:      # the kernel these arguments would run on (vault_gemm_mxfp8_plan): 0, 5, 6, or -EINVAL
-        return int(L.load(_FMT.get()).vault_gemm_mxfp8_plan(C.byref(a)))
     a.persist = GEMM_SCHED
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
+    if plan_only:      # the kernel these arguments would run on (vault_gemm_mxfp8_plan): 0, 5, 6, or -EINVAL
+        return int(L.load(_FMT.get()).vault_gemm_mxfp8_plan(C.byref(a)))
     _invoke("vault_gemm_mxfp8", C.byref(a), C.c_void_p(_p(As)), C.c_void_p(_p(Bs)), _stream(), struct=a, drop=drop)
 
 
