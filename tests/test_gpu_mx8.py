@@ -341,3 +341,37 @@ def test_model_class_switch():
         c = model(**kw).clone()
     assert model._engine._w8 and torch.equal(a, c)
     assert 0 < (a - b).abs().max().item() < 0.05 * a.abs().max().item() + 2e-2
+
+
+def test_fp8_forward_keeps_head_major_qkv_and_8bit_gelu_prime():
+    """fp8-forward mode at a batch where the engine plans the head-major qkv layout and the 8-bit gelu' (full width, 2 + 2 layers,
+    B = 208): the plans are taken (vault_gemm_mxfp8_plan says the 8-wave form runs) and change addresses / the storage of gelu'
+    only - logits bit-identical to the same engine with both plans off, gradients equal up to the 8-bit rounding of gelu'
+    (step 0.005) and summation order."""
+    from vault_amd.engine import VaultEngine
+    from vault_amd.spec import LMSpec, VaultSpec, ViltSpec, build_state, synthetic_batch
+    spec = VaultSpec(vilt=ViltSpec(num_hidden_layers=2), lm=LMSpec.bertweet_base(), n_classes=3)
+    spec.lm.num_hidden_layers = 2
+    state = build_state(spec, 3)
+    bn = synthetic_batch(spec, 208, seed=708, n_classes=3)
+    db = {k: torch.from_numpy(v).cuda() for k, v in bn.items()}
+    res = []
+    for plans in (True, False):
+        eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.1, half="bf16", fp8_forward=True)
+        eng.HEAD_MAJOR, eng.GELU8, eng.HEAD_MAJOR_MIN_ROWS = plans, plans, 0
+        eng.drop_seed = 77
+        out = eng.forward(db, train=True, labels=db["labels"], need_hidden=False)
+        eng.zero_grad()
+        eng.backward()
+        torch.cuda.synchronize()
+        assert (eng.last["qkv_hm"], eng.last["lm_qkv_hm"]) == ((eng.last["Mp"], eng.last["Mlp"]) if plans else (0, 0))
+        assert (eng.last["gelu8_active"] is not None) == plans
+        assert len(eng._w8) == 2 * 4
+        res.append((out["logits"].clone(), float(out["loss"]), eng.params.g[:eng.params.n_train].clone()))
+        del eng
+    a, b = res
+    assert torch.equal(a[0], b[0])
+    assert abs(a[1] - b[1]) < 1e-6
+    rel = float((a[2] - b[2]).norm() / b[2].norm())
+    print(f"fp8 forward, plans on vs off: gradient rel diff {rel:.2e}")
+    assert rel < 5e-3
