@@ -83,6 +83,9 @@ __device__ __forceinline__ s16x4 tr16_asm(uint32_t lds_addr) {
   return v;
 }
 
+#ifndef R256_ORDER
+#define R256_ORDER -1     // issue order inside a phase: see PHASE_BODY
+#endif
 // NTQ = 16-column MFMA tiles per wave per B half: 4 -> 256-wide block tile, 3 -> 192-wide (N = 768 gives
 // 4 x 185 = 740 tiles = 2.9 rounds of 256 CUs instead of 555 = 2.2 rounds: 96 % instead of 72 % of the
 // last round's CUs busy)
@@ -93,6 +96,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   constexpr int BNT = NTQ * 64;                     // block tile width
+  constexpr int PH_ORDER = (R256_ORDER >= 0) ? R256_ORDER : (EPI == EPI_F32_ATOMIC ? 0 : 1);   // (PHASE_BODY, below)
   constexpr int PB = (B_MODE == 0) ? NTQ : 4;       // global_load_lds pieces per wave per B half-tile
   constexpr int W32 = 3 * 4 + 2 * PB;               // pieces of the five youngest half-tiles: 3 A + 2 B
   constexpr int W23 = 2 * 4 + 3 * PB;               //                                       2 A + 3 B
@@ -389,16 +393,14 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     MMA1(KS, MT, 0, MB, NB, RA, RB) INS_A;                                                 \
     MMA1(KS, MT, 1, MB, NB, RA, RB) MMA1(KS, MT, 2, MB, NB, RA, RB) INS_B;                 \
     MMA1(KS, MT, 3, MB, NB, RA, RB)
-// Placement of a phase's four staging pieces against its eight fragment reads.  1 (default since round 5): the reads in the first
-// four MFMA groups, the pieces in gaps of their own behind them - in the step 38.02 -> 37.91 ms (three interleaved same-box pairs,
-// tools/r05_call15.sh; weight gradients 0.5763 -> 0.5729 ms per launch); 0: a piece and a read per group (rounds 1-4); 2: pieces first
-// (slower).  tools/pf_bench.py: within 1 % on the isolated kernels either way - the kernel is bound by the aggregate of its address
-// path, not by where in a phase its instructions sit.
-#ifndef R256_ORDER
-#define R256_ORDER 1
-#endif
-#if R256_ORDER == 0
-#define PHASE_BODY(LOADUH, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB) \
+// Placement of a phase's four staging pieces against its eight fragment reads.  1: the reads in the first four MFMA groups, the
+// pieces in gaps of their own behind them - in the step 38.02 -> 37.91 ms (three interleaved same-box pairs, tools/r05_call15.sh);
+// 0: a piece and a read per group (rounds 1-4); 2: pieces first (slower).  tools/pf_bench.py: within 1 % on the isolated kernels
+// either way - the kernel is bound by the aggregate of its address path, not by where in a phase its instructions sit.
+// Default (R256_ORDER undefined or < 0): 1 for the forward and data-gradient instantiations, 0 for the weight gradients - there 1 is
+// worth 3.4 us of a 575 us launch but raises the HBM fetch of a launch by 8-12 % (1,019 -> 1,105-1,140 MB, same-box --pmc passes,
+// tools/r05_call27.sh: the pieces of a phase leave later, the blocks of an XCD drift apart and share fewer L2 hits).
+#define PHASE_BODY_0(LOADUH, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB) \
     GA(0, 0, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 0), LOADUH(RN, LBUF, LH, 0, 0)) \
     GA(0, 1, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 1), LOADUH(RN, LBUF, LH, 1, 0)) \
     GA(0, 2, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 2), LOADUH(RN, LBUF, LH, 2, 0)) \
@@ -407,8 +409,8 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     GA(1, 1, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 2, 1), LOADUH(RN, LBUF, LH, 3, 1)) \
     GA(1, 2, MB, NB, RA, RB, , )                                               \
     GA(1, 3, MB, NB, RA, RB, , )
-#elif R256_ORDER == 1   // the reads first, the pieces in gaps of their own
-#define PHASE_BODY(LOADUH, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB) \
+// the reads first, the pieces in gaps of their own
+#define PHASE_BODY_1(LOADUH, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB) \
     GA(0, 0, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 0, 0), LOADUH(RN, LBUF, LH, 1, 0)) \
     GA(0, 1, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 2, 0), LOADUH(RN, LBUF, LH, 3, 0)) \
     GA(0, 2, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 0, 1), LOADUH(RN, LBUF, LH, 1, 1)) \
@@ -417,8 +419,8 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     GA(1, 1, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 1), )                         \
     GA(1, 2, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 2), )                         \
     GA(1, 3, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 3), )
-#else                   // the pieces first, in gaps of their own, then the reads
-#define PHASE_BODY(LOADUH, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB) \
+// the pieces first, in gaps of their own, then the reads
+#define PHASE_BODY_2(LOADUH, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB) \
     GA(0, 0, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 0), )                         \
     GA(0, 1, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 1), )                         \
     GA(0, 2, MB, NB, RA, RB, PIECE(IH, IBUF, IT, 2), )                         \
@@ -427,7 +429,10 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     GA(1, 1, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 2, 0), LOADUH(RN, LBUF, LH, 3, 0)) \
     GA(1, 2, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 0, 1), LOADUH(RN, LBUF, LH, 1, 1)) \
     GA(1, 3, MB, NB, RA, RB, LOADUH(RN, LBUF, LH, 2, 1), LOADUH(RN, LBUF, LH, 3, 1))
-#endif
+#define PHASE_BODY(...)                                                        \
+    if constexpr (PH_ORDER == 0) { PHASE_BODY_0(__VA_ARGS__) }                 \
+    else if constexpr (PH_ORDER == 1) { PHASE_BODY_1(__VA_ARGS__) }            \
+    else { PHASE_BODY_2(__VA_ARGS__) }
 #define PHASE(WAITN, WAITF, LOADUH, RN, LBUF, LH, PIECE, IH, IBUF, IT, MB, NB, RA, RB) \
   {                                                                            \
     __builtin_amdgcn_s_setprio(1);                                             \
