@@ -166,6 +166,14 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const h16* __re
   const QkvLayout lay(H, heads, hm_rows);
   const int ld = lay.ld;
   const h16* qbase = qkv + row0 * ld + (size_t)h * lay.hs;
+  // the query fragments of this wave's first tile are requested BEFORE the K / V staging: their round trip runs under it
+  // (behind the staging barrier it would be a second exposed memory latency per workgroup)
+  h16x8 qf[2];
+  {
+    const int qrow = min(wave * 16 + l15, S - 1);
+    qf[0] = *reinterpret_cast<const h16x8*>(qbase + (size_t)qrow * ld + 8 * g);
+    qf[1] = *reinterpret_cast<const h16x8*>(qbase + (size_t)qrow * ld + 32 + 8 * g);
+  }
   stage_rows<SK, NWV * 64>(Ks, qbase + lay.pl, ld, S, tid);
   stage_rows<SK, NWV * 64>(Vs, qbase + 2 * (size_t)lay.pl, ld, S, tid);
   for (int k = tid; k < SK; k += NWV * 64)
@@ -175,10 +183,11 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_fwd_kernel(const h16* __re
   const int nqt = (S + 15) >> 4;
   const uint32_t bh = (uint32_t)(b * heads + h);
   for (int qt = wave; qt < nqt; qt += NWV) {
-    const int qrow = min(qt * 16 + l15, S - 1);
-    h16x8 qf[2];
-    qf[0] = *reinterpret_cast<const h16x8*>(qbase + (size_t)qrow * ld + 8 * g);
-    qf[1] = *reinterpret_cast<const h16x8*>(qbase + (size_t)qrow * ld + 32 + 8 * g);
+    if (qt != wave) {
+      const int qrow = min(qt * 16 + l15, S - 1);
+      qf[0] = *reinterpret_cast<const h16x8*>(qbase + (size_t)qrow * ld + 8 * g);
+      qf[1] = *reinterpret_cast<const h16x8*>(qbase + (size_t)qrow * ld + 32 + 8 * g);
+    }
     // pass 1: row maximum only (scores are recomputed in pass 2: the matrix pipe is nearly idle in this
     // kernel, while keeping all 12 score tiles live costs 48 registers and the occupancy that hides LDS latency)
     // (the key-mask bias, 0 or -inf per key = accumulator row, is the MFMA's initial accumulator: no add)
