@@ -159,6 +159,32 @@ def test_8wave_form_equals_the_simple_kernel_bit_for_bit(M, N, K, epi, cfg):
         assert torch.equal(u0[:m_valid], u1[:m_valid])
 
 
+def test_8wave_gelu_form_with_8bit_gelu_prime_repeats_and_matches_the_simple_kernel():
+    """The instantiation in which hipcc had restored the bias pointer with v_readlane_b32 directly in front of the asm bias loads
+    (no wait states: garbage bias in whole wave tiles, different ones every run - DESIGN 4.2a).  The build now scans the ISA for the
+    pattern; this is the behavioural side: six runs, each equal to the simple kernel's 16-bit output, with and without a bias."""
+    from vault_amd import ops
+    M, N, K = 1280, 3072, 768
+    g = torch.Generator().manual_seed(22)
+    x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    q_a, s_a = _quant_gpu(x)
+    q_w, s_w = _quant_gpu(w)
+    for bias in (torch.randn(N, generator=g).cuda(), None):
+        ref = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        ref2 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        ops.gemm_mxfp8(q_a, s_a, q_w, s_w, ref, M, N, K, N, EPI_GELU, bias=bias, out2=ref2, cfg=0)
+        images = []
+        for _ in range(6):
+            out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            u8 = torch.zeros(M * N, dtype=torch.uint8, device="cuda")
+            ops.gemm_mxfp8(q_a, s_a, q_w, s_w, out, M, N, K, N, EPI_GELU, bias=bias, out2=u8, cfg=5, aux_u8=True)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
+            images.append(u8)
+        assert all(torch.equal(images[0], u) for u in images[1:])
+
+
 def test_8wave_form_exact_on_integer_data():
     """The operand map, the scale bytes (two per register, selected by op_sel_hi) and the permuted weight rows of the 8-wave
     form: integer data with power-of-two block scales that differ from row to row and block to block."""
