@@ -694,3 +694,14 @@ def test_isa_check_finds_an_unpadded_sgpr_reload_in_front_of_vmem():
     found = sgpr_vmem_hazards(bad + padded + far + other)
     assert len(found) == 1 and found[0].startswith("_Z3badv") and "0 wait states" in found[0]
     assert sgpr_vmem_hazards(bad, "padded") == []
+
+
+def test_isa_check_reports_spilling_kernels():
+    """vault_amd/isa_check.py spilling_kernels: the build refuses register spills in gemm256.hip / gemm8w.hip (build.py NO_SPILL)."""
+    from vault_amd.isa_check import spilling_kernels
+    from vault_amd import build
+    meta = ("amdhsa.kernels:\n  - .agpr_count: 0\n    .name:           _Z1av\n    .sgpr_count: 10\n    .vgpr_count: 64\n"
+            "    .vgpr_spill_count: 0\n  - .agpr_count: 128\n    .name:           _Z1bv\n    .sgpr_count: 90\n    .vgpr_count: 256\n"
+            "    .vgpr_spill_count: 62\n")
+    assert spilling_kernels(meta) == ["_Z1bv: 62 spilled VGPRs"]
+    assert set(build.NO_SPILL) == {"gemm256.hip", "gemm8w.hip"}

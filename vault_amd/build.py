@@ -12,7 +12,7 @@ import os
 import subprocess
 import sys
 
-from .isa_check import sgpr_vmem_hazards
+from .isa_check import sgpr_vmem_hazards, spilling_kernels
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -22,6 +22,8 @@ OBJ = os.path.join(CSRC, "_obj")
 VARIANTS = {"bf16": (OUT, OBJ, []),
             "fp16": (os.path.join(HERE, "libvault_hip_f16.so"), os.path.join(CSRC, "_obj_f16"), ["-DVAULT_F16"])}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# kernel files whose kernels must not spill (asm global accesses with hand-counted vmcnt waits, register budgets chosen per kernel)
+NO_SPILL = ("gemm256.hip", "gemm8w.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17",
          "-Wno-unused-result"]
 
@@ -57,10 +59,15 @@ def _compile(job) -> str:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
     stem = src[:-4]
     isa = os.path.join(objdir, f"{stem}-hip-amdgcn-amd-amdhsa-gfx950.s")
-    found = sgpr_vmem_hazards(open(isa).read())
+    isa_text = open(isa).read()
+    found = sgpr_vmem_hazards(isa_text)
+    spills = spilling_kernels(isa_text) if src in NO_SPILL else []
     for f in os.listdir(objdir):
         if f.startswith(stem + "-h") or f.startswith(stem + ".hip-"):
             os.remove(os.path.join(objdir, f))
+    if spills:
+        os.remove(obj)
+        raise RuntimeError(f"{src}: register spills in a kernel file with hand-counted vmcnt waits (isa_check.py):\n" + "\n".join(spills))
     if found:
         os.remove(obj)
         raise RuntimeError(f"{src}: VALU-writes-SGPR -> VMEM hazard in front of an asm statement (isa_check.py):\n" + "\n".join(found))

@@ -44,3 +44,15 @@ def sgpr_vmem_hazards(asm_text: str, kernel_substr: str = "") -> List[str]:
                 ws += (int(nop.group(1)) + 1) if nop else 1
                 j -= 1
     return out
+
+
+def spilling_kernels(asm_text: str) -> List[str]:
+    """'kernel: n spilled VGPRs' for every kernel of a hipcc -S file whose metadata reports scratch spills.  The GEMM kernels
+    issue every global access through asm with hand-counted `s_waitcnt vmcnt(N)`: a spill puts compiler-issued scratch loads /
+    stores (counted by the same counter) between them - the waits then over-wait at best - and costs what the register budget was
+    chosen to avoid; the build refuses spills in those files (build.py NO_SPILL)."""
+    out = []
+    for m in re.finditer(r'\.name:\s+(\S+)\s*\n(?:.*\n)*?\s*\.vgpr_spill_count:\s+(\d+)', asm_text):
+        if int(m.group(2)) > 0:
+            out.append(f"{m.group(1)}: {m.group(2)} spilled VGPRs")
+    return out
