@@ -697,7 +697,7 @@ def test_isa_check_finds_an_unpadded_sgpr_reload_in_front_of_vmem():
 
 
 def test_isa_check_reports_spilling_kernels():
-    """vault_amd/isa_check.py spilling_kernels: the build refuses register spills in gemm256.hip / gemm8w.hip (build.py NO_SPILL)."""
+    """vault_amd/isa_check.py spilling_kernels: the build lists register spills in gemm256.hip / gemm8w.hip (build.py NO_SPILL)."""
     from vault_amd.isa_check import spilling_kernels
     from vault_amd import build
     meta = ("amdhsa.kernels:\n  - .agpr_count: 0\n    .name:           _Z1av\n    .sgpr_count: 10\n    .vgpr_count: 64\n"

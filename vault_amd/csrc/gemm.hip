@@ -326,7 +326,8 @@ int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) 
     //   (N = 768: 740 vs 555 tiles, N = 2304: 2220 vs 1665); 256x128 / 128x128 otherwise
     auto eff = [](long tiles) { return (double)tiles / (double)(((tiles + 255) / 256) * 256); };
     if (p.M % 256 == 0 && p.N % 256 == 0) {
-      cfg = (p.K >= 512 || a_mode == 1) ? 3 : 2;
+      // (the ring kernel's (1,1) form exists for the weight-gradient epilogue only)
+      cfg = ((p.K >= 512 && a_mode == 0) || (a_mode == 1 && epi == EPI_F32_ATOMIC)) ? 3 : 2;
       if (p.N % 192 == 0 && a_mode == 0 && epi != EPI_F32_ATOMIC && p.splits == 1 && p.K >= 512 &&
           eff((long)(p.M / 256) * (p.N / 192)) > 1.02 * eff((long)(p.M / 256) * (p.N / 256)))
         cfg = 4;

@@ -698,8 +698,11 @@ int dispatch256(const GemmParams& p, int a_mode, int b_mode, int epi, hipStream_
   switch (key) {
     case 0: VAULT_DISPATCH(0, 0)
     case 1: VAULT_DISPATCH(0, 1)
-    case 3:
-      if constexpr (NTQ == 4) { VAULT_DISPATCH(1, 1) } else return VAULT_EINVAL;
+    case 3:   // (both operands K-major: the weight gradients only - the other epilogues of this form spill and nothing uses them)
+      if constexpr (NTQ == 4) {
+        if (epi == EPI_F32_ATOMIC) return launch256<1, 1, EPI_F32_ATOMIC, NTQ>(p, st);
+      }
+      return VAULT_EINVAL;
     default: return VAULT_EINVAL;
   }
 #undef VAULT_DISPATCH

@@ -50,7 +50,7 @@ def spilling_kernels(asm_text: str) -> List[str]:
     """'kernel: n spilled VGPRs' for every kernel of a hipcc -S file whose metadata reports scratch spills.  The GEMM kernels
     issue every global access through asm with hand-counted `s_waitcnt vmcnt(N)`: a spill puts compiler-issued scratch loads /
     stores (counted by the same counter) between them - the waits then over-wait at best - and costs what the register budget was
-    chosen to avoid; the build refuses spills in those files (build.py NO_SPILL)."""
+    chosen to avoid; the build lists them per GEMM kernel file (build.py NO_SPILL -> csrc/_obj*/<file>.spills.txt)."""
     out = []
     for m in re.finditer(r'\.name:\s+(\S+)\s*\n(?:.*\n)*?\s*\.vgpr_spill_count:\s+(\d+)', asm_text):
         if int(m.group(2)) > 0:
