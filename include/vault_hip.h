@@ -83,6 +83,13 @@ typedef struct vault_gemm_args {
   void* out_q; void* out_scale;   /* ABI 10, vault_gemm_mxfp8 on kernel 5 with epi 1 only (both or neither): also write the
                   MXFP8 image of the 16-bit output - e4m3 [M][N] + E8M0 [M][N / 32], byte for byte what vault_quant_mxfp8 makes
                   of `out` - the A operand of the next vault_gemm_mxfp8 (FFN-in's GELU output feeding FFN-out) */
+  void* splitk_ws; long long splitk_bytes;   /* ABI 11, optional: workspace for SPLIT-K with the reduction inside the launch - a_mode 0,
+                  epi 0 (b_mode 1) or epi 3 (b_mode 0), N % 192 == 0, on the ring kernel's 192-wide tiles (cfg 4): every K split of a
+                  tile stores its f32 accumulators into a slab, the split that arrives last adds them up in split order and runs the
+                  epilogue (bit-reproducible).  Layout: 16 KiB of tile counters - ZERO before the first call, left zero by every
+                  call - then tiles x splits slabs of 256 x 192 floats.  With a workspace, cfg < 0 and splits <= 1 the library
+                  splits where that fills the chip (few row tiles, long contractions: vault_gemm_plan reports cfg 4 either way);
+                  splits > 1 with cfg 4 forces the count.  One workspace must not serve launches that can run concurrently. */
 } vault_gemm_args;
 int vault_gemm(const vault_gemm_args* args, void* stream);
 /* the kernel / tile configuration vault_gemm would run these arguments on (the resolved `cfg`, 0..8), or -EINVAL */
@@ -374,6 +381,9 @@ typedef struct vault_layer_args {
   float *m1, *r1, *m2, *r2;
   uint32_t attn_drop_thresh, hid_drop_thresh, drop_seed, drop_stream_base; float attn_drop_scale, hid_drop_scale;
   int persist;                                                          /* GEMM scheduling, as vault_gemm_args.persist */
+  void* splitk_ws; long long splitk_bytes;                              /* ABI 11, optional: vault_gemm_args.splitk_ws for the layer's
+                                                                           N = H Linears with long contractions (FFN-out forward, FFN-in /
+                                                                           QKV data gradients) */
 } vault_layer_args;
 /* backward: dy = gradient at the layer output (ViLT: dy_f32 = residual-stream gradient + dy_bf16 = its bf16 copy, the
  * FFN-out dY; LM: dy_bf16 (optional) + dy_f32, summed).  Outputs: dx_f32 / dx_bf16 at the layer input (LM: the two parts

@@ -16,9 +16,11 @@ EPI_BF16, EPI_GELU, EPI_DGELU, EPI_RES, EPI_PATCH, EPI_ATOMIC = range(6)
 
 def _gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, cfg=-1, m_valid=0, splits=1, bias=None,
           res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, accumulate=0, colsum=None, persist=0, batch=0,
-          batch_a=0, batch_b=0, batch_o=0, aux_u8=0, plan_only=False, out_hm=0, a_hm=0):
+          batch_a=0, batch_b=0, batch_o=0, aux_u8=0, plan_only=False, out_hm=0, a_hm=0, splitk_ws=None):
     lib = L.load()
     a = L.GemmArgs()
+    if splitk_ws is not None:
+        a.splitk_ws, a.splitk_bytes = splitk_ws.data_ptr(), splitk_ws.numel() * splitk_ws.element_size()
     a.aux_u8 = aux_u8
     a.out_hm, a.a_hm = out_hm, a_hm
     a.A, a.B, a.out = A.data_ptr(), B.data_ptr(), out.data_ptr()
@@ -655,3 +657,92 @@ def test_grouped_weight_gradients_head_major_dy(splits):
             ref = dys[k][l].float().t() @ xs[k][l].float()
             err = float((dws[k][l].view(no, ni) - ref).abs().max())
             assert err <= 2e-3 * float(ref.abs().max()), (k, l, err)
+
+
+# ---- split-K with the reduction inside the launch (ring kernel, 192-wide tiles: gemm256.hip SK; vault_gemm_args.splitk_ws)
+@pytest.mark.parametrize("persist", [0, 1])
+@pytest.mark.parametrize("epi", ["dgrad", "res"])
+@pytest.mark.parametrize("shape", [(1280, 3072, 2), (6144, 3072, 2), (6144, 2304, 3), (2560, 3072, 4), (12032, 3072, 2), (768, 1536, 3)])
+def test_ring_kernel_split_k_reduces_inside_the_launch(shape, epi, persist):
+    """N = 768 Linears with long contractions at small batches (FFN-in / QKV data gradients: (0,1) EPI_BF16 + column sums; FFN-out
+    forward: (0,0) EPI_F32_RES): every K split stores its accumulators into the caller's workspace, the split that draws the last
+    ticket adds the slabs in split order and runs the epilogue.  Checked: every output word against the f32 product of the same
+    operands and against the un-split kernel (accumulation order only), rows >= m_valid untouched, three runs bit-identical
+    (the result must not depend on which split arrives last), the tile counters zero again after every launch, with fewer items
+    than blocks (one item per block), more (376 and 564 items: persistent blocks take a second, staged item behind a hand-off) and
+    under the dynamic tile scheduler (persist = 1)."""
+    M, K, splits = shape
+    N = 768
+    m_valid = M - 41
+    ws = torch.zeros(16384 + (M // 256) * 4 * splits * 256 * 192 * 4, dtype=torch.uint8, device="cuda")
+    runs = []
+    if epi == "dgrad":
+        dY = _rand(M, K, seed=401).bfloat16()
+        W = _rand(K, N, scale=0.05, seed=402).bfloat16()
+        ref = dY.float() @ W.float()
+        for rep in range(3):
+            out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+            cs = torch.zeros(N, device="cuda")
+            _gemm(dY, W, out, M, N, K, K, N, N, 0, 1, EPI_BF16, cfg=4, splits=splits, m_valid=m_valid, colsum=cs, persist=persist,
+                  splitk_ws=ws)
+            runs.append((out, cs))
+        base = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        _gemm(dY, W, base, M, N, K, K, N, N, 0, 1, EPI_BF16, cfg=4, m_valid=m_valid)
+        torch.cuda.synchronize()
+        out, cs = runs[0]
+        scale = ref.abs().max().item()
+        assert (out[:m_valid].float() - ref[:m_valid]).abs().max().item() <= scale * 2 ** -7
+        # against the un-split kernel: the f32 sums differ by their order only - at most one bf16 step, and rarely
+        d = (out[:m_valid].float() - base[:m_valid].float()).abs()
+        assert d.max().item() <= scale * 2 ** -7 and (d > 0).float().mean().item() < 0.02
+        csr = out[:m_valid].float().sum(0)
+        assert (cs - csr).abs().max().item() <= 2e-3 * csr.abs().max().item() + 1e-2
+        assert bool((out[m_valid:] == 7.0).all())
+    else:
+        A = _rand(M, K, seed=411).bfloat16()
+        W = _rand(N, K, scale=0.05, seed=412).bfloat16()
+        bias, res = _rand(N, seed=413), _rand(M, N, seed=414)
+        ref = A.float() @ W.float().t() + bias + res
+        for rep in range(3):
+            out = torch.full((M, N), 7.0, device="cuda")
+            _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_RES, cfg=4, splits=splits, m_valid=m_valid, bias=bias, res=res, persist=persist,
+                  splitk_ws=ws)
+            runs.append((out,))
+        base = torch.zeros(M, N, device="cuda")
+        _gemm(A, W, base, M, N, K, K, K, N, 0, 0, EPI_RES, cfg=4, m_valid=m_valid, bias=bias, res=res)
+        torch.cuda.synchronize()
+        out = runs[0][0]
+        scale = (A.float() @ W.float().t()).abs().max().item()
+        assert (out[:m_valid] - ref[:m_valid]).abs().max().item() <= 2e-4 * scale
+        assert (out[:m_valid] - base[:m_valid]).abs().max().item() <= 2e-5 * scale
+        assert bool((out[m_valid:] == 7.0).all())
+    for r in runs[1:]:
+        for a_, b_ in zip(runs[0], r):
+            assert torch.equal(a_, b_)
+    assert int(ws[:16384].view(torch.int32).abs().max().item()) == 0
+
+
+def test_split_k_is_planned_only_with_a_workspace_and_refused_elsewhere():
+    """The automatic choice splits a long contraction of few row tiles (cfg 4 + splits) only when the caller lends a workspace
+    (it is a no-op for the plan otherwise); a split count on an epilogue / kernel without the in-launch reduction is refused
+    instead of writing partial sums."""
+    M, N, K = 6144, 768, 3072
+    dY = _rand(M, K, seed=421).bfloat16()
+    W = _rand(K, N, scale=0.05, seed=422).bfloat16()
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    ws = torch.zeros(16384 + 96 * 2 * 256 * 192 * 4, dtype=torch.uint8, device="cuda")
+    assert _gemm(dY, W, out, M, N, K, K, N, N, 0, 1, EPI_BF16, plan_only=True, splitk_ws=ws) == 4
+    assert _gemm(dY, W, out, M, N, K, K, N, N, 0, 1, EPI_BF16, plan_only=True) in (0, 7)
+    _gemm(dY, W, out, M, N, K, K, N, N, 0, 1, EPI_BF16, splitk_ws=ws)            # automatic: two splits
+    torch.cuda.synchronize()
+    ref = dY.float() @ W.float()
+    assert (out.float() - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7
+    for kw in (dict(cfg=4, splits=2), dict(cfg=3, splits=2, splitk_ws=ws), dict(cfg=0, splits=2, splitk_ws=ws),
+               dict(cfg=4, splits=2, splitk_ws=ws[:16384 + 1000])):
+        with pytest.raises(RuntimeError):
+            _gemm(dY, W, out, M, N, K, K, N, N, 0, 1, EPI_BF16, **kw)
+    W2 = _rand(3072, 768, scale=0.05, seed=423).bfloat16()
+    A2 = _rand(M, 768, seed=424).bfloat16()
+    o2 = torch.zeros(M, 3072, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError):        # (GELU epilogue: no split-K form)
+        _gemm(A2, W2, o2, M, 3072, 768, 768, 768, 3072, 0, 0, EPI_GELU, cfg=4, splits=2, splitk_ws=ws)

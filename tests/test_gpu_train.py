@@ -749,3 +749,13 @@ def test_optimizer_leaves_stored_weight_gradient_ranges_unzeroed_and_nobody_buil
     torch.cuda.synchronize()
     ga, gb = ea.params.g[:P.n_train], eb.params.g[:P.n_train]
     assert ea._g_stale_key is None and float((ga - gb).norm() / gb.norm()) < 1e-5
+    # a fused step, then an API-level backward and a MANUAL optimizer_step(): the public call takes no zero mask, so
+    # every gradient it read is cleared - the next API-level backward does not build on the previous one's weight gradients
+    db0 = {k: torch.from_numpy(v).cuda() for k, v in batches[0].items() if k != "labels"}
+    sa(db0, torch.from_numpy(batches[0]["labels"]).cuda())
+    assert ea._g_stale_key is not None
+    ea.forward(db, train=True, labels=db["labels"], need_hidden=False)
+    ea.backward()
+    sa.optimizer_step()
+    torch.cuda.synchronize()
+    assert float(ea.params.g[:P.n_train].abs().max()) == 0.0

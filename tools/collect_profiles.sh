@@ -12,7 +12,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity --no-h2d --no-other-configs > $O/pmc_$C.log 2>&1
   python tools/pmc_summary.py $O/pmc_$C $C > $O/pmc_$C.txt
 done
-python tools/make_pmc_json.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE "gemm256_kernel<1, 1, 5, 4>" $O/pmc_gemm_wgrad.json 256 bertweet "gemm256_kernel<1,1,5,4> (weight-gradient ring GEMM, EPI_F32_ATOMIC): all launches of one step - grouped launches (tiles of all four Linear kinds packed into rounds of 256) + the patch projection"
+python tools/make_pmc_json.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE "gemm256_kernel<1, 1, 5, 4," $O/pmc_gemm_wgrad.json 256 bertweet "gemm256_kernel<1,1,5,4> (weight-gradient ring GEMM, EPI_F32_ATOMIC): all launches of one step - grouped launches (tiles of all four Linear kinds packed into rounds of 256) + the patch projection"
 python tools/make_pmc_json.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE "gemm8w_kernel<7, 4|gemm8w_kernel<1, 4" $O/pmc_gemm_ffn1.json 256 bertweet "gemm8w_kernel<7,4,true> / <1,4,true> (8-wave register-direct GEMM, three A slots, GELU epilogue with 8-bit / bf16 gelu', 256-wide tiles): FFN-in forward; per step 12 ViLT launches (M=47360, 8-bit gelu') + 12 LM launches (M=10240, bf16 gelu')"
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o run -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity --no-h2d --no-other-configs > $O/pmc_mfma.log 2>&1

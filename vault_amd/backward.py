@@ -44,7 +44,10 @@ class BackwardMixin:
         if gw is None:
             return
         nk = Mtok_pad // 64
-        if Mtok_pad <= 16384 and Nout % 128 == 0 and Kin % 128 == 0:
+        # (a WIDE weight with a short contraction - the patch projection's 768 x 3072 at B <= 113: 36 ring tiles x 7 splits fill
+        #  the chip; as 144 simple tiles x 3 splits it took 352 us of the B = 64 step, 0.12 PFLOP/s: profiles/r06_small_batch_*)
+        wide = Nout % 256 == 0 and Kin % 256 == 0 and (Nout // 256) * (Kin // 256) >= 24
+        if Mtok_pad <= 16384 and Nout % 128 == 0 and Kin % 128 == 0 and not wide:
             # short contractions (the LM's 40-token sequences: 10240 rows at B = 256): 128x128 tiles with few splits
             # beat the 256x256 ring kernel, whose tiles x splits cannot fill the chip without very short K ranges
             # (tools/wgrad_sweep.py; in-step A/B on one box: +1.0 % samples/s)
@@ -106,12 +109,18 @@ class BackwardMixin:
         if cfg == 3:
             fl = 2.0 * m_valid * Nout * Kin * G
             ops.pycall(lambda: self._prof_end("wgrad", fl, st))
-    def _wgrad_group_size(self, n_layers, after_layer):
-        """Layers per deferred weight-gradient group.  A data-parallel step (``after_layer``: the reducer's stage listener)
-        keeps groups of LM_WGRAD_GROUP layers - the upper group's gradient range goes on the wire under the backward of the
-        layers below it; a single process takes the whole stack (1,296 tiles = five full rounds + 16 tiles, against two
-        remainders of 136: B = 256, same box, 40.2 -> 39.8 ms per step; equal at B = 64)."""
-        g = self.LM_WGRAD_GROUP if after_layer is not None else 0
+    def _wgrad_group_size(self, n_layers, after_layer, stack="lm"):
+        """Layers per deferred weight-gradient group.  A single process takes the whole stack (1,296 tiles = five full rounds +
+        16 tiles, against two remainders of 136: B = 256, same box, 40.2 -> 39.8 ms per step; equal at B = 64) - so does a
+        step that runs the reducer on ONE rank (VAULT_FORCE_DP: nothing goes on a wire, nothing is there to overlap).  With
+        more ranks (``dp_world``, set by TrainStep) the LM stack keeps groups of LM_WGRAD_GROUP layers - the upper group's
+        gradient range goes on the wire under the backward of the layers below it - and the ViLT stack stays whole when a
+        trained LM stack follows: its whole range (half of the gradient bytes) is exchanged under the LM backward."""
+        if after_layer is None or self.dp_world <= 1:
+            return n_layers
+        if stack == "vilt" and self.spec.lm is not None and not self.freeze_lm:
+            return n_layers
+        g = self.LM_WGRAD_GROUP
         return g if g > 0 else n_layers
 
     def _wgrad_group(self, kinds, layers, i0, hi, Mtok_pad, m_valid):
@@ -308,7 +317,7 @@ class BackwardMixin:
             # A = gradient at the layer output (FFN-out's dY), B = gradient behind the attention block (attn-out's dY)
             dxbA_all = self._stack(ws, "v_dxbA", nv, (Mp, H), bf); dxbB_all = self._stack(ws, "v_dxbB", nv, (Mp, H), bf)
             dU_all = self._stack(ws, "v_dU", nv, (Mp, FF), bf); dqkv_all = self._stack(ws, "v_dqkv", nv, (Mp, 3 * H), bf)
-            vgroup = self._wgrad_group_size(nv, after_layer)
+            vgroup = self._wgrad_group_size(nv, after_layer, "vilt")
         dxb_top = dxbA_all[nv - 1] if vbatch else dxb[0]
         ops.pycall(dxb_top.zero_)
         # ------------------------------ tail ------------------------------
@@ -462,7 +471,9 @@ class BackwardMixin:
             ops.image_rows_bwd(dx0, gpos, gmt[ws.get("img_type", 1)], P.gr("embeddings.cls_token", shape=(H,)),
                                P.gr("embeddings.patch_embeddings.projection.bias"), dyp, NP, H, B, S, T)
         if ws.get("img_embeds") is None:
-            self._wgrad(dyp, ws["apatch"], "embeddings.patch_embeddings.projection.weight", None, Mpp, H, Kp, B * NP)
+            # (small batches: beside the chain, like the stack's deferred launches - nothing below reads this gradient)
+            self._wgrads_aside(lambda: self._wgrad(dyp, ws["apatch"], "embeddings.patch_embeddings.projection.weight", None,
+                                                   Mpp, H, Kp, B * NP), after_layer)
         dvs = buf("d_vt_sum", (Mlp, H))
         # text rows: out = LN(.) + mtype[0]  =>  d mtype[0] = sum dy = THIS backward's d beta: taken through a scratch
         # vector (the gradient buffers accumulate across backward passes: multi-image heads, gradient accumulation)

@@ -25,6 +25,7 @@ static GemmParams params_of(const vault_gemm_args* a) {
   p.aux_u8 = a->aux_u8;
   p.out_hm = a->out_hm; p.a_hm = a->a_hm;
   p.out_q = a->out_q; p.out_scale = a->out_scale;
+  p.sk_ws = a->splitk_ws; p.sk_bytes = a->splitk_ws ? a->splitk_bytes : 0;
   return p;
 }
 
@@ -79,7 +80,7 @@ extern "C" int vault_wgrad_grouped(const vault_wgrad_grouped_args* a, void* stre
   return vault_gemm256_grouped_launch(p, reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" int vault_abi_version(void) { return 10; }
+extern "C" int vault_abi_version(void) { return 11; }
 #ifdef VAULT_F16
 extern "C" int vault_operand_format(void) { return 1; }
 #else

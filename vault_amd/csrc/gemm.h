@@ -63,6 +63,12 @@ struct GemmParams {
   // next forward Linear's A operand without a pass over `out`.  Null = off.
   void* out_q;
   void* out_scale;
+  // Split-K with the reduction inside the launch (ring kernel, gemm256.hip SK: (0,1) EPI_BF16 and (0,0) EPI_F32_RES, 192- / 256-wide
+  // tiles, splits > 1): the caller's workspace - GEMM_SK_COUNTER_BYTES of tile counters (ZERO before the first launch; every
+  // launch leaves them zero), then one f32 slab of 256 x tile-width floats per (tile, split).  Not shared by launches that can
+  // run at the same time.  Null: splits > 1 is refused for these epilogues.
+  void* sk_ws;
+  long long sk_bytes;
   // Grouped weight gradients (ring kernel, (1,1) operand modes, EPI_F32_ATOMIC): ONE launch over up to three segments of
   // DIFFERENT weight-gradient kinds that share the contraction (the tokens) and therefore the cost per 256 x 256 tile: the
   // work list is their concatenation, so a launch can be sized to exactly one round of the 256 CUs (e.g. the 216 FFN-out
@@ -79,6 +85,9 @@ struct GemmParams {
     int a_hm;                         // > 0: dY is head-major [M / 64][a_hm rows][64] (the QKV kind's dqkv)
   } seg[3];
 };
+
+constexpr int GEMM_SK_COUNTER_BYTES = 16384;                       // 4096 tile counters in front of the slabs
+constexpr int GEMM_SK_MAX_TILES = GEMM_SK_COUNTER_BYTES / 4;
 
 #ifdef __HIPCC__
 // Linear block id -> (tile_m, tile_n).  Blocks with equal id % 8 share an XCD (and its 4 MiB L2): each XCD

@@ -303,6 +303,30 @@ int vault_gemm256_launch(const GemmParams& p, int a_mode, int b_mode, int epi, i
 bool vault_gemm8w_supports(const GemmParams& p, int a_mode, int b_mode, int epi, int ntw);
 int vault_gemm8w_launch(const GemmParams& p, int epi, int ntw, hipStream_t st);
 
+// Split count of the in-launch split-K reduction (gemm256.hip SK: 192-wide ring tiles, (0,1) EPI_BF16 / (0,0) EPI_F32_RES) for a
+// launch whose tiles fill less than a round of the chip: 1 = do not split.  Model (us; tools/splitk_bench.py): a K tile of a
+// 256 x 192 item takes a CU ~1.13; a split adds ~5 for its slab and ticket, the reducer ~2.5 per slab it reads; un-split, the
+// launch takes one round of whole contractions.  Splits must fit the caller's workspace.
+static int gemm_sk_splits(const GemmParams& p, int a_mode, int b_mode, int epi) {
+  if (p.sk_ws == nullptr || a_mode != 0 || p.batch > 1 || p.split3 || (p.M & 255) || p.N % 192 || (p.K & 63) || p.out_hm) return 1;
+  if (!((b_mode == 1 && epi == EPI_BF16) || (b_mode == 0 && epi == EPI_F32_RES && p.res != nullptr))) return 1;
+  const long tiles = (long)(p.M >> 8) * (p.N / 192);
+  const int nk = p.K >> 6;
+  if (tiles > GEMM_SK_MAX_TILES) return 1;
+  auto rounds = [](long items) { return (double)((items + 255) / 256); };
+  const double tk = 1.13, epi_us = 6.0;
+  double best = rounds(tiles) * (nk * tk + epi_us);
+  int best_s = 1;
+  for (int sp = 2; sp <= 4; ++sp) {
+    const int per = (nk + sp - 1) / sp;
+    if (per < 8 || (per * (sp - 1)) >= nk) continue;            // (every split a real share of the contraction)
+    if (p.sk_bytes < GEMM_SK_COUNTER_BYTES + tiles * sp * (256LL * 192 * 4)) continue;
+    const double t = rounds(tiles * sp) * (per * tk + 5.0) + (sp == 2 ? 2.5 : 2.5 * sp) + epi_us;
+    if (t < 0.85 * best) { best = t; best_s = sp; }
+  }
+  return best_s;
+}
+
 // argument checks + kernel choice: the resolved cfg (0..8), or -VAULT_EINVAL
 int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) {
   if (p.splits < 1) p.splits = 1;
@@ -372,6 +396,12 @@ int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) 
     if (ok4 && (!ok3 || eff8((long)(p.M / 256) * (p.N / 256)) >= 0.9 * eff8((long)(p.M / 256) * (p.N / 192)))) cfg = 5;
     else if (ok3) cfg = 6;
   }
+  // split-K with the reduction inside the launch (cfg 4 + splits, round 6) where the caller gave a workspace and the model above
+  // says the launch fills the chip better that way: the N = 768 Linears with K = 3072 / 2304 at small batches
+  if (auto_cfg && p.splits == 1 && (cfg == 0 || cfg == 1 || cfg == 4 || cfg == 7 || cfg == 8)) {
+    const int sp = gemm_sk_splits(p, a_mode, b_mode, epi);
+    if (sp > 1) { cfg = 4; p.splits = sp; }
+  }
   // 256 x 128 tiles of the ring kernel (cfg 8) where the 192-wide ones are a single partial round that the 128-wide ones
   // still cover in one: N = 768 at 32..42 row tiles (the LM stack at per-GPU batch 256: 160 -> 240 tiles on 256 CUs;
   // tools/tile128_bench.py, M = 10240: attention-out 27.9 -> 23.9 us, FFN-out 62.6 -> 51.6, FFN-in dgrad 59.9 -> 48.1, QKV
@@ -389,6 +419,11 @@ int vault_gemm_resolve(GemmParams& p, int a_mode, int b_mode, int epi, int cfg) 
   } else if (p.aux_u8) {
     return -VAULT_EINVAL;       // the 8-bit gelu' exists in the 8-wave kernel's tile order only
   }
+  // split-K of a non-accumulating epilogue: the ring kernel's 192-wide SK form with a workspace, nothing else
+  if (p.splits > 1 && epi != EPI_F32_ATOMIC &&
+      !(cfg == 4 && p.sk_ws != nullptr && a_mode == 0 && p.batch <= 1 && !p.split3 && !p.out_hm &&
+        ((b_mode == 1 && epi == EPI_BF16) || (b_mode == 0 && epi == EPI_F32_RES && p.res != nullptr))))
+    return -VAULT_EINVAL;
   if (cfg == 8 && (p.M % 256 || p.N % 128 || p.K % 64 || p.splits > 1 || p.batch > 1 || a_mode != 0 ||
                    !((b_mode == 0 && epi == EPI_F32_RES && p.res != nullptr) || (b_mode == 1 && epi == EPI_BF16))))
     return -VAULT_EINVAL;

@@ -36,11 +36,23 @@
 #ifndef R256_ABLATE
 #define R256_ABLATE 0
 #endif
+// Two translation units compile this file (round 6): gemm256.hip itself (R256_DYN 0: the static walk only - every block takes
+// items b, b + grid, ...) and gemm256_dyn.hip (R256_DYN 1: the kernels that can also hand their items out dynamically, for
+// data-parallel steps).  The scheduler's state (ticket in hand, last ticket, counters, per-XCD list sizes) lives across the
+// main loop in SGPRs the kernel does not have: with it in every instantiation all 256-wide forms spilled 3-7 registers
+// (compiler-issued scratch traffic in the `vmcnt` the asm loads are counted in); without it they do not.
+#ifndef R256_DYN
+#define R256_DYN 0
+#endif
 
 // Diagnostic build only (-DR256_STAMP=1, tools/clock_stamp.py; no stamp executes in the shipped kernel): every block leaves the
 // shader-clock and the 100 MHz real-time ticks it ran for - the clock the chip HOLDS under this kernel is their quotient
 // (MI355X_MICROARCH.md "DVFS give-back" item 6).  The values go to a buffer nothing else reads.
 #ifndef R256_STAMP
+#define R256_STAMP 0
+#endif
+#if R256_DYN   // (the stamps are taken in the static translation unit only: one definition of the buffer and its reader)
+#undef R256_STAMP
 #define R256_STAMP 0
 #endif
 #if R256_STAMP
@@ -64,6 +76,9 @@ constexpr int BUFB = 4 * HT;   // one K tile: A0 A1 B0 B1
 // not see these waits: fragment reads are therefore issued between the two halves of a phase's MFMA
 // cluster, after the point where hipcc places its own (already satisfied) lgkmcnt wait.
 #define WAITBAR(N) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(N) : "memory")
+// in front of an asm VMEM statement whose SGPR base hipcc may have restored from a VGPR lane right before it (gemm8w.hip
+// W8_SGPR_PAD; vault_amd/isa_check.py fails the build where one is missing): the slab accesses of the split-K hand-off
+#define R256_SGPR_PAD "s_nop 4\n\t"
 
 // The same with the count selected by a uniform flag INSIDE the asm statement (relative branches): a C++ branch
 // here would cut the loop body into basic blocks, and hipcc then shuffles the accumulators between register
@@ -89,7 +104,15 @@ __device__ __forceinline__ s16x4 tr16_asm(uint32_t lds_addr) {
 // NTQ = 16-column MFMA tiles per wave per B half: 4 -> 256-wide block tile, 3 -> 192-wide (N = 768 gives
 // 4 x 185 = 740 tiles = 2.9 rounds of 256 CUs instead of 555 = 2.2 rounds: 96 % instead of 72 % of the
 // last round's CUs busy)
-template <int A_MODE, int B_MODE, int EPI, int NTQ>
+// SK (round 6): the instantiation also takes SPLIT-K work items of the 16-bit / f32-residual epilogues (GemmParams::splits > 1 with
+// a workspace, sk_ws): an item contracts one K range of its tile; every split stores its accumulators as they stand into its
+// slab of the workspace (write-through stores), the block's last wave-0 lane then draws a ticket from the tile's counter, and
+// the split whose ticket is the last one adds the slabs up (ascending z: the result does not depend on who came last) and runs
+// the epilogue - the in-launch reduction of cdna_hip_programming.md's projection-GEMM recipe (sc1 stores -> vmcnt(0) -> barrier ->
+// one relaxed agent-scope add; the reducer reads with sc1 loads).  Nobody waits for anybody: no residency assumption.  For the
+// N = 768 Linears with long contractions at small batches: 96 tiles x 48 K tiles at B = 32 are one 37 %-full round, 192 items
+// of 24 K tiles fill 75 % of the CUs for half the time.  A separate instantiation, so that the un-split kernels keep their code.
+template <int A_MODE, int B_MODE, int EPI, int NTQ, bool DYN, bool SK = false>
 __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   H16_SATURATE();
 #if R256_STAMP
@@ -131,6 +154,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   // ---- staging sources: uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset, two 1-KiB pieces
   //      per wave per half-tile
   int m0, n0, nk;
+  int cur_z = 0, cur_tl = 0;                          // SK: split and tile of the current work item
   float* out_cur = reinterpret_cast<float*>(p.out);   // EPI_F32_ATOMIC: this work item's problem (batched launches)
   int ldo_cur = p.ldo, mvalid_cur = p.m_valid;        // ... and its output geometry (grouped launches)
   const char* a_base;
@@ -146,9 +170,11 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   // per work item in grouped launches, from an opaque copy of the lane id so that nothing extra stays live)
   auto lane_offsets = [&](int lda_, int ldb_, int a_hm_ = 0) {
     const int ln_ = lane_id_volatile();
+    int wv_ = wave;     // (opaque too: the splat of 16 wave would otherwise be kept in a VGPR across the main loop - and spilled)
+    asm volatile("" : "+s"(wv_));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int j = wave * 4 + i;
+      const int j = wv_ * 4 + i;
       const int r8 = ln_ >> 3, r = 8 * j + r8;
       const int c = (ln_ & 7) ^ (((r8 >> 1) & 3) << 1);
       const int krow = 4 * j + (ln_ >> 4), pos16 = ln_ & 15;
@@ -160,7 +186,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
       else a_off[i] = ((uint32_t)krow * 64u + (uint32_t)(cb >> 2) * 2u * (uint32_t)a_hm_ * 64u + (uint32_t)((cb & 3) * 16 + (pos16 & 1) * 8)) * 2u;
       if constexpr (B_MODE == 0) {
         // half-tile image: 2 wave-columns x NTQ*16 rows of 128 B; piece jb = wave*PB + i covers rows 8jb..8jb+7
-        const int jb = wave * PB + (i < PB ? i : PB - 1), rb = 8 * jb + r8;
+        const int jb = wv_ * PB + (i < PB ? i : PB - 1), rb = 8 * jb + r8;
         const int wcol = rb / (NTQ * 16), within = rb - wcol * (NTQ * 16);
         b_off[i] = (uint32_t)((wcol * (NTQ * 32) + within) * ldb_ + c * 8) * 2u;
       } else {
@@ -236,6 +262,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
       }
     }
     const int z = lin / ntiles, tl = lin - z * ntiles;
+    if constexpr (SK) { cur_z = z; cur_tl = tl; }
     int tile_m, tile_n;
     gemm_raster(tl, tiles_m, tiles_n, p.gn, tile_m, tile_n);
     m0 = tile_m << 8; n0 = tile_n * BNT;
@@ -264,7 +291,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
   const int TICKET_ITEMS = (nwork <= 2 * (int)gridDim.x) ? 1 : 2;
   int pend_w = -1;           // thread 0: second item of the current ticket, not yet started
   int last_tk = 0;           // thread 0: last ticket drawn from the own list
-  const bool dyn = (p.persist & 1) != 0;   // dynamic hand-out of work items (else: block b walks b, b + grid, ...)
+  const bool dyn = DYN && (p.persist & 1) != 0;   // dynamic hand-out of work items (else: block b walks b, b + grid, ...)
   unsigned int* const tickets = g_ring_tickets[(p.persist >> 8) & 1];   // bit 8: launch parity (set by the launcher)
   if (dyn && blockIdx.x == 0 && tid < 8) g_ring_tickets[((p.persist >> 8) & 1) ^ 1][tid] = 0u;
   if (!grouped) lane_offsets(p.lda, p.ldb);
@@ -584,7 +611,79 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const int wnext = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(sched_lds));
     const bool more = wnext >= 0;
+    const int ez = cur_z, etl = cur_tl;
     if (more) setup(wnext);
+    bool staged = false;      // SK: the next item's first K tiles were issued with the slab stores (not by the epilogue's hook)
+    if constexpr (SK) {
+      if (p.splits > 1) {     // uniform
+        constexpr int SLAB = 256 * BNT * 4;                 // one tile of f32 accumulators: [8 x TN registers of 4][256 threads]
+        constexpr int TNK = 2 * NTQ;
+        char* const slabs = reinterpret_cast<char*>(p.sk_ws) + GEMM_SK_COUNTER_BYTES;
+        const uint32_t voff = (uint32_t)lane_id_volatile() * 16u + (uint32_t)wave * 1024u;
+        {
+          char* const mine = slabs + ((size_t)etl * p.splits + ez) * SLAB;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (more) stage_first(i);
+#pragma unroll
+            for (int j = 0; j < TNK; ++j)
+              asm volatile(R256_SGPR_PAD "global_store_dwordx4 %0, %1, %2 sc1" ::"v"(voff), "a"(acc[i][j]), "s"(mine + (i * TNK + j) * 4096) : "memory");
+          }
+        }
+        // every wave's stores (and the staged tiles) have retired; then ONE lane draws the tile's ticket
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid == 0) {
+          unsigned int* cnt = reinterpret_cast<unsigned int*>(p.sk_ws) + etl;
+          const unsigned int old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (old == (unsigned int)(p.splits - 1))            // the last ticket: nobody else touches this counter in this launch
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sched_lds[1] = (int)old;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int ticket = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(sched_lds + 1));
+        staged = more;
+        if (ticket != p.splits - 1) {     // another split of this tile comes later and reduces
+          if (!more) break;
+          behind_stores = false;          // (everything issued so far has retired)
+          w = wnext;
+          continue;
+        }
+        // ---- reducer: acc = sum of the slabs in ascending z.  Two splits: registers + the other slab (IEEE addition commutes:
+        //      the same bits whichever split reduces); more: all slabs re-read in order, this split's own included
+        const bool two = p.splits == 2;
+        if (!two) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < TNK; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int zz = 0; zz < p.splits; ++zz) {
+          if (two && zz == ez) continue;
+          const char* const src = slabs + ((size_t)etl * p.splits + zz) * SLAB;
+          f32x4 q[2][TNK];
+#pragma unroll
+          for (int j = 0; j < TNK; ++j)
+            asm volatile(R256_SGPR_PAD "global_load_dwordx4 %0, %1, %2 sc1" : "=&v"(q[0][j]) : "v"(voff), "s"(src + j * 4096) : "memory");
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (i + 1 < 8) {
+#pragma unroll
+              for (int j = 0; j < TNK; ++j)
+                asm volatile(R256_SGPR_PAD "global_load_dwordx4 %0, %1, %2 sc1" : "=&v"(q[(i + 1) & 1][j]) : "v"(voff),
+                             "s"(src + ((i + 1) * TNK + j) * 4096) : "memory");
+              asm volatile("s_waitcnt vmcnt(%0)" ::"i"(TNK) : "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#pragma unroll
+            for (int j = 0; j < TNK; ++j) {
+              asm volatile("" : "+v"(q[i & 1][j]));
+              acc[i][j] += q[i & 1][j];
+            }
+          }
+        }
+      }
+    }
     if constexpr (EPI == EPI_F32_ATOMIC) {
       GemmParams pe = p;
       pe.out = eout;   // (the tile being written belongs to the previous work item's problem)
@@ -593,7 +692,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const GemmParams p) {
                                             [&](int step) { if (more) stage_first(step); }, more ? 4 : 0);
     } else {
       gemm_epilogue<8, TN, EPI, 2, 2, true>(acc, p, smem + 2 * BUFB, em0, en0, wr * 128, wc * (NTQ * 32), wave, lane,
-                                            [&](int step) { if (more) stage_first(step); }, more ? 4 : 0);
+                                            [&](int step) { if (more && !staged) stage_first(step); }, (more && !staged) ? 4 : 0);
     }
     if (!more) break;
     behind_stores = (em0 + 256 <= emvalid);
@@ -639,12 +738,13 @@ inline RingSched& ring_sched(int dev) {
   return s[(dev >= 0 && dev < 64) ? dev : 0];
 }
 
-template <int A_MODE, int B_MODE, int EPI, int NTQ>
-int launch256(const GemmParams& p, hipStream_t st) {
+template <int A_MODE, int B_MODE, int EPI, int NTQ, bool SK>
+int launch256_k(const GemmParams& p, hipStream_t st) {
+  constexpr bool DYN = (R256_DYN != 0);
   constexpr int BNT = NTQ * 64;
   if ((p.M & 255) || (p.N % BNT) || (p.K & 63)) return VAULT_EINVAL;
   constexpr int LDS = 2 * BUFB + 4 * 16 * ((NTQ == 3 ? 96 : 64) + 4) * 4 + 16;   // ring + epilogue scratch (gemm_epi.h: 16 x LD floats per wave) + scheduler word
-  auto kern = gemm256_kernel<A_MODE, B_MODE, EPI, NTQ>;
+  auto kern = gemm256_kernel<A_MODE, B_MODE, EPI, NTQ, DYN, SK>;
   static bool attr_done[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VAULT_EINVAL;
@@ -663,10 +763,17 @@ int launch256(const GemmParams& p, hipStream_t st) {
   const int nk_total = p.K >> 6;
   const int per = (nk_total + p.splits - 1) / p.splits;
   q.splits = (nk_total + per - 1) / per;                        // every split owns at least one K tile
+  if constexpr (SK) {   // split-K items with the in-launch reduction: the caller's counters + slabs must cover (tile, split)
+    const long long tiles = (long long)(p.M >> 8) * (p.N / BNT);
+    if (q.splits > 1 && (p.sk_ws == nullptr || p.batch > 1 || tiles > GEMM_SK_MAX_TILES ||
+                         p.sk_bytes < GEMM_SK_COUNTER_BYTES + tiles * q.splits * (256LL * BNT * 4)))
+      return VAULT_EINVAL;
+  }
   const int nwork = (p.M >> 8) * (p.N / BNT) * q.splits * ((EPI == EPI_F32_ATOMIC && p.batch > 1) ? p.batch : 1);
   dim3 grid(std::min(nwork, 256), 1, 1);
   int persist = p.persist & 0xff;
   int parity = 0;
+  if (!DYN) persist &= ~1;
   if (persist & 1) {
     RingSched& rs = ring_sched(dev);
     if (!rs.bound) { rs.bound = true; rs.stream = st; }
@@ -676,6 +783,18 @@ int launch256(const GemmParams& p, hipStream_t st) {
   q.persist = persist | (parity << 8);
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, q);
   return (int)hipGetLastError();
+}
+
+template <int A_MODE, int B_MODE, int EPI, int NTQ>
+int launch256(const GemmParams& p, hipStream_t st) {
+  // split-K of a 16-bit / f32-residual epilogue: the SK instantiations (kernel header), where they exist
+  // (192-wide tiles: N = 768; the 256-wide form's reducer does not fit the register file beside 256 accumulators)
+  constexpr bool SK_OK = A_MODE == 0 && NTQ == 3 && ((B_MODE == 1 && EPI == EPI_BF16) || (B_MODE == 0 && EPI == EPI_F32_RES));
+  if (EPI != EPI_F32_ATOMIC && p.splits > 1) {
+    if constexpr (SK_OK) return launch256_k<A_MODE, B_MODE, EPI, NTQ, true>(p, st);
+    else return VAULT_EINVAL;
+  }
+  return launch256_k<A_MODE, B_MODE, EPI, NTQ, false>(p, st);
 }
 
 template <int NTQ>
@@ -689,7 +808,9 @@ int dispatch256(const GemmParams& p, int a_mode, int b_mode, int epi, hipStream_
       else return launch256<AM, BMD, EPI_BF16_GELU_INF, NTQ>(p, st);                  \
     case EPI_BF16_DGELU: return launch256<AM, BMD, EPI_BF16_DGELU, NTQ>(p, st);       \
     case EPI_F32_RES: return launch256<AM, BMD, EPI_F32_RES, NTQ>(p, st);             \
-    case EPI_F32_PATCH: return launch256<AM, BMD, EPI_F32_PATCH, NTQ>(p, st);         \
+    case EPI_F32_PATCH:   /* (the patch embedding is a forward-form GEMM) */          \
+      if constexpr (BMD == 0) return launch256<AM, BMD, EPI_F32_PATCH, NTQ>(p, st);   \
+      else return VAULT_EINVAL;                                                       \
     case EPI_F32_ATOMIC:                                                              \
       if constexpr (NTQ == 4) return launch256<AM, BMD, EPI_F32_ATOMIC, NTQ>(p, st);  \
       else return VAULT_EINVAL;                                                       \
@@ -710,8 +831,19 @@ int dispatch256(const GemmParams& p, int a_mode, int b_mode, int epi, hipStream_
 
 }  // namespace
 
+#if R256_DYN
+#define R256_PUBLIC(NAME) NAME##_dyn
+#else
+#define R256_PUBLIC(NAME) NAME
+int vault_gemm256_grouped_launch_dyn(const GemmParams& p, hipStream_t st);
+int vault_gemm256_launch_dyn(const GemmParams& p, int a_mode, int b_mode, int epi, int ntq, hipStream_t st);
+#endif
+
 // Grouped weight gradients (GemmParams::seg): validated here, launched on the (1,1) atomic-epilogue instantiation.
-int vault_gemm256_grouped_launch(const GemmParams& p, hipStream_t st) {
+int R256_PUBLIC(vault_gemm256_grouped_launch)(const GemmParams& p, hipStream_t st) {
+#if !R256_DYN
+  if (p.persist & 1) return vault_gemm256_grouped_launch_dyn(p, st);   // dynamic hand-out: the other translation unit's kernels
+#endif
   if (p.nseg < 1 || p.nseg > 3 || (p.K & 63) || p.splits < 1) return VAULT_EINVAL;
   GemmParams q = p;
   int total = 0;
@@ -730,7 +862,7 @@ int vault_gemm256_grouped_launch(const GemmParams& p, hipStream_t st) {
   q.M = 256; q.N = 256; q.lda = p.seg[0].lda; q.ldb = p.seg[0].ldb; q.ldo = p.seg[0].ldo; q.m_valid = 256;
   q.batch = 0; q.gn = 1;
   constexpr int LDS = 2 * BUFB + 4 * 16 * (64 + 4) * 4 + 16;
-  auto kern = gemm256_kernel<1, 1, EPI_F32_ATOMIC, 4>;
+  auto kern = gemm256_kernel<1, 1, EPI_F32_ATOMIC, 4, (R256_DYN != 0)>;
   static bool attr_done[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VAULT_EINVAL;
@@ -744,6 +876,7 @@ int vault_gemm256_grouped_launch(const GemmParams& p, hipStream_t st) {
   q.splits = (nk_total + per - 1) / per;
   const int nwork = total * q.splits;
   int persist = p.persist & 0xff, parity = 0;
+  if (!R256_DYN) persist &= ~1;
   if (persist & 1) {
     RingSched& rs = ring_sched(dev);
     if (!rs.bound) { rs.bound = true; rs.stream = st; }
@@ -755,7 +888,10 @@ int vault_gemm256_grouped_launch(const GemmParams& p, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-int vault_gemm256_launch(const GemmParams& p, int a_mode, int b_mode, int epi, int ntq, hipStream_t st) {
+int R256_PUBLIC(vault_gemm256_launch)(const GemmParams& p, int a_mode, int b_mode, int epi, int ntq, hipStream_t st) {
+#if !R256_DYN
+  if (p.persist & 1) return vault_gemm256_launch_dyn(p, a_mode, b_mode, epi, ntq, st);
+#endif
   if (ntq == 2) {
     // 256 x 128 tiles (cfg 8): the N = 768 Linears of a 40-row-tile problem (the LM stack at batch 256) are 160 tiles at
     // 192 columns - 62 % of the CUs, one round - and 240 at 128; residual forward and (0,1) data gradient only

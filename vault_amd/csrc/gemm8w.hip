@@ -782,10 +782,10 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(const GemmParams p) {
               if (FULL || m < p.m_valid) {
                 const u32x2 qv = {q2.x, q2.y};
                 const uint32_t oq = offq + (uint32_t)mt * (16u * (uint32_t)p.N) + (j ? 32u : 0u);
-                asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(oq), "v"(qv), "s"(oq_) : "memory");
+                asm volatile(W8_SGPR_PAD "global_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(oq), "v"(qv), "s"(oq_) : "memory");
                 if (eg == 0) {
                   const uint32_t osv = offs + (uint32_t)mt * (16u * (uint32_t)(p.N >> 5)) + (uint32_t)j;
-                  asm volatile("global_store_byte %0, %1, %2\n\ts_nop 1" ::"v"(osv), "v"(e8), "s"(os_) : "memory");
+                  asm volatile(W8_SGPR_PAD "global_store_byte %0, %1, %2\n\ts_nop 1" ::"v"(osv), "v"(e8), "s"(os_) : "memory");
                 }
               }
             }

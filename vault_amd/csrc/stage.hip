@@ -57,7 +57,8 @@ extern "C" int vault_vilt_layer_fwd(const vault_layer_args* L, void* st) {
   CHK(gemm(L->ctx, L->wo, L->xm, Mp, H, H, H, H, H, 0, 0, 3, M, st, L->persist, L->bo, L->x_in));
   CHK(ln_fwd(L->xm, L->ln2w, L->ln2b, L->eps, M, H, L->n2, nullptr, L->m2, L->r2, st));
   CHK(gemm(L->n2, L->wi, L->act, Mp, FF, H, H, H, FF, 0, 0, 1, M, st, L->persist, L->bi, nullptr, nullptr, L->u));
-  CHK(gemm(L->act, L->wf, L->x_out, Mp, H, FF, FF, FF, H, 0, 0, 3, M, st, L->persist, L->bf, L->xm));
+  CHK(gemm(L->act, L->wf, L->x_out, Mp, H, FF, FF, FF, H, 0, 0, 3, M, st, L->persist, L->bf, L->xm, nullptr, nullptr, nullptr, 1, 0, -1,
+           0, 0, 0, 1.f, L->splitk_ws, L->splitk_bytes));
   return VAULT_OK;
 }
 
@@ -77,7 +78,8 @@ extern "C" int vault_vilt_layer_bwd(const vault_layer_bwd_args* G, void* st) {
     CHK(wgrad(G->dy_bf16, L->act, G->g_wf, Mp, H, FF, st, L->persist));
     CHK(wgrad(G->dU, L->n2, G->g_wi, Mp, FF, H, st, L->persist));
   }
-  CHK(gemm(G->dU, L->wi, G->dN, Mp, H, FF, FF, H, H, 0, 1, 0, M, st, L->persist));
+  CHK(gemm(G->dU, L->wi, G->dN, Mp, H, FF, FF, H, H, 0, 1, 0, M, st, L->persist, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, -1,
+           0, 0, 0, 1.f, L->splitk_ws, L->splitk_bytes));
   // x' = x + attn-out: LN2 backward adds the residual gradient; its bf16 output is attn-out's dY (column sums = d bo)
   CHK(ln_bwd(L->xm, L->m2, L->r2, L->ln2w, M, H, G->dN, nullptr, G->dy_f32, bf16_stream ? nullptr : G->dmid_f32, G->dmid_bf16, G->g_ln2w,
              G->g_ln2b, G->g_bo, st, 0, 0, 0, 1.f, bf16_stream ? G->dy_bf16 : nullptr));
@@ -85,7 +87,8 @@ extern "C" int vault_vilt_layer_bwd(const vault_layer_bwd_args* G, void* st) {
   else { CHK(gemm(G->dmid_bf16, L->wo, G->dctx, Mp, H, H, H, H, H, 0, 1, 0, M, st, L->persist)); }
   if (G->do_wgrad) CHK(wgrad(G->dmid_bf16, L->ctx, G->g_wo, Mp, H, H, st, L->persist));
   CHK(attn(L, 1, G->dctx, G->dqkv, st));
-  CHK(gemm(G->dqkv, L->wqkv, G->dN, Mp, H, 3 * H, 3 * H, H, H, 0, 1, 0, M, st, L->persist));
+  CHK(gemm(G->dqkv, L->wqkv, G->dN, Mp, H, 3 * H, 3 * H, H, H, 0, 1, 0, M, st, L->persist, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0,
+           -1, 0, 0, 0, 1.f, L->splitk_ws, L->splitk_bytes));
   if (G->do_wgrad) CHK(wgrad(G->dqkv, L->n1, G->g_wqkv, Mp, 3 * H, H, st, L->persist));
   if (G->g_bqkv) CHK(vault_colsum(G->dqkv, 3 * H, M, 3 * H, G->g_bqkv, st));
   // d x = LN1 backward (dN) + residual gradient; bf16 copy = dY of the layer below (column sums = its d b2)
@@ -106,7 +109,7 @@ extern "C" int vault_lm_layer_fwd(const vault_layer_args* L, void* st) {
   CHK(ln_fwd(L->xm, L->ln1w, L->ln1b, L->eps, M, H, L->n2, L->y1, L->m1, L->r1, st));
   CHK(gemm(L->n2, L->wi, L->act, Mp, FF, H, H, H, FF, 0, 0, 1, M, st, L->persist, L->bi, nullptr, nullptr, L->u));
   CHK(gemm(L->act, L->wf, L->h2, Mp, H, FF, FF, FF, H, 0, 0, 3, M, st, L->persist, L->bf, L->y1, nullptr, nullptr, nullptr, 1, 0, -1,
-           L->hid_drop_thresh, L->drop_seed, L->drop_stream_base + 4, L->hid_drop_scale));
+           L->hid_drop_thresh, L->drop_seed, L->drop_stream_base + 4, L->hid_drop_scale, L->splitk_ws, L->splitk_bytes));
   CHK(ln_fwd(L->h2, L->ln2w, L->ln2b, L->eps, M, H, L->x_out_bf16, L->x_out, L->m2, L->r2, st));
   return VAULT_OK;
 }
@@ -127,7 +130,8 @@ extern "C" int vault_lm_layer_bwd(const vault_layer_bwd_args* G, void* st) {
     CHK(wgrad(G->dmid_bf16, L->act, G->g_wf, Mp, H, FF, st, L->persist));
     CHK(wgrad(G->dU, L->n2, G->g_wi, Mp, FF, H, st, L->persist));
   }
-  CHK(gemm(G->dU, L->wi, G->dN, Mp, H, FF, FF, H, H, 0, 1, 0, M, st, L->persist));
+  CHK(gemm(G->dU, L->wi, G->dN, Mp, H, FF, FF, H, H, 0, 1, 0, M, st, L->persist, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, -1,
+           0, 0, 0, 1.f, L->splitk_ws, L->splitk_bytes));
   // y1 = LN1(h1): d y1 = dN (bf16) + d h2 (f32, the residual) ; d h1 -> dx_f32 (the f32 part of d y: h1 = ... + y),
   // its bf16 (dropout-masked) copy = attn-out's dY
   CHK(ln_bwd(L->xm, L->m1, L->r1, L->ln1w, M, H, G->dN, G->dmid_f32, nullptr, G->dx_f32, G->dh1_bf16, G->g_ln1w, G->g_ln1b, G->g_bo, st,
@@ -138,7 +142,8 @@ extern "C" int vault_lm_layer_bwd(const vault_layer_bwd_args* G, void* st) {
   CHK(attn(L, 1, G->dctx, G->dqkv, st));
   // d y (layer input) = dqkv . Wqkv (bf16 -> dx_bf16) + d h1 (f32 -> dx_f32, the residual): consumed by the LN2 backward
   // of the layer below
-  CHK(gemm(G->dqkv, L->wqkv, G->dx_bf16, Mp, H, 3 * H, 3 * H, H, H, 0, 1, 0, M, st, L->persist));
+  CHK(gemm(G->dqkv, L->wqkv, G->dx_bf16, Mp, H, 3 * H, 3 * H, H, H, 0, 1, 0, M, st, L->persist, nullptr, nullptr, nullptr, nullptr, nullptr, 1,
+           0, -1, 0, 0, 0, 1.f, L->splitk_ws, L->splitk_bytes));
   if (G->do_wgrad) CHK(wgrad(G->dqkv, L->x_in_bf16, G->g_wqkv, Mp, 3 * H, H, st, L->persist));
   if (G->g_bqkv) CHK(vault_colsum(G->dqkv, 3 * H, M, 3 * H, G->g_bqkv, st));
   return VAULT_OK;

@@ -11,8 +11,9 @@ namespace stage {
 inline int gemm(const void* A, const void* B, void* out, int M, int N, int K, int lda, int ldb, int ldo, int a_mode, int b_mode, int epi,
          int m_valid, void* st, int persist, const float* bias = nullptr, const float* res = nullptr, const void* aux = nullptr,
          void* out2 = nullptr, float* colsum = nullptr, int splits = 1, int accumulate = 0, int cfg = -1,
-         uint32_t dthr = 0, uint32_t dseed = 0, uint32_t dstream = 0, float dscale = 1.f) {
+         uint32_t dthr = 0, uint32_t dseed = 0, uint32_t dstream = 0, float dscale = 1.f, void* sk_ws = nullptr, long long sk_bytes = 0) {
   vault_gemm_args a{};
+  a.splitk_ws = sk_ws; a.splitk_bytes = sk_bytes;
   a.A = A; a.B = B; a.out = out; a.out2 = out2; a.bias = bias; a.res = res; a.aux = aux; a.colsum = colsum;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldo = ldo; a.m_valid = m_valid;
   a.a_mode = a_mode; a.b_mode = b_mode; a.epi = epi; a.cfg = cfg; a.splits = splits; a.accumulate = accumulate;

@@ -108,6 +108,7 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
         self.last: Optional[dict] = None
         self._wgrad_stream, self._wgrad_pending = None, False
         self._wgrad_side = False
+        self.dp_world = 1          # ranks of the data-parallel step this engine runs in (TrainStep sets it: backward._wgrad_group_size)
         self._grads_zero = False
         self._g_dirty = False      # the flat gradient buffer may hold gradients of an API-level backward (not yet consumed / zeroed)
         self._g_stale_key = None   # tape key of the fused step whose stored weight-gradient ranges the optimizer left un-zeroed
@@ -192,6 +193,20 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
         return self._ws[key]
 
     # ---- helpers ----------------------------------------------------------------------------
+    def _sk_ws(self):
+        """Workspace the library may use to split the contraction of a GEMM that fills less than a round of the chip - the N = H
+        Linears with K = FF / 3H at small batches (FFN-out forward, FFN-in / QKV data gradients: 96 tiles of 48 K tiles at B = 32
+        become 192 items of 24) - and reduce inside the launch (csrc/gemm256.hip SK).  One per engine: its GEMMs run on one
+        stream (the weight gradients of the second stream accumulate by atomics and take none); counters zero at allocation,
+        every launch leaves them zero.  64 MiB: two splits of up to 170 tiles, four of 85.  None when switched off."""
+        if not self.SPLITK:
+            return None
+        t = self._ws.get("splitk_ws")
+        if t is None:
+            t = torch.zeros(self.SPLITK_WS_BYTES, dtype=torch.uint8, device=self.device)
+            self._ws["splitk_ws"] = t
+        return t
+
     def _fp8_scratch(self, M, K):
         """MXFP8 image of the A operand of the GEMM about to run (consumed at once: one buffer per shape)."""
         key = ("fp8_a", M, K)
@@ -270,6 +285,8 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
             ops.gemm_mxfp8(aq, asc, wq, wsc, out, M, N, K, N, epi, m_valid=m_valid, bias=bias, **kw)
             return emit_q
         else:
+            if epi == ops.EPI_F32_RES and K >= 1536:
+                kw.setdefault("splitk_ws", self._sk_ws())
             ops.gemm(a_bf16, P.wb(wname, n_elems=N * K, shape=(N, K)), out, M, N, K, K, K, N if ldo is None else ldo,
                      0, 0, epi, m_valid=m_valid, bias=bias, **kw)
 
@@ -294,6 +311,8 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
             # forward-form operands on the transposed shadow W^T [Kin][Nout]: the register-direct GEMM
             ops.gemm(dy_bf16, wt, out, M, Kin, Nout, Nout, Nout, Kin, 0, 0, epi, m_valid=m_valid, **kw)
             return
+        if epi == ops.EPI_BF16 and Nout >= 1536:
+            kw.setdefault("splitk_ws", self._sk_ws())
         ops.gemm(dy_bf16, P.wb(wname, n_elems=Nout * Kin, shape=(Nout, Kin)), out, M, Kin, Nout, Nout, Kin, Kin, 0, 1,
                  epi, m_valid=m_valid, **kw)
 
@@ -301,6 +320,8 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
     FFN_OUT_FP8 = False            # fp8-forward mode: FFN-out on MXFP8 operands too (see _fp8_refresh_weights: measured, slower)
     HEAD_MAJOR = True              # qkv / dqkv of large batches in the head-major layout [3][heads][rows][64] (see _plan_head_major)
     HEAD_MAJOR_MIN_ROWS = 16384    # ... from this many (padded) token rows of a stack
+    SPLITK = True                  # lend the GEMMs a workspace for split-K with the in-launch reduction (vault_gemm_args.splitk_ws; see _sk_ws)
+    SPLITK_WS_BYTES = 16384 + (64 << 20)
     WGRAD_SIDE_ITEMS = 224         # items per grouped launch on the second stream (B = 64, same box: 256: 13.50 / 13.59 ms, 224: 13.32 / 13.46, 192: 13.23 / 13.47, 160: 13.63 / 13.53)
 
 
@@ -383,6 +404,9 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
                   bqkv=P.w(ln.qb, n_elems=3 * H, shape=(3 * H,)), bo=P.w(ln.ob), bi=P.w(ln.ib), bf=P.w(ln.fb),
                   ln1w=P.w(ln.ln1w), ln1b=P.w(ln.ln1b), ln2w=P.w(ln.ln2w), ln2b=P.w(ln.ln2b),
                   x_in=x_in, x_out=x_out, x_in_bf16=x_in_bf16, x_out_bf16=x_out_bf16, keymask=keymask, **bufs)
+        sk = self._sk_ws()
+        if sk is not None:
+            kw.update(splitk_ws=sk, splitk_bytes=sk.numel())
         if drops is not None:
             da, dh = drops
             kw.update(attn_drop_thresh=da.thresh, attn_drop_scale=da.scale, hid_drop_thresh=dh.thresh, hid_drop_scale=dh.scale,

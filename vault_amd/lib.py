@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VAULT_HIP_LIB") or os.path.join(_HERE, "libvault_hip.so")
 # the same sources compiled for the IEEE fp16 operand type (csrc/common.h `h16`, build.py VARIANTS): same exported ABI
 LIB_PATH_F16 = os.environ.get("VAULT_HIP_LIB_F16") or os.path.join(_HERE, "libvault_hip_f16.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 FORMATS = ("bf16", "fp16")
 _libs = {}
 
@@ -29,6 +29,7 @@ class GemmArgs(C.Structure):
         ("batch", C.c_int), ("batch_a", C.c_longlong), ("batch_b", C.c_longlong), ("batch_o", C.c_longlong),
         ("aux_u8", C.c_int), ("out_hm", C.c_int), ("a_hm", C.c_int),
         ("out_q", C.c_void_p), ("out_scale", C.c_void_p),
+        ("splitk_ws", C.c_void_p), ("splitk_bytes", C.c_longlong),
     ]
 
 

@@ -185,8 +185,11 @@ GEMM_SCHED = 0       # (tests set it directly to exercise the mode on one GPU)
 
 def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_valid=0, splits=1, accumulate=0,
          bias=None, res=None, aux=None, out2=None, addtab=None, rpg=0, gstride=0, goff=0, drop: Drop = NO_DROP,
-         colsum=None, split3=False, batch=0, batch_a=0, batch_b=0, batch_o=0, aux_u8=False, plan_only=False, out_hm=0, a_hm=0):
+         colsum=None, split3=False, batch=0, batch_a=0, batch_b=0, batch_o=0, aux_u8=False, plan_only=False, out_hm=0, a_hm=0,
+         splitk_ws=None):
     a = L.GemmArgs()
+    if splitk_ws is not None:       # caller-owned workspace of the in-launch split-K reduction (vault_gemm_args.splitk_ws)
+        a.splitk_ws, a.splitk_bytes = _p(splitk_ws), splitk_ws.numel() * splitk_ws.element_size()
     a.aux_u8 = 1 if aux_u8 else 0
     a.out_hm, a.a_hm = int(out_hm), int(a_hm)     # head-major output / A operand (vault_gemm_args.out_hm / a_hm)
     a.A, a.B, a.out, a.out2 = _h(A), _h(B), _h(out), _h(out2)
@@ -558,7 +561,8 @@ class LayerArgs(C.Structure):
                                            "ln2w", "ln2b", "x_in", "x_in_bf16", "x_out", "x_out_bf16", "keymask", "n1", "qkv",
                                            "ctx", "lse", "xm", "y1", "n2", "act", "u", "h2", "m1", "r1", "m2", "r2")] +
                 [(n, C.c_uint32) for n in ("attn_drop_thresh", "hid_drop_thresh", "drop_seed", "drop_stream_base")] +
-                [("attn_drop_scale", C.c_float), ("hid_drop_scale", C.c_float), ("persist", C.c_int)])
+                [("attn_drop_scale", C.c_float), ("hid_drop_scale", C.c_float), ("persist", C.c_int),
+                 ("splitk_ws", C.c_void_p), ("splitk_bytes", C.c_longlong)])
 
 
 class LayerBwdArgs(C.Structure):

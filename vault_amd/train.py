@@ -237,7 +237,12 @@ class BucketReducer:
         by the union).  Every later step carries a two-word header (token count, ids given) per rank in the same all-gather:
         a rank with more ids than the capacity, or one that switched between ids and ``inputs_embeds``, makes EVERY rank raise
         when the table is exchanged (``_check_headers``) - a decision taken on one rank only would leave the others waiting
-        in their next collective until it times out."""
+        in their next collective until it times out.
+
+        The bucket frontier starts over here as well: a step that raised from inside the exchange (the header / id checks run
+        under ``_launch``) never reached ``finish()``, and a frontier left at its position would make ``on_stage`` skip every
+        upper range of the next step without an error (the replicas would diverge silently)."""
+        self.reset(wait=True)
         self.wire_bytes = 0
         self._union_ready, self._n_keys = None, 0
         if self.sparse is None:
@@ -351,6 +356,16 @@ class BucketReducer:
                                    "gradient rows outside the union of this step's token ids")
 
     # ---- bucket logic ---------------------------------------------------------------------------------------
+    def reset(self, wait: bool = False):
+        """Forget the ranges launched so far: top-down frontier at the end of the buffer, nothing launched, no events.
+        ``wait``: the compute stream first waits for exchanges still in flight (a step that raised left them behind: whatever
+        the caller does to the gradient buffer next must not race with them)."""
+        if wait:
+            self._wait(self.done)
+        self.hi, self.bottom, self.min_seen = self.n, 0, self.n
+        self.done.clear()
+        self.launched.clear()
+
     def on_stage(self, tag: str):
         lo = self.stage_lo.get(tag)
         if lo is None:
@@ -403,10 +418,8 @@ class BucketReducer:
 
     def finish(self):
         self._wait(self.done)
-        self.done.clear()
         missing = (self.bottom, self.hi) if self.hi != self.bottom else None
-        self.hi, self.bottom, self.min_seen = self.n, 0, self.n      # (reset first: the reducer stays usable after the error)
-        self.launched.clear()
+        self.reset()      # (first: the reducer stays usable after the error)
         if missing is not None:
             raise RuntimeError("gradient range [%d, %d) was never reduced" % missing)
 
@@ -444,6 +457,7 @@ class TrainStep:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
             self.world = dist.get_world_size(process_group)
+        engine.dp_world = self.world
         # VAULT_FORCE_DP=1 exercises the bucketed all-reduce path even with a single rank (debug/testing)
         if self.world > 1:
             # every rank draws its own dropout masks: the keep/drop hash takes (seed, stream, LOCAL element index), so
@@ -487,6 +501,10 @@ class TrainStep:
         tape (ops.Tape); later calls copy the batch into the persistent input buffers and replay it."""
         eng = self.engine
         B, T = batch["input_ids"].shape
+        if self.reducer:
+            # (a step that raised inside the exchange never reached finish(): its frontier and its events are dropped here,
+            #  before anything below touches the gradient buffer)
+            self.reducer.reset(wait=True)
         if eng._g_dirty:
             # gradients of an API-level backward (loss.backward() through the module) are still in the flat buffer: the fused step
             # starts from zeros (it STORES its un-split weight-gradient tiles and lets AdamW clear the buffer afterwards)
@@ -503,11 +521,11 @@ class TrainStep:
             # from here to the enqueued AdamW (which clears it) the flat gradient buffer holds this step's partial gradients: an
             # exception in between (the reducer's checks raise and stay usable) must not leave them for the next step, which
             # STORES its un-split weight-gradient tiles but atomically ADDS bias / LayerNorm / embedding / split-K gradients
-            eng._g_dirty = True
             if eng._g_stale_key is not None and eng._g_stale_key != key:
                 # the previous fused step (another shape / mode: another tape) left the ranges ITS successor would have stored
                 # un-zeroed; this step may accumulate there
                 eng.zero_grad()
+            eng._g_dirty = True        # (after the zeroing above, which clears the flag)
             if self.reducer:
                 # the token ids of every rank name the rows of the word-embedding table this step touches: their
                 # all-gather + union start now on the communication stream (inputs_embeds: no row is touched)
@@ -532,14 +550,14 @@ class TrainStep:
                 # embeddings: the lowest addresses) is still being all-reduced, then on the rest
                 x = self.reducer.finish_upper()
                 if 0 < x < eng.params.n_train:
-                    self.optimizer_step(lo=x, hi=eng.params.n_train, advance=False)
+                    self.optimizer_step(lo=x, hi=eng.params.n_train, advance=False, zero_mask=self._zero_mask)
                     self.reducer.finish()
-                    self.optimizer_step(lo=0, hi=x)
+                    self.optimizer_step(lo=0, hi=x, zero_mask=self._zero_mask)
                 else:
                     self.reducer.finish()
-                    self.optimizer_step()
+                    self.optimizer_step(zero_mask=self._zero_mask)
             else:
-                self.optimizer_step()
+                self.optimizer_step(zero_mask=self._zero_mask)
             eng._g_dirty = False       # (the optimizer pass over [0, n_train) is enqueued: it zeroes what it reads ...)
             eng._g_stale_key = key if self._zero_mask is not None else None     # (... but for the ranges the next step stores)
         self.loss = self._loss_buf
@@ -562,9 +580,12 @@ class TrainStep:
         self._zero_mask_key = key
         return torch.from_numpy(m).to(self.engine.device)
 
-    def optimizer_step(self, lo: int = 0, hi: Optional[int] = None, advance: bool = True):
+    def optimizer_step(self, lo: int = 0, hi: Optional[int] = None, advance: bool = True,
+                       zero_mask: Optional[torch.Tensor] = None):
         """Fused HF-AdamW over elements [lo, hi) of the flat parameter buffer (default: all trainable ones);
-        ``advance=False`` leaves the step counter alone (first part of a split update)."""
+        ``advance=False`` leaves the step counter alone (first part of a split update).  ``zero_mask`` (one byte per 64
+        elements of the WHOLE buffer, 0 = leave the gradient un-zeroed) is the fused step's own: a caller that steps the
+        optimizer by hand (gradient accumulation, a manual loop) gets every gradient it read cleared."""
         eng = self.engine
         P = eng.params
         hi = P.n_train if hi is None else hi
@@ -576,7 +597,7 @@ class TrainStep:
             if hi > lo:
                 # (the gradients carry the operand format's power-of-two scale - fp16: engine.grad_scale - and the sum
                 #  over the ranks: both are divided out here)
-                zm = self._zero_mask
+                zm = zero_mask
                 if zm is not None and (lo % 64 or (hi - lo) % 64):
                     zm = None          # (never for the engine's 64-aligned stage boundaries)
                 ops.adamw_step(P.p[lo:hi], P.g[lo:hi], P.m[lo:hi], P.v[lo:hi], P.pb[lo:hi], hi - lo, self.current_lr(),
