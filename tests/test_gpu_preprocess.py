@@ -148,7 +148,8 @@ def test_patch_unfold_straight_from_the_resize_kernel():
         params.append(eng.params.p.clone())
     assert torch.equal(outs[0], outs[1])
     d = (params[0] - params[1]).abs()
-    assert float(d.mean()) < 2e-6 and float((d > 2e-5).float().mean()) < 0.03      # float-atomic summation order only
+    # (float-atomic summation order only; round 6: the patch projection's weight gradient is 7 splits of ring tiles now)
+    assert float(d.mean()) < 3e-6 and float((d > 2e-5).float().mean()) < 0.03
     with pytest.raises(ValueError):
         eng.forward(dict(input_ids=ids, attention_mask=am, pixel_patches=po[:-1]), train=False)
     # what the processor knows about padding travels with the patches: a padded image or another canvas is refused on the host

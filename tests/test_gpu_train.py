@@ -439,13 +439,15 @@ def test_frozen_lm_train_step_trajectory_vs_oracle():
 
 
 @pytest.mark.parametrize("wire", ["fp32", "bf16"])
-def test_train_step_over_rccl_single_rank(wire):
+def test_train_step_over_rccl_single_rank(wire, monkeypatch):
     """The data-parallel path on its production transport: ``torch.distributed`` backend "nccl" (= RCCL on ROCm) with one
     rank and VAULT_FORCE_DP=1 - bucketed all-reduce launched from inside backward on a side stream, split optimizer step
     (upper range while the last bucket is on the wire).  With one rank the all-reduce is the identity: the parameters
     must land exactly where the plain single-process step lands."""
     import os
     import torch.distributed as dist
+    from vault_amd.train import BucketReducer
+    monkeypatch.setattr(BucketReducer, "SINGLE_RANK_COLLECTIVES", True)      # (the RCCL calls themselves, with one rank)
     spec = VaultSpec.tiny(3, "roberta")
     spec.lm.hidden_dropout_prob = 0.0; spec.lm.attention_probs_dropout_prob = 0.0
     bn = synthetic_batch(spec, 8, seed=41, n_classes=3)

@@ -497,6 +497,15 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_kernel(const h16* __re
 #ifndef ATTN_ST_NT
 #define ATTN_ST_NT 0      // development: 1 = non-temporal output stores
 #endif
+#ifndef ATTN_BWD_KT
+#define ATTN_BWD_KT 1     // 16-row tiles per wave of the S <= 192 backward: 1 = 12 waves, 2 = 6 waves, 3 = 4 waves (round 6: measured
+                          // slower, profiles/r06_dev_attn_bwd_tiles_per_wave.txt - phase 1 is bound by vector issue and latency, not by LDS bytes)
+#endif
+#ifndef ATTN_P1_UNROLL
+#define ATTN_P1_UNROLL 1  // development: unroll factor of the phase-1 loop over the 32-query steps
+#endif
+#define ATTN_STR_(X) #X
+#define ATTN_STR(X) ATTN_STR_(X)
 #if ATTN_WL && defined(ATTN_LOADS_FIRST) && ATTN_LOADS_FIRST
 #error "ATTN_LOADS_FIRST counts the half-line form's stores: build it with -DATTN_WL=0"
 #endif
@@ -572,7 +581,18 @@ __device__ __forceinline__ const char* attn_uniform(const void* p) {
                                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u));
 }
 
-template <int NKT, int NWV, bool DROP = true, int WPE = 1>
+// `s_waitcnt vmcnt(N)` for a compile-time N
+template <int N>
+__device__ __forceinline__ void attn_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// KT (round 6) = 16-row tiles per wave: wave w owns key tiles w KT .. w KT + KT - 1 in phase 1 and the same query tiles in phase 2.
+// Phase 1 is bound by LDS reads (profiles/r06_dev_attn_bwd_ablation.txt: 65-70 us of the launch, nothing hidden behind the
+// memory pipeline): every wave reads ALL of Q and dO (row fragments for S^T / dP, transposed ones for dV / dK) whatever keys it
+// owns - 12 waves of one tile read them 12 times, 6 waves of two tiles 6 times, each fragment feeding two MFMAs from registers.
+// Every output element is computed by the same sequence of operations as with KT = 1 (bit-identical dq / dk / dv).
+template <int NKT, int NWV, bool DROP = true, int WPE = 1, int KT = 1>
 __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* __restrict__ qkv, const float* __restrict__ keymask,
                                                          const h16* __restrict__ ctx, const h16* __restrict__ dctx,
                                                          const float* __restrict__ lse, h16* __restrict__ dqkv, int S,
@@ -583,8 +603,9 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
   constexpr int DS_LD = ds_ld<SK>();
   constexpr int NT = NWV * 64;
   constexpr int NC = (SK * 8) / NT;   // 16-byte chunks per thread and matrix
-  static_assert(2 * NKT == NWV, "one 16-row tile per wave");
-  static_assert((SK * 8) % NT == 0 && SK <= NT && NC == 2, "chunk / row bookkeeping (two 1 KiB DMA pieces per wave)");
+  constexpr int LQ = 3 * NC + 2;      // loads of fetch_q_do per wave
+  static_assert(2 * NKT == NWV * KT, "KT 16-row tiles per wave");
+  static_assert((SK * 8) % NT == 0 && SK <= NT && NC >= 2 && NC <= 6 && KT >= 1 && KT <= 3, "chunk / row bookkeeping (NC 1 KiB DMA pieces per wave)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
   char* Ks = smem + SK * 128;
@@ -598,15 +619,27 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
   float* cs_lds = dl_s + SK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
+  const int tile0 = wave * KT;     // first 16-row tile of this wave
   const QkvLayout lay(H, heads, hm_rows);
   const int ld = lay.ld;
   const float sl2 = scale * LOG2E;
   const uint32_t ks_lds = (uint32_t)(size_t)LDS_PTR(char, Ks);
   const int G = (int)gridDim.x;
-  const bool wave_rows = __builtin_amdgcn_readfirstlane((int)(wave * 16 < (ATTN_ABLATE == 5 ? -S : S))) != 0;   // this wave's tile has rows to store
+  const int S_st = (ATTN_ABLATE == 5 ? -S : S);
+  // store instructions this wave issues per output matrix (wave-uniform: the counted waits below rely on it)
+#if ATTN_WL   // (per tile: instruction A if the tile has rows, instruction B if it has more than 8)
+  int nst_ = 0;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) nst_ += ((tile0 + kt) * 16 < S_st ? 1 : 0) + ((tile0 + kt) * 16 + 8 < S_st ? 1 : 0);
+#else         // (two half-line stores per tile with rows)
+  int nst_ = 0;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) nst_ += ((tile0 + kt) * 16 < S_st ? 2 : 0);
+#endif
+  const int nst = __builtin_amdgcn_readfirstlane(nst_);
 
   u32x4 rq[NC], rd[NC], ro[NC];    // Q, dO, O chunks of the item after next (rows >= S: row S - 1 again, see below)
-  u32x4 rkf[2], rvf[2];            // this wave's own K / V tile of the next item as MFMA fragments
+  u32x4 rkf[KT][2], rvf[KT][2];    // this wave's own K / V tiles of the next item as MFMA fragments
   float rl = 0.f, rm = 1.f;
   // Rows >= S are never zero-filled: they re-read row S - 1.  Finite stand-ins are enough - a query row >= S has -lse = -inf,
   // so its probabilities and dS are exactly 0; a key row >= S has the -inf mask as initial accumulator - and unconditional
@@ -618,18 +651,22 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
     off_q[i] = (uint32_t)row * (uint32_t)(ld * 2) + (uint32_t)pos * 16u;
     off_o[i] = (uint32_t)row * (uint32_t)(H * 2) + (uint32_t)pos * 16u;
   }
-  const uint32_t off_frag = (uint32_t)min(wave * 16 + l15, S - 1) * (uint32_t)(ld * 2) + (uint32_t)g * 16u;   // own key row, d = 8 g (+ 32 s)
-  const uint32_t off_out = (uint32_t)(wave * 16 + l15) * (uint32_t)(ld * 2) + (uint32_t)g * 16u;             // own row, d = 8 g (+ 32 hf)
+  uint32_t off_frag[KT];           // own key rows, d = 8 g (+ 32 s)
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+    off_frag[kt] = (uint32_t)min((tile0 + kt) * 16 + l15, S - 1) * (uint32_t)(ld * 2) + (uint32_t)g * 16u;
+  const uint32_t tile_step = 16u * (uint32_t)(ld * 2);                                                           // bytes between the wave's tiles
+#if !ATTN_WL
+  const uint32_t off_out = (uint32_t)(tile0 * 16 + l15) * (uint32_t)(ld * 2) + (uint32_t)g * 16u;             // own row, d = 8 g (+ 32 hf)
+#endif
 #if ATTN_WL
   // Whole-line stores: a lane holds the 16-byte chunks g (hf = 0) and 4 + g (hf = 1) of its row's 128-byte head slice, so a
   // store of one hf writes 16 half lines.  Lanes l15 and l15 ^ 8 swap one chunk each (DPP row_ror:8): instruction A then
   // writes rows 0-7 of the tile as whole lines (lanes l15 < 8: chunk g, lanes l15 >= 8: chunk 4 + g of row l15 - 8),
   // instruction B rows 8-15.  (Measured beforehand with the addresses alone: 5-8 % of the kernel.)
-  const int row_a = wave * 16 + (l15 & 7);                                                                    // B: + 8
+  const int row_a = tile0 * 16 + (l15 & 7);                                                                   // B: + 8 ; tile kt: + 16 kt
   const uint32_t off_wl = (uint32_t)row_a * (uint32_t)(ld * 2) + (uint32_t)(l15 >> 3) * 64u + (uint32_t)g * 16u;
   const uint32_t off_wl_b = 8u * (uint32_t)(ld * 2);
-  const int S_st = (ATTN_ABLATE == 5 ? -S : S);
-  const bool wave_rows_b = __builtin_amdgcn_readfirstlane((int)(wave * 16 + 8 < S_st)) != 0;   // rows for instruction B too
   auto wl_pair = [&](const u32x4& x, const u32x4& y, u32x4& a, u32x4& b) {     // x: chunk g, y: chunk 4 + g of the own row
     const bool lo8 = l15 < 8;
 #pragma unroll
@@ -648,7 +685,7 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
 #endif
     b = item / heads; h = item - b * heads;
   };
-  auto fetch_q_do = [&](int item) {      // 2 NC + NC + 2 = 8 loads per wave, unconditional
+  auto fetch_q_do = [&](int item) {      // LQ = 3 NC + 2 loads per wave, unconditional
     int b, h;
     item_bh(item, b, h);
     const size_t row0 = (size_t)b * S;
@@ -664,18 +701,20 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
     attn_gload4(rl, attn_uniform(lse + (size_t)item * S), off_stat);
     attn_gload4(rm, attn_uniform(keymask != nullptr ? keymask + (size_t)b * S : lse + (size_t)item * S), off_stat);
   };
-  auto fetch_kv_frags = [&](int item) {  // 4 loads per wave, unconditional
+  auto fetch_kv_frags = [&](int item) {  // 4 KT loads per wave, unconditional
     int b, h;
     item_bh(item, b, h);
     const char* kb = attn_uniform(qkv + (size_t)b * S * ld + (size_t)h * lay.hs + lay.pl);
     const char* vb = attn_uniform(qkv + (size_t)b * S * ld + (size_t)h * lay.hs + 2 * (size_t)lay.pl);
 #pragma unroll
-    for (int s_ = 0; s_ < 2; ++s_) {
-      attn_gload16(rkf[s_], kb, off_frag + 64u * s_);
-      attn_gload16(rvf[s_], vb, off_frag + 64u * s_);
-    }
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        attn_gload16(rkf[kt][s_], kb, off_frag[kt] + 64u * s_);
+        attn_gload16(rvf[kt][s_], vb, off_frag[kt] + 64u * s_);
+      }
   };
-  // the K image of an item by LDS-DMA: two 1 KiB pieces (8 rows) per wave, XOR swizzle on the source chunk; rows >= S are
+  // the K image of an item by LDS-DMA: NC 1 KiB pieces (8 rows each) per wave, XOR swizzle on the source chunk; rows >= S are
   // never written (they stay zero from the start of the kernel)
   auto dma_k = [&](int item) {
     int b, h;
@@ -690,7 +729,9 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
   };
   // registers -> the images phase 2 does not read: Q, dO, delta, key bias, -lse (call only behind a wait for the loads)
   auto write_q_do = [&]() {
-    asm volatile("" : "+v"(rq[0]), "+v"(rq[1]), "+v"(rd[0]), "+v"(rd[1]), "+v"(ro[0]), "+v"(ro[1]), "+v"(rl), "+v"(rm));
+#pragma unroll
+    for (int i = 0; i < NC; ++i) asm volatile("" : "+v"(rq[i]), "+v"(rd[i]), "+v"(ro[i]));
+    asm volatile("" : "+v"(rl), "+v"(rm));
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = tid + i * NT, row = c >> 3, pos = c & 7;
@@ -727,9 +768,13 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
   write_q_do();
   if (item + G < items) fetch_q_do(item + G);
   for (; item < items; item += G) {
-    asm volatile("" : "+v"(rkf[0]), "+v"(rkf[1]), "+v"(rvf[0]), "+v"(rvf[1]));   // (landed: waited for in front of the DMA / above)
-    const h16x8 kf0 = __builtin_bit_cast(h16x8, rkf[0]), kf1 = __builtin_bit_cast(h16x8, rkf[1]);
-    const h16x8 vf0 = __builtin_bit_cast(h16x8, rvf[0]), vf1 = __builtin_bit_cast(h16x8, rvf[1]);
+    h16x8 kf0[KT], kf1[KT], vf0[KT], vf1[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      asm volatile("" : "+v"(rkf[kt][0]), "+v"(rkf[kt][1]), "+v"(rvf[kt][0]), "+v"(rvf[kt][1]));   // (landed: waited for in front of the DMA / above)
+      kf0[kt] = __builtin_bit_cast(h16x8, rkf[kt][0]); kf1[kt] = __builtin_bit_cast(h16x8, rkf[kt][1]);
+      vf0[kt] = __builtin_bit_cast(h16x8, rvf[kt][0]); vf1[kt] = __builtin_bit_cast(h16x8, rvf[kt][1]);
+    }
     int b, h;
     item_bh(item, b, h);
 #if ATTN_ABLATE == 2
@@ -742,19 +787,23 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // Q / dO images + statistics of this item complete
     const bool more = item + G < items, more2 = item + 2 * G < items;
 
-    // ---------------- phase 1: wave = key tile `wave`; dK, dV in registers, dS^T -> LDS ----------------
-    const float mk = mb[wave * 16 + l15];
-    f32x4 dk[4], dv[4];
+    // ---------------- phase 1: wave = key tiles tile0 ..; dK, dV in registers, dS^T -> LDS ----------------
+    float mk[KT];
+    f32x4 dk[KT][4], dv[KT][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < KT; ++kt) {
+      mk[kt] = mb[(tile0 + kt) * 16 + l15];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dk[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
     {
-      char* dsrow = dSs + (wave * 16 + l15) * DS_LD + 8 * g;
-#pragma unroll 1
+      char* dsrow = dSs + (tile0 * 16 + l15) * DS_LD + 8 * g;      // tile kt: + 16 kt DS_LD
+_Pragma(ATTN_STR(unroll ATTN_P1_UNROLL))
       for (int T = 0; T < ((ATTN_ABLATE == 1 || ATTN_ABLATE == 4) ? 0 : NKT); ++T) {
-        f32x4 p2[2], ds2[2];
+        f32x4 p2[KT][2], ds2[KT][2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const int qt = 2 * T + hh;
@@ -762,38 +811,49 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
           const h16x8 d0 = frag_rows(Ds, qt, 0, g, l15), d1 = frag_rows(Ds, qt, 1, g, l15);
           const f32x4 nl4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * g);
           const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dl_s + qt * 16 + 4 * g);
-          f32x4 a = {mk, mk, mk, mk}, dp = {0.f, 0.f, 0.f, 0.f};     // (the key mask is the initial accumulator)
-          a = mfma16(q0, kf0, a);
-          a = mfma16(q1, kf1, a);
-          dp = mfma16(d0, vf0, dp);
-          dp = mfma16(d1, vf1, dp);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(a[r], sl2, nl4[r]));
-            float dpv = dp[r];
-            if (DROP && dr.thresh != 0u) {
-              const uint32_t k_l = (uint32_t)(wave * 16 + l15);
-              const uint32_t idx = (bh * (uint32_t)S + (uint32_t)(qt * 16 + 4 * g + r)) * (uint32_t)S + k_l;
-              const bool keep = dropout_keep(dr.seed, dr.stream, idx, dr.thresh);
-              dpv = keep ? dpv * dr.scale : 0.f;
-              ds2[hh][r] = pv * (dpv - dl4[r]);
-              pv = keep ? pv * dr.scale : 0.f;
-            } else {
-              ds2[hh][r] = pv * (dpv - dl4[r]);
+          for (int kt = 0; kt < KT; ++kt) {
+            f32x4 a = {mk[kt], mk[kt], mk[kt], mk[kt]}, dp = {0.f, 0.f, 0.f, 0.f};     // (the key mask is the initial accumulator)
+            a = mfma16(q0, kf0[kt], a);
+            a = mfma16(q1, kf1[kt], a);
+            dp = mfma16(d0, vf0[kt], dp);
+            dp = mfma16(d1, vf1[kt], dp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(a[r], sl2, nl4[r]));
+              float dpv = dp[r];
+              if (DROP && dr.thresh != 0u) {
+                const uint32_t k_l = (uint32_t)((tile0 + kt) * 16 + l15);
+                const uint32_t idx = (bh * (uint32_t)S + (uint32_t)(qt * 16 + 4 * g + r)) * (uint32_t)S + k_l;
+                const bool keep = dropout_keep(dr.seed, dr.stream, idx, dr.thresh);
+                dpv = keep ? dpv * dr.scale : 0.f;
+                ds2[kt][hh][r] = pv * (dpv - dl4[r]);
+                pv = keep ? pv * dr.scale : 0.f;
+              } else {
+                ds2[kt][hh][r] = pv * (dpv - dl4[r]);
+              }
+              p2[kt][hh][r] = pv;
             }
-            p2[hh][r] = pv;
           }
         }
-        const h16x8 pf = pack_frag(p2[0], p2[1]);
-        const h16x8 dsf = pack_frag(ds2[0], ds2[1]);
-        // dS^T[key = this lane's][queries 32 T + 16 hh + 4 g + 0..3]: two 8-byte stores
-        const u32x4 dsw = __builtin_bit_cast(u32x4, dsf);
-        *reinterpret_cast<uint2*>(dsrow + T * 64) = uint2{dsw[0], dsw[1]};
-        *reinterpret_cast<uint2*>(dsrow + T * 64 + 32) = uint2{dsw[2], dsw[3]};
+        h16x8 pf[KT], dsf[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          pf[kt] = pack_frag(p2[kt][0], p2[kt][1]);
+          dsf[kt] = pack_frag(ds2[kt][0], ds2[kt][1]);
+          // dS^T[key = this lane's][queries 32 T + 16 hh + 4 g + 0..3]: two 8-byte stores
+          const u32x4 dsw = __builtin_bit_cast(u32x4, dsf[kt]);
+          *reinterpret_cast<uint2*>(dsrow + kt * 16 * DS_LD + T * 64) = uint2{dsw[0], dsw[1]};
+          *reinterpret_cast<uint2*>(dsrow + kt * 16 * DS_LD + T * 64 + 32) = uint2{dsw[2], dsw[3]};
+        }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          dv[dt] = mfma16(frag_tr8(Ds, T, dt >> 1, dt & 1, g, l15), pf, dv[dt]);
-          dk[dt] = mfma16(frag_tr8(Qs, T, dt >> 1, dt & 1, g, l15), dsf, dk[dt]);
+          const h16x8 trd = frag_tr8(Ds, T, dt >> 1, dt & 1, g, l15), trq = frag_tr8(Qs, T, dt >> 1, dt & 1, g, l15);
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) {
+            dv[kt][dt] = mfma16(trd, pf[kt], dv[kt][dt]);
+            dk[kt][dt] = mfma16(trq, dsf[kt], dk[kt][dt]);
+          }
         }
       }
     }
@@ -801,23 +861,27 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
     // this item (DMA issued an item ago), the Q / dO / O registers of the next item (requested an item ago) and old stores -
     // is needed right behind the barrier; phase 1 issued no memory operation
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (cs_out != nullptr && cs_thirds == 3) {      // key / value bias gradient: column sums of this wave's dk (scaled) / dv tile
-      attn_tile_colsum(dk, scale, cs_lds + H + h * 64, g, l15);
-      attn_tile_colsum(dv, 1.0f, cs_lds + 2 * H + h * 64, g, l15);
+    if (cs_out != nullptr && cs_thirds == 3) {      // key / value bias gradient: column sums of this wave's dk (scaled) / dv tiles
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        attn_tile_colsum(dk[kt], scale, cs_lds + H + h * 64, g, l15);
+        attn_tile_colsum(dv[kt], 1.0f, cs_lds + 2 * H + h * 64, g, l15);
+      }
     }
     if (more) write_q_do();                                           // images of the next item: phase 2 reads only K and dS^T
 #if ATTN_LOADS_FIRST
     if (more) fetch_kv_frags(item + G);
     if (more2) fetch_q_do(item + 2 * G);
 #endif
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
 #if ATTN_WL
-    {
       char* dstk = dqbase + 2 * (size_t)lay.pl;        // (byte offsets: K part at + pl elements, V part at + 2 pl elements)
       char* dstv = dqbase + 4 * (size_t)lay.pl;
       u32x4 wk[2], wv[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {    // tiles (2 hf, 2 hf + 1): d = 32 hf + 8 g + 0..7 of this lane's row
-        const f32x4 ka = dk[2 * hf], kb2 = dk[2 * hf + 1], va = dv[2 * hf], vb2 = dv[2 * hf + 1];
+        const f32x4 ka = dk[kt][2 * hf], kb2 = dk[kt][2 * hf + 1], va = dv[kt][2 * hf], vb2 = dv[kt][2 * hf + 1];
         wk[hf] = u32x4{pack_h16x2(ka[0] * scale, ka[1] * scale), pack_h16x2(ka[2] * scale, ka[3] * scale),
                        pack_h16x2(kb2[0] * scale, kb2[1] * scale), pack_h16x2(kb2[2] * scale, kb2[3] * scale)};
         wv[hf] = u32x4{pack_h16x2(va[0], va[1]), pack_h16x2(va[2], va[3]), pack_h16x2(vb2[0], vb2[1]), pack_h16x2(vb2[2], vb2[3])};
@@ -825,106 +889,105 @@ __global__ __launch_bounds__(NWV * 64, WPE) void attn_bwd_one_kernel(const h16* 
       u32x4 ka_, kb_, va_, vb_;
       wl_pair(wk[0], wk[1], ka_, kb_);
       wl_pair(wv[0], wv[1], va_, vb_);
-      if (row_a < S_st) {
-        ATTN_STORE16(dstk + off_wl, ka_);
-        ATTN_STORE16(dstv + off_wl, va_);
+      const uint32_t ow = off_wl + (uint32_t)kt * tile_step;
+      if (row_a + 16 * kt < S_st) {
+        ATTN_STORE16(dstk + ow, ka_);
+        ATTN_STORE16(dstv + ow, va_);
       }
-      if (row_a + 8 < S_st) {
-        ATTN_STORE16(dstk + (off_wl + off_wl_b), kb_);
-        ATTN_STORE16(dstv + (off_wl + off_wl_b), vb_);
+      if (row_a + 16 * kt + 8 < S_st) {
+        ATTN_STORE16(dstk + (ow + off_wl_b), kb_);
+        ATTN_STORE16(dstv + (ow + off_wl_b), vb_);
       }
-    }
 #else
-    if (wave * 16 + l15 < (ATTN_ABLATE == 5 ? -S : S)) {
-      char* dstk = dqbase + 2 * (size_t)lay.pl;        // (byte offsets: K part at + pl elements, V part at + 2 pl elements)
-      char* dstv = dqbase + 4 * (size_t)lay.pl;
+      if ((tile0 + kt) * 16 + l15 < S_st) {
+        char* dstk = dqbase + 2 * (size_t)lay.pl;        // (byte offsets: K part at + pl elements, V part at + 2 pl elements)
+        char* dstv = dqbase + 4 * (size_t)lay.pl;
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {    // tiles (2 hf, 2 hf + 1): d = 32 hf + 8 g + 0..7 of this lane's row
-        const f32x4 ka = dk[2 * hf], kb2 = dk[2 * hf + 1], va = dv[2 * hf], vb2 = dv[2 * hf + 1];
-        const u32x4 wk = {pack_h16x2(ka[0] * scale, ka[1] * scale), pack_h16x2(ka[2] * scale, ka[3] * scale),
-                          pack_h16x2(kb2[0] * scale, kb2[1] * scale), pack_h16x2(kb2[2] * scale, kb2[3] * scale)};
-        const u32x4 wv = {pack_h16x2(va[0], va[1]), pack_h16x2(va[2], va[3]), pack_h16x2(vb2[0], vb2[1]), pack_h16x2(vb2[2], vb2[3])};
-        ATTN_STORE16(dstk + (off_out + 64u * hf), wk);
-        ATTN_STORE16(dstv + (off_out + 64u * hf), wv);
+        for (int hf = 0; hf < 2; ++hf) {    // tiles (2 hf, 2 hf + 1): d = 32 hf + 8 g + 0..7 of this lane's row
+          const f32x4 ka = dk[kt][2 * hf], kb2 = dk[kt][2 * hf + 1], va = dv[kt][2 * hf], vb2 = dv[kt][2 * hf + 1];
+          const u32x4 wk = {pack_h16x2(ka[0] * scale, ka[1] * scale), pack_h16x2(ka[2] * scale, ka[3] * scale),
+                            pack_h16x2(kb2[0] * scale, kb2[1] * scale), pack_h16x2(kb2[2] * scale, kb2[3] * scale)};
+          const u32x4 wv = {pack_h16x2(va[0], va[1]), pack_h16x2(va[2], va[3]), pack_h16x2(vb2[0], vb2[1]), pack_h16x2(vb2[2], vb2[3])};
+          ATTN_STORE16(dstk + (off_out + (uint32_t)kt * tile_step + 64u * hf), wk);
+          ATTN_STORE16(dstv + (off_out + (uint32_t)kt * tile_step + 64u * hf), wv);
+        }
       }
-    }
 #endif
+    }
     // requests of the following items, issued here so that they are in flight for a whole item: the K / V fragments of the
-    // next item first (4 loads), then the Q / dO / O chunks + statistics of the item after next (8 loads)
+    // next item first (4 KT loads), then the Q / dO / O chunks + statistics of the item after next (LQ loads)
 #if !ATTN_LOADS_FIRST
     if (more) fetch_kv_frags(item + G);
     if (more2) fetch_q_do(item + 2 * G);
 #endif
-    // ---------------- phase 2: wave = query tile `wave`; dQ = dS K ----------------
+    // ---------------- phase 2: wave = query tiles tile0 ..; dQ = dS K ----------------
     {
-      f32x4 o[4];
+      f32x4 o[KT][4];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const char* dsb = dSs + (4 * g + (l15 >> 2)) * DS_LD + wave * 32 + (l15 & 3) * 8;
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const char* dsb = dSs + (4 * g + (l15 >> 2)) * DS_LD + tile0 * 32 + (l15 & 3) * 8;     // query tile kt: + 32 kt
 #pragma unroll
       for (int T = 0; T < ((ATTN_ABLATE == 1 || ATTN_ABLATE == 3) ? 0 : NKT); ++T) {
         const char* a = dsb + T * 32 * DS_LD;
-        const h16x8 dsB = cat_tr(lds_read_tr16(a), lds_read_tr16(a + 16 * DS_LD));
+        h16x8 dsB[KT];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-          o[dt] = mfma16(frag_tr8(Ks, T, dt >> 1, dt & 1, g, l15), dsB, o[dt]);
+        for (int kt = 0; kt < KT; ++kt) dsB[kt] = cat_tr(lds_read_tr16(a + kt * 32), lds_read_tr16(a + kt * 32 + 16 * DS_LD));
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const h16x8 trk = frag_tr8(Ks, T, dt >> 1, dt & 1, g, l15);
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) o[kt][dt] = mfma16(trk, dsB[kt], o[kt][dt]);
+        }
       }
-      // query bias gradient: column sums of this wave's dq tile (rows q >= S are zero: their probabilities are)
-      if (cs_out != nullptr) attn_tile_colsum(o, scale, cs_lds + h * 64, g, l15);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        // query bias gradient: column sums of this wave's dq tile (rows q >= S are zero: their probabilities are)
+        if (cs_out != nullptr) attn_tile_colsum(o[kt], scale, cs_lds + h * 64, g, l15);
 #if ATTN_WL
-      {
         u32x4 wq[2], qa_, qb_;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-          const f32x4 qa = o[2 * hf], qb2 = o[2 * hf + 1];
+          const f32x4 qa = o[kt][2 * hf], qb2 = o[kt][2 * hf + 1];
           wq[hf] = u32x4{pack_h16x2(qa[0] * scale, qa[1] * scale), pack_h16x2(qa[2] * scale, qa[3] * scale),
                          pack_h16x2(qb2[0] * scale, qb2[1] * scale), pack_h16x2(qb2[2] * scale, qb2[3] * scale)};
         }
         wl_pair(wq[0], wq[1], qa_, qb_);
-        if (row_a < S_st) ATTN_STORE16(dqbase + off_wl, qa_);
-        if (row_a + 8 < S_st) ATTN_STORE16(dqbase + (off_wl + off_wl_b), qb_);
-      }
+        const uint32_t ow = off_wl + (uint32_t)kt * tile_step;
+        if (row_a + 16 * kt < S_st) ATTN_STORE16(dqbase + ow, qa_);
+        if (row_a + 16 * kt + 8 < S_st) ATTN_STORE16(dqbase + (ow + off_wl_b), qb_);
 #else
-      if (wave * 16 + l15 < (ATTN_ABLATE == 5 ? -S : S)) {
+        if ((tile0 + kt) * 16 + l15 < S_st) {
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          const f32x4 qa = o[2 * hf], qb2 = o[2 * hf + 1];
-          const u32x4 w = {pack_h16x2(qa[0] * scale, qa[1] * scale), pack_h16x2(qa[2] * scale, qa[3] * scale),
-                           pack_h16x2(qb2[0] * scale, qb2[1] * scale), pack_h16x2(qb2[2] * scale, qb2[3] * scale)};
-          ATTN_STORE16(dqbase + (off_out + 64u * hf), w);
+          for (int hf = 0; hf < 2; ++hf) {
+            const f32x4 qa = o[kt][2 * hf], qb2 = o[kt][2 * hf + 1];
+            const u32x4 w = {pack_h16x2(qa[0] * scale, qa[1] * scale), pack_h16x2(qa[2] * scale, qa[3] * scale),
+                             pack_h16x2(qb2[0] * scale, qb2[1] * scale), pack_h16x2(qb2[2] * scale, qb2[3] * scale)};
+            ATTN_STORE16(dqbase + (off_out + (uint32_t)kt * tile_step + 64u * hf), w);
+          }
         }
-      }
 #endif
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with K and dS^T
     if (more) {
-      // the next item's K / V fragments must have landed; behind them in the (in-order) counter: 8 loads of the item after
-      // next if requested, and this wave's 2 dQ stores if its tile has rows - both wave-uniform, so the count is exact
-#if ATTN_LOADS_FIRST   // (+ the 4 dK / dV stores)
-      if (more2) {
-        if (wave_rows) asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      } else {
-        if (wave_rows) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      // the next item's K / V fragments must have landed; behind them in the (in-order) counter: LQ loads of the item after
+      // next if requested, and this wave's dQ stores (nst of them: wave-uniform) - so the count is exact
+#if ATTN_LOADS_FIRST   // (+ the dK / dV stores: twice as many again)
+      const int behind = 3 * nst;
 #else
-#if ATTN_WL   // (dQ stores: instruction A if the tile has rows, instruction B if it has more than 8)
-      if (more2) {
-        if (wave_rows_b) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if (wave_rows) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      } else {
-        if (wave_rows_b) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (wave_rows) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-#else
-      if (more2) {
-        if (wave_rows) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      } else {
-        if (wave_rows) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      const int behind = nst;
 #endif
-#endif
+      static_assert(2 * KT * (ATTN_LOADS_FIRST ? 3 : 1) <= 18, "cases below");
+#define ATTN_WAIT_CASE(N) case N: if (more2) attn_wait_vm<LQ + N>(); else attn_wait_vm<N>(); break;
+      switch (behind) {
+        ATTN_WAIT_CASE(0) ATTN_WAIT_CASE(1) ATTN_WAIT_CASE(2) ATTN_WAIT_CASE(3) ATTN_WAIT_CASE(4) ATTN_WAIT_CASE(5) ATTN_WAIT_CASE(6)
+        ATTN_WAIT_CASE(7) ATTN_WAIT_CASE(8) ATTN_WAIT_CASE(9) ATTN_WAIT_CASE(10) ATTN_WAIT_CASE(11) ATTN_WAIT_CASE(12)
+        ATTN_WAIT_CASE(13) ATTN_WAIT_CASE(14) ATTN_WAIT_CASE(15) ATTN_WAIT_CASE(16) ATTN_WAIT_CASE(17) ATTN_WAIT_CASE(18)
+        default: attn_wait_vm<0>(); break;
+      }
+#undef ATTN_WAIT_CASE
       dma_k(item + G);
     }
   }
@@ -1018,7 +1081,8 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
   const bool drop = a->drop_thresh != 0u;
 #define ONE_V(DR)                                                                                                             \
     {                                                                                                                         \
-      auto kern = attn_bwd_one_kernel<6, 12, DR>;   /* 152 KiB of LDS (+ 4 KiB of bias partials): one 12-wave workgroup per CU, persistent */ \
+      /* 152 KiB of LDS (+ 4 KiB of bias partials): one workgroup per CU, persistent; ATTN_BWD_KT key tiles per wave */ \
+      auto kern = attn_bwd_one_kernel<6, 12 / ATTN_BWD_KT, DR, (ATTN_BWD_KT == 1 ? 1 : (ATTN_BWD_KT == 2 ? 2 : 1)), ATTN_BWD_KT>;   \
       static bool attr_done_dev[64] = {}; int attr_dev = 0; (void)hipGetDevice(&attr_dev); bool& attr_done = attr_done_dev[(attr_dev >= 0 && attr_dev < 64) ? attr_dev : 0];                                                                                          \
       if (!attr_done) {                                                                                                       \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
@@ -1026,7 +1090,7 @@ extern "C" int vault_attention_bwd(const vault_attn_args* a, void* stream) {
         if (e != hipSuccess) return (int)e;                                                                                   \
         attr_done = true;                                                                                                     \
       }                                                                                                                       \
-      hipLaunchKernelGGL(kern, dim3(items < 256 ? items : 256), dim3(768), attn_one_lds_bytes<6>() + cs_bytes, st,            \
+      hipLaunchKernelGGL(kern, dim3(items < 256 ? items : 256), dim3(768 / ATTN_BWD_KT), attn_one_lds_bytes<6>() + cs_bytes, st, \
                          reinterpret_cast<const h16*>(a->qkv), a->keymask, reinterpret_cast<const h16*>(a->ctx),            \
                          reinterpret_cast<const h16*>(a->dctx), a->lse, reinterpret_cast<h16*>(a->dqkv), a->S, a->H,        \
                          a->heads, items, scale, dr, a->qkv_hm, a->bias_partials, a->bias_thirds);                            \

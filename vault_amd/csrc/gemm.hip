@@ -304,27 +304,21 @@ bool vault_gemm8w_supports(const GemmParams& p, int a_mode, int b_mode, int epi,
 int vault_gemm8w_launch(const GemmParams& p, int epi, int ntw, hipStream_t st);
 
 // Split count of the in-launch split-K reduction (gemm256.hip SK: 192-wide ring tiles, (0,1) EPI_BF16 / (0,0) EPI_F32_RES) for a
-// launch whose tiles fill less than a round of the chip: 1 = do not split.  Model (us; tools/splitk_bench.py): a K tile of a
-// 256 x 192 item takes a CU ~1.13; a split adds ~5 for its slab and ticket, the reducer ~2.5 per slab it reads; un-split, the
-// launch takes one round of whole contractions.  Splits must fit the caller's workspace.
+// launch whose tiles fill less than a round of the chip: 1 = do not split.  Measured (tools/splitk_bench.py,
+// profiles/r06_dev_splitk_bench.txt; N = 768, K = 3072 / 2304, us): a K tile of a 256 x 192 item takes a CU ~1.0; the hand-off
+// costs ~10 at two splits (every split stores a 192 KiB slab at the same moment: 37 MB at 96 tiles - the launch's own operand
+// bytes once more - and the reducers read half of it back) and ~3.5 more per further slab the reducer reads.  So two splits pay
+// where the un-split alternatives are one half-empty round - 65..128 tiles (M = 4,352..8,192: ViLT at B = 24..44): 46-51 -> 42-45
+// (K = 3072), 40 -> 37 (K = 2304) - and nowhere else: below, the 64 x 128 / 128 x 128 kernels (more CUs staging at once) are at
+// 17-32 against 31-38; above, 128-wide ring tiles fill the round (43-46 against 66-84).
 static int gemm_sk_splits(const GemmParams& p, int a_mode, int b_mode, int epi) {
   if (p.sk_ws == nullptr || a_mode != 0 || p.batch > 1 || p.split3 || (p.M & 255) || p.N % 192 || (p.K & 63) || p.out_hm) return 1;
   if (!((b_mode == 1 && epi == EPI_BF16) || (b_mode == 0 && epi == EPI_F32_RES && p.res != nullptr))) return 1;
   const long tiles = (long)(p.M >> 8) * (p.N / 192);
   const int nk = p.K >> 6;
-  if (tiles > GEMM_SK_MAX_TILES) return 1;
-  auto rounds = [](long items) { return (double)((items + 255) / 256); };
-  const double tk = 1.13, epi_us = 6.0;
-  double best = rounds(tiles) * (nk * tk + epi_us);
-  int best_s = 1;
-  for (int sp = 2; sp <= 4; ++sp) {
-    const int per = (nk + sp - 1) / sp;
-    if (per < 8 || (per * (sp - 1)) >= nk) continue;            // (every split a real share of the contraction)
-    if (p.sk_bytes < GEMM_SK_COUNTER_BYTES + tiles * sp * (256LL * 192 * 4)) continue;
-    const double t = rounds(tiles * sp) * (per * tk + 5.0) + (sp == 2 ? 2.5 : 2.5 * sp) + epi_us;
-    if (t < 0.85 * best) { best = t; best_s = sp; }
-  }
-  return best_s;
+  if (tiles < 65 || tiles > 128 || nk < 32) return 1;
+  if (p.sk_bytes < GEMM_SK_COUNTER_BYTES + tiles * 2 * (256LL * 192 * 4)) return 1;
+  return 2;
 }
 
 // argument checks + kernel choice: the resolved cfg (0..8), or -VAULT_EINVAL

@@ -118,6 +118,10 @@ class BucketReducer:
     """
 
     WIRE_PIECE = 1 << 25      # bf16 wire: elements per reduce-scatter / all-gather round (64 MiB of bf16 scratch x 2)
+    # One rank (VAULT_FORCE_DP=1 on a single GPU): run the transport's collectives anyway - the tests that exercise the RCCL calls
+    # with one process set this; by default the identity sum is skipped, so that the one-rank line of bench.py shows what the
+    # data-parallel CODE PATH costs (buckets, events, stage notes, split optimizer pass), not RCCL's degenerate copy kernels
+    SINGLE_RANK_COLLECTIVES = False
 
     def __init__(self, flat_grad: torch.Tensor, stage_lo: Dict[str, int], last_tag: str, bucket_elems: int,
                  dist, group=None, comm_stream=None, compute_device=None, wire: str = "fp32",
@@ -196,8 +200,8 @@ class BucketReducer:
     def _sum_over_ranks(self, view: torch.Tensor):
         """view (contiguous f32, 4-element aligned) <- its sum over the ranks, in the configured wire format."""
         n = view.numel()
-        if n == 0:
-            return
+        if n == 0 or (self.world == 1 and not self.SINGLE_RANK_COLLECTIVES):
+            return      # (one rank - VAULT_FORCE_DP on a single GPU: the sum is the identity, nothing goes on a wire)
         if self.wire == "fp32":
             self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
             self.wire_bytes += 2 * 4 * n * (self.world - 1) // self.world
