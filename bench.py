@@ -673,7 +673,7 @@ def main():
         blk_lm = block("lm_fwd", "lm_bwd", FLOP_LM_BLOCK_FWD,
                        f"12 LM layers (HF modeling_roberta.py:222-398), {B * 40} token rows, "
                        + ("forward only (frozen LM)" if args.freeze_lm else "forward + backward + weight gradients"))
-        r_wgrad = roof("wgrad", "gemm256_kernel<1,1,5,4> (A[K][M]^T B[K][N], EPI_F32_ATOMIC): the weight-gradient GEMMs, "
+        r_wgrad = roof("wgrad", "gemm256_kernel<1,1,5,4,false,false> (static tile walk, no split-K form; A[K][M]^T B[K][N], EPI_F32_ATOMIC): the weight-gradient GEMMs, "
                                 f"dW[N x K] += dY[tokens][N]^T X[tokens][K] - grouped launches (vault_wgrad_grouped): the 256 x 256 tiles "
                                 f"of all four Linear kinds (FFN-out, FFN-in, attention-out, QKV) of a stack's layers packed into "
                                 f"rounds of 256 ({M} ViLT tokens / {B * 40} LM tokens per layer), and the patch projection",
@@ -688,6 +688,9 @@ def main():
             "ms_per_step_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)],
             "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "mxfp8 forward GEMMs / bf16 backward" if args.fp8_forward else args.half,
+            "value_input_form": "since round 5 the image is resident as `pixel_patches` (the patch-embedding operand, what the input "
+                                "pipeline writes); rounds 1-4 timed f32 `pixel_values` with the unfold inside the step - that form is "
+                                "`with_f32_pixel_values` in this line (0.3 % apart)",
             "data": "synthetic",
             "config": {"workload": f"ViLT-B32 + {args.lm} fine-tune step (fwd+bwd+AdamW), per-GPU batch {B}, "
                                    f"40 text tokens + 384x384 image (185-token fused sequence; resident as the patch-embedding "

@@ -37,12 +37,13 @@ def test_adamw_kernel_matches_hf_formula(correct_bias, wd):
     assert torch.equal(pb, dp.bfloat16())
 
 
-def test_two_step_trajectory_vs_oracle():
+@pytest.mark.parametrize("half", ["fp16", "bf16"])      # (the API default format and the bench's, not bf16 alone)
+def test_two_step_trajectory_vs_oracle(half):
     spec = VaultSpec.tiny(3, "roberta")
     spec.lm.hidden_dropout_prob = 0.0; spec.lm.attention_probs_dropout_prob = 0.0
     bn = synthetic_batch(spec, 4, seed=21, n_classes=3)
     state = build_state(spec, 0)
-    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half="bf16")
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half=half)
     step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10)
     db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
     labels = torch.from_numpy(bn["labels"]).cuda()
@@ -63,7 +64,7 @@ def test_two_step_trajectory_vs_oracle():
             for k, p in P.items():
                 if p.grad is not None:
                     O.hf_adamw_step(p, p.grad, m[k], v2[k], lr, t)
-    assert abs(losses[0] - ref_losses[0]) < 2e-3
+    assert abs(losses[0] - ref_losses[0]) < (2e-3 if half == "bf16" else 3e-4)
     # sign-like AdamW updates (no bias correction: |update| ~ 3.2 lr at step 1) amplify bf16 gradient
     # noise a little: the loss trajectory must track the oracle's closely and move the same way
     for a, b in zip(losses, ref_losses):
@@ -397,7 +398,8 @@ def test_evaluate_pass_matches_oracle_predictions():
     assert 0.0 <= res["macro_f1_score"] <= 1.0
 
 
-def test_frozen_lm_train_step_trajectory_vs_oracle():
+@pytest.mark.parametrize("half", ["fp16", "bf16"])
+def test_frozen_lm_train_step_trajectory_vs_oracle(half):
     """BASELINE config 4's step: ``TrainStep`` on an engine with ``freeze_lm=True`` (LM forward only, gradient buckets
     ending at the ViLT embeddings, AdamW over the shortened trainable range) for three steps, against the oracle
     stepping only the non-LM parameters with the HF-AdamW formula; the frozen parameters must not move at all."""
@@ -405,7 +407,7 @@ def test_frozen_lm_train_step_trajectory_vs_oracle():
     spec.lm.hidden_dropout_prob = 0.0; spec.lm.attention_probs_dropout_prob = 0.0
     bn = synthetic_batch(spec, 4, seed=31, n_classes=3)
     state = build_state(spec, 0)
-    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, freeze_lm=True, half="bf16")
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, freeze_lm=True, half=half)
     step = TrainStep(eng, learning_rate=5e-5, warmup_ratio=0.0, total_steps=10)
     db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
     labels = torch.from_numpy(bn["labels"]).cuda()
@@ -544,7 +546,9 @@ def test_full_size_loss_trajectory_20_steps_vs_fp32_oracle(half):
     if half == "fp16":
         assert max(diffs) < 1e-3, (max(diffs), losses, ref)
     else:
-        assert diffs[0] < 3e-3 and sum(diffs) / len(diffs) < 4e-3 and max(diffs) < 3e-2, (diffs, losses, ref)
+        # (the tight bound sits on what is deterministic - the first TWO losses are forwards on the initial weights,
+        #  the schedule's first learning rate is 0 - the chaotic part of the trajectory keeps the statistical bounds)
+        assert max(diffs[:2]) < 3e-3 and sum(diffs) / len(diffs) < 4e-3 and max(diffs) < 3e-2, (diffs, losses, ref)
     assert ref[-1] < ref[0] and losses[-1] < losses[0]                 # both trajectories descend
     # the drop over the run agrees within 15 %
     assert abs((losses[0] - losses[-1]) - (ref[0] - ref[-1])) < 0.15 * abs(ref[0] - ref[-1]) + 2e-3

@@ -436,7 +436,59 @@ int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, i
   GemmParams p = p_in;
   const int cfg = vault_gemm_resolve(p, a_mode, b_mode, epi, cfg_in);
   if (cfg < 0) return -cfg;
+  if ((cfg == 5 || cfg == 6) && cfg_in < 0 && !p.aux_u8 && !p.out_hm && !p.split3) {
+    // Tail of the last round (round 6): the 8-wave kernel's tiles come in rounds of 256, and a last round
+    // that is mostly empty costs a whole one - 384 tiles of 256 x 192 (FFN-in at B = 32) take two.  Where whole rounds come
+    // first and the rest is at most 512 tiles of 128 x 128 (one round of the double-buffered kernel, two blocks per CU), the
+    // row panels of the full rounds go to the 8-wave kernel and the remaining ROW PANELS to the small tiles: two launches, same
+    // arithmetic per element (K in ascending 32-steps through the same MFMA), no kernel change.  Not with the 8-bit gelu' or
+    // the head-major output (8-wave kernel only: the large batches that plan them), not with an explicit cfg.
+    const int ntw = cfg == 5 ? 4 : 3, tn = p.N / (64 * ntw), tm = p.M >> 8;
+    const long tiles = (long)tm * tn, full = tiles / 256, rem = tiles - full * 256;
+    const int R = (int)((full * 256) / tn), tail = tm - R;
+    if (full >= 1 && rem > 0 && R >= 1 && tail >= 1 && (long)tail * 2 * (p.N / 128) <= 512 && p.N % 128 == 0) {
+      const int r0 = R << 8;
+      GemmParams q = p;
+      q.M = r0; q.m_valid = std::min(p.m_valid, r0);
+      int rc = vault_gemm8w_launch(q, epi, ntw, st);
+      if (rc != 0 || p.m_valid <= r0) return rc;
+      q = p;
+      q.M = p.M - r0; q.m_valid = p.m_valid - r0;
+      q.A = p.A + (size_t)r0 * p.lda;
+      q.out = reinterpret_cast<h16*>(p.out) + (size_t)r0 * p.ldo;
+      if (p.out2) q.out2 = reinterpret_cast<h16*>(p.out2) + (size_t)r0 * p.ldo;
+      if (p.aux) q.aux = p.aux + (size_t)r0 * p.ldo;
+      return vault_gemm_launch(q, a_mode, b_mode, epi, 0, st);
+    }
+  }
   if (cfg == 5 || cfg == 6) return vault_gemm8w_launch(p, epi, cfg == 5 ? 4 : 3, st);
+  if (cfg == 4 && cfg_in < 0 && p.splits == 1 && a_mode == 0 && p.batch <= 1 && p.N % 128 == 0 && !p.split3 &&
+      ((b_mode == 0 && epi == EPI_F32_RES && p.res != nullptr && p.drop_thresh == 0u) ||      // (dropout masks are keyed by the
+       (b_mode == 1 && epi == EPI_BF16 && p.colsum == nullptr))) {                              //  element offset from `out`)
+    // The same for the ring kernel's 192-wide launches (N = 768): whole rounds on 256 x 192 tiles, the remaining row panels on
+    // 256 x 128 tiles (cfg 8) where those are at most one round - 372 tiles at 93 row panels (B = 128) are one full round + 29
+    // panels = 174 smaller tiles instead of two rounds.
+    const int tn = p.N / 192, tn8 = p.N / 128, tm = p.M >> 8;
+    const long tiles = (long)tm * tn, full = tiles / 256, rem = tiles - full * 256;
+    const int R = (int)((full * 256) / tn), tail = tm - R;
+    if (full >= 1 && rem > 0 && R >= 1 && tail >= 1 && (long)tail * tn8 <= 256) {
+      const int r0 = R << 8;
+      GemmParams q = p;
+      q.M = r0; q.m_valid = std::min(p.m_valid, r0);
+      int rc = vault_gemm256_launch(q, a_mode, b_mode, epi, 3, st);
+      if (rc != 0 || p.m_valid <= r0) return rc;
+      q = p;
+      q.M = p.M - r0; q.m_valid = p.m_valid - r0;
+      q.A = p.a_hm ? p.A + (size_t)r0 * 64 : p.A + (size_t)r0 * p.lda;      // (head-major A: rows inside every plane)
+      if (epi == EPI_F32_RES) {
+        q.out = reinterpret_cast<float*>(p.out) + (size_t)r0 * p.ldo;
+        q.res = p.res + (size_t)r0 * p.ldo;
+      } else {
+        q.out = reinterpret_cast<h16*>(p.out) + (size_t)r0 * p.ldo;
+      }
+      return vault_gemm256_launch(q, a_mode, b_mode, epi, 2, st);
+    }
+  }
   if (cfg == 3) return vault_gemm256_launch(p, a_mode, b_mode, epi, 4, st);
   if (cfg == 4) return vault_gemm256_launch(p, a_mode, b_mode, epi, 3, st);
   if (cfg == 8) return vault_gemm256_launch(p, a_mode, b_mode, epi, 2, st);
