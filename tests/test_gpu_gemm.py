@@ -747,44 +747,6 @@ def test_split_k_is_planned_only_with_a_workspace_and_refused_elsewhere():
         _gemm(A2, W2, o2, M, 3072, 768, 768, 768, 3072, 0, 0, EPI_GELU, cfg=4, splits=2, splitk_ws=ws)
 
 
-@pytest.mark.parametrize("epi", ["bf16", "gelu", "dgelu"])
-@pytest.mark.parametrize("m_valid", [6144 - 37, 4000])
-def test_8wave_kernel_tail_rows_on_small_tiles(epi, m_valid):
-    """The automatic choice cuts a launch whose last round of 256 x 192 tiles is mostly empty (384 tiles: FFN-in at 24 row
-    panels) into the row panels of the full round on the 8-wave kernel + the remaining row panels on 128 x 128 tiles
-    (gemm.hip vault_gemm_launch).  The result equals the un-cut 8-wave launch (explicit cfg 6) bit for bit - every element
-    is the same sequence of MFMA steps and the same epilogue arithmetic - with the valid rows ending inside the tail and
-    inside the first part; the plan still names the 8-wave kernel."""
-    M, N, K = 6144, 3072, 768
-    A = _rand(M, K, seed=501).bfloat16()
-    W = _rand(N, K, scale=0.05, seed=502).bfloat16()
-    bias = _rand(N, seed=503)
-    gp = (torch.rand(M, N, device="cuda") * 1.1).bfloat16()
-    outs = []
-    for cfg in (-1, 6):
-        out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
-        out2 = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
-        cs = torch.zeros(N, device="cuda")
-        if epi == "bf16":
-            assert _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_BF16, cfg=cfg, bias=bias, m_valid=m_valid, plan_only=True) == 6
-            _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_BF16, cfg=cfg, bias=bias, m_valid=m_valid, colsum=cs)
-        elif epi == "gelu":
-            _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_GELU, cfg=cfg, bias=bias, m_valid=m_valid, out2=out2)
-        else:
-            _gemm(A, W, out, M, N, K, K, K, N, 0, 0, EPI_DGELU, cfg=cfg, m_valid=m_valid, aux=gp, colsum=cs)
-        torch.cuda.synchronize()
-        outs.append((out, out2, cs))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    assert bool((outs[0][0][m_valid:] == 7.0).all())
-    z = A.float() @ W.float().t()
-    ref = z + bias if epi != "dgelu" else z * gp.float()
-    if epi == "gelu":
-        ref = 0.5 * ref * (1 + torch.erf(ref / math.sqrt(2)))
-    assert (outs[0][0][:m_valid].float() - ref[:m_valid]).abs().max().item() <= ref.abs().max().item() * 2 ** -7 + 1e-3
-    if epi != "gelu":
-        assert (outs[0][2] - outs[1][2]).abs().max().item() <= 2e-3 * outs[1][2].abs().max().item() + 1e-2
-
-
 @pytest.mark.parametrize("epi", ["dgrad", "res"])
 def test_ring_kernel_tail_rows_on_128_wide_tiles(epi):
     """N = 768 at 93 row panels (B = 128): 372 tiles of 256 x 192 are 1.45 rounds; the automatic choice runs 64 panels (one full

@@ -308,7 +308,7 @@ int vault_gemm8w_launch(const GemmParams& p, int epi, int ntw, hipStream_t st);
 // profiles/r06_dev_splitk_bench.txt; N = 768, K = 3072 / 2304, us): a K tile of a 256 x 192 item takes a CU ~1.0; the hand-off
 // costs ~10 at two splits (every split stores a 192 KiB slab at the same moment: 37 MB at 96 tiles - the launch's own operand
 // bytes once more - and the reducers read half of it back) and ~3.5 more per further slab the reducer reads.  So two splits pay
-// where the un-split alternatives are one half-empty round - 65..128 tiles (M = 4,352..8,192: ViLT at B = 24..44): 46-51 -> 42-45
+// where the un-split alternatives are one half-empty round - 88 / 96..128 tiles (M = 5,632..8,192: ViLT at B = 31..44): 46-51 -> 42-45
 // (K = 3072), 40 -> 37 (K = 2304) - and nowhere else: below, the 64 x 128 / 128 x 128 kernels (more CUs staging at once) are at
 // 17-32 against 31-38; above, 128-wide ring tiles fill the round (43-46 against 66-84).
 static int gemm_sk_splits(const GemmParams& p, int a_mode, int b_mode, int epi) {
@@ -316,7 +316,9 @@ static int gemm_sk_splits(const GemmParams& p, int a_mode, int b_mode, int epi) 
   if (!((b_mode == 1 && epi == EPI_BF16) || (b_mode == 0 && epi == EPI_F32_RES && p.res != nullptr))) return 1;
   const long tiles = (long)(p.M >> 8) * (p.N / 192);
   const int nk = p.K >> 6;
-  if (tiles < 65 || tiles > 128 || nk < 32) return 1;
+  // (the f32-residual forward gains 4 % at 96 tiles and loses against the 128 x 128 kernel at 80 - the LM stack at B = 128, measured
+  //  in the step of BASELINE config 4: -5 % on its LM block; the data gradients gain 7-17 % at 96)
+  if (tiles < (epi == EPI_F32_RES ? 96 : 88) || tiles > 128 || nk < 32) return 1;
   if (p.sk_bytes < GEMM_SK_COUNTER_BYTES + tiles * 2 * (256LL * 192 * 4)) return 1;
   return 2;
 }
@@ -436,38 +438,21 @@ int vault_gemm_launch(const GemmParams& p_in, int a_mode, int b_mode, int epi, i
   GemmParams p = p_in;
   const int cfg = vault_gemm_resolve(p, a_mode, b_mode, epi, cfg_in);
   if (cfg < 0) return -cfg;
-  if ((cfg == 5 || cfg == 6) && cfg_in < 0 && !p.aux_u8 && !p.out_hm && !p.split3) {
-    // Tail of the last round (round 6): the 8-wave kernel's tiles come in rounds of 256, and a last round
-    // that is mostly empty costs a whole one - 384 tiles of 256 x 192 (FFN-in at B = 32) take two.  Where whole rounds come
-    // first and the rest is at most 512 tiles of 128 x 128 (one round of the double-buffered kernel, two blocks per CU), the
-    // row panels of the full rounds go to the 8-wave kernel and the remaining ROW PANELS to the small tiles: two launches, same
-    // arithmetic per element (K in ascending 32-steps through the same MFMA), no kernel change.  Not with the 8-bit gelu' or
-    // the head-major output (8-wave kernel only: the large batches that plan them), not with an explicit cfg.
-    const int ntw = cfg == 5 ? 4 : 3, tn = p.N / (64 * ntw), tm = p.M >> 8;
-    const long tiles = (long)tm * tn, full = tiles / 256, rem = tiles - full * 256;
-    const int R = (int)((full * 256) / tn), tail = tm - R;
-    if (full >= 1 && rem > 0 && R >= 1 && tail >= 1 && (long)tail * 2 * (p.N / 128) <= 512 && p.N % 128 == 0) {
-      const int r0 = R << 8;
-      GemmParams q = p;
-      q.M = r0; q.m_valid = std::min(p.m_valid, r0);
-      int rc = vault_gemm8w_launch(q, epi, ntw, st);
-      if (rc != 0 || p.m_valid <= r0) return rc;
-      q = p;
-      q.M = p.M - r0; q.m_valid = p.m_valid - r0;
-      q.A = p.A + (size_t)r0 * p.lda;
-      q.out = reinterpret_cast<h16*>(p.out) + (size_t)r0 * p.ldo;
-      if (p.out2) q.out2 = reinterpret_cast<h16*>(p.out2) + (size_t)r0 * p.ldo;
-      if (p.aux) q.aux = p.aux + (size_t)r0 * p.ldo;
-      return vault_gemm_launch(q, a_mode, b_mode, epi, 0, st);
-    }
-  }
+  // (Round 6, VERDICT r05 item 1a, measured and NOT kept for the 8-wave kernel: its launches cut into the row panels of the full
+  //  rounds + the remaining row panels on 128 x 128 tiles.  A round of the double-buffered kernel's small tiles takes as long as a
+  //  round of 256 x 192 register-direct tiles at K = 768 (19.4 against 16 us at 348 / 256 tiles): FFN-in at 24 row panels 47.5 cut
+  //  against 45.0 un-cut, attention-out dgrad at 93 panels 45 against 33 - profiles/r06_dev_tail_rows.txt.  The ring kernel's
+  //  192-wide launches below do gain: their tail runs on the same kernel's 128-wide tiles.)
   if (cfg == 5 || cfg == 6) return vault_gemm8w_launch(p, epi, cfg == 5 ? 4 : 3, st);
   if (cfg == 4 && cfg_in < 0 && p.splits == 1 && a_mode == 0 && p.batch <= 1 && p.N % 128 == 0 && !p.split3 &&
       ((b_mode == 0 && epi == EPI_F32_RES && p.res != nullptr && p.drop_thresh == 0u) ||      // (dropout masks are keyed by the
        (b_mode == 1 && epi == EPI_BF16 && p.colsum == nullptr))) {                              //  element offset from `out`)
-    // The same for the ring kernel's 192-wide launches (N = 768): whole rounds on 256 x 192 tiles, the remaining row panels on
-    // 256 x 128 tiles (cfg 8) where those are at most one round - 372 tiles at 93 row panels (B = 128) are one full round + 29
-    // panels = 174 smaller tiles instead of two rounds.
+    // Tail of the last round (round 6) for the ring kernel's 192-wide launches (N = 768): the tiles come in
+    // rounds of 256 and a mostly empty last round costs a whole one.  Whole rounds run on 256 x 192 tiles, the remaining ROW PANELS
+    // on 256 x 128 tiles (cfg 8) where those are at most one round: two launches of one kernel family, the same arithmetic per
+    // element (bit-identical), no kernel change.  tools/splitk_bench.py, us: 139 row panels (B = 192; 2 rounds + 66 tiles) 172 / 142 /
+    // 103 cut against 197 / 168 / 123 un-cut (FFN-out forward / FFN-in dgrad / QKV dgrad); 93 panels (B = 128) 132 / 102 / 80
+    // against 132 / 105 / 83.  Not with dropout in the residual epilogue (masks are keyed by the element offset from `out`).
     const int tn = p.N / 192, tn8 = p.N / 128, tm = p.M >> 8;
     const long tiles = (long)tm * tn, full = tiles / 256, rem = tiles - full * 256;
     const int R = (int)((full * 256) / tn), tail = tm - R;
