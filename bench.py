@@ -677,10 +677,10 @@ def main():
                                 f"dW[N x K] += dY[tokens][N]^T X[tokens][K] - grouped launches (vault_wgrad_grouped): the 256 x 256 tiles "
                                 f"of all four Linear kinds (FFN-out, FFN-in, attention-out, QKV) of a stack's layers packed into "
                                 f"rounds of 256 ({M} ViLT tokens / {B * 40} LM tokens per layer), and the patch projection",
-                       "r05_pmc_gemm_wgrad.json")
+                       "r06_pmc_gemm_wgrad.json")
         r_ffn1 = roof("ffn1", "gemm8w_kernel<7,4,true> / <1,4,true> (GELU epilogue with the 8-bit tile-native / bf16 gelu', 256-wide tiles, register-direct): FFN-in forward, ViLT "
                               f"[{M}x{v.intermediate_size}x{v.hidden_size}] + LM [{B * 40}x{v.intermediate_size}x{v.hidden_size}]",
-                      "r05_pmc_gemm_ffn1.json")
+                      "r06_pmc_gemm_ffn1.json")
         out = {
             "metric": "train samples/sec (img+text pairs) ViLT-B32+BERTweet, bs256, 1/2/4/8 MI355X",
             "value": round(sps, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -18,6 +18,28 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
 rows.sort()
 marks = [e for s, e, n, q in rows if marker in n]
+if "--per-step" in sys.argv:
+    # one line per step of the whole trace: wall, union-busy time, time of the longest kernels - to see where steps of different
+    # loops of one run (bench.py: resident inputs, host->device copies, uint8 pipeline) differ
+    import bisect
+    starts = [r[0] for r in rows]
+    for i in range(1, len(marks)):
+        a, b = marks[i - 1], marks[i]
+        win_ = rows[bisect.bisect_left(starts, a):bisect.bisect_left(starts, b)]
+        win_ = [(s, min(e, b), n, q) for s, e, n, q in win_ if e > a]
+        ev_ = sorted([(s, 1) for s, e, n, q in win_] + [(e, -1) for s, e, n, q in win_])
+        busy_, depth_, last_ = 0, 0, a
+        for t, k in ev_:
+            if depth_ >= 1:
+                busy_ += t - last_
+            depth_ += k; last_ = t
+        byq = collections.defaultdict(float)
+        for s, e, n, q in win_:
+            byq[q] += e - s
+        extra = {n_[:40]: round(sum(e - s for s, e, n, q in win_ if n_ in n) / 1e3, 1) for n_ in ("preprocess", "im2col", "copyBuffer", "elementwise")}
+        print(f"step {i:3d}: wall {(b - a) / 1e3:9.1f} us  busy {busy_ / 1e3:9.1f}  idle {(b - a - busy_) / 1e3:7.1f}  launches {len(win_):4d}  per queue "
+              f"{ {q: round(v / 1e3, 1) for q, v in byq.items()} }  {extra}")
+    sys.exit(0)
 if len(marks) < nsteps + 1:
     sys.exit(f"only {len(marks)} marker kernels")
 t0, t1 = marks[-nsteps - 1], marks[-1]
