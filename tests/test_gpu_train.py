@@ -22,9 +22,14 @@ def test_adamw_kernel_matches_hf_formula(correct_bias, wd):
     p_ref = p.astype(np.float64)
     m_ref = np.zeros(n); v_ref = np.zeros(n)
     dp = torch.from_numpy(p).cuda(); dm = torch.zeros(n, device="cuda"); dv = torch.zeros(n, device="cuda")
-    pb = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    pb = dp.bfloat16()            # (the 16-bit shadow starts as the image of the parameters, as ParamStore makes it)
     for t in range(1, 5):
         g = (rng.standard_normal(n) * 10.0 ** rng.uniform(-6, 0, n)).astype(np.float32)
+        # rows of an embedding table: the first third never receives a gradient (round 6: the kernel then skips its stores - with
+        # weight decay it must not), the second third only in the first two steps (its moments keep decaying, it keeps moving)
+        g[: n // 3] = 0.0
+        if t > 2:
+            g[n // 3: 2 * n // 3] = 0.0
         lr = linear_schedule(2e-5, t - 1, 2, 10)
         dg = torch.from_numpy(g * 4.0).cuda()   # pretend 4 ranks summed -> grad_scale 1/4
         bc = np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) if correct_bias else 1.0
@@ -35,6 +40,11 @@ def test_adamw_kernel_matches_hf_formula(correct_bias, wd):
     np.testing.assert_allclose(dp.cpu().numpy(), p_ref, atol=2e-7, rtol=1e-6)
     np.testing.assert_allclose(dm.cpu().numpy(), m_ref, atol=1e-8, rtol=1e-4)
     assert torch.equal(pb, dp.bfloat16())
+    if wd == 0.0:      # never touched, no decay: bit-identical to where they started
+        assert np.array_equal(dp[: n // 3].cpu().numpy(), p[: n // 3]) and float(dm[: n // 3].abs().max()) == 0.0
+    else:
+        assert not np.array_equal(dp[: n // 3].cpu().numpy(), p[: n // 3])
+    assert float(np.abs(dp[n // 3: 2 * n // 3].cpu().numpy() - p[n // 3: 2 * n // 3]).min()) > 0.0     # touched once: still moving
 
 
 @pytest.mark.parametrize("half", ["fp16", "bf16"])      # (the API default format and the bench's, not bf16 alone)

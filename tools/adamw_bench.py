@@ -29,3 +29,24 @@ e.record()
 torch.cuda.synchronize()
 t = s.elapsed_time(e) / 10
 print(f"{fmt} zero_grad={zero} n={n}: {t * 1e3:.1f} us, {34 * n / t / 1e9:.2f} TB/s of 34 B per parameter")
+
+# round 6: elements that never received a gradient (g = m = v = 0, no weight decay) take no stores - the first `frac` of the
+# buffer idle (an embedding table's untouched rows), the rest as above
+for frac in (0.0, 0.22, 1.0):
+    k = int(n * frac) // 4 * 4
+    def fz():
+        g.normal_(std=1e-3); g[:k] = 0
+        m[:k] = 0; v[:k] = 0
+    fz()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(6):
+        g[:k] = 0            # (the pass zeroes g; idle elements must stay idle, the others get their gradient back below)
+        g[k:].normal_(std=1e-3)
+        torch.cuda.synchronize()
+        s.record()
+        with ops.operand_format(fmt):
+            ops.adamw_step(p, g, m, v, pb, n, 2e-5, 0.9, 0.999, 1e-8, 0.0, grad_scale=1.0, zero_grad=zero)
+        e.record(); torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) * 1e3)
+    print(f"no weight decay, {frac:.0%} of the elements idle (g = m = v = 0): {min(ts):7.1f} us (min of 6), {sorted(ts)[3]:7.1f} (median)")

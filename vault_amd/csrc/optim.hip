@@ -2,7 +2,8 @@
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= step_size * m / (sqrt(v) + eps) ; p -= lr*wd*p
 //   step_size = lr (correct_bias=False, the reference default: ref vault/tmsc_utils/trainer.py:69,244-254)
 //               or lr*sqrt(1-b2^t)/(1-b1^t), computed on the host.
-// One pass: 16 B/param read (p,g,m,v), 12 B written (p,m,v) + 2 B bf16 shadow (+4 B when zeroing g; `zero_mask`, one byte
+// One pass: 16 B/param read (p,g,m,v), 12 B written (p,m,v) + 2 B bf16 shadow (+4 B when zeroing g; nothing written for elements
+// with g = m = v = 0 and no weight decay: round 6; `zero_mask`, one byte
 // per 64 elements, lets the caller skip the zeroing of ranges the next backward STORES into - the un-split weight-gradient
 // tiles of the fused train step - instead of accumulating onto).
 #include "common.h"
@@ -20,6 +21,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     f32x4 gv = reinterpret_cast<f32x4*>(g)[i];
     f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
     f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+    // Elements that never received a gradient (g = m = v = 0: the rows of an embedding table no token has named yet - a fifth
+    // of the parameters is the 64,001-row word table, of which a step touches at most B x T rows) stay exactly as they are
+    // without weight decay: m' = v' = 0, p' = p - step * 0 / (0 + eps) = p.  Their five stores (p, m, v, the 16-bit shadow, the
+    // gradient's zero) are skipped: 18 of the 34 B per parameter, bit-identical results.
+    if (lr_wd == 0.f) {
+      bool idle = true;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) idle = idle && gv[e] == 0.f && mv[e] == 0.f && vv[e] == 0.f;
+      if (idle) continue;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float ge = gv[e] * gscale;
