@@ -26,6 +26,12 @@
 #include "gemm.h"
 #include "gemm_epi.h"
 
+#ifndef GEMM_NS4_MIN_K
+#define GEMM_NS4_MIN_K 768    // shortest contraction that takes the four-stage 128 x 128 form (rounds 3-5: 1536; round 6: K = 768 at <= 256
+                              // tiles - the LM stack's N = 3072 / 2304 Linears at B <= 32 - 16.1 -> 15.5, 13.2 -> 12.9, 12.6 -> 12.2 us, +0.2-0.3 % of the
+                              // B = 32 step: profiles/r06_dev_four_stage_k768.txt)
+#endif
+
 namespace {
 
 constexpr int BK = 64;
@@ -283,7 +289,7 @@ int launch_modes(const GemmParams& p, int cfg, hipStream_t st) {
       // double-buffered blocks per CU are faster (QKV forward 20.3 against 23.3 us), and a single block's K loop stays bound
       // by its CU's L2 -> LDS rate (32 KiB per 2.1 MFLOP step)
       if constexpr (A_MODE == 0 && EPI != EPI_F32_ATOMIC) {
-        if (p.splits <= 1 && (long)(p.M / 128) * (p.N / 128) <= 256 && p.K >= 1536)
+        if (p.splits <= 1 && (long)(p.M / 128) * (p.N / 128) <= 256 && p.K >= GEMM_NS4_MIN_K)
           return launch_cfg<128, 128, 2, 2, A_MODE, B_MODE, EPI, 4>(p, st);
       }
       return launch_cfg<128, 128, 2, 2, A_MODE, B_MODE, EPI>(p, st);
