@@ -617,6 +617,14 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
                 ops.im2col(pix, apatch, B, v.num_channels, v.image_size, v.patch_size, split3=pr)
                 if pr and ws["train"]:    # the weight gradient's operand
                     ops.im2col(pix, buf("apatch", (Mpp, Kp), bf), B, v.num_channels, v.image_size, v.patch_size)
+                # the f32 pixel staging buffer (input_buffers()["pixel_values"]) is free from here on: nothing later in the step
+                # reads it (the weight gradient contracts the unfolded operand).  A loader that writes its host -> device copy
+                # straight into that buffer waits for this event on its copy stream (bench.py, with_h2d_input_copies): the next
+                # batch's pixels then travel under the rest of THIS step, without a device-to-device restage
+                ev = ws.get("pixels_consumed")
+                if ev is None:
+                    ev = ws["pixels_consumed"] = torch.cuda.Event()
+                ops.pycall(lambda ev=ev: ev.record(torch.cuda.current_stream()))
             ops.image_consts(P.w("embeddings.patch_embeddings.projection.bias"), P.w("embeddings.position_embeddings"),
                              mt[ws.get("img_type", 1)], P.w("embeddings.cls_token"), addtab, x[0], NP, H, B, S, T)
         ops.gemm(apatch, P.wb3(wpn, H, Kp) if pr else P.wb(wpn, shape=(H, Kp)), x[0], Mpp, H, W3 * Kp, W3 * Kp, W3 * Kp,
