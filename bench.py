@@ -539,13 +539,20 @@ def main():
                 copy_stream.wait_event(consumed[k % nb])
                 for name in ("input_ids", "attention_mask", "labels"):
                     devb[k % nb][name].copy_(host[k % nb][name], non_blocking=True)
-                proc.from_packed(himg[k % nb].view(-1), sizes, out=devb[k % nb], patch_out=devp[k % nb],
-                                 patch_size=spec.vilt.patch_size)
+                proc.from_packed(himg[k % nb].view(-1), sizes, patch_out=devp[k % nb], patch_size=spec.vilt.patch_size,
+                                 want_mask=False)           # (fully valid 384 x 384 canvases: the engine needs no mask)
                 ready[k % nb].record(copy_stream)
 
         for i in range(nb):
             consumed[i].record(torch.cuda.current_stream(dev))
+        # the resize kernel's output IS the patch GEMM's operand: the recorded step re-points its two launches at this step's
+        # tensor instead of copying it into the engine's buffer (VaultEngine.adopt_pixel_patches)
+        eng.adopt_pixel_patches = True
         prefetch_u8(0)
+        d = devb[0]
+        for k in range(2):            # (the step with this input form records its own tape: outside the timed region)
+            torch.cuda.current_stream(dev).wait_event(ready[0])
+            stepper({"input_ids": d["input_ids"], "attention_mask": d["attention_mask"], "pixel_patches": devp[0]}, d["labels"])
         sync_all()
         t0 = time.perf_counter()
         for k in range(args.steps):
@@ -557,6 +564,7 @@ def main():
             consumed[k % nb].record(torch.cuda.current_stream(dev))
         sync_all()
         dt3 = time.perf_counter() - t0
+        eng.adopt_pixel_patches = False
         if world > 1:
             t = torch.tensor([dt3], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -564,8 +572,10 @@ def main():
         u8 = {"value": round(B * world * args.steps / dt3, 2), "ms_per_step": round(dt3 / args.steps * 1e3, 3),
               "what": f"the same steps fed from pinned uint8 images ({HW} x {HW} x 3 per sample, {B * HW * HW * 3 / 1e6:.0f} MB per step): "
                       "host->device copy + GPU resize / normalise / pad (vault_image_preprocess, bit-identical to the HF ViLT "
-                      "processor) on a side stream, double-buffered, overlapped with the previous step; the resize kernel writes the "
-                      "patch-embedding GEMM's bf16 operand directly (no f32 pixel tensor, no unfold pass)"}
+                      "processor; both passes in one launch, the 8-bit intermediate in LDS) on a side stream, double-buffered, "
+                      "overlapped with the previous step; the resize kernel writes the patch-embedding GEMM's bf16 operand directly "
+                      "(no f32 pixel tensor, no unfold pass, no pixel mask) and the step's GEMMs read it where it was written "
+                      "(no restage copy)"}
 
     precise_fwd = None
     if rank == 0 and not args.no_parity and not args.fp8_forward:

@@ -512,8 +512,15 @@ typedef struct vault_preprocess_args {
    * patch: the Conv2d weight's own order, HF:models/vilt/modeling_vilt.py:290-300).  With it pixel_values may be NULL: the
    * f32 NCHW tensor and the separate unfold pass (vault_im2col) are skipped.  H, W multiples of ps; ps % 4 == 0. */
   void* patch_unfold_bf16; int ps;
+  /* ABI 12, optional (both zero = unknown): the batch's largest tap count (max of every ksize_h / ksize_v) and the most source
+   * rows ONE band of 32 output rows reads (max over images and bands of: first row + tap count of the band's last output row,
+   * minus the first row of its first).  With them, and when such a band fits the LDS (480 x 480 -> 384 x 384: 74 KiB), both
+   * passes run in ONE launch with the 8-bit intermediate in LDS - `tmp` is then not touched and may be NULL
+   * (vault_image_preprocess_is_fused tells, from the maxima alone).  Same bytes out as the two-pass form. */
+  int ksize_max, band_rows_max;
 } vault_preprocess_args;
 int vault_image_preprocess(const vault_preprocess_args* args, void* stream);
+int vault_image_preprocess_is_fused(const vault_preprocess_args* args);   /* 1: the one-launch form will run (tmp unused) */
 
 /* Bytes of device memory one forward (+ backward when train) pass over the stages needs for a batch of B items with T text
  * tokens: every activation the stage structs name (saved tensors of all layers, embeddings, head) plus the backward

@@ -161,3 +161,38 @@ def test_patch_unfold_straight_from_the_resize_kernel():
         eng.forward(dict(ok, valid_hw=[(size, size)] * 3 + [(size, size - 16)]), train=False)
     with pytest.raises(ValueError):
         eng.forward(dict(ok, canvas=(size, 2 * size)), train=False)
+
+
+def test_one_launch_form_equals_the_two_pass_form_and_the_oracle():
+    """The fused kernel (both passes of a 32-row band in one workgroup, 8-bit intermediate in LDS) against the two-pass form
+    (intermediate in HBM) and the CPU oracle: same bytes - down- and upscaling, tap counts beyond one 8-tap chunk, ragged
+    batches with padded bands, every output form (f32 canvas, int64 / f32 mask, 16-bit unfold), odd source offsets (the
+    16-byte staging loads start at any byte), and no mask at all."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(31)
+    batches = ([(480, 480)] * 3, [(100, 150), (384, 384), (200, 120)], [(700, 701), (500, 333)], [(33, 33), (96, 64), (2, 3), (1, 1)],
+               [(385, 641), (641, 385), (37, 41)], [(901, 517)])
+    for sizes in batches:
+        imgs = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in sizes]
+        if len(imgs) > 1:
+            imgs[1][::2] = 255; imgs[1][1::2] = 0              # ringing: the clip after each pass matters
+        host = torch.from_numpy(np.concatenate([im.reshape(-1) for im in imgs])).pin_memory()
+        one, two = DeviceImageProcessor(), DeviceImageProcessor(fused=False)
+        a, b = one.from_packed(host, sizes), two.from_packed(host, sizes)
+        assert one._plan_dev[2] is None and two._plan_dev[2] is not None          # (no HBM intermediate / the HBM intermediate)
+        pv_ref, pm_ref = PO.preprocess(imgs)
+        assert np.array_equal(a["pixel_values"].cpu().numpy(), pv_ref) and np.array_equal(a["pixel_mask"].cpu().numpy(), pm_ref)
+        assert torch.equal(a["pixel_values"], b["pixel_values"]) and torch.equal(a["pixel_mask"], b["pixel_mask"])
+        mf = DeviceImageProcessor(mask_dtype=torch.float32).from_packed(host, sizes)
+        assert torch.equal(mf["pixel_mask"], a["pixel_mask"].float()) and torch.equal(mf["pixel_values"], a["pixel_values"])
+        B, _, H, W = a["pixel_values"].shape
+        rows, Kp = B * (H // 32) * (W // 32), 3 * 32 * 32
+        po = torch.full((rows, Kp), 7.0, dtype=torch.bfloat16, device="cuda")
+        res = one.from_packed(host, sizes, patch_out=po, want_mask=False)
+        assert res["pixel_mask"] is None and res["valid_hw"] == a["valid_hw"]
+        assert torch.equal(po, F.unfold(a["pixel_values"], kernel_size=32, stride=32).transpose(1, 2).reshape(rows, Kp).bfloat16())
+    # a batch whose band does not fit the LDS runs the two-pass form by itself
+    big = DeviceImageProcessor()
+    imgs = [rng.integers(0, 256, size=(64, 1200, 3), dtype=np.uint8)]
+    o = big.from_packed(torch.from_numpy(imgs[0].reshape(-1)).pin_memory(), [(64, 1200)])
+    assert big._plan_dev[2] is not None and np.array_equal(o["pixel_values"].cpu().numpy(), PO.preprocess(imgs)[0])

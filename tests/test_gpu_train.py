@@ -775,3 +775,47 @@ def test_optimizer_leaves_stored_weight_gradient_ranges_unzeroed_and_nobody_buil
     sa.optimizer_step()
     torch.cuda.synchronize()
     assert float(ea.params.g[:P.n_train].abs().max()) == 0.0
+
+
+def test_adopted_pixel_patches_feed_the_recorded_step_without_a_copy():
+    """``VaultEngine.adopt_pixel_patches``: the caller's ``pixel_patches`` tensor IS the patch-embedding GEMM's operand (forward
+    and weight gradient) - a loader that alternates two tensors saves the device-to-device restage.  The recorded step re-points
+    its two launches at each step's tensor (ops.Tape.rebind): same trajectory as the copying path, on different batches; the
+    engine's own buffer is not written; a tensor that does not qualify (row count not a whole padded count) is copied."""
+    import torch.nn.functional as F
+    spec = VaultSpec.tiny(3, "roberta")
+    spec.lm.hidden_dropout_prob = 0.0; spec.lm.attention_probs_dropout_prob = 0.0
+    state = build_state(spec, 0)
+    B, ps = 64, spec.vilt.patch_size                    # 64 x 36 patches: a whole number of 256-row panels
+    batches = [synthetic_batch(spec, B, seed=70 + i, n_classes=3) for i in range(4)]
+    res = {}
+    for adopt in (False, True):
+        eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half="bf16")
+        eng.adopt_pixel_patches = adopt
+        step = TrainStep(eng, learning_rate=1e-4, warmup_ratio=0.0, total_steps=10, assume_full_pixel_mask=True)
+        two = [torch.empty(B * spec.vilt.num_patches, 3 * ps * ps, dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+        losses = []
+        for i, bn in enumerate(batches):
+            pv = torch.from_numpy(bn["pixel_values"]).cuda()
+            two[i % 2].copy_(F.unfold(pv, kernel_size=ps, stride=ps).transpose(1, 2).reshape(two[0].shape))
+            db = {"input_ids": torch.from_numpy(bn["input_ids"]).cuda(), "attention_mask": torch.from_numpy(bn["attention_mask"]).cuda(),
+                  "pixel_patches": two[i % 2]}
+            losses.append(float(step(db, torch.from_numpy(bn["labels"]).cuda())))
+        if adopt:
+            assert len(step._tape.rebinds) == 2
+            own = eng.input_buffers(B, batches[0]["input_ids"].shape[1])["pixel_patches"]
+            assert float(own.float().abs().sum()) == 0.0                  # never written: the GEMMs read the caller's tensors
+        res[adopt] = (losses, eng.params.p.clone())
+    torch.cuda.synchronize()
+    la, lb = res[False][0], res[True][0]
+    assert abs(la[0] - lb[0]) < 1e-6 and max(abs(a - b) for a, b in zip(la, lb)) < 5e-4, (la, lb)
+    assert len(set(round(x, 4) for x in lb)) > 1
+    d = (res[False][1] - res[True][1]).abs()
+    assert float(d.mean()) < 3e-6 and float((d > 2e-5).float().mean()) < 0.03
+    # 4 x 36 rows are not a whole padded panel count: copied, as without the flag
+    eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half="bf16")
+    eng.adopt_pixel_patches = True
+    bn = synthetic_batch(spec, 4, seed=2, n_classes=3)
+    po = F.unfold(torch.from_numpy(bn["pixel_values"]).cuda(), kernel_size=ps, stride=ps).transpose(1, 2).reshape(4 * spec.vilt.num_patches, -1).bfloat16()
+    ws = eng.stage_inputs({"input_ids": torch.from_numpy(bn["input_ids"]).cuda(), "pixel_patches": po}, True, None)
+    assert not ws["patch_adopted"] and ws["apatch_in"].data_ptr() != po.data_ptr()

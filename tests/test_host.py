@@ -64,7 +64,7 @@ def test_library_exports_every_declared_symbol(fmt):
     for n in names:
         assert hasattr(lib, n), n
     lib.vault_abi_version.restype = ctypes.c_int
-    assert lib.vault_abi_version() == 11
+    assert lib.vault_abi_version() == 12
     lib.vault_operand_format.restype = ctypes.c_int
     assert lib.vault_operand_format() == ("bf16", "fp16").index(fmt)
 

@@ -472,7 +472,8 @@ class BackwardMixin:
                                P.gr("embeddings.patch_embeddings.projection.bias"), dyp, NP, H, B, S, T)
         if ws.get("img_embeds") is None:
             # (small batches: beside the chain, like the stack's deferred launches - nothing below reads this gradient)
-            self._wgrads_aside(lambda: self._wgrad(dyp, ws["apatch"], "embeddings.patch_embeddings.projection.weight", None,
+            self._wgrads_aside(lambda: self._wgrad(dyp, ws["apatch_in"] if ws.get("patches_in") else ws["apatch"],
+                                                   "embeddings.patch_embeddings.projection.weight", None,
                                                    Mpp, H, Kp, B * NP), after_layer)
         dvs = buf("d_vt_sum", (Mlp, H))
         # text rows: out = LN(.) + mtype[0]  =>  d mtype[0] = sum dy = THIS backward's d beta: taken through a scratch

@@ -80,7 +80,7 @@ extern "C" int vault_wgrad_grouped(const vault_wgrad_grouped_args* a, void* stre
   return vault_gemm256_grouped_launch(p, reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" int vault_abi_version(void) { return 11; }
+extern "C" int vault_abi_version(void) { return 12; }
 #ifdef VAULT_F16
 extern "C" int vault_operand_format(void) { return 1; }
 #else

@@ -108,6 +108,11 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
         self.last: Optional[dict] = None
         self._wgrad_stream, self._wgrad_pending = None, False
         self._wgrad_side = False
+        # True: a `pixel_patches` tensor (contiguous, whole padded row count) becomes the patch-embedding GEMM's operand AS IS -
+        # forward and weight gradient read the caller's memory, nothing is copied (a recorded step re-points its launches:
+        # ops.Tape.rebind).  The caller then keeps the tensor unchanged until the step's kernels have run (an event recorded
+        # after the step), e.g. by alternating two tensors; False: the patches are copied into the engine's own buffer
+        self.adopt_pixel_patches = False
         self.dp_world = 1          # ranks of the data-parallel step this engine runs in (TrainStep sets it: backward._wgrad_group_size)
         self._grads_zero = False
         self._g_dirty = False      # the flat gradient buffer may hold gradients of an API-level backward (not yet consumed / zeroed)
@@ -600,6 +605,8 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
         v = spec.vilt
         B, T, S, H, NP = (ws[k] for k in ("B", "T", "S", "H", "NP"))
         apatch = buf("apatch_3" if pr else "apatch", (Mpp, W3 * Kp), bf)
+        if ws.get("patches_in"):
+            apatch = ws["apatch_in"]          # (the engine's own buffer or the caller's tensor: staging._stage_pixel_patches)
         addtab = buf("addtab", (NP, H))
         wpn = "embeddings.patch_embeddings.projection.weight"
         if ws["ragged"]:

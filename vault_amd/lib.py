@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VAULT_HIP_LIB") or os.path.join(_HERE, "libvault_hip.so")
 # the same sources compiled for the IEEE fp16 operand type (csrc/common.h `h16`, build.py VARIANTS): same exported ABI
 LIB_PATH_F16 = os.environ.get("VAULT_HIP_LIB_F16") or os.path.join(_HERE, "libvault_hip_f16.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 FORMATS = ("bf16", "fp16")
 _libs = {}
 

@@ -102,6 +102,15 @@ class Tape:
     def __init__(self):
         self.calls = []
         self.seeded = []
+        # one operand that changes address between replays (the caller's `pixel_patches` tensor, adopted as the patch
+        # GEMM's operand): [lo, hi) while recording, and the (argument struct, member, offset) places that pointed into it
+        self.rebind_range = None
+        self.rebinds = []
+
+    def rebind(self, base: int):
+        """Point every recorded use of the rebindable operand at its new address."""
+        for s, f, off in self.rebinds:
+            setattr(s, f, base + off)
 
     def replay(self, seed: Optional[int] = None):
         if seed is not None:
@@ -204,6 +213,12 @@ def gemm(A, B, out, M, N, K, lda, ldb, ldo, a_mode, b_mode, epi, *, cfg=-1, m_va
     a.drop_thresh, a.drop_seed, a.drop_stream, a.drop_scale = drop.thresh, drop.seed, drop.stream, drop.scale
     if plan_only:      # the kernel configuration these arguments would run on (vault_gemm_plan): >= 0, or -EINVAL
         return int(L.load(_FMT.get()).vault_gemm_plan(C.byref(a)))
+    if _TAPE is not None and _TAPE.rebind_range is not None:
+        lo, hi = _TAPE.rebind_range
+        for f in ("A", "B"):
+            p = getattr(a, f) or 0
+            if lo <= p < hi:
+                _TAPE.rebinds.append((a, f, p - lo))
     _invoke("vault_gemm", C.byref(a), _stream(), struct=a, drop=drop)
 
 

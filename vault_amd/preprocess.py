@@ -29,7 +29,8 @@ class PreprocessArgs(C.Structure):
     """vault_preprocess_args (include/vault_hip.h)."""
     _fields_ = [(n, C.c_void_p) for n in ("src", "tmp", "plan", "desc", "lut", "pixel_values", "pixel_mask", "pixel_mask_f32")] + [
         (n, C.c_int) for n in ("B", "H", "W", "max_h_in", "max_w_out", "max_w_in")] + [("src_bytes", C.c_longlong),
-                                                                                        ("patch_unfold_bf16", C.c_void_p), ("ps", C.c_int)]
+                                                                                        ("patch_unfold_bf16", C.c_void_p), ("ps", C.c_int),
+                                                                                        ("ksize_max", C.c_int), ("band_rows_max", C.c_int)]
 
 
 def resize_output_size(h: int, w: int, shorter: int = 384, size_divisor: int = 32) -> Tuple[int, int]:
@@ -71,6 +72,18 @@ def resample_taps(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray]:
     return bounds, q
 
 
+BAND_ROWS = 32          # output rows one workgroup of the one-launch form resamples (csrc/preprocess.hip FB_ROWS)
+
+
+@lru_cache(maxsize=4096)
+def band_source_rows(in_size: int, out_size: int) -> int:
+    """The most source rows one band of BAND_ROWS output rows reads (vault_preprocess_args.band_rows_max for one image)."""
+    b, _ = resample_taps(in_size, out_size)
+    first = b[0::BAND_ROWS, 0]
+    last = np.minimum(np.arange(0, out_size, BAND_ROWS) + BAND_ROWS, out_size) - 1
+    return int(np.max(b[last, 0] + b[last, 1] - first))
+
+
 def normalise_lut(rescale_factor: float, mean: Sequence[float], std: Sequence[float]) -> np.ndarray:
     """[3][256] float32: the value the HF processor produces for each 8-bit level (rescale in float64, cast to float32,
     normalise in float32; HF:image_transforms.py:118-122,417-439)."""
@@ -100,7 +113,7 @@ class DeviceImageProcessor:
 
     def __init__(self, device="cuda:0", shortest_edge: int = 384, size_divisor: int = 32, rescale_factor: float = 1 / 255,
                  image_mean: Sequence[float] = (0.5, 0.5, 0.5), image_std: Sequence[float] = (0.5, 0.5, 0.5),
-                 mask_dtype: torch.dtype = torch.int64):
+                 mask_dtype: torch.dtype = torch.int64, fused: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("DeviceImageProcessor needs a GPU (the HIP library has no CPU path)")
         L.load()
@@ -109,11 +122,15 @@ class DeviceImageProcessor:
         self.device = torch.device(device)
         self.shortest_edge, self.size_divisor = shortest_edge, size_divisor
         self.mask_dtype = mask_dtype
+        # one launch with the 8-bit intermediate in LDS when a band of the batch fits (csrc/preprocess.hip resize_fused_kernel);
+        # False: always the two-pass form (intermediate in HBM) - same bytes out, for comparison
+        self.fused = fused
         self._lut = torch.from_numpy(normalise_lut(rescale_factor, image_mean, image_std)).to(self.device)
         self._plan_key, self._plan_dev = None, None        # device-side plan of the last batch geometry (loaders repeat it)
 
     def plan(self, sizes: List[Tuple[int, int]]):
-        """Host plan of a batch: (descriptor bytes, plan int32 array, src bytes, tmp bytes, H, W, max_h_in, max_w_out)."""
+        """Host plan of a batch: (descriptor bytes, plan int32 array, src bytes, tmp bytes, H, W, max_h_in, max_w_out,
+        ksize_max, band_rows_max) - the last two for the one-launch form (vault_preprocess_args, ABI 12)."""
         descs = (ImageDesc * len(sizes))()
         parts: List[np.ndarray] = []
         off = 0
@@ -127,7 +144,7 @@ class DeviceImageProcessor:
 
         cache: Dict[Tuple[int, int], Tuple[int, int, int]] = {}
         src_off = tmp_off = 0
-        H = W = max_h_in = max_w_out = 0
+        H = W = max_h_in = max_w_out = ksize_max = band_rows_max = 0
         for i, (h, w) in enumerate(sizes):
             oh, ow = resize_output_size(h, w, self.shortest_edge, self.size_divisor)
             if oh <= 0 or ow <= 0:
@@ -139,16 +156,18 @@ class DeviceImageProcessor:
                     b, q = resample_taps(n_in, n_out)
                     cache[(n_in, n_out)] = (put(b), put(q), q.shape[1])
                 bo, ko, ks = cache[(n_in, n_out)]
+                ksize_max = max(ksize_max, ks)
                 if axis == "h":
                     d.hb_off, d.hk_off, d.ksize_h = bo, ko, ks
                 else:
                     d.vb_off, d.vk_off, d.ksize_v = bo, ko, ks
+            band_rows_max = max(band_rows_max, band_source_rows(h, oh))
             src_off += h * w * 3
             tmp_off += h * ((ow * 3 + 3) & ~3)            # intermediate rows padded to 4-byte multiples
             H, W, max_h_in, max_w_out = max(H, oh), max(W, ow), max(max_h_in, h), max(max_w_out, ow)
         if off >= 2 ** 31:
             raise ValueError("plan too large")
-        return bytes(descs), np.concatenate(parts).astype(np.int32), src_off, tmp_off, H, W, max_h_in, max_w_out
+        return bytes(descs), np.concatenate(parts).astype(np.int32), src_off, tmp_off, H, W, max_h_in, max_w_out, ksize_max, band_rows_max
 
     def __call__(self, images, return_tensors: str = "pt", **unused) -> Dict[str, torch.Tensor]:
         if return_tensors != "pt":
@@ -166,24 +185,34 @@ class DeviceImageProcessor:
         return {"pixel_values": out["pixel_values"], "pixel_mask": out["pixel_mask"]}   # (the HF processor's keys only)
 
     def from_packed(self, host_u8: torch.Tensor, sizes, out: Dict[str, torch.Tensor] = None,
-                    patch_out: Optional[torch.Tensor] = None, patch_size: int = 32) -> Dict[str, torch.Tensor]:
+                    patch_out: Optional[torch.Tensor] = None, patch_size: int = 32, want_mask: bool = True) -> Dict[str, torch.Tensor]:
         """The loader-facing form: ``host_u8`` = the images back to back ([h][w][3] uint8 each, ``sizes`` = their (h, w)) in ONE
         host tensor - pinned, as a decoder writing straight into a staging buffer leaves them - copied and processed on the
         current stream.  ``out``: optional preallocated ``pixel_values`` / ``pixel_mask`` of the batch's padded shape (e.g. the
         engine's own input staging buffers: no device-to-device copy afterwards).  ``patch_out``: a bf16
         [B * (H / ps) * (W / ps), 3 ps ps] tensor that receives the patch-embedding GEMM's operand (the unfold of the
         padded canvas) straight from the resize kernel; the f32 ``pixel_values`` tensor is then not written at all
-        (the returned dict carries ``pixel_patches`` instead): hand that to the engine as ``batch["pixel_patches"]``."""
+        (the returned dict carries ``pixel_patches`` instead): hand that to the engine as ``batch["pixel_patches"]``.
+        ``want_mask=False``: the pixel mask is not written (``valid_hw`` carries the same information from the host; a
+        [B, H, W] int64 mask is 302 MB of writes per 256 images)."""
         sizes = [tuple(int(v) for v in hw) for hw in sizes]
         B = len(sizes)
         key = tuple(sizes)
         if self._plan_key != key:
-            desc_b, plan, src_bytes, tmp_bytes, H, W, max_h_in, max_w_out = self.plan(sizes)
+            desc_b, plan, src_bytes, tmp_bytes, H, W, max_h_in, max_w_out, ksize_max, band_rows_max = self.plan(sizes)
             dev = self.device
+            if not self.fused:
+                ksize_max = band_rows_max = 0               # (unknown maxima: the library runs the two-pass form)
+            probe = PreprocessArgs()
+            probe.max_w_in, probe.max_w_out = max(w for _, w in sizes), max_w_out
+            probe.ksize_max, probe.band_rows_max = ksize_max, band_rows_max
+            one_launch = bool(L.load().vault_image_preprocess_is_fused(C.byref(probe)))
             self._plan_key, self._plan_dev = key, (
                 torch.from_numpy(plan).to(dev), torch.frombuffer(bytearray(desc_b), dtype=torch.uint8).to(dev),
-                torch.empty(tmp_bytes, dtype=torch.uint8, device=dev), src_bytes, H, W, max_h_in, max_w_out)
-        plan_d, desc_d, tmp, src_bytes, H, W, max_h_in, max_w_out = self._plan_dev
+                # the 8-bit intermediate of the two-pass form (the one-launch form keeps it in LDS)
+                None if one_launch else torch.empty(tmp_bytes, dtype=torch.uint8, device=dev),
+                src_bytes, H, W, max_h_in, max_w_out, ksize_max, band_rows_max)
+        plan_d, desc_d, tmp, src_bytes, H, W, max_h_in, max_w_out, ksize_max, band_rows_max = self._plan_dev
         if host_u8.dtype != torch.uint8 or host_u8.numel() != src_bytes:
             raise ValueError("host_u8 must hold exactly the images of `sizes`, uint8")
         dev = self.device
@@ -197,20 +226,24 @@ class DeviceImageProcessor:
                 if H % ps or W % ps or ps % 4 or patch_out.dtype not in (torch.bfloat16, torch.float16) or not patch_out.is_contiguous() or \
                         patch_out.numel() < B * (H // ps) * (W // ps) * 3 * ps * ps:
                     raise ValueError(f"patch_out must be contiguous bf16 / fp16 with >= {B * (H // ps) * (W // ps)} rows of {3 * ps * ps}")
-            pm = out["pixel_mask"] if out is not None else torch.empty(B, H, W, dtype=self.mask_dtype, device=dev)
-            if (pv is not None and (tuple(pv.shape) != (B, 3, H, W) or pv.dtype != torch.float32)) or tuple(pm.shape) != (B, H, W) or pm.dtype != self.mask_dtype:
+            pm = None
+            if want_mask:
+                pm = out["pixel_mask"] if out is not None else torch.empty(B, H, W, dtype=self.mask_dtype, device=dev)
+            if (pv is not None and (tuple(pv.shape) != (B, 3, H, W) or pv.dtype != torch.float32)) or \
+                    (pm is not None and (tuple(pm.shape) != (B, H, W) or pm.dtype != self.mask_dtype)):
                 raise ValueError(f"out tensors must be pixel_values [{B},3,{H},{W}] float32 and pixel_mask [{B},{H},{W}] {self.mask_dtype}")
             if self.mask_dtype not in (torch.int64, torch.float32):
                 raise ValueError("mask_dtype must be torch.int64 (HF) or torch.float32")
             a = PreprocessArgs()
-            a.src, a.tmp, a.plan, a.desc, a.lut, a.pixel_values = (src.data_ptr(), tmp.data_ptr(), plan_d.data_ptr(), desc_d.data_ptr(),
+            a.src, a.tmp, a.plan, a.desc, a.lut, a.pixel_values = (src.data_ptr(), None if tmp is None else tmp.data_ptr(), plan_d.data_ptr(), desc_d.data_ptr(),
                                                                    self._lut.data_ptr(), None if pv is None else pv.data_ptr())
             if patch_out is not None:
                 a.patch_unfold_bf16, a.ps = patch_out.data_ptr(), int(patch_size)
-            if self.mask_dtype == torch.int64:
+            if pm is not None and self.mask_dtype == torch.int64:
                 a.pixel_mask = pm.data_ptr()
-            else:
+            elif pm is not None:
                 a.pixel_mask_f32 = pm.data_ptr()
+            a.ksize_max, a.band_rows_max = ksize_max, band_rows_max
             a.B, a.H, a.W, a.max_h_in, a.max_w_out = B, H, W, max_h_in, max_w_out
             a.max_w_in, a.src_bytes = max(w for _, w in sizes), src_bytes
             # (the unfold is written in patch_out's own 16-bit format: by the library built for it)

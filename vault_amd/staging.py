@@ -162,7 +162,14 @@ class StagingMixin:
         buf = lambda name, shape, dtype=torch.float32: self._buf(ws, name, shape, dtype)  # noqa: E731
         self._stage_text(ws, ids, temb, B, T, H)
         ap = buf("apatch", (_pad(B * NP), Kp), self.hdt)
-        ap[:B * NP].copy_(pp.reshape(B * NP, Kp))          # (onto itself when the caller wrote into input_buffers()["pixel_patches"])
+        adopt = bool(self.adopt_pixel_patches) and pp.is_contiguous() and _pad(B * NP) == B * NP and pp.data_ptr() % 256 == 0 \
+            and pp.device == ap.device
+        if adopt:
+            ws["apatch_in"] = pp.reshape(B * NP, Kp)       # the GEMMs read the caller's tensor (VaultEngine.adopt_pixel_patches)
+        else:
+            ap[:B * NP].copy_(pp.reshape(B * NP, Kp))      # (onto itself when the caller wrote into input_buffers()["pixel_patches"])
+            ws["apatch_in"] = ap
+        ws["patch_adopted"] = adopt
         ws["img_embeds"] = None
         km = buf("keymask", (B, S))
         am = batch.get("attention_mask")

@@ -521,7 +521,7 @@ class TrainStep:
             # types were given, the launch stream, the GEMM scheduling mode and the forward number format
             key = ws["key"] + (ws["tt"] is None, torch.cuda.current_stream().cuda_stream, ops.GEMM_SCHED,
                                bool(eng.fp8_forward), labels.dtype.is_floating_point, bool(ws.get("patches_in")), self.precise_forward,
-                               eng.half, eng.grad_scale)
+                               eng.half, eng.grad_scale, bool(ws.get("patches_in") and ws.get("patch_adopted")))
             # from here to the enqueued AdamW (which clears it) the flat gradient buffer holds this step's partial gradients: an
             # exception in between (the reducer's checks raise and stay usable) must not leave them for the next step, which
             # STORES its un-split weight-gradient tiles but atomically ADDS bias / LayerNorm / embedding / split-K gradients
@@ -536,10 +536,16 @@ class TrainStep:
                 self.reducer.begin_step(ws["ids"] if ws.get("txt_embeds") is None else None)
             if self.use_tape and self._tape is not None and self._tape_key == key and self._tape_ws is ws:
                 eng.drop_seed = (eng.drop_seed + 1) & 0xFFFFFFFF
+                if self._tape.rebinds:       # (the adopted pixel_patches tensor of THIS step: VaultEngine.adopt_pixel_patches)
+                    self._tape.rebind(ws["apatch_in"].data_ptr())
                 self._tape.replay(seed=eng.drop_seed)
             else:
                 eng.drop_seed = (eng.drop_seed + 1) & 0xFFFFFFFF
                 tape = ops.start_tape() if self.use_tape else None
+                adopted = bool(ws.get("patches_in") and ws.get("patch_adopted"))
+                if tape is not None and adopted:
+                    ap_in = ws["apatch_in"]
+                    tape.rebind_range = (ap_in.data_ptr(), ap_in.data_ptr() + ap_in.numel() * ap_in.element_size())
                 try:
                     out = eng.forward_staged(ws, need_hidden=False, loss_scale=1.0 / B, precise=self.precise_forward)
                     # gradients are zero here: the fused optimizer clears them after use (they start at 0)
@@ -547,6 +553,9 @@ class TrainStep:
                 finally:
                     if self.use_tape:
                         ops.stop_tape()
+                if tape is not None and adopted and len(tape.rebinds) < 2:
+                    raise RuntimeError("adopted pixel_patches: the recorded step does not show the operand's two uses "
+                                       "(patch-embedding GEMM, its weight gradient)")
                 self._tape, self._tape_key, self._tape_ws, self._loss_buf = tape, key, ws, out["loss"]
                 self._zero_mask = self._build_zero_mask(eng._stored_ranges)
             if self.reducer:
