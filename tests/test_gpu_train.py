@@ -819,3 +819,28 @@ def test_adopted_pixel_patches_feed_the_recorded_step_without_a_copy():
     po = F.unfold(torch.from_numpy(bn["pixel_values"]).cuda(), kernel_size=ps, stride=ps).transpose(1, 2).reshape(4 * spec.vilt.num_patches, -1).bfloat16()
     ws = eng.stage_inputs({"input_ids": torch.from_numpy(bn["input_ids"]).cuda(), "pixel_patches": po}, True, None)
     assert not ws["patch_adopted"] and ws["apatch_in"].data_ptr() != po.data_ptr()
+
+
+def test_vilt_weight_gradients_beside_the_lm_backward_give_the_same_step():
+    """``VaultEngine.WGRAD_BESIDE_LM_ITEMS`` (off by default: profiles/r06_dev_wgrads_beside_lm.txt): the ViLT stack's grouped
+    weight-gradient launches on the second stream beside the LM backward, joined before the optimizer - same trajectory."""
+    spec = VaultSpec.tiny(3, "roberta")
+    spec.lm.hidden_dropout_prob = 0.0; spec.lm.attention_probs_dropout_prob = 0.0
+    state = build_state(spec, 0)
+    B = 112                                             # (> 16,384 token rows: the small-batch rule of the second stream is off)
+    bn = synthetic_batch(spec, B, seed=5, n_classes=3)
+    db = {k: torch.from_numpy(v).cuda() for k, v in bn.items() if k != "labels"}
+    labels = torch.from_numpy(bn["labels"]).cuda()
+    res = {}
+    for items in (0, 192):
+        eng = VaultEngine(spec, "cuda:0", state=state, classifier_dropout=0.0, half="bf16")
+        eng.WGRAD_BESIDE_LM_ITEMS = items
+        step = TrainStep(eng, learning_rate=1e-4, warmup_ratio=0.0, total_steps=10, assume_full_pixel_mask=True)
+        losses = [float(step(db, labels)) for _ in range(3)]
+        assert (eng._wgrad_stream is not None) == (items > 0)
+        res[items] = (losses, eng.params.p.clone())
+    torch.cuda.synchronize()
+    la, lb = res[0][0], res[192][0]
+    assert abs(la[0] - lb[0]) < 1e-6 and max(abs(a - b) for a, b in zip(la, lb)) < 5e-4, (la, lb)
+    d = (res[0][1] - res[192][1]).abs()
+    assert float(d.mean()) < 3e-6 and float((d > 2e-5).float().mean()) < 0.03

@@ -13,12 +13,12 @@ from .params import _in_format, _pad
 
 class BackwardMixin:
     # ---- deferred weight gradients on a second stream -------------------------------------------
-    def _wgrads_aside(self, launch, after_layer):
+    def _wgrads_aside(self, launch, after_layer, items=0):
         """Run ``launch()`` (the batched weight-gradient GEMMs of a group of layers) on the engine's second stream when the
         backward chain leaves CUs idle (few token rows: a chain GEMM of a small batch is a single partial round of tiles).
         Nothing in the chain reads the weight gradients: only the optimizer, which waits for the stream (_join_wgrads).
         Not in data-parallel steps (``after_layer``: the reducer starts on the main stream's events)."""
-        if not self._wgrad_side or after_layer is not None:
+        if not (self._wgrad_side or items > 0) or after_layer is not None:
             launch()
             return
         if self._wgrad_stream is None:
@@ -27,7 +27,11 @@ class BackwardMixin:
         ops.pycall(lambda: ev.record(main))
         ops.pycall(lambda: side.wait_event(ev))
         with torch.cuda.stream(side):
-            launch()
+            self._wgrad_items = items       # (items per grouped launch of THIS group: _wgrad_group)
+            try:
+                launch()
+            finally:
+                self._wgrad_items = 0
         self._wgrad_pending = True
 
     def _join_wgrads(self):
@@ -150,7 +154,7 @@ class BackwardMixin:
         nk = Mtok_pad // 64
         # items per launch: one per CU; beside a backward chain on another stream (small batches) fewer, so that the chain's
         # kernels find free CUs while a launch's persistent blocks hold theirs (WGRAD_SIDE_ITEMS)
-        CU = self.WGRAD_SIDE_ITEMS if self._wgrad_side else 256
+        CU = self._wgrad_items or (self.WGRAD_SIDE_ITEMS if self._wgrad_side else 256)
         # items of every kind in list order, cut into launches of CU items (<= 3 segments each)
         remaining = []
         for k, (dY_all, X_all, wsel, Nout, Kin) in enumerate(kinds):
@@ -447,7 +451,10 @@ class BackwardMixin:
                     self._wgrad_group(((dxbA_all, ws["act_all"], "fw", H, FF), (dU_all, ws["n2_all"], "iw", FF, H),
                                        (dxbB_all, ws["ctx_all"], "ow", H, H), (dqkv_all, ws["n1_all"], "qw", 3 * H, H, vhm)),
                                       self.vl, i, hi, Mp, M)
-                self._wgrads_aside(launch, after_layer)
+                # the whole stack's group, launched when the ViLT chain is through, with a trained LM stack's backward next: that
+                # chain's GEMMs are partial rounds of tiles at any batch (40 row panels at B = 256) - the group runs beside it
+                beside = self.WGRAD_BESIDE_LM_ITEMS if (i == 0 and hi == nv and spec.lm is not None and not self.freeze_lm and not self._wgrad_side) else 0
+                self._wgrads_aside(launch, after_layer, items=beside)
                 for j in reversed(range(i, hi)):
                     note(f"vilt{j}")
 

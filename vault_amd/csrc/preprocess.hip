@@ -261,10 +261,6 @@ __global__ __launch_bounds__(FB_THREADS) void resize_fused_kernel(const uint8_t*
   }
   if (ok) {
     const int ksh = d.ksize_h, ksv = d.ksize_v, rowb = d.w_in * 3;
-    for (int i = t; i < d.w_out * ksh; i += FB_THREADS) htap[i] = plan[d.hk_off + i];
-    for (int i = t; i < d.w_out; i += FB_THREADS) hbnd[i] = plan[d.hb_off + 2 * i] | (plan[d.hb_off + 2 * i + 1] << 16);
-    for (int i = t; i < rows_here * ksv; i += FB_THREADS) vtap[i] = plan[d.vk_off + (size_t)y_lo * ksv + i];
-    if (t < rows_here) vbnd[t] = (plan[d.vb_off + 2 * (y_lo + t)] - ys) | (plan[d.vb_off + 2 * (y_lo + t) + 1] << 16);
     // ---- horizontal pass over the band's source rows, FB_G at a time
     const int ngroups = (nrows + FB_G - 1) / FB_G;
     uint4 pf[FB_PF];
@@ -296,6 +292,11 @@ __global__ __launch_bounds__(FB_THREADS) void resize_fused_kernel(const uint8_t*
       }
     };
     if (!(FB_ABL & 8)) prefetch(0); else { for (int j = 0; j < FB_PF; ++j) pf[j] = uint4{1u, 2u, 3u, 4u}; }
+    // (the first group's source loads are in flight while the plan comes in)
+    for (int i = t; i < d.w_out * ksh; i += FB_THREADS) htap[i] = plan[d.hk_off + i];
+    for (int i = t; i < d.w_out; i += FB_THREADS) hbnd[i] = plan[d.hb_off + 2 * i] | (plan[d.hb_off + 2 * i + 1] << 16);
+    for (int i = t; i < rows_here * ksv; i += FB_THREADS) vtap[i] = plan[d.vk_off + (size_t)y_lo * ksv + i];
+    if (t < rows_here) vbnd[t] = (plan[d.vb_off + 2 * (y_lo + t)] - ys) | (plan[d.vb_off + 2 * (y_lo + t) + 1] << 16);
     const int x_first = t % d.w_out, r_first = 2 * (t / d.w_out), x_step = FB_THREADS % d.w_out, r_step = 2 * (FB_THREADS / d.w_out);
     for (int g = 0; g < ngroups; ++g) {
       int nr = nrows - g * FB_G; if (nr > FB_G) nr = FB_G;
@@ -330,7 +331,8 @@ __global__ __launch_bounds__(FB_THREADS) void resize_fused_kernel(const uint8_t*
           else if (kc == 7) hchunk<7>(sp, rowb, tp, 7, a);
           else if (kc == 6) hchunk<6>(sp, rowb, tp, 6, a);
           else if (kc == 5) hchunk<5>(sp, rowb, tp, 5, a);
-          else hchunk<8>(sp, rowb, tp, kc, a);
+          else if (kc == 4) hchunk<4>(sp, rowb, tp, 4, a);
+          else hchunk<4>(sp, rowb, tp, kc, a);
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r)

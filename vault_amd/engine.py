@@ -108,6 +108,7 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
         self.last: Optional[dict] = None
         self._wgrad_stream, self._wgrad_pending = None, False
         self._wgrad_side = False
+        self._wgrad_items = 0
         # True: a `pixel_patches` tensor (contiguous, whole padded row count) becomes the patch-embedding GEMM's operand AS IS -
         # forward and weight gradient read the caller's memory, nothing is copied (a recorded step re-points its launches:
         # ops.Tape.rebind).  The caller then keeps the tensor unchanged until the step's kernels have run (an event recorded
@@ -327,6 +328,12 @@ class VaultEngine(StagingMixin, HeadsMixin, BackwardMixin):
     HEAD_MAJOR_MIN_ROWS = 16384    # ... from this many (padded) token rows of a stack
     SPLITK = True                  # lend the GEMMs a workspace for split-K with the in-launch reduction (vault_gemm_args.splitk_ws; see _sk_ws)
     SPLITK_WS_BYTES = 16384 + (64 << 20)
+    # items per grouped launch of the ViLT stack's weight gradients when they run BESIDE the LM backward on the second stream
+    # (0: in front of it, serial).  Measured at B = 256, one box (profiles/r06_dev_wgrads_beside_lm.txt): 37.85 ms serial, 37.66 /
+    # 37.79 / 37.58 / 37.57 / 38.17 with 256 / 224 / 192 / 160 / 128 items - the LM chain's launches keep their CUs busy (86 % of
+    # their CU time is tile time, not idle CUs), so there is little to fill; and the shared CUs stretch the weight-gradient
+    # launches the `roofline` line times (0.53 -> 0.40 of peak as measured by the stream's events).  Off.
+    WGRAD_BESIDE_LM_ITEMS = 0
     WGRAD_SIDE_ITEMS = 224         # items per grouped launch on the second stream (B = 64, same box: 256: 13.50 / 13.59 ms, 224: 13.32 / 13.46, 192: 13.23 / 13.47, 160: 13.63 / 13.53)
 
 

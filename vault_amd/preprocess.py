@@ -69,7 +69,9 @@ def resample_taps(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray]:
     w = np.where(ww[:, None] != 0.0, w / np.where(ww == 0.0, 1.0, ww)[:, None], w)
     q = np.trunc(np.where(w < 0, -0.5 + w * (1 << PRECISION_BITS), 0.5 + w * (1 << PRECISION_BITS))).astype(np.int32)
     bounds = np.stack([xmin, n], 1).astype(np.int32)
-    return bounds, q
+    # columns past the widest window hold zeros only (Pillow's ksize is an upper bound: 480 -> 384 has ksize 7 and 5-tap
+    # windows): the table keeps the widest window's width - it is the kernels' row stride AND the one-launch kernel's tap count
+    return bounds, np.ascontiguousarray(q[:, :max(int(n.max()), 1)])
 
 
 BAND_ROWS = 32          # output rows one workgroup of the one-launch form resamples (csrc/preprocess.hip FB_ROWS)
