@@ -147,6 +147,7 @@ class DeviceImageProcessor:
         cache: Dict[Tuple[int, int], Tuple[int, int, int]] = {}
         src_off = tmp_off = 0
         H = W = max_h_in = max_w_out = ksize_max = band_rows_max = 0
+        taps_fit = True       # every tap within the one-launch kernel's 24-bit multiplier (weights are below 2 in magnitude: always)
         for i, (h, w) in enumerate(sizes):
             oh, ow = resize_output_size(h, w, self.shortest_edge, self.size_divisor)
             if oh <= 0 or ow <= 0:
@@ -156,6 +157,7 @@ class DeviceImageProcessor:
             for axis, (n_in, n_out) in (("h", (w, ow)), ("v", (h, oh))):
                 if (n_in, n_out) not in cache:
                     b, q = resample_taps(n_in, n_out)
+                    taps_fit = taps_fit and int(np.abs(q).max()) < (1 << 23)
                     cache[(n_in, n_out)] = (put(b), put(q), q.shape[1])
                 bo, ko, ks = cache[(n_in, n_out)]
                 ksize_max = max(ksize_max, ks)
@@ -169,6 +171,8 @@ class DeviceImageProcessor:
             H, W, max_h_in, max_w_out = max(H, oh), max(W, ow), max(max_h_in, h), max(max_w_out, ow)
         if off >= 2 ** 31:
             raise ValueError("plan too large")
+        if not taps_fit:
+            ksize_max = band_rows_max = 0                  # (unknown maxima: the two-pass form, 32-bit multiplies)
         return bytes(descs), np.concatenate(parts).astype(np.int32), src_off, tmp_off, H, W, max_h_in, max_w_out, ksize_max, band_rows_max
 
     def __call__(self, images, return_tensors: str = "pt", **unused) -> Dict[str, torch.Tensor]:
