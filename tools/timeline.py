@@ -36,7 +36,7 @@ if "--per-step" in sys.argv:
         byq = collections.defaultdict(float)
         for s, e, n, q in win_:
             byq[q] += e - s
-        extra = {n_[:40]: round(sum(e - s for s, e, n, q in win_ if n_ in n) / 1e3, 1) for n_ in ("preprocess", "im2col", "copyBuffer", "elementwise")}
+        extra = {n_[:40]: round(sum(e - s for s, e, n, q in win_ if n_ in n) / 1e3, 1) for n_ in ("resize_", "im2col", "copyBuffer", "elementwise")}
         print(f"step {i:3d}: wall {(b - a) / 1e3:9.1f} us  busy {busy_ / 1e3:9.1f}  idle {(b - a - busy_) / 1e3:7.1f}  launches {len(win_):4d}  per queue "
               f"{ {q: round(v / 1e3, 1) for q, v in byq.items()} }  {extra}")
     sys.exit(0)
