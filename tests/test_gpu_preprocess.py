@@ -196,3 +196,31 @@ def test_one_launch_form_equals_the_two_pass_form_and_the_oracle():
     imgs = [rng.integers(0, 256, size=(64, 1200, 3), dtype=np.uint8)]
     o = big.from_packed(torch.from_numpy(imgs[0].reshape(-1)).pin_memory(), [(64, 1200)])
     assert big._plan_dev[2] is not None and np.array_equal(o["pixel_values"].cpu().numpy(), PO.preprocess(imgs)[0])
+
+
+def test_one_launch_form_on_random_geometries():
+    """Twelve random ragged batches (sides 17 .. 1100, any aspect): the one-launch kernel's bytes equal the two-pass kernels'
+    wherever the library takes it (and the library takes it for most), for both output forms."""
+    rng = np.random.default_rng(123)
+    fused_runs = 0
+    for trial in range(12):
+        n = int(rng.integers(1, 5))
+        sizes = [(int(rng.integers(17, 1100)), int(rng.integers(17, 1100))) for _ in range(n)]
+        sizes = [(h, w) for h, w in sizes if max(h, w) / min(h, w) < 12] or [(64, 64)]      # (very thin images resize to nothing)
+        imgs = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in sizes]
+        host = torch.from_numpy(np.concatenate([im.reshape(-1) for im in imgs])).pin_memory()
+        one, two = DeviceImageProcessor(), DeviceImageProcessor(fused=False)
+        try:
+            a = one.from_packed(host, sizes)
+        except ValueError:                       # an image that resizes to an empty one: the HF processor fails on it too
+            continue
+        b = two.from_packed(host, sizes)
+        fused_runs += one._plan_dev[2] is None
+        assert torch.equal(a["pixel_values"], b["pixel_values"]) and torch.equal(a["pixel_mask"], b["pixel_mask"]), sizes
+        B, _, H, W = a["pixel_values"].shape
+        po1 = torch.full((B * (H // 32) * (W // 32), 3072), 7.0, dtype=torch.bfloat16, device="cuda")
+        po2 = torch.full_like(po1, 3.0)
+        one.from_packed(host, sizes, patch_out=po1, want_mask=False)
+        two.from_packed(host, sizes, patch_out=po2)
+        assert torch.equal(po1, po2), sizes
+    assert fused_runs >= 6
